@@ -1,0 +1,176 @@
+"""ctypes binding of the plain-C oracle (oracle/mdvt_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmdvt_oracle.so")
+
+MODE_POINTS = 0
+MODE_MESH = 1
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("W", C.c_int32), ("H", C.c_int32),
+        ("mode", C.c_int32), ("remove_edges", C.c_int32), ("edge_points", C.c_int32),
+        ("general", C.c_int32), ("has_T", C.c_int32), ("_pad", C.c_int32),
+        ("K", C.c_double * 4), ("Kr", C.c_double * 4),
+        ("ipd_m", C.c_double), ("max_depth", C.c_double), ("depth_scale", C.c_double),
+        ("conv_angle", C.c_double),
+        ("T", C.c_double * 16),
+        ("key_rgb", C.c_uint8 * 4),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "mdvt_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "mdvt_oracle.h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u8p, f32p, f64p = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_double)
+        L.orc_decode_depth.argtypes = [u8p, C.c_int, C.c_int, C.c_double, C.c_double, f32p]
+        L.orc_decode_depth.restype = None
+        L.orc_encode_depth.argtypes = [f32p, C.c_int, C.c_int, C.c_double, u8p]
+        L.orc_encode_depth.restype = None
+        L.orc_camera_matrix.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, f64p]
+        L.orc_camera_matrix.restype = C.c_int
+        L.orc_unproject_f64.argtypes = [f32p, C.c_int, C.c_int, f64p, C.c_int, f64p]
+        L.orc_unproject_f64.restype = None
+        L.orc_edge_filter.argtypes = [f32p, C.c_int, C.c_int, f64p, C.c_int, u8p, u8p, f64p]
+        L.orc_edge_filter.restype = None
+        L.orc_convergence_angle.argtypes = [C.c_double, C.c_double]
+        L.orc_convergence_angle.restype = C.c_double
+        L.orc_render_stereo.argtypes = [C.POINTER(OrcParams), u8p, u8p, u8p, u8p, u8p, u8p, f32p, f32p]
+        L.orc_render_stereo.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def decode_depth(rgb: np.ndarray, max_depth: float, depth_scale: float = 1.0) -> np.ndarray:
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    H, W = rgb.shape[:2]
+    out = np.empty((H, W), np.float32)
+    lib().orc_decode_depth(_p(rgb, C.c_uint8), W, H, float(max_depth), float(depth_scale), _p(out, C.c_float))
+    return out
+
+
+def encode_depth(depth: np.ndarray, max_depth: float) -> np.ndarray:
+    depth = np.ascontiguousarray(depth, np.float32)
+    H, W = depth.shape
+    out = np.empty((H, W, 3), np.uint8)
+    lib().orc_encode_depth(_p(depth, C.c_float), W, H, float(max_depth), _p(out, C.c_uint8))
+    return out
+
+
+def camera_matrix(xfov, yfov, W, H) -> np.ndarray:
+    K = np.empty(9, np.float64)
+    rc = lib().orc_camera_matrix(np.nan if xfov is None else float(xfov),
+                                 np.nan if yfov is None else float(yfov), int(W), int(H), _p(K, C.c_double))
+    if rc != 0:
+        raise ValueError("either xfov or yfov is required")
+    return K.reshape(3, 3)
+
+
+def k4(K: np.ndarray) -> np.ndarray:
+    K = np.asarray(K, np.float64)
+    return np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]], np.float64)
+
+
+def unproject_f64(depth: np.ndarray, K: np.ndarray, of_by_one: bool) -> np.ndarray:
+    depth = np.ascontiguousarray(depth, np.float32)
+    H, W = depth.shape
+    out = np.empty((H * W, 3), np.float64)
+    kk = k4(K)
+    lib().orc_unproject_f64(_p(depth, C.c_float), W, H, _p(kk, C.c_double), int(of_by_one), _p(out, C.c_double))
+    return out
+
+
+def edge_filter(depth: np.ndarray, K: np.ndarray, of_by_one: bool, want_normals: bool = False):
+    """-> (tri_invalid u8[2*(H-1)*(W-1)] in draw order, unused u8[H*W], normals f64[H*W,3] | None)"""
+    depth = np.ascontiguousarray(depth, np.float32)
+    H, W = depth.shape
+    tri = np.empty(2 * (H - 1) * (W - 1), np.uint8)
+    unused = np.empty(H * W, np.uint8)
+    normals = np.empty((H * W, 3), np.float64) if want_normals else None
+    kk = k4(K)
+    lib().orc_edge_filter(_p(depth, C.c_float), W, H, _p(kk, C.c_double), int(of_by_one),
+                          _p(tri, C.c_uint8), _p(unused, C.c_uint8),
+                          _p(normals, C.c_double) if want_normals else None)
+    return tri, unused, normals
+
+
+def convergence_angle(distance: float, ipd_m: float) -> float:
+    return float(lib().orc_convergence_angle(float(distance), float(ipd_m)))
+
+
+def make_params(W, H, K, *, Kr=None, ipd_m=0.065, max_depth=100.0, depth_scale=1.0, mode=MODE_POINTS,
+                remove_edges=False, edge_points=False, conv_angle=0.0, T=None, key_rgb=(0, 0, 0),
+                force_general=False) -> OrcParams:
+    p = OrcParams()
+    p.W, p.H = int(W), int(H)
+    p.mode = int(mode)
+    p.remove_edges = int(bool(remove_edges))
+    p.edge_points = int(bool(edge_points))
+    kk = k4(K)
+    kr = kk if Kr is None else k4(Kr)
+    for i in range(4):
+        p.K[i] = kk[i]
+        p.Kr[i] = kr[i]
+    p.ipd_m = float(ipd_m)
+    p.max_depth = float(max_depth)
+    p.depth_scale = float(depth_scale)
+    p.conv_angle = float(conv_angle or 0.0)
+    p.has_T = int(T is not None)
+    if T is not None:
+        Tm = np.asarray(T, np.float64).reshape(16)
+        for i in range(16):
+            p.T[i] = Tm[i]
+    p.general = int(bool(force_general) or T is not None or p.conv_angle != 0.0 or not np.array_equal(kk, kr))
+    for i in range(3):
+        p.key_rgb[i] = int(key_rgb[i])
+    return p
+
+
+def render_stereo(p: OrcParams, depth_rgb: np.ndarray, color_rgb: np.ndarray, want_depth: bool = False):
+    """-> dict(left_rgb, right_rgb, left_mask, right_mask[, left_depth, right_depth])"""
+    depth_rgb = np.ascontiguousarray(depth_rgb, np.uint8)
+    color_rgb = np.ascontiguousarray(color_rgb, np.uint8)
+    H, W = p.H, p.W
+    assert depth_rgb.shape == (H, W, 3) and color_rgb.shape == (H, W, 3)
+    out = {
+        "left_rgb": np.empty((H, W, 3), np.uint8), "right_rgb": np.empty((H, W, 3), np.uint8),
+        "left_mask": np.empty((H, W), np.uint8), "right_mask": np.empty((H, W), np.uint8),
+    }
+    ld = rd = None
+    if want_depth:
+        out["left_depth"] = np.empty((H, W), np.float32)
+        out["right_depth"] = np.empty((H, W), np.float32)
+        ld, rd = _p(out["left_depth"], C.c_float), _p(out["right_depth"], C.c_float)
+    rc = lib().orc_render_stereo(C.byref(p), _p(depth_rgb, C.c_uint8), _p(color_rgb, C.c_uint8),
+                                 _p(out["left_rgb"], C.c_uint8), _p(out["right_rgb"], C.c_uint8),
+                                 _p(out["left_mask"], C.c_uint8), _p(out["right_mask"], C.c_uint8), ld, rd)
+    if rc != 0:
+        raise ValueError(f"orc_render_stereo failed: {rc}")
+    return out

@@ -1,0 +1,489 @@
+/*
+ * mdvt_oracle.c -- plain-C CPU restatement of the stereo-rerender hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see mdvt_oracle.h).  It is written as the obvious sequential
+ * algorithm -- full-frame z-buffers, painter's loop in draw order with a strict LESS depth
+ * test -- and deliberately shares no code with the HIP kernels it checks.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC  (oracle/Makefile).
+ * All f32 arithmetic below is written one operation per expression node; with contraction off
+ * the compiler evaluates exactly the sequence DESIGN.md section "Arithmetic decree" lists.
+ */
+#include "mdvt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_NEAR 1e-4f            /* ctr.set_constant_z_near(0.0001), dmt:1520 */
+#define ORC_SUBPIX 256            /* raster sub-pixel grid (decree)            */
+#define ORC_SNAP_LIMIT 4194304.0f /* |u|,|v| clamp before snapping (2^22 px)   */
+
+/* ------------------------------------------------------------------------------------------ */
+/* codec                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* dfh:21-23: e.astype(float32) * (float(max_depth)/255**4); the python scalar is "weak", so the
+ * multiply is f32 x f32 with the scalar rounded to f32 first. */
+static float orc_decode_mult(double max_depth) { return (float)(max_depth / 4228250625.0); }
+
+static inline float orc_decode_px(const uint8_t* px, float mult, float scale)
+{
+    /* dfh:67-69 (bit16): byte3 <- R, byte2 <- B, G ignored.  float(u32) is exact (16 sig. bits). */
+    uint32_t code = ((uint32_t)px[0] << 24) | ((uint32_t)px[2] << 16);
+    float d = (float)code * mult;
+    return d * scale;                 /* sr:541  depth *= master_fov_scale_depth (f32 in place) */
+}
+
+void orc_decode_depth(const uint8_t* rgb, int W, int H, double max_depth, double depth_scale, float* out)
+{
+    const float mult = orc_decode_mult(max_depth);
+    const float scale = (float)depth_scale;
+    const size_t n = (size_t)W * (size_t)H;
+    for (size_t i = 0; i < n; ++i) out[i] = orc_decode_px(rgb + 3 * i, mult, scale);
+}
+
+void orc_encode_depth(const float* depth, int W, int H, double max_depth, uint8_t* rgb)
+{
+    /* dfh:7-9: clip to [0,max] (f32 array clipped with python scalars -> stays f32), multiply in
+     * f64 by 255**4/max_depth, truncate to uint32.  dfh:53-55: R = G = byte 3, B = byte 2. */
+    const double multi = 4228250625.0 / max_depth;
+    const float fmax = (float)max_depth;
+    const size_t n = (size_t)W * (size_t)H;
+    for (size_t i = 0; i < n; ++i) {
+        float d = depth[i];
+        if (d > fmax) d = fmax;       /* np.clip: min(max(d, 0), max); NaN propagates -> code 0 below */
+        if (d < 0.0f) d = 0.0f;
+        double e = multi * (double)d;
+        uint32_t code = (e >= 0.0 && e < 4294967296.0) ? (uint32_t)e : 0u;
+        rgb[3 * i + 0] = (uint8_t)(code >> 24);
+        rgb[3 * i + 1] = (uint8_t)(code >> 24);
+        rgb[3 * i + 2] = (uint8_t)((code >> 16) & 0xff);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* camera                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+int orc_camera_matrix(double xfov_deg, double yfov_deg, int W, int H, double* K9)
+{
+    const int hx = !isnan(xfov_deg), hy = !isnan(yfov_deg);
+    double fx = 0.0, fy = 0.0;
+    if (!hx && !hy) return -1;
+    /* np.deg2rad(x) == x * (pi/180) */
+    if (hx) fx = (double)W / (2.0 * tan((xfov_deg * (M_PI / 180.0)) / 2.0));
+    if (hy) fy = (double)H / (2.0 * tan((yfov_deg * (M_PI / 180.0)) / 2.0));
+    if (!hy) fy = fx;
+    if (!hx) fx = fy;
+    K9[0] = fx;  K9[1] = 0.0; K9[2] = (double)W / 2.0;
+    K9[3] = 0.0; K9[4] = fy;  K9[5] = (double)H / 2.0;
+    K9[6] = 0.0; K9[7] = 0.0; K9[8] = 1.0;
+    return 0;
+}
+
+double orc_convergence_angle(double distance, double ipd_m) { return atan((ipd_m / 2.0) / distance); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* f64 unprojection + edge filter (pinned by goldens from the reference)                      */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline double orc_grid_f64(int idx, int n, int of_by_one)
+{
+    /* dmt:1117-1122: x.astype(float32); x *= (width+1)/width  (f32 array times weak python float) */
+    if (!of_by_one) return (double)idx;
+    const float s = (float)(((double)n + 1.0) / (double)n);
+    return (double)((float)idx * s);
+}
+
+void orc_unproject_f64(const float* depth, int W, int H, const double* K4, int of_by_one, double* out)
+{
+    const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    for (int i = 0; i < H; ++i) {
+        const double y = orc_grid_f64(i, H, of_by_one);
+        for (int j = 0; j < W; ++j) {
+            const double x = orc_grid_f64(j, W, of_by_one);
+            const double z = (double)depth[(size_t)i * W + j];
+            double* o = out + 3 * ((size_t)i * W + j);
+            o[0] = (x - cx) * z / fx;          /* dmt:1127 */
+            o[1] = (y - cy) * z / fy;          /* dmt:1128 */
+            o[2] = z;
+        }
+    }
+}
+
+/* cos(radians(89.0)) as NumPy evaluates it (dmt:1287); pinned by tests/golden. */
+static const double ORC_COS_89 = 0x1.1df0b2b89dd37p-6;
+
+static int orc_tri_invalid(const double* a, const double* b, const double* c, double* nrm)
+{
+    /* dmt:1283-1294 */
+    const double e1[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] };
+    const double e2[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+    const double n[3] = { e1[1] * e2[2] - e1[2] * e2[1],
+                          e1[2] * e2[0] - e1[0] * e2[2],
+                          e1[0] * e2[1] - e1[1] * e2[0] };
+    const double v[3] = { -((a[0] + b[0]) + c[0]) / 3.0,
+                          -((a[1] + b[1]) + c[1]) / 3.0,
+                          -((a[2] + b[2]) + c[2]) / 3.0 };
+    const double dot = (n[0] * v[0] + n[1] * v[1]) + n[2] * v[2];
+    const double len_n = sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+    const double len_v = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    const double cosine = dot / (len_n * len_v + 1e-15);
+    if (nrm) {
+        /* dmt:1346-1353: area2 = np.linalg.norm(normals, axis=1) -> sqrt of the sum of squares;
+         * unit normal, or (1,1,1) where the triangle is degenerate. */
+        if (len_n > 0.0) { nrm[0] = n[0] / len_n; nrm[1] = n[1] / len_n; nrm[2] = n[2] / len_n; }
+        else { nrm[0] = nrm[1] = nrm[2] = 1.0; }
+    }
+    return cosine < ORC_COS_89;
+}
+
+void orc_edge_filter(const float* depth, int W, int H, const double* K4, int of_by_one,
+                     uint8_t* tri_invalid, uint8_t* unused, double* normals)
+{
+    const size_t nv = (size_t)W * H;
+    const size_t ncell = (size_t)(W - 1) * (H - 1);
+    double* P = (double*)malloc(nv * 3 * sizeof(double));
+    orc_unproject_f64(depth, W, H, K4, of_by_one, P);
+    memset(unused, 0, nv);
+    if (normals) memset(normals, 0, nv * 3 * sizeof(double));
+    /* draw order (dmt:1243-1254): all tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]) row-major over cells,
+     * then all tri2 = (v[i,j], v[i+1,j+1], v[i,j+1]). */
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < H - 1; ++i) {
+            for (int j = 0; j < W - 1; ++j) {
+                const size_t i1 = (size_t)i * W + j, i2 = (size_t)(i + 1) * W + j;
+                const size_t i3 = (size_t)(i + 1) * W + j + 1, i4 = (size_t)i * W + j + 1;
+                const size_t v0 = i1, v1 = pass == 0 ? i2 : i3, v2 = pass == 0 ? i3 : i4;
+                double nrm[3];
+                const int inv = orc_tri_invalid(P + 3 * v0, P + 3 * v1, P + 3 * v2, normals ? nrm : NULL);
+                tri_invalid[(size_t)pass * ncell + (size_t)i * (W - 1) + j] = (uint8_t)inv;
+                if (inv) { unused[v0] = 1; unused[v1] = 1; unused[v2] = 1; }   /* dmt:1339-1344 */
+                if (normals) {                                                  /* dmt:1358-1364 */
+                    memcpy(normals + 3 * v0, nrm, sizeof nrm);
+                    memcpy(normals + 3 * v1, nrm, sizeof nrm);
+                    memcpy(normals + 3 * v2, nrm, sizeof nrm);
+                }
+            }
+        }
+    }
+    free(P);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* per-eye vertex programme (f32, decree)                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+    int W, H;
+    int general;
+    int of_by_one;
+    float mult, scale;          /* codec */
+    float fx, fy, cx, cy;       /* input camera, f32 */
+    float fxr, fyr, cxr, cyr;   /* render camera, f32 */
+    float sx, sy;               /* (W+1)/W, (H+1)/H in f32 (or 1) */
+    float sW, sH;               /* (W-1)/W, (H-1)/H in f32: the edge points' "undo" (sr:599-600) */
+    float dl;                   /* fxr * ipd/2 in f32: pure-shift disparity numerator */
+    float sign;                 /* +1 left eye, -1 right eye (pure shift) */
+    float M[12];                /* general: 3x4 eye*pose matrix, f32 */
+} orc_eye;
+
+static void orc_eye_setup(const orc_params* p, int eye /*0 left, 1 right*/, orc_eye* e)
+{
+    memset(e, 0, sizeof *e);
+    e->W = p->W; e->H = p->H;
+    e->general = p->general;
+    e->of_by_one = (p->mode == ORC_MODE_MESH);        /* sr:574-580 */
+    e->mult = orc_decode_mult(p->max_depth);
+    e->scale = (float)p->depth_scale;
+    e->fx = (float)p->K[0];  e->fy = (float)p->K[1];  e->cx = (float)p->K[2];  e->cy = (float)p->K[3];
+    e->fxr = (float)p->Kr[0]; e->fyr = (float)p->Kr[1]; e->cxr = (float)p->Kr[2]; e->cyr = (float)p->Kr[3];
+    e->sx = e->of_by_one ? (float)(((double)p->W + 1.0) / (double)p->W) : 1.0f;
+    e->sy = e->of_by_one ? (float)(((double)p->H + 1.0) / (double)p->H) : 1.0f;
+    e->sW = (float)(((double)p->W - 1.0) / (double)p->W);
+    e->sH = (float)(((double)p->H - 1.0) / (double)p->H);
+    const double half = p->ipd_m / 2.0;
+    e->dl = (float)(p->Kr[0] * half);
+    e->sign = eye == 0 ? 1.0f : -1.0f;
+    /* general: M = Translate(+-ipd/2) * Ry(-+a) * T   (sr:615-619, 724-725, 832-836).
+     * Ry(t) = [[c,0,s],[0,1,0],[-s,0,c]] (Open3D get_rotation_matrix_from_xyz((0,t,0))). */
+    const double t = eye == 0 ? -p->conv_angle : p->conv_angle;
+    const double c = cos(t), s = sin(t);
+    const double R[3][3] = { { c, 0.0, s }, { 0.0, 1.0, 0.0 }, { -s, 0.0, c } };
+    double T[16] = { 1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1 };
+    if (p->has_T) memcpy(T, p->T, sizeof T);
+    const double shift[3] = { eye == 0 ? half : -half, 0.0, 0.0 };
+    for (int r = 0; r < 3; ++r) {
+        for (int col = 0; col < 3; ++col)
+            e->M[4 * r + col] = (float)((R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col]);
+        e->M[4 * r + 3] = (float)(((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r]);
+    }
+}
+
+typedef struct { float u, v, z; int ok; } orc_vert;
+
+/* Mesh / point vertex (i,j) with source depth zsrc -> screen position + eye-space depth. */
+static inline orc_vert orc_vertex(const orc_eye* e, int i, int j, float zsrc)
+{
+    orc_vert o;
+    const float gx = (float)j * e->sx;
+    const float gy = (float)i * e->sy;
+    if (!e->general) {
+        /* pure shift: u = grid_x + fx*s/Z, v = grid_y (exact-arithmetic form of dmt:1127-1128
+         * followed by the +-ipd/2 translate and the pinhole projection with K == Krender). */
+        const float d = e->dl / zsrc;
+        o.u = e->sign > 0.0f ? gx + d : gx - d;
+        o.v = gy;
+        o.z = zsrc;
+        o.ok = zsrc > ORC_NEAR;
+        return o;
+    }
+    const float xc = ((gx - e->cx) * zsrc) / e->fx;
+    const float yc = ((gy - e->cy) * zsrc) / e->fy;
+    const float* M = e->M;
+    const float X = ((M[0] * xc + M[1] * yc) + M[2] * zsrc) + M[3];
+    const float Y = ((M[4] * xc + M[5] * yc) + M[6] * zsrc) + M[7];
+    const float Z = ((M[8] * xc + M[9] * yc) + M[10] * zsrc) + M[11];
+    o.ok = (zsrc > ORC_NEAR) && (Z > ORC_NEAR);
+    o.u = (e->fxr * X) / Z + e->cxr;
+    o.v = (e->fyr * Y) / Z + e->cyr;
+    o.z = Z;
+    return o;
+}
+
+/* Edge point (vertex of a removed triangle) -> integer pixel by round-half-even (sr:746, 858),
+ * after the "undo off by one" scaling of X and Y (sr:599-600). */
+static inline int orc_edge_point(const orc_eye* e, int i, int j, float zsrc, int* px, int* py, float* zout)
+{
+    const float gx = (float)j * e->sx;
+    const float gy = (float)i * e->sy;
+    float u, v, z;
+    if (!(zsrc > ORC_NEAR)) return 0;
+    if (!e->general) {
+        const float ex = ((gx - e->cx) * e->sW) + e->cx;
+        const float d = e->dl / zsrc;
+        u = e->sign > 0.0f ? ex + d : ex - d;
+        v = (float)i;                 /* exact-arithmetic row: i*(1-1/H^2)+1/2 rounds to i (decree) */
+        z = zsrc;
+    } else {
+        const float xc = (((gx - e->cx) * zsrc) / e->fx) * e->sW;
+        const float yc = (((gy - e->cy) * zsrc) / e->fy) * e->sH;
+        const float* M = e->M;
+        const float X = ((M[0] * xc + M[1] * yc) + M[2] * zsrc) + M[3];
+        const float Y = ((M[4] * xc + M[5] * yc) + M[6] * zsrc) + M[7];
+        z = ((M[8] * xc + M[9] * yc) + M[10] * zsrc) + M[11];
+        if (!(z > ORC_NEAR)) return 0;
+        u = (e->fxr * X) / z + e->cxr;
+        v = (e->fyr * Y) / z + e->cyr;
+    }
+    if (!(u > -1.0f && u < (float)e->W + 1.0f && v > -1.0f && v < (float)e->H + 1.0f)) return 0;
+    const int x = (int)rintf(u), y = (int)rintf(v);
+    if (x < 0 || x >= e->W || y < 0 || y >= e->H) return 0;
+    *px = x; *py = y; *zout = z;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* rasteriser (decree: 1/256 sub-pixel snap, integer edge functions, top-left rule, no culling) */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline int64_t orc_snap(float x)
+{
+    if (x > ORC_SNAP_LIMIT) x = ORC_SNAP_LIMIT;
+    if (x < -ORC_SNAP_LIMIT) x = -ORC_SNAP_LIMIT;
+    return (int64_t)rintf(x * (float)ORC_SUBPIX);
+}
+
+static inline int64_t orc_floordiv(int64_t a, int64_t b) /* b > 0 */
+{
+    int64_t q = a / b;
+    if ((a % b) < 0) --q;
+    return q;
+}
+
+typedef struct {
+    int W, H;
+    float* zbuf;        /* mesh: interpolated 1/Z (bigger = nearer), 0 = empty; points: Z, INF = empty */
+    uint8_t* rgb;       /* H*W*3 */
+    uint8_t* covered;   /* H*W   */
+} orc_target;
+
+static inline int orc_edge_in(int64_t w, int64_t dx, int64_t dy)
+{
+    if (w > 0) return 1;
+    if (w < 0) return 0;
+    return (dy < 0) || (dy == 0 && dx > 0);    /* top-left rule, clockwise (y down) orientation */
+}
+
+static void orc_raster_tri(orc_target* t, const orc_vert* a, const orc_vert* b, const orc_vert* c,
+                           const uint8_t* ca, const uint8_t* cb, const uint8_t* cc)
+{
+    if (!(a->ok && b->ok && c->ok)) return;     /* near-plane: drop the whole triangle (decree) */
+    const int64_t X0 = orc_snap(a->u), Y0 = orc_snap(a->v);
+    const int64_t X1 = orc_snap(b->u), Y1 = orc_snap(b->v);
+    const int64_t X2 = orc_snap(c->u), Y2 = orc_snap(c->v);
+    int64_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
+    if (area2 == 0) return;
+    const int64_t s = area2 > 0 ? 1 : -1;
+    area2 *= s;
+    int64_t minX = X0 < X1 ? X0 : X1; if (X2 < minX) minX = X2;
+    int64_t maxX = X0 > X1 ? X0 : X1; if (X2 > maxX) maxX = X2;
+    int64_t minY = Y0 < Y1 ? Y0 : Y1; if (Y2 < minY) minY = Y2;
+    int64_t maxY = Y0 > Y1 ? Y0 : Y1; if (Y2 > maxY) maxY = Y2;
+    const int64_t half = ORC_SUBPIX / 2;
+    int64_t px0 = orc_floordiv(minX - half + ORC_SUBPIX - 1, ORC_SUBPIX);   /* ceil((minX-128)/256) */
+    int64_t px1 = orc_floordiv(maxX - half, ORC_SUBPIX);
+    int64_t py0 = orc_floordiv(minY - half + ORC_SUBPIX - 1, ORC_SUBPIX);
+    int64_t py1 = orc_floordiv(maxY - half, ORC_SUBPIX);
+    if (px0 < 0) px0 = 0;
+    if (py0 < 0) py0 = 0;
+    if (px1 > t->W - 1) px1 = t->W - 1;
+    if (py1 > t->H - 1) py1 = t->H - 1;
+    /* directed edges opposite each vertex, orientation-normalised */
+    const int64_t dx0 = s * (X2 - X1), dy0 = s * (Y2 - Y1);   /* v1 -> v2, weight of v0 */
+    const int64_t dx1 = s * (X0 - X2), dy1 = s * (Y0 - Y2);   /* v2 -> v0, weight of v1 */
+    const int64_t dx2 = s * (X1 - X0), dy2 = s * (Y1 - Y0);   /* v0 -> v1, weight of v2 */
+    const float iz0 = 1.0f / a->z, iz1 = 1.0f / b->z, iz2 = 1.0f / c->z;
+    const float fa = (float)area2;
+    for (int64_t py = py0; py <= py1; ++py) {
+        const int64_t Yc = py * ORC_SUBPIX + half;
+        for (int64_t px = px0; px <= px1; ++px) {
+            const int64_t Xc = px * ORC_SUBPIX + half;
+            const int64_t w0 = s * ((X2 - X1) * (Yc - Y1) - (Y2 - Y1) * (Xc - X1));
+            const int64_t w1 = s * ((X0 - X2) * (Yc - Y2) - (Y0 - Y2) * (Xc - X2));
+            const int64_t w2 = s * ((X1 - X0) * (Yc - Y0) - (Y1 - Y0) * (Xc - X0));
+            if (!(orc_edge_in(w0, dx0, dy0) && orc_edge_in(w1, dx1, dy1) && orc_edge_in(w2, dx2, dy2)))
+                continue;
+            const float l0 = (float)w0 / fa, l1 = (float)w1 / fa, l2 = (float)w2 / fa;
+            const float q0 = l0 * iz0, q1 = l1 * iz1, q2 = l2 * iz2;
+            const float iz = (q0 + q1) + q2;
+            const size_t o = (size_t)py * t->W + (size_t)px;
+            if (!(iz > t->zbuf[o])) continue;          /* GL_LESS on depth == GREATER on 1/Z; first drawn wins ties */
+            t->zbuf[o] = iz;
+            t->covered[o] = 1;
+            for (int ch = 0; ch < 3; ++ch) {
+                const float num = (q0 * (float)ca[ch] + q1 * (float)cb[ch]) + q2 * (float)cc[ch];
+                float val = rintf(num / iz);
+                if (!(val >= 0.0f)) val = 0.0f;
+                if (val > 255.0f) val = 255.0f;
+                t->rgb[3 * o + ch] = (uint8_t)val;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* one eye                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+static void orc_render_eye(const orc_params* p, int eye, const float* depth, const uint8_t* color,
+                           const uint8_t* tri_invalid, const uint8_t* unused,
+                           uint8_t* out_rgb, uint8_t* out_mask, float* out_depth)
+{
+    const int W = p->W, H = p->H;
+    const size_t n = (size_t)W * H;
+    orc_eye e;
+    orc_eye_setup(p, eye, &e);
+
+    orc_target t;
+    t.W = W; t.H = H;
+    t.zbuf = (float*)malloc(n * sizeof(float));
+    t.rgb = (uint8_t*)calloc(n, 3);
+    t.covered = (uint8_t*)calloc(n, 1);
+
+    orc_vert* V = (orc_vert*)malloc(n * sizeof(orc_vert));
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j)
+            V[(size_t)i * W + j] = orc_vertex(&e, i, j, depth[(size_t)i * W + j]);
+
+    if (p->mode == ORC_MODE_POINTS) {
+        /* GL_POINTS of size 1 (dmt:1510): pixel = (floor u, floor v); nearest Z wins; ties go to
+         * the lower source index (GL_LESS + draw order).  Vertices of removed triangles are parked
+         * behind the camera (dmt:1091) == not drawn. */
+        for (size_t k = 0; k < n; ++k) t.zbuf[k] = INFINITY;
+        for (size_t k = 0; k < n; ++k) {
+            const orc_vert* v = &V[k];
+            if (!v->ok) continue;
+            if (unused && unused[k]) continue;
+            if (!(v->u >= 0.0f && v->u < (float)W && v->v >= 0.0f && v->v < (float)H)) continue;
+            const int px = (int)floorf(v->u), py = (int)floorf(v->v);
+            const size_t o = (size_t)py * W + px;
+            if (!(v->z < t.zbuf[o])) continue;
+            t.zbuf[o] = v->z;
+            t.covered[o] = 1;
+            memcpy(t.rgb + 3 * o, color + 3 * k, 3);
+        }
+        if (out_depth)
+            for (size_t k = 0; k < n; ++k) out_depth[k] = t.covered[k] ? t.zbuf[k] : 0.0f;
+    } else {
+        for (size_t k = 0; k < n; ++k) t.zbuf[k] = 0.0f;
+        const size_t ncell = (size_t)(W - 1) * (H - 1);
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i = 0; i < H - 1; ++i)
+                for (int j = 0; j < W - 1; ++j) {
+                    if (tri_invalid && tri_invalid[(size_t)pass * ncell + (size_t)i * (W - 1) + j])
+                        continue;                            /* dmt:1372: zeroed == draws nothing */
+                    const size_t i1 = (size_t)i * W + j, i2 = (size_t)(i + 1) * W + j;
+                    const size_t i3 = (size_t)(i + 1) * W + j + 1, i4 = (size_t)i * W + j + 1;
+                    const size_t v0 = i1, v1 = pass == 0 ? i2 : i3, v2 = pass == 0 ? i3 : i4;
+                    orc_raster_tri(&t, &V[v0], &V[v1], &V[v2], color + 3 * v0, color + 3 * v1, color + 3 * v2);
+                }
+        if (out_depth)
+            for (size_t k = 0; k < n; ++k) out_depth[k] = t.covered[k] ? 1.0f / t.zbuf[k] : 0.0f;
+    }
+
+    /* hole mask (sr:740): colour-key compare against the background colour. */
+    for (size_t k = 0; k < n; ++k) {
+        const uint8_t* c = t.rgb + 3 * k;
+        const int hole = !t.covered[k] ||
+                         (c[0] == p->key_rgb[0] && c[1] == p->key_rgb[1] && c[2] == p->key_rgb[2]);
+        out_mask[k] = hole ? 255 : 0;
+        if (hole) { out_rgb[3 * k] = out_rgb[3 * k + 1] = out_rgb[3 * k + 2] = 0; }   /* sr:793 */
+        else memcpy(out_rgb + 3 * k, c, 3);
+    }
+
+    /* edge points (sr:745-781, 813-814): far-to-near overwrite == nearest wins, only into holes. */
+    if (p->edge_points && unused) {
+        float* ez = (float*)malloc(n * sizeof(float));
+        for (size_t k = 0; k < n; ++k) ez[k] = INFINITY;
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                const size_t k = (size_t)i * W + j;
+                int px, py; float z;
+                if (!unused[k]) continue;
+                if (!orc_edge_point(&e, i, j, depth[k], &px, &py, &z)) continue;
+                const size_t o = (size_t)py * W + px;
+                if (!out_mask[o]) continue;                  /* sr:776: only where still background */
+                if (!(z < ez[o])) continue;                  /* ties: lower source index wins (decree) */
+                ez[o] = z;
+                memcpy(out_rgb + 3 * o, color + 3 * k, 3);
+            }
+        free(ez);
+    }
+
+    free(V); free(t.covered); free(t.rgb); free(t.zbuf);
+}
+
+int orc_render_stereo(const orc_params* p, const uint8_t* depth_rgb, const uint8_t* color_rgb,
+                      uint8_t* left_rgb, uint8_t* right_rgb, uint8_t* left_mask, uint8_t* right_mask,
+                      float* left_depth, float* right_depth)
+{
+    if (!p || p->W < 2 || p->H < 2) return -1;
+    if (p->mode != ORC_MODE_POINTS && p->mode != ORC_MODE_MESH) return -1;
+    const int W = p->W, H = p->H;
+    const size_t n = (size_t)W * H;
+    float* depth = (float*)malloc(n * sizeof(float));
+    orc_decode_depth(depth_rgb, W, H, p->max_depth, p->depth_scale, depth);
+
+    uint8_t* tri_invalid = NULL; uint8_t* unused = NULL;
+    if (p->remove_edges) {
+        tri_invalid = (uint8_t*)malloc(2 * (size_t)(W - 1) * (H - 1));
+        unused = (uint8_t*)malloc(n);
+        orc_edge_filter(depth, W, H, p->K, p->mode == ORC_MODE_MESH, tri_invalid, unused, NULL);
+    }
+    orc_render_eye(p, 0, depth, color_rgb, tri_invalid, unused, left_rgb, left_mask, left_depth);
+    orc_render_eye(p, 1, depth, color_rgb, tri_invalid, unused, right_rgb, right_mask, right_depth);
+    free(tri_invalid); free(unused); free(depth);
+    return 0;
+}

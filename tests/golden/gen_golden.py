@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the reference's own pure-NumPy functions.
+
+Run ONLY in the build container (needs /root/reference).  Nothing of the reference travels: the
+fixtures hold inputs and the reference functions' outputs, nothing else.  cv2 / open3d / OpenGL /
+glfw are absent here, so empty stub modules are registered before the import; only
+functions that never touch those packages are called.
+
+    python tests/golden/gen_golden.py            # rewrites the fixtures in tests/golden/
+
+Recorded with every fixture: numpy / scipy versions (the unprojection dtype is NumPy-major
+dependent).
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    _stub("cv2"); _stub("glfw"); _stub("OpenGL"); _stub("OpenGL.GL")
+    _stub("OpenGL.GL.shaders", compileProgram=None, compileShader=None)
+
+    class _TriangleMesh:  # ndarray-backed stand-in for o3d.geometry.TriangleMesh
+        def __init__(s):
+            s.vertices = np.zeros((0, 3)); s.triangles = np.zeros((0, 3), np.int32); s.vertex_colors = np.zeros((0, 3))
+
+        def transform(s, T):
+            pass
+
+    o3d = _stub("open3d")
+    o3d.geometry = types.SimpleNamespace(TriangleMesh=_TriangleMesh)
+    o3d.utility = types.SimpleNamespace(Vector3dVector=lambda a: np.array(a, np.float64),
+                                        Vector3iVector=lambda a: np.array(a, np.int32))
+    sys.path.insert(0, REF)
+    import depth_frames_helper as dfh
+    import depth_map_tools as dmt
+    import stereo_rerender as sr
+    import infill_common as ic
+    return dfh, dmt, sr, ic
+
+
+def main():
+    import scipy
+    dfh, dmt, sr, ic = import_reference()
+    sys.path.insert(0, REPO)
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
+
+    meta = {"numpy": np.__version__, "scipy": scipy.__version__, "reference_snapshot": "2026-05-15"}
+    rng = np.random.default_rng(20260927)
+
+    # ------------------------------------------------------------------ codec
+    kat_rgb = np.array([[0, 0, 0], [0, 0, 1], [0, 9, 1], [1, 1, 0], [2, 2, 133], [252, 252, 5],
+                        [255, 255, 255], [255, 0, 0], [0, 255, 255], [128, 7, 64]], np.uint8).reshape(1, -1, 3)
+    kat_dec = {str(md): dfh.decode_rgb_depth_frame(kat_rgb, md, True) for md in (100, 20, 655)}
+    rnd_rgb = rng.integers(0, 256, (12, 16, 3), dtype=np.uint8)
+    rnd_dec = dfh.decode_rgb_depth_frame(rnd_rgb, 100, True)
+    enc_in = np.concatenate([np.array([1.0, 2.5, 0.0015, 100.0, 150.0, -3.0, 0.0, 99.9999, 1.5499e-3, 1.55e-3], np.float32),
+                             rng.uniform(0, 110, 86).astype(np.float32)]).reshape(8, 12)
+    enc_u32 = dfh.encode_depth_as_uint32(enc_in, 100)
+    enc_bgr = dfh.encode_data_as_BGR(enc_u32, 12, 8, bit16=True)
+    enc_u32_20 = dfh.encode_depth_as_uint32(enc_in, 20)
+    # round trip through the decoder (what a depth video delivers)
+    rt = dfh.decode_rgb_depth_frame(np.ascontiguousarray(enc_bgr[..., ::-1]), 100, True)
+    np.savez_compressed(os.path.join(HERE, "codec.npz"),
+                        kat_rgb=kat_rgb, kat_dec_100=kat_dec["100"], kat_dec_20=kat_dec["20"], kat_dec_655=kat_dec["655"],
+                        rnd_rgb=rnd_rgb, rnd_dec=rnd_dec, enc_in=enc_in, enc_u32=enc_u32, enc_bgr=enc_bgr,
+                        enc_u32_20=enc_u32_20, roundtrip=rt, meta=json.dumps(meta))
+
+    # ------------------------------------------------------------------ camera / scalars
+    cam_cases = [(45, None, 640, 480), (45, None, 1920, 1080), (45, None, 3840, 2160), (60, None, 1920, 1080),
+                 (None, 30, 1920, 1080), (70, 40, 1280, 720), (90.5, None, 16, 12), (45, None, 3, 2)]
+    cam_in = np.array([[np.nan if a is None else a, np.nan if b is None else b, w, h] for a, b, w, h in cam_cases], np.float64)
+    cam_K = np.stack([dmt.compute_camera_matrix(a, b, w, h) for a, b, w, h in cam_cases])
+    cam_fov = np.array([dmt.fov_from_camera_matrix(K) for K in cam_K], np.float64)
+    conv_in = np.array([[2.0, 0.065], [0.5, 0.063], [10.0, 0.065], [1e-3, 0.065], [100.0, 0.07]], np.float64)
+    conv_out = np.array([sr.convergence_angle(d, p) for d, p in conv_in], np.float64)
+    cos89 = np.array([np.cos(np.radians(89.0))], np.float64)
+    nan_series = [float("nan"), 2.0, float("nan"), float("nan"), 3.5, 4.0, float("nan")]
+    nan_filled = sr.fill_nan_with_closest(list(nan_series))
+    series = {}
+    for name, n in (("s7", 7), ("s120", 120), ("s300", 300)):
+        y = (3.0 + np.sin(np.arange(n) / 9.0) + 0.1 * rng.standard_normal(n)).tolist()
+        series[name + "_in"] = np.array(y, np.float64)
+        series[name + "_out"] = np.asarray(sr.curve_fit(list(y)), np.float64)
+    np.savez_compressed(os.path.join(HERE, "camera.npz"), cam_in=cam_in, cam_K=cam_K, cam_fov=cam_fov,
+                        conv_in=conv_in, conv_out=conv_out, cos89=cos89,
+                        nan_in=np.array(nan_series, np.float64), nan_out=np.array(nan_filled, np.float64),
+                        meta=json.dumps(meta), **series)
+
+    # ------------------------------------------------------------------ unprojection + mesh / edge filter
+    geo = {}
+    tiny = np.array([[2, 2, 4], [2, 1, 4]], np.float32)
+    Kt = dmt.compute_camera_matrix(45, None, 3, 2)
+    geo["tiny_depth"] = tiny
+    geo["tiny_K"] = Kt
+    for obo in (False, True):
+        pts, h, w = dmt.create_point_cloud_from_depth(tiny, Kt, obo)
+        geo[f"tiny_pts_obo{int(obo)}"] = pts
+
+    scenes = {
+        # name: (W, H, xfov, scene seed, max_depth, zero-depth patch)
+        "a": (48, 32, 45.0, 11, 100, False),
+        "b": (64, 48, 60.0, 12, 100, True),
+        "c": (40, 24, 45.0, 13, 20, False),
+    }
+    for name, (W, H, xfov, seed, md, zero_patch) in scenes.items():
+        sc = SyntheticScene(W, H, seed=seed, n_fg=5)
+        depth_rgb, color = sc.frame(0, md)
+        if zero_patch:
+            depth_rgb[5:8, 9:13] = 0          # Z = 0 vertices (SURVEY.md 9a "zero depth")
+            depth_rgb[20, 30] = (0, 0, 1)     # one LSB
+        K = dmt.compute_camera_matrix(xfov, None, W, H)
+        depth = dfh.decode_rgb_depth_frame(depth_rgb, md, True)
+        geo[f"{name}_depth_rgb"] = depth_rgb
+        geo[f"{name}_color"] = color
+        geo[f"{name}_K"] = K
+        geo[f"{name}_max_depth"] = np.array([md], np.float64)
+        geo[f"{name}_depth"] = depth
+        for obo in (False, True):
+            pts, _, _ = dmt.create_point_cloud_from_depth(depth, K, obo)
+            geo[f"{name}_pts_obo{int(obo)}"] = pts
+            assert pts.dtype == np.float64, "fixture assumes NumPy >= 2 promotion (SURVEY.md 9 quirk 5)"
+            mesh, unused, normals = dmt.get_mesh_from_depth_map(depth, K, color, None, remove_edges=True,
+                                                                of_by_one=obo, return_normals_of_removed=True)
+            tris = np.asarray(mesh.triangles)
+            # zeroed (0,0,0) == removed (dmt:1372); a real triangle never has three equal indices
+            geo[f"{name}_tri_invalid_obo{int(obo)}"] = np.all(tris == 0, axis=1).copy()
+            geo[f"{name}_unused_obo{int(obo)}"] = np.asarray(unused, np.int64)
+            geo[f"{name}_removed_normals_obo{int(obo)}"] = np.asarray(normals, np.float64)
+            geo[f"{name}_colors_obo{int(obo)}"] = np.array(mesh.vertex_colors, np.float64, copy=True)
+            # mesh re-use path (dmt:1264-1269): second frame through the same mesh object
+            depth_rgb2, color2 = sc.frame(1, md)
+            depth2 = dfh.decode_rgb_depth_frame(depth_rgb2, md, True)
+            mesh2, unused2, _ = dmt.get_mesh_from_depth_map(depth2, K, color2, mesh, remove_edges=True,
+                                                            of_by_one=obo, return_normals_of_removed=True)
+            geo[f"{name}_f1_depth_rgb"] = depth_rgb2
+            geo[f"{name}_f1_tri_invalid_obo{int(obo)}"] = np.all(np.asarray(mesh2.triangles) == 0, axis=1)
+            geo[f"{name}_f1_unused_obo{int(obo)}"] = np.asarray(unused2, np.int64)
+    # master-FOV scale (sr:537-541) applied the way the loop does it: in place on the f32 depth
+    d = dfh.decode_rgb_depth_frame(geo["a_depth_rgb"], 100, True)
+    import math
+    scale = 1.0 / (math.tan(math.radians(45.0 / 2)) / math.tan(math.radians(60.0 / 2)))
+    d *= scale
+    geo["a_depth_scaled_60_to_45"] = d
+    geo["scale_60_to_45"] = np.array([scale], np.float64)
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), meta=json.dumps(meta), **geo)
+
+    for f in ("codec.npz", "camera.npz", "geometry.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+"""Pin the oracle (oracle/mdvt_oracle.c and oracle/oracle_np.py) against golden vectors generated
+from the reference's own pure-NumPy functions (tests/golden/gen_golden.py) and against the
+known-answer values of SURVEY.md section 10."""
+import json
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+# ------------------------------------------------------------------------------- codec
+def test_codec_known_answers(orc):
+    rgb = np.array([[[0, 0, 0], [0, 0, 1], [0, 9, 1], [1, 1, 0], [2, 2, 133], [255, 255, 255]]], np.uint8)
+    want = np.array([0x00000000, 0x3ACB27E0, 0x3ACB27E0, 0x3ECB27E0, 0x3F7FEDBC, 0x42CB2715], np.uint32)
+    assert np.array_equal(bits(orc.decode_depth(rgb, 100)).ravel(), want)
+    assert np.array_equal(bits(onp.decode_rgb_depth_frame(rgb, 100)).ravel(), want)
+
+
+def test_codec_decode_golden(orc, golden):
+    g = golden("codec")
+    for md in (100, 20, 655):
+        want = g[f"kat_dec_{md}"]
+        assert np.array_equal(bits(orc.decode_depth(g["kat_rgb"], md)), bits(want))
+        assert np.array_equal(bits(onp.decode_rgb_depth_frame(g["kat_rgb"], md)), bits(want))
+    assert np.array_equal(bits(orc.decode_depth(g["rnd_rgb"], 100)), bits(g["rnd_dec"]))
+    assert np.array_equal(bits(onp.decode_rgb_depth_frame(g["rnd_rgb"], 100)), bits(g["rnd_dec"]))
+
+
+def test_codec_encode_golden(orc, golden):
+    g = golden("codec")
+    enc_in = g["enc_in"]
+    # SURVEY.md 10 KATs: 1.0 -> 0x02852E0A, 2.5 -> 0x064CF319, 100/150 -> 0xFC05FC01, -3 -> 0
+    code = onp.encode_depth_as_uint32(enc_in, 100)
+    assert code.ravel()[0] == 0x02852E0A and code.ravel()[1] == 0x064CF319
+    assert code.ravel()[3] == 0xFC05FC01 and code.ravel()[4] == 0xFC05FC01 and code.ravel()[5] == 0
+    assert np.array_equal(code, g["enc_u32"])
+    assert np.array_equal(onp.encode_depth_as_uint32(enc_in, 20), g["enc_u32_20"])
+    rgb_ref = g["enc_bgr"][..., ::-1]                    # the reference returns B,G,R
+    assert np.array_equal(onp.encode_data_as_rgb16(code), rgb_ref)
+    assert np.array_equal(orc.encode_depth(enc_in, 100), rgb_ref)
+    # decoder(encoder(x)) as a depth video delivers it
+    assert np.array_equal(bits(orc.decode_depth(orc.encode_depth(enc_in, 100), 100)), bits(g["roundtrip"]))
+
+
+def test_codec_roundtrip_is_one_sided(orc):
+    rng = np.random.default_rng(3)
+    d = rng.uniform(0, 100, (32, 32)).astype(np.float32)
+    back = orc.decode_depth(orc.encode_depth(d, 100), 100)
+    err = d.astype(np.float64) - back.astype(np.float64)
+    assert err.min() > -1e-5 and err.max() < 100 * 65536 / 255 ** 4 + 1e-5   # [0, 1.55 mm)
+
+
+def test_meta_records_numpy_version(golden):
+    meta = json.loads(str(golden("geometry")["meta"]))
+    assert meta["numpy"].split(".")[0] >= "2"
+
+
+# ------------------------------------------------------------------------------- camera / scalars
+def test_camera_matrix_golden(orc, golden):
+    g = golden("camera")
+    for row, K in zip(g["cam_in"], g["cam_K"]):
+        xf = None if math.isnan(row[0]) else row[0]
+        yf = None if math.isnan(row[1]) else row[1]
+        W, H = int(row[2]), int(row[3])
+        assert np.array_equal(onp.compute_camera_matrix(xf, yf, W, H), K)
+        assert np.array_equal(orc.camera_matrix(xf, yf, W, H), K)
+    assert g["cam_K"][0][0, 0] == 772.5483399593904
+    assert g["cam_K"][1][0, 0] == 2317.6450198781713
+    assert g["cam_K"][2][0, 0] == 4635.290039756343
+    for K, fov in zip(g["cam_K"], g["cam_fov"]):
+        assert np.array_equal(np.array(onp.fov_from_camera_matrix(K)), fov)
+
+
+def test_camera_matrix_needs_a_fov(orc):
+    with pytest.raises(ValueError):
+        orc.camera_matrix(None, None, 4, 4)
+    with pytest.raises(ValueError):
+        onp.compute_camera_matrix(None, None, 4, 4)
+
+
+def test_convergence_and_scalars(orc, golden):
+    g = golden("camera")
+    for (d, p), want in zip(g["conv_in"], g["conv_out"]):
+        assert onp.convergence_angle(d, p) == want
+        assert orc.convergence_angle(d, p) == want
+    assert onp.convergence_angle(2.0, 0.065) == 0.016248569888034862
+    assert g["cos89"][0] == float.fromhex("0x1.1df0b2b89dd37p-6")
+    assert onp.master_fov_scale_depth(60.0, 45.0) == 1.3938468501173518
+    with pytest.raises(ValueError):
+        onp.convergence_angle(0, 0.065)
+
+
+def test_convergence_prepass(golden):
+    g = golden("camera")
+    got = onp.fill_nan_with_closest(g["nan_in"].tolist())
+    assert np.array_equal(np.array(got), g["nan_out"])
+    for n in ("s7", "s120", "s300"):
+        assert np.array_equal(onp.curve_fit(g[n + "_in"].tolist()), g[n + "_out"])
+
+
+# ------------------------------------------------------------------------------- geometry
+def test_unproject_tiny_known_answer(orc, golden):
+    g = golden("geometry")
+    d, K = g["tiny_depth"], g["tiny_K"]
+    assert K[0, 0] == 3.621320343559643
+    for obo in (0, 1):
+        want = g[f"tiny_pts_obo{obo}"]
+        assert np.array_equal(orc.unproject_f64(d, K, bool(obo)), want)
+        assert np.array_equal(onp.unproject(d, K, bool(obo)), want)
+    np.testing.assert_allclose(g["tiny_pts_obo1"][:3, 0], [-0.82842712, -0.09204744, 1.28866450], atol=1e-8)
+
+
+@pytest.mark.parametrize("scene", ["a", "b", "c"])
+@pytest.mark.parametrize("obo", [0, 1])
+def test_geometry_golden(orc, golden, scene, obo):
+    g = golden("geometry")
+    K, md = g[f"{scene}_K"], float(g[f"{scene}_max_depth"][0])
+    depth = orc.decode_depth(g[f"{scene}_depth_rgb"], md)
+    assert np.array_equal(bits(depth), bits(g[f"{scene}_depth"]))
+    H, W = depth.shape
+    want_pts = g[f"{scene}_pts_obo{obo}"]
+    assert np.array_equal(orc.unproject_f64(depth, K, bool(obo)), want_pts)
+    assert np.array_equal(onp.unproject(depth, K, bool(obo)), want_pts)
+
+    tri, unused, normals = orc.edge_filter(depth, K, bool(obo), want_normals=True)
+    want_inv = g[f"{scene}_tri_invalid_obo{obo}"]
+    want_unused = g[f"{scene}_unused_obo{obo}"]
+    assert want_inv.sum() > 50, "fixture must actually trip the 89 degree filter"
+    assert np.array_equal(tri.astype(bool), want_inv)
+    assert np.array_equal(np.nonzero(unused)[0], want_unused)
+    assert np.array_equal(normals[want_unused], g[f"{scene}_removed_normals_obo{obo}"])
+
+    inv, unused_np, vn = onp.edge_filter(want_pts, H, W)
+    assert np.array_equal(inv, want_inv)
+    assert np.array_equal(unused_np, want_unused)
+    assert np.array_equal(vn[unused_np], g[f"{scene}_removed_normals_obo{obo}"])
+
+    # second frame through a re-used mesh object gives the same answer as a fresh one (dmt:1264-1269)
+    depth1 = orc.decode_depth(g[f"{scene}_f1_depth_rgb"], md)
+    tri1, unused1, _ = orc.edge_filter(depth1, K, bool(obo))
+    assert np.array_equal(tri1.astype(bool), g[f"{scene}_f1_tri_invalid_obo{obo}"])
+    assert np.array_equal(np.nonzero(unused1)[0], g[f"{scene}_f1_unused_obo{obo}"])
+
+
+def test_vertex_colours_are_u8_over_255(golden):
+    g = golden("geometry")
+    assert np.array_equal(g["a_colors_obo1"], g["a_color"].reshape(-1, 3) / 255.0)   # dmt:1228
+    # (c/255 -> *255 -> astype(uint8)) is lossless for all 256 codes in f32 (sr:819)
+    c = (np.arange(256, dtype=np.float64) / 255.0).astype(np.float32)
+    assert np.array_equal((c * 255).astype(np.uint8), np.arange(256, dtype=np.uint8))
+
+
+def test_master_scale_golden(orc, golden):
+    g = golden("geometry")
+    scale = float(g["scale_60_to_45"][0])
+    assert scale == onp.master_fov_scale_depth(60.0, 45.0)
+    got = orc.decode_depth(g["a_depth_rgb"], 100, scale)
+    assert np.array_equal(bits(got), bits(g["a_depth_scaled_60_to_45"]))
+    assert np.array_equal(bits(onp.decode_rgb_depth_frame(g["a_depth_rgb"], 100, scale)), bits(g["a_depth_scaled_60_to_45"]))
