@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo frames/s of the MI355X stereo-rerender path + achieved HBM GB/s vs roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of --frames synthetic 1920x1080 frames
+(BASELINE.json configs[1]'s shape, batched so the working set exceeds the 256 MiB Infinity Cache),
+already resident in HBM when the timed region starts.  Weak scaling: every rank renders its own
+batch; `value` = frames all ranks rendered / max-over-ranks wall time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming peak
+BYTES_PER_PX = 14              # 3 depth-RGB + 3 colour read, 2 x (3 RGB + 1 mask) written
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=32, help="frames per step (per rank)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--mode", choices=["points", "mesh"], default="points")
+    ap.add_argument("--remove-edges", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
+    return ap.parse_args()
+
+
+def cpu_baseline(W, H, mode, remove_edges, budget_s):
+    """The plain-C oracle (a port: the reference's NumPy/Open3D loop cannot run here) timed on one
+    host core over whole frames of the same workload until ~budget_s have elapsed."""
+    from oracle import c_oracle as co
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
+    from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
+    co.build()
+    sc = SyntheticScene(W, H, config_id=2)
+    K = compute_camera_matrix(45.0, None, W, H)
+    p = co.make_params(W, H, K, ipd_m=0.065, max_depth=100.0, depth_scale=1.0,
+                       mode=co.MODE_POINTS if mode == "points" else co.MODE_MESH,
+                       remove_edges=remove_edges, edge_points=remove_edges)
+    frames = [sc.frame(t) for t in range(2)]
+    co.render_stereo(p, *frames[0])        # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        co.render_stereo(p, *frames[n % 2])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 400:
+            break
+    return {"value": n / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frame(s) of {W}x{H} {mode} through oracle/mdvt_oracle.c (gcc -O2, 1 thread) in {dt:.1f} s"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    from metric_depth_video_toolbox_amd import distributed as D
+    from metric_depth_video_toolbox_amd.stereo_rerender import StereoRerenderer
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
+
+    rank, world = D.init_process_group()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    W, H, N = args.width, args.height, args.frames
+
+    # rank 0 owns the clip parameters and broadcasts them (RCCL over xGMI when world > 1)
+    clip = None
+    if rank == 0:
+        flags = (1 if args.mode == "points" else 0) | (2 if args.remove_edges else 0) | (4 if args.remove_edges else 0)
+        clip = D.ClipParameters(W, H, N * world, 0.065, 100.0, 45.0, flags,
+                                np.full(N * world, 45.0), np.zeros(N * world))
+    clip = D.broadcast_clip_parameters(clip, src=0, device=dev)
+    lo, hi = D.frame_range(rank, world, clip.n_frames)
+
+    r = StereoRerenderer(clip.W, clip.H, device=local, pupillary_distance=int(round(clip.ipd_m * 1000)),
+                         max_depth=clip.max_depth, master_xfov=clip.master_xfov,
+                         render_as_pointcloud=bool(clip.mode_flags & 1), remove_edges=bool(clip.mode_flags & 2),
+                         dont_place_points_in_edges=not bool(clip.mode_flags & 4))
+    params = [r.frame_params(xfov=float(clip.xfov[t])) for t in range(lo, hi)]
+
+    # synthetic frames of this rank's range, resident in HBM before the timed region
+    sc = SyntheticScene(W, H, config_id=2)
+    d_np, c_np = sc.clip(hi - lo, t0=lo)
+    depth_rgb = torch.from_numpy(d_np).to(dev)
+    color_rgb = torch.from_numpy(c_np).to(dev)
+    del d_np, c_np
+    n_local = hi - lo
+    sbs = torch.empty((n_local, H, 2 * W, 3), dtype=torch.uint8, device=dev)
+    mask = torch.empty((n_local, H, 2 * W), dtype=torch.uint8, device=dev)
+
+    def step():
+        r.render(depth_rgb, color_rgb, params, out_sbs=sbs, out_mask=mask)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    # HIP events on the stream the kernels are launched on (torch's current stream): one pair per step
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        evs[k][0].record()
+        step()
+        evs[k][1].record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    wall = time.perf_counter() - t0
+    wall = D.max_over_ranks(wall, device=dev)
+    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    hole_px = float((mask[0] > 0).sum().item())
+    stats = D.gather_rank_stats(n_local * args.steps, wall, hole_px, device=dev)
+
+    if rank == 0:
+        total_frames = float(stats[:, 0].sum())
+        fps = total_frames / wall
+        bytes_per_launch = BYTES_PER_PX * W * H * n_local
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "stereo frames/sec at 1920x1080 (+ achieved HBM GB/s vs roofline)",
+            "value": fps, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/f32", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} stereo reproject, 65 mm baseline, xfov 45, {args.mode} mode"
+                                   f"{' + remove_edges' if args.remove_edges else ''}, {n_local} distinct frames per step per GPU, "
+                                   "inputs resident in HBM (BASELINE.json configs[1] shape, batched past the 256 MiB Infinity Cache)",
+                       "frames_per_step_per_gpu": n_local, "parallelism": f"frames sharded over {world} rank(s), "
+                       "one broadcast of the parameter block, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_points_rows<4,0>" if args.mode == "points" else "k_mesh_rows",
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, args.mode, args.remove_edges, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    r.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

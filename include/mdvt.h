@@ -1,0 +1,119 @@
+/*
+ * mdvt.h -- C ABI of the MI355X-native stereo-rerender path (libmdvt_hip.so).
+ *
+ * The reference (calledit/metric_depth_video_toolbox) is pure Python and exposes no FFI: the
+ * path's interface is the frame loop of stereo_rerender.py (sr:471-944) and the helper functions
+ * it calls.  Each entry point below names the reference code it replaces (file:line into the
+ * reference tree; dfh = depth_frames_helper.py, dmt = depth_map_tools.py, sr = stereo_rerender.py).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, PODs.  No torch / HIP types in any signature (a hipStream_t is
+ *     passed as void*; NULL = the default stream).
+ *   - every image pointer is DEVICE memory owned by the caller (e.g. torch.Tensor.data_ptr());
+ *     the library never frees or retains it beyond the stream-ordered work of the call.
+ *   - calls are asynchronous w.r.t. the host on the given stream.
+ *   - return 0 (MDVT_OK) or a negative mdvt_status; mdvt_last_error() gives the text.
+ *   - one ctx per (device, stream) user; a ctx is not thread-safe, distinct ctxs are independent.
+ *   - there is NO CPU fallback: without a HIP device mdvt_create fails with MDVT_ERR_NO_DEVICE.
+ */
+#ifndef MDVT_H
+#define MDVT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDVT_VERSION_MAJOR 0
+#define MDVT_VERSION_MINOR 1
+#define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
+
+typedef struct mdvt_ctx mdvt_ctx;
+
+typedef enum mdvt_status {
+    MDVT_OK = 0,
+    MDVT_ERR_INVALID_ARG = -1,   /* ValueError / AssertionError in the reference (sr:319-323, 507) */
+    MDVT_ERR_HIP = -2,           /* a HIP runtime call failed                                      */
+    MDVT_ERR_UNSUPPORTED = -3,   /* valid request this build does not implement                    */
+    MDVT_ERR_NO_DEVICE = -4,     /* no usable gfx950 device                                        */
+    MDVT_ERR_OOM = -5
+} mdvt_status;
+
+typedef enum mdvt_mode {
+    MDVT_MODE_POINTS = 0,        /* --render_as_pointcloud: GL_POINTS size 1 (sr:576-580, dmt:1086-1102, 1510) */
+    MDVT_MODE_MESH = 1           /* default: grid mesh, 2 triangles per cell (dmt:1243-1254)                   */
+} mdvt_mode;
+
+/* Clip-constant settings: the argparse-derived scalars of sr:273-316 that the loop body reads. */
+typedef struct mdvt_config {
+    int32_t mode;                /* mdvt_mode                                                       */
+    int32_t remove_edges;        /* sr:568-573 (implied by --infill_mask / --remove_edges / --do_basic_infill) */
+    int32_t edge_points;         /* !--dont_place_points_in_edges (sr:589-606); needs remove_edges   */
+    int32_t reserved0;
+    double ipd_m;                /* --pupillary_distance / 1000 (sr:458-459)                         */
+    double max_depth;            /* --max_depth (dfh:22)                                             */
+    uint8_t key_rgb[4];          /* bg_color*255: (0,0,0), or (0,255,0) with --infill_mask (sr:555-558) */
+    uint32_t reserved1;
+} mdvt_config;
+
+/* Per-frame parameters: what sr:515-541, 563-566 and 707-721 compute before the render calls. */
+typedef struct mdvt_frame_params {
+    double K[9];                 /* dmt.compute_camera_matrix(xfov, yfov, W, H), row major (dmt:902) */
+    double Krender[9];           /* render_cam_matrix (== K unless --vr180, sr:526-535)              */
+    double depth_scale;          /* master_fov_scale_depth (sr:537-541)                              */
+    double convergence_angle;    /* radians; 0 or NaN = no toe-in (sr:707-724)                       */
+    double T[16];                /* transformations[frame], row-major 4x4 (sr:563-566); used iff has_T */
+    int32_t has_T;
+    int32_t reserved;
+} mdvt_frame_params;
+
+/* Device buffers of one call.  *_pitch = bytes between rows, *_stride = bytes between frames of a
+ * batch.  RGB images are interleaved u8 (the layout cv2 hands sr:489-509 after cvtColor).  For a
+ * side-by-side output (cv2.hconcat, sr:918) point right_rgb at left_rgb + 3*W with rgb_pitch = 6*W.
+ * Optional outputs may be NULL. */
+typedef struct mdvt_io {
+    const uint8_t* depth_rgb;  size_t depth_pitch;  size_t depth_stride;   /* RGB-coded 16-bit depth (dfh:63-75) */
+    const uint8_t* color_rgb;  size_t color_pitch;  size_t color_stride;   /* colour frame                       */
+    uint8_t* left_rgb; uint8_t* right_rgb; size_t rgb_pitch;  size_t rgb_stride;    /* sr:819, 907           */
+    uint8_t* left_mask; uint8_t* right_mask; size_t mask_pitch; size_t mask_stride; /* 255 = hole (sr:740, 854) */
+    float* left_depth; float* right_depth; size_t zout_pitch; size_t zout_stride;   /* optional; 0 = background (dmt:1563) */
+} mdvt_io;
+
+int mdvt_version(void);
+
+/* Creates a context for W x H frames on HIP device `device`.  flags: reserved, pass 0. */
+int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flags);
+int mdvt_destroy(mdvt_ctx* ctx);
+/* Text of the last error on this ctx (or of the last failed mdvt_create when ctx == NULL). */
+const char* mdvt_last_error(const mdvt_ctx* ctx);
+
+int mdvt_set_config(mdvt_ctx* ctx, const mdvt_config* cfg);
+
+/* One iteration of the frame loop sr:512-907 for both eyes: decode -> (edge filter) -> unproject ->
+ * pose / eye transform -> z-buffered render -> colour-key hole mask -> (edge-point splat). */
+int mdvt_render_stereo(mdvt_ctx* ctx, const mdvt_frame_params* params, const mdvt_io* io, void* stream);
+/* The same for n_frames independent frames in one submission (params: host array of n_frames). */
+int mdvt_render_stereo_batch(mdvt_ctx* ctx, int n_frames, const mdvt_frame_params* params,
+                             const mdvt_io* io, void* stream);
+
+/* dfh.decode_rgb_depth_frame(rgb, max_depth, True) (dfh:99-103), then sr:541's `depth *= scale`. */
+int mdvt_decode_depth(mdvt_ctx* ctx, const uint8_t* d_rgb, size_t rgb_pitch, float* d_depth, size_t depth_pitch,
+                      double max_depth, double depth_scale, void* stream);
+/* dfh.encode_depth_as_uint32 + dfh.encode_data_as_BGR(bit16=True) (dfh:5-11, 48-61; sr:930-936).
+ * bgr != 0 writes B,G,R byte order (what the reference hands to cv2.VideoWriter), else R,G,B. */
+int mdvt_encode_depth(mdvt_ctx* ctx, const float* d_depth, size_t depth_pitch, uint8_t* d_rgb, size_t rgb_pitch,
+                      double max_depth, int bgr, void* stream);
+
+/* dmt.get_mesh_from_depth_map(..., remove_edges=True, return_normals_of_removed=True)'s filter
+ * (dmt:1283-1294, 1339-1376) on its own: d_tri_invalid[2*(H-1)*(W-1)] u8 in draw order (all tri1 then
+ * all tri2), d_unused[H*W] u8 (1 = vertex of a removed triangle).  Either output may be NULL. */
+int mdvt_edge_filter(mdvt_ctx* ctx, const uint8_t* d_depth_rgb, size_t depth_pitch, const double K[9],
+                     double depth_scale, int of_by_one, uint8_t* d_tri_invalid, uint8_t* d_unused, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDVT_H */

@@ -1,0 +1,125 @@
+"""ctypes binding of libmdvt_hip.so (the C ABI declared in include/mdvt.h).
+
+There is no CPU fallback: if the shared library is missing or no gfx950 device is present, the
+render entry points raise.  ``load()`` only dlopen()s the library (possible without a GPU);
+``Context`` needs a device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmdvt_hip.so")
+
+MDVT_OK = 0
+MODE_POINTS = 0
+MODE_MESH = 1
+
+STATUS_NAMES = {0: "MDVT_OK", -1: "MDVT_ERR_INVALID_ARG", -2: "MDVT_ERR_HIP", -3: "MDVT_ERR_UNSUPPORTED",
+                -4: "MDVT_ERR_NO_DEVICE", -5: "MDVT_ERR_OOM"}
+
+# every symbol include/mdvt.h declares
+SYMBOLS = ("mdvt_version", "mdvt_create", "mdvt_destroy", "mdvt_last_error", "mdvt_set_config",
+           "mdvt_render_stereo", "mdvt_render_stereo_batch", "mdvt_decode_depth", "mdvt_encode_depth",
+           "mdvt_edge_filter")
+
+
+class MdvtError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {text}")
+        self.code = code
+
+
+class MdvtConfig(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("remove_edges", C.c_int32), ("edge_points", C.c_int32), ("reserved0", C.c_int32),
+                ("ipd_m", C.c_double), ("max_depth", C.c_double), ("key_rgb", C.c_uint8 * 4), ("reserved1", C.c_uint32)]
+
+
+class MdvtFrameParams(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("Krender", C.c_double * 9), ("depth_scale", C.c_double),
+                ("convergence_angle", C.c_double), ("T", C.c_double * 16), ("has_T", C.c_int32), ("reserved", C.c_int32)]
+
+
+class MdvtIO(C.Structure):
+    _fields_ = [("depth_rgb", C.c_void_p), ("depth_pitch", C.c_size_t), ("depth_stride", C.c_size_t),
+                ("color_rgb", C.c_void_p), ("color_pitch", C.c_size_t), ("color_stride", C.c_size_t),
+                ("left_rgb", C.c_void_p), ("right_rgb", C.c_void_p), ("rgb_pitch", C.c_size_t), ("rgb_stride", C.c_size_t),
+                ("left_mask", C.c_void_p), ("right_mask", C.c_void_p), ("mask_pitch", C.c_size_t), ("mask_stride", C.c_size_t),
+                ("left_depth", C.c_void_p), ("right_depth", C.c_void_p), ("zout_pitch", C.c_size_t), ("zout_stride", C.c_size_t)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libmdvt_hip.so and declare prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built and there is no CPU fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C metric_depth_video_toolbox_amd/csrc`).")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.mdvt_version.restype = C.c_int
+    L.mdvt_version.argtypes = []
+    L.mdvt_create.restype = C.c_int
+    L.mdvt_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_uint32]
+    L.mdvt_destroy.restype = C.c_int
+    L.mdvt_destroy.argtypes = [vp]
+    L.mdvt_last_error.restype = C.c_char_p
+    L.mdvt_last_error.argtypes = [vp]
+    L.mdvt_set_config.restype = C.c_int
+    L.mdvt_set_config.argtypes = [vp, C.POINTER(MdvtConfig)]
+    L.mdvt_render_stereo.restype = C.c_int
+    L.mdvt_render_stereo.argtypes = [vp, C.POINTER(MdvtFrameParams), C.POINTER(MdvtIO), vp]
+    L.mdvt_render_stereo_batch.restype = C.c_int
+    L.mdvt_render_stereo_batch.argtypes = [vp, C.c_int, C.POINTER(MdvtFrameParams), C.POINTER(MdvtIO), vp]
+    L.mdvt_decode_depth.restype = C.c_int
+    L.mdvt_decode_depth.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_double, C.c_double, vp]
+    L.mdvt_encode_depth.restype = C.c_int
+    L.mdvt_encode_depth.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_double, C.c_int, vp]
+    L.mdvt_edge_filter.restype = C.c_int
+    L.mdvt_edge_filter.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_double), C.c_double, C.c_int, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names from SYMBOLS that the loaded library actually exports (used by the CPU-only tests)."""
+    L = load()
+    return [s for s in SYMBOLS if hasattr(L, s)]
+
+
+class Context:
+    """Owns one mdvt_ctx.  ``check`` turns a negative status into MdvtError with the library's text."""
+
+    def __init__(self, device: int, width: int, height: int):
+        self._L = load()
+        self._h = C.c_void_p()
+        rc = self._L.mdvt_create(C.byref(self._h), int(device), int(width), int(height), 0)
+        if rc != MDVT_OK:
+            raise MdvtError(rc, (self._L.mdvt_last_error(None) or b"").decode())
+        self.device, self.W, self.H = int(device), int(width), int(height)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def check(self, rc: int):
+        if rc != MDVT_OK:
+            raise MdvtError(rc, (self._L.mdvt_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.mdvt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

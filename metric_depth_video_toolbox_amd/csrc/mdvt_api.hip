@@ -1,0 +1,388 @@
+// mdvt_api.hip -- the C ABI of include/mdvt.h: context, parameter preparation, launch sequencing.
+// Host code only; the kernels are in mdvt_kernels.hip.  Compiled with -ffp-contract=off (the f64
+// composition of the eye matrices below is part of the arithmetic decree).
+#include "mdvt_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace mdvt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr int kParamSlots = 8;        // pinned staging ring for per-frame constants
+constexpr int kWorkspaceChunk = 8;    // frames per launch when a global workspace is needed
+
+struct ParamSlot {
+    FrameDev* host = nullptr;         // pinned
+    FrameDev* dev = nullptr;
+    size_t capacity = 0;              // frames
+    hipEvent_t done = nullptr;        // H2D copy + the kernels reading it have been submitted/finished
+    bool used = false;
+};
+
+}  // namespace
+
+struct mdvt_ctx {
+    int device = 0;
+    int W = 0, H = 0;
+    mdvt_config cfg{};
+    bool cfg_set = false;
+    std::string err;
+    ParamSlot slots[kParamSlots];
+    int next_slot = 0;
+    // workspace for the general path / edge filter, sized for ws_frames frames
+    int ws_frames = 0;
+    bool ws_keys = false, ws_ekeys = false, ws_edges = false;
+    unsigned long long* keys[2] = {nullptr, nullptr};
+    unsigned long long* ekeys[2] = {nullptr, nullptr};
+    uint8_t* tri_invalid = nullptr;
+    uint8_t* unused = nullptr;
+};
+
+namespace {
+
+int fail(mdvt_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define MDVT_HIP(c, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail((c), MDVT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// Everything the kernels need about one frame, derived in f64 and rounded once to f32.
+int fill_frame_dev(mdvt_ctx* c, const mdvt_frame_params& p, FrameDev& f)
+{
+    const mdvt_config& cfg = c->cfg;
+    const int W = c->W, H = c->H;
+    const double fx = p.K[0], fy = p.K[4], cx = p.K[2], cy = p.K[5];
+    const double fxr = p.Krender[0], fyr = p.Krender[4], cxr = p.Krender[2], cyr = p.Krender[5];
+    if (!(fx > 0.0) || !(fy > 0.0) || !(fxr > 0.0) || !(fyr > 0.0))
+        return fail(c, MDVT_ERR_INVALID_ARG, "camera matrix needs positive focal lengths");
+    if (cxr * 2.0 != (double)W || cyr * 2.0 != (double)H)
+        return fail(c, MDVT_ERR_UNSUPPORTED,
+                    "render size (2*cx, 2*cy) = (%g, %g) differs from the frame size %dx%d (--vr180 is not built)",
+                    cxr * 2.0, cyr * 2.0, W, H);
+    if (!(p.depth_scale > 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "depth_scale must be > 0");
+    memset(&f, 0, sizeof f);
+    f.mult = (float)(cfg.max_depth / 4228250625.0);
+    f.scale = (float)p.depth_scale;
+    const double half = cfg.ipd_m / 2.0;
+    f.dl = (float)(fxr * half);
+    f.fx = (float)fx; f.fy = (float)fy; f.cx = (float)cx; f.cy = (float)cy;
+    f.fxr = (float)fxr; f.fyr = (float)fyr; f.cxr = (float)cxr; f.cyr = (float)cyr;
+    const bool mesh = cfg.mode == MDVT_MODE_MESH;
+    f.sx = mesh ? (float)(((double)W + 1.0) / (double)W) : 1.0f;
+    f.sy = mesh ? (float)(((double)H + 1.0) / (double)H) : 1.0f;
+    f.sW = (float)(((double)W - 1.0) / (double)W);
+    f.sH = (float)(((double)H - 1.0) / (double)H);
+    f.Kd[0] = fx; f.Kd[1] = fy; f.Kd[2] = cx; f.Kd[3] = cy;
+    const double conv = (p.convergence_angle == p.convergence_angle) ? p.convergence_angle : 0.0;   // NaN -> none
+    const bool same_k = fx == fxr && fy == fyr && cx == cxr && cy == cyr;
+    f.general = (p.has_T || conv != 0.0 || !same_k) ? 1 : 0;
+    double T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (p.has_T) {
+        memcpy(T, p.T, sizeof T);
+        if (fabs(T[12]) > 1e-12 || fabs(T[13]) > 1e-12 || fabs(T[14]) > 1e-12 || fabs(T[15] - 1.0) > 1e-12)
+            return fail(c, MDVT_ERR_UNSUPPORTED, "pose matrix must be affine (last row 0 0 0 1)");
+    }
+    for (int eye = 0; eye < 2; ++eye) {
+        // M = Translate(+-ipd/2) * Ry(-+a) * T;  Ry(t) = [[c,0,s],[0,1,0],[-s,0,c]]
+        const double t = eye == 0 ? -conv : conv;
+        const double cs = cos(t), sn = sin(t);
+        const double R[3][3] = {{cs, 0.0, sn}, {0.0, 1.0, 0.0}, {-sn, 0.0, cs}};
+        const double shift[3] = {eye == 0 ? half : -half, 0.0, 0.0};
+        for (int r = 0; r < 3; ++r) {
+            for (int col = 0; col < 3; ++col)
+                f.M[eye][4 * r + col] = (float)((R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col]);
+            f.M[eye][4 * r + 3] = (float)(((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r]);
+        }
+    }
+    return MDVT_OK;
+}
+
+// Stage n FrameDev records to the device through the pinned ring; returns the device pointer.
+int stage_params(mdvt_ctx* c, const std::vector<FrameDev>& v, hipStream_t s, const FrameDev** dev, ParamSlot** slot_out)
+{
+    ParamSlot& sl = c->slots[c->next_slot];
+    c->next_slot = (c->next_slot + 1) % kParamSlots;
+    if (sl.used) MDVT_HIP(c, hipEventSynchronize(sl.done));     // slot is being reused: its last user must be done
+    if (sl.capacity < v.size()) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        sl.host = nullptr; sl.dev = nullptr; sl.capacity = 0;
+        size_t cap = 16;
+        while (cap < v.size()) cap *= 2;
+        MDVT_HIP(c, hipHostMalloc((void**)&sl.host, cap * sizeof(FrameDev), hipHostMallocDefault));
+        MDVT_HIP(c, hipMalloc((void**)&sl.dev, cap * sizeof(FrameDev)));
+        sl.capacity = cap;
+    }
+    if (!sl.done) MDVT_HIP(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    memcpy(sl.host, v.data(), v.size() * sizeof(FrameDev));
+    MDVT_HIP(c, hipMemcpyAsync(sl.dev, sl.host, v.size() * sizeof(FrameDev), hipMemcpyHostToDevice, s));
+    sl.used = true;
+    *dev = sl.dev;
+    *slot_out = &sl;
+    return MDVT_OK;
+}
+
+int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, bool need_edges)
+{
+    const size_t npx = (size_t)c->W * c->H;
+    const size_t ntri = 2 * (size_t)(c->W - 1) * (c->H - 1);
+    const bool grow = frames > c->ws_frames;
+    if (grow || (need_keys && !c->ws_keys)) {
+        for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); c->keys[e] = nullptr; }
+        c->ws_keys = false;
+    }
+    if (grow || (need_ekeys && !c->ws_ekeys)) {
+        for (int e = 0; e < 2; ++e) { if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); c->ekeys[e] = nullptr; }
+        c->ws_ekeys = false;
+    }
+    if (grow || (need_edges && !c->ws_edges)) {
+        if (c->tri_invalid) (void)hipFree(c->tri_invalid);
+        if (c->unused) (void)hipFree(c->unused);
+        c->tri_invalid = nullptr; c->unused = nullptr; c->ws_edges = false;
+    }
+    if (grow) c->ws_frames = frames;
+    const size_t nf = (size_t)c->ws_frames;
+    if (need_keys && !c->ws_keys) {
+        for (int e = 0; e < 2; ++e) MDVT_HIP(c, hipMalloc((void**)&c->keys[e], nf * npx * sizeof(unsigned long long)));
+        c->ws_keys = true;
+    }
+    if (need_ekeys && !c->ws_ekeys) {
+        for (int e = 0; e < 2; ++e) MDVT_HIP(c, hipMalloc((void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long)));
+        c->ws_ekeys = true;
+    }
+    if (need_edges && !c->ws_edges) {
+        MDVT_HIP(c, hipMalloc((void**)&c->tri_invalid, nf * ntri));
+        MDVT_HIP(c, hipMalloc((void**)&c->unused, nf * npx));
+        c->ws_edges = true;
+    }
+    return MDVT_OK;
+}
+
+bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int mdvt_version(void) { return MDVT_VERSION; }
+
+const char* mdvt_last_error(const mdvt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flags)
+{
+    if (!out) return fail(nullptr, MDVT_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (flags != 0) return fail(nullptr, MDVT_ERR_INVALID_ARG, "flags must be 0");
+    if (width < 2 || height < 2 || width > 65535 || height > 32767)
+        return fail(nullptr, MDVT_ERR_INVALID_ARG, "frame size %dx%d out of range (2..65535 x 2..32767)", width, height);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, MDVT_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, MDVT_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, count - 1);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return fail(nullptr, MDVT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MDVT_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    mdvt_ctx* c = new (std::nothrow) mdvt_ctx();
+    if (!c) return fail(nullptr, MDVT_ERR_OOM, "out of host memory");
+    c->device = device; c->W = width; c->H = height;
+    c->cfg.mode = MDVT_MODE_POINTS; c->cfg.ipd_m = 0.063; c->cfg.max_depth = 100.0;   // argparse defaults (sr:284, 288)
+    *out = c;
+    return MDVT_OK;
+}
+
+int mdvt_destroy(mdvt_ctx* c)
+{
+    if (!c) return MDVT_OK;
+    DeviceGuard g(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& sl : c->slots) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); }
+    if (c->tri_invalid) (void)hipFree(c->tri_invalid);
+    if (c->unused) (void)hipFree(c->unused);
+    delete c;
+    return MDVT_OK;
+}
+
+int mdvt_set_config(mdvt_ctx* c, const mdvt_config* cfg)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!cfg) return fail(c, MDVT_ERR_INVALID_ARG, "cfg is NULL");
+    if (cfg->mode != MDVT_MODE_POINTS && cfg->mode != MDVT_MODE_MESH) return fail(c, MDVT_ERR_INVALID_ARG, "unknown mode %d", cfg->mode);
+    if (!(cfg->max_depth > 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "max_depth must be > 0");
+    if (!(cfg->ipd_m >= 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "ipd_m must be >= 0");
+    if (cfg->edge_points && !cfg->remove_edges) return fail(c, MDVT_ERR_INVALID_ARG, "edge_points needs remove_edges (sr:589)");
+    c->cfg = *cfg;
+    c->cfg_set = true;
+    return MDVT_OK;
+}
+
+int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params* params, const mdvt_io* io, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (n_frames <= 0 || !params || !io) return fail(c, MDVT_ERR_INVALID_ARG, "n_frames/params/io invalid");
+    if (!io->depth_rgb || !io->color_rgb || !io->left_rgb || !io->right_rgb || !io->left_mask || !io->right_mask)
+        return fail(c, MDVT_ERR_INVALID_ARG, "depth_rgb, color_rgb, left/right rgb and mask buffers are required");
+    const int W = c->W, H = c->H;
+    if (io->depth_pitch < (size_t)3 * W || io->color_pitch < (size_t)3 * W || io->rgb_pitch < (size_t)3 * W ||
+        io->mask_pitch < (size_t)W)
+        return fail(c, MDVT_ERR_INVALID_ARG, "a pitch is smaller than one row");   // sr:507 shape assert
+    const bool zout = io->left_depth || io->right_depth;
+    if (zout && io->zout_pitch < (size_t)4 * W) return fail(c, MDVT_ERR_INVALID_ARG, "zout_pitch smaller than one row");
+    DeviceGuard g(c->device);
+    hipStream_t s = (hipStream_t)stream;
+
+    std::vector<FrameDev> fd((size_t)n_frames);
+    int general = 0;
+    for (int k = 0; k < n_frames; ++k) {
+        const int rc = fill_frame_dev(c, params[k], fd[(size_t)k]);
+        if (rc != MDVT_OK) return rc;
+        general |= fd[(size_t)k].general;
+    }
+    if (general) for (auto& f : fd) f.general = 1;      // one code path per launch
+
+    const FrameDev* dfp = nullptr;
+    ParamSlot* slot = nullptr;
+    int rc = stage_params(c, fd, s, &dfp, &slot);
+    if (rc != MDVT_OK) return rc;
+
+    RenderPlan plan{};
+    plan.mode = c->cfg.mode;
+    plan.remove_edges = c->cfg.remove_edges;
+    plan.edge_points = c->cfg.remove_edges && c->cfg.edge_points;
+    plan.general = general;
+    plan.vec4 = (W % 4 == 0) && aligned(io->depth_rgb, 4) && aligned(io->color_rgb, 4) && aligned(io->left_rgb, 4) &&
+                aligned(io->right_rgb, 4) && aligned(io->left_mask, 4) && aligned(io->right_mask, 4) &&
+                io->depth_pitch % 4 == 0 && io->color_pitch % 4 == 0 && io->rgb_pitch % 4 == 0 && io->mask_pitch % 4 == 0 &&
+                io->depth_stride % 4 == 0 && io->color_stride % 4 == 0 && io->rgb_stride % 4 == 0 && io->mask_stride % 4 == 0 &&
+                (!zout || ((!io->left_depth || aligned(io->left_depth, 16)) && (!io->right_depth || aligned(io->right_depth, 16)) &&
+                           io->zout_pitch % 16 == 0 && io->zout_stride % 16 == 0));
+
+    const bool need_ws = plan.general || plan.remove_edges || plan.mode == MDVT_MODE_MESH;
+    const bool need_keys = plan.general;
+    const bool need_ekeys = plan.general && plan.edge_points;
+    const int chunk = need_ws ? (n_frames < kWorkspaceChunk ? n_frames : kWorkspaceChunk) : n_frames;
+    if (need_ws && (rc = ensure_workspace(c, chunk, need_keys, need_ekeys, plan.remove_edges)) != MDVT_OK) return rc;
+
+    RenderArgs a{};
+    a.depth = io->depth_rgb; a.depth_pitch = io->depth_pitch; a.depth_stride = io->depth_stride;
+    a.color = io->color_rgb; a.color_pitch = io->color_pitch; a.color_stride = io->color_stride;
+    a.rgb[0] = io->left_rgb; a.rgb[1] = io->right_rgb; a.rgb_pitch = io->rgb_pitch; a.rgb_stride = io->rgb_stride;
+    a.mask[0] = io->left_mask; a.mask[1] = io->right_mask; a.mask_pitch = io->mask_pitch; a.mask_stride = io->mask_stride;
+    a.zout[0] = io->left_depth; a.zout[1] = io->right_depth; a.zout_pitch = io->zout_pitch; a.zout_stride = io->zout_stride;
+    a.fp = dfp;
+    a.W = W; a.H = H;
+    a.key_rgb = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
+    a.keys[0] = c->keys[0]; a.keys[1] = c->keys[1];
+    a.ekeys[0] = c->ekeys[0]; a.ekeys[1] = c->ekeys[1];
+    a.tri_invalid = c->tri_invalid; a.unused = c->unused;
+    a.ws_stride_px = (size_t)W * H;
+    a.ws_stride_tri = 2 * (size_t)(W - 1) * (H - 1);
+
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        plan.n = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
+        a.frame0 = f0;
+        if (plan.remove_edges) {
+            MDVT_HIP(c, hipMemsetAsync(c->unused, 0, (size_t)plan.n * a.ws_stride_px, s));
+            MDVT_HIP(c, launch_edge_filter(a.depth, a.depth_pitch, a.depth_stride, dfp, f0, plan.n, W, H,
+                                           plan.mode == MDVT_MODE_MESH, c->tri_invalid, a.ws_stride_tri,
+                                           c->unused, a.ws_stride_px, s));
+        }
+        hipError_t e = launch_render(plan, a, s);
+        if (e == hipErrorNotSupported) return fail(c, MDVT_ERR_UNSUPPORTED, "render mode %d is not built yet", plan.mode);
+        if (e != hipSuccess) return fail(c, MDVT_ERR_HIP, "render launch failed: %s", hipGetErrorString(e));
+    }
+    MDVT_HIP(c, hipEventRecord(slot->done, s));
+    return MDVT_OK;
+}
+
+int mdvt_render_stereo(mdvt_ctx* c, const mdvt_frame_params* params, const mdvt_io* io, void* stream)
+{
+    return mdvt_render_stereo_batch(c, 1, params, io, stream);
+}
+
+int mdvt_decode_depth(mdvt_ctx* c, const uint8_t* d_rgb, size_t rgb_pitch, float* d_depth, size_t depth_pitch,
+                      double max_depth, double depth_scale, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_rgb || !d_depth) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (rgb_pitch < (size_t)3 * c->W || depth_pitch < (size_t)4 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (!(max_depth > 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "max_depth must be > 0");
+    DeviceGuard g(c->device);
+    MDVT_HIP(c, launch_decode_depth(d_rgb, rgb_pitch, d_depth, depth_pitch, c->W, c->H,
+                                    (float)(max_depth / 4228250625.0), (float)depth_scale, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
+int mdvt_encode_depth(mdvt_ctx* c, const float* d_depth, size_t depth_pitch, uint8_t* d_rgb, size_t rgb_pitch,
+                      double max_depth, int bgr, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_rgb || !d_depth) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (rgb_pitch < (size_t)3 * c->W || depth_pitch < (size_t)4 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (!(max_depth > 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "max_depth must be > 0");
+    DeviceGuard g(c->device);
+    MDVT_HIP(c, launch_encode_depth(d_depth, depth_pitch, d_rgb, rgb_pitch, c->W, c->H, max_depth, bgr, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
+int mdvt_edge_filter(mdvt_ctx* c, const uint8_t* d_depth_rgb, size_t depth_pitch, const double K[9], double depth_scale,
+                     int of_by_one, uint8_t* d_tri_invalid, uint8_t* d_unused, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_depth_rgb || !K) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (depth_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    DeviceGuard g(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<FrameDev> fd(1);
+    FrameDev& f = fd[0];
+    memset(&f, 0, sizeof f);
+    f.mult = (float)(c->cfg.max_depth / 4228250625.0);
+    f.scale = (float)depth_scale;
+    f.Kd[0] = K[0]; f.Kd[1] = K[4]; f.Kd[2] = K[2]; f.Kd[3] = K[5];
+    const FrameDev* dfp = nullptr;
+    ParamSlot* slot = nullptr;
+    int rc = stage_params(c, fd, s, &dfp, &slot);
+    if (rc != MDVT_OK) return rc;
+    if (d_unused) MDVT_HIP(c, hipMemsetAsync(d_unused, 0, (size_t)c->W * c->H, s));
+    MDVT_HIP(c, launch_edge_filter(d_depth_rgb, depth_pitch, 0, dfp, 0, 1, c->W, c->H, of_by_one ? 1 : 0,
+                                   d_tri_invalid, 0, d_unused, 0, s));
+    MDVT_HIP(c, hipEventRecord(slot->done, s));
+    return MDVT_OK;
+}
+
+}  // extern "C"

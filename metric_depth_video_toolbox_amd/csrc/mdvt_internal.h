@@ -1,0 +1,72 @@
+// mdvt_internal.h -- shared between the C-ABI host code (mdvt_api.hip) and the kernels
+// (mdvt_kernels.hip).  Not part of the public interface (that is include/mdvt.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "mdvt.h"
+
+namespace mdvt {
+
+// Near plane of the reference's render call: ctr.set_constant_z_near(0.0001) (dmt:1520).
+constexpr float kNear = 1e-4f;
+// Rasteriser sub-pixel grid and the clamp applied before snapping (DESIGN.md "Arithmetic decree").
+constexpr int kSubpix = 256;
+constexpr float kSnapLimit = 4194304.0f;
+
+// Per-frame constants, derived on the host in f64 and rounded once (see fill_frame_dev()).
+struct FrameDev {
+    float mult;          // f32(max_depth / 255^4)                          dfh:22
+    float scale;         // f32(master_fov_scale_depth)                     sr:541
+    float dl;            // f32(Krender.fx * ipd/2): pure-shift disparity numerator
+    float fx, fy, cx, cy;        // input camera (f32)
+    float fxr, fyr, cxr, cyr;    // render camera (f32)
+    float sx, sy;        // (W+1)/W, (H+1)/H in f32 for the mesh grid, 1 for points   dmt:1117-1122
+    float sW, sH;        // (W-1)/W, (H-1)/H in f32: edge points' "undo"              sr:599-600
+    int32_t general;     // 0: pure +-ipd/2 shift, 1: pose / convergence / K != Krender
+    float M[2][12];      // per eye 3x4 = Translate(+-ipd/2) * Ry(-+a) * T, f32       sr:615-619, 724-725, 832-836
+    double Kd[4];        // fx, fy, cx, cy in f64 for the 89-degree edge filter       dmt:1127-1128, 1283-1294
+};
+
+struct RenderArgs {
+    const uint8_t* depth; size_t depth_pitch, depth_stride;
+    const uint8_t* color; size_t color_pitch, color_stride;
+    uint8_t* rgb[2];  size_t rgb_pitch, rgb_stride;
+    uint8_t* mask[2]; size_t mask_pitch, mask_stride;
+    float* zout[2];   size_t zout_pitch, zout_stride;
+    const FrameDev* fp;          // device array, one per frame of the batch
+    int32_t W, H;
+    int32_t frame0;              // first frame of this launch within the batch
+    uint32_t key_rgb;            // R | G<<8 | B<<16
+    // workspace (general path / edge filter); per frame-in-flight slices
+    unsigned long long* keys[2]; // [slot][H*W] 64-bit z keys per eye
+    unsigned long long* ekeys[2];// edge-point keys per eye
+    uint8_t* tri_invalid;        // [slot][2*(H-1)*(W-1)]
+    uint8_t* unused;             // [slot][H*W]
+    size_t ws_stride_px;         // H*W (elements) between slots
+    size_t ws_stride_tri;        // 2*(H-1)*(W-1)
+};
+
+// launchers implemented in mdvt_kernels.hip; all return hipError_t from hipGetLastError()
+hipError_t launch_decode_depth(const uint8_t* rgb, size_t rgb_pitch, float* out, size_t out_pitch, int W, int H,
+                               float mult, float scale, hipStream_t s);
+hipError_t launch_encode_depth(const float* depth, size_t depth_pitch, uint8_t* rgb, size_t rgb_pitch, int W, int H,
+                               double max_depth, int bgr, hipStream_t s);
+hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t stride, const FrameDev* fp, int frame0,
+                              int n, int W, int H, int of_by_one, uint8_t* tri_invalid, size_t tri_stride,
+                              uint8_t* unused, size_t unused_stride, hipStream_t s);
+
+struct RenderPlan {
+    int mode;            // mdvt_mode
+    int remove_edges;
+    int edge_points;
+    int general;         // any frame of the launch needs the general path
+    int vec4;            // W%4==0 and every pointer/pitch 4-byte aligned
+    int n;               // frames in this launch
+};
+hipError_t launch_render(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+size_t render_lds_bytes(const RenderPlan& plan, int W);
+
+}  // namespace mdvt

