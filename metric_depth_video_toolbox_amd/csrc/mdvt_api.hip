@@ -200,8 +200,8 @@ int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flag
     if (!out) return fail(nullptr, MDVT_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (flags != 0) return fail(nullptr, MDVT_ERR_INVALID_ARG, "flags must be 0");
-    if (width < 2 || height < 2 || width > 65535 || height > 32767)
-        return fail(nullptr, MDVT_ERR_INVALID_ARG, "frame size %dx%d out of range (2..65535 x 2..32767)", width, height);
+    if (width < 1 || height < 1 || width > 65535 || height > 32767)
+        return fail(nullptr, MDVT_ERR_INVALID_ARG, "frame size %dx%d out of range (1..65535 x 1..32767)", width, height);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -258,6 +258,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     if (!io->depth_rgb || !io->color_rgb || !io->left_rgb || !io->right_rgb || !io->left_mask || !io->right_mask)
         return fail(c, MDVT_ERR_INVALID_ARG, "depth_rgb, color_rgb, left/right rgb and mask buffers are required");
     const int W = c->W, H = c->H;
+    if (W < 2 || H < 2) return fail(c, MDVT_ERR_INVALID_ARG, "rendering needs at least a 2x2 frame");
     if (io->depth_pitch < (size_t)3 * W || io->color_pitch < (size_t)3 * W || io->rgb_pitch < (size_t)3 * W ||
         io->mask_pitch < (size_t)W)
         return fail(c, MDVT_ERR_INVALID_ARG, "a pitch is smaller than one row");   // sr:507 shape assert
@@ -292,7 +293,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                 (!zout || ((!io->left_depth || aligned(io->left_depth, 16)) && (!io->right_depth || aligned(io->right_depth, 16)) &&
                            io->zout_pitch % 16 == 0 && io->zout_stride % 16 == 0));
 
-    const bool need_ws = plan.general || plan.remove_edges || plan.mode == MDVT_MODE_MESH;
+    const bool need_ws = plan.general || plan.remove_edges;
     const bool need_keys = plan.general;
     const bool need_ekeys = plan.general && plan.edge_points;
     const int chunk = need_ws ? (n_frames < kWorkspaceChunk ? n_frames : kWorkspaceChunk) : n_frames;
@@ -366,6 +367,7 @@ int mdvt_edge_filter(mdvt_ctx* c, const uint8_t* d_depth_rgb, size_t depth_pitch
     if (!c) return MDVT_ERR_INVALID_ARG;
     if (!d_depth_rgb || !K) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
     if (depth_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (c->W < 2 || c->H < 2) return fail(c, MDVT_ERR_INVALID_ARG, "the edge filter needs at least a 2x2 frame");
     DeviceGuard g(c->device);
     hipStream_t s = (hipStream_t)stream;
     std::vector<FrameDev> fd(1);

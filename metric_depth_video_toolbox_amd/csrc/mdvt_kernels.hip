@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256) k_points_rows(RenderArgs a)
 template <int FLAGS>
 __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
 {
-    constexpr bool UNUSED = FLAGS & 2, EDGE = FLAGS & 4;
+    constexpr bool UNUSED = FLAGS & 2, EDGE = FLAGS & 4, EDGE_ONLY = FLAGS & 8;
     const int W = a.W, H = a.H;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
@@ -359,6 +359,7 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
     const bool un = UNUSED && a.unused[(size_t)fr * a.ws_stride_px + (size_t)i * W + j];
     const uint32_t src = ((uint32_t)i << 16) | (uint32_t)j;
     if (!un) {
+        if (EDGE_ONLY) return;
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
             const Vert v = vertex_general(fp, fp.M[eye], xc, yc, z);
@@ -420,6 +421,331 @@ __global__ void __launch_bounds__(256) k_points_resolve_general(RenderArgs a)
 }
 
 // =================================================================================================
+// MESH MODE, pure stereo shift: one workgroup per (frame, output row), z-buffer in LDS
+// =================================================================================================
+//
+// With v = grid_y (depth independent) every vertex row is a horizontal line on screen, so an output
+// scanline is covered by ONE row of grid cells (two when the scanline passes exactly through a vertex
+// row): the 2-D rasterisation collapses to interval coverage along x.  One thread per cell walks the
+// pixel centres inside the cell's two triangles for both eyes and posts
+//        key = ~bits(1/Z interpolated) << 32 | pass << 17 | rowsel << 16 | j
+// to the LDS z-buffer (min == nearest, ties to the earlier triangle in the reference's draw order:
+// all tri1 before all tri2, row-major inside, dmt:1243-1254).  The resolve phase re-evaluates the
+// winning triangle at the pixel centre and shades it perspective-correctly.
+
+struct RowVerts {            // the two vertex rows of one cell row, staged as raw RGB bytes in LDS
+    const uint8_t* d0; const uint8_t* d1;    // depth rows c, c+1
+    const uint8_t* c0; const uint8_t* c1;    // colour rows c, c+1
+};
+
+__device__ __forceinline__ uint32_t lds_px(const uint8_t* row, int j)
+{
+    // unaligned 3-byte pixel from a dword-aligned LDS row: two aligned dwords + funnel shift
+    const uint32_t off = 3u * (uint32_t)j;
+    const uint32_t* p = (const uint32_t*)(row + (off & ~3u));
+    const uint32_t lo = p[0], hi = p[1];
+    return __builtin_amdgcn_alignbyte(hi, lo, off & 3u) & 0xFFFFFFu;
+}
+
+// Triangle `pass` (0: tri1 = A,B,C; 1: tri2 = A,C,D) of cell column j for one eye, pure shift.
+__device__ __forceinline__ bool mesh_tri_pure(TriSetup& t, uint32_t (&col)[3], const RowVerts& rv, int j, int pass,
+                                              int eye, float gy0, float gy1, const FrameDev& fp)
+{
+    const float gx0 = (float)j * fp.sx, gx1 = (float)(j + 1) * fp.sx;
+    // vertex order of the reference: tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]); tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
+    const uint8_t* dr[3] = {rv.d0, pass == 0 ? rv.d1 : rv.d1, pass == 0 ? rv.d1 : rv.d0};
+    const uint8_t* cr[3] = {rv.c0, pass == 0 ? rv.c1 : rv.c1, pass == 0 ? rv.c1 : rv.c0};
+    const int jj[3] = {j, pass == 0 ? j : j + 1, j + 1};
+    const float gxs[3] = {gx0, pass == 0 ? gx0 : gx1, gx1};
+    const float gys[3] = {gy0, gy1, pass == 0 ? gy1 : gy0};
+    Vert v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float z = decode_z(code16_of(lds_px(dr[k], jj[k])), fp.mult, fp.scale);
+        const float d = fp.dl / z;
+        v[k] = vertex_pure(gxs[k], gys[k], z, d, eye);
+        col[k] = lds_px(cr[k], jj[k]);
+    }
+    return tri_setup(t, v[0], v[1], v[2]);
+}
+
+template <int PX, int FLAGS>
+__global__ void __launch_bounds__(256) k_mesh_rows(RenderArgs a)
+{
+    constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = a.W, H = a.H;
+    const int rowbytes = ((3 * W + 3) & ~3) + 8;       // dword rows with slack for the two-dword pixel read
+    u64* zb = (u64*)smem;                              // [2][W]
+    uint8_t* raw = (uint8_t*)(zb + 2 * (size_t)W);     // [2 images][3 rows][rowbytes]
+    uint32_t* eb = (uint32_t*)(raw + 6 * (size_t)rowbytes);   // [2][W] edge-point keys (EDGEPTS)
+
+    const int fr = blockIdx.x / H;
+    const int k = blockIdx.x - fr * H;                 // output row
+    const int f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const int tid = threadIdx.x;
+
+    // ---- which cell rows can cover scanline k (uniform) ----
+    const i64 Yc = (i64)k * kSubpix + kSubpix / 2;
+    int ilo = (int)(((float)k + 0.5f) / fp.sy);
+    ilo = ilo < 0 ? 0 : (ilo > H - 1 ? H - 1 : ilo);
+    while (ilo > 0 && snap((float)ilo * fp.sy) > Yc) --ilo;
+    while (ilo + 1 <= H - 1 && snap((float)(ilo + 1) * fp.sy) <= Yc) ++ilo;
+    const bool on_row = snap((float)ilo * fp.sy) == Yc;
+    const int cand_hi = (ilo <= H - 2) ? ilo : -1;
+    const int cand_lo = (on_row && ilo >= 1) ? ilo - 1 : -1;
+    const int c_first = cand_lo >= 0 ? cand_lo : cand_hi;     // first cell row (rowsel 0)
+    const int ncand = (cand_lo >= 0 ? 1 : 0) + (cand_hi >= 0 ? 1 : 0);
+    const int nvrows = ncand == 0 ? 0 : ncand + 1;            // vertex rows c_first .. c_first+ncand
+
+    for (int x = tid; x < 2 * W; x += blockDim.x) zb[x] = kEmpty64;
+    if (EDGEPTS) for (int x = tid; x < 2 * W; x += blockDim.x) eb[x] = kEmpty32;
+    // ---- stage the vertex rows (raw bytes, coalesced dwords) ----
+    {
+        const int ndw = (3 * W + 3) / 4;
+        for (int r = 0; r < nvrows; ++r) {
+            const uint8_t* dsrc = a.depth + (size_t)f * a.depth_stride + (size_t)(c_first + r) * a.depth_pitch;
+            const uint8_t* csrc = a.color + (size_t)f * a.color_stride + (size_t)(c_first + r) * a.color_pitch;
+            uint8_t* ddst = raw + (size_t)r * rowbytes;
+            uint8_t* cdst = raw + (size_t)(3 + r) * rowbytes;
+            if (PX == 4) {
+                for (int x = tid; x < ndw; x += blockDim.x) {
+                    ((uint32_t*)ddst)[x] = ((const uint32_t*)dsrc)[x];
+                    ((uint32_t*)cdst)[x] = ((const uint32_t*)csrc)[x];
+                }
+            } else {
+                for (int x = tid; x < 3 * W; x += blockDim.x) { ddst[x] = dsrc[x]; cdst[x] = csrc[x]; }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- rasterise: one thread per cell of each candidate cell row ----
+    for (int rs = 0; rs < ncand; ++rs) {
+        const int c = c_first + rs;
+        RowVerts rv;
+        rv.d0 = raw + (size_t)rs * rowbytes;        rv.d1 = raw + (size_t)(rs + 1) * rowbytes;
+        rv.c0 = raw + (size_t)(3 + rs) * rowbytes;  rv.c1 = raw + (size_t)(4 + rs) * rowbytes;
+        const float gy0 = (float)c * fp.sy, gy1 = (float)(c + 1) * fp.sy;
+        const uint8_t* tinv = EDGES ? a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)c * (W - 1) : nullptr;
+        const size_t ncell = (size_t)(W - 1) * (H - 1);
+        for (int j = tid; j < W - 1; j += blockDim.x) {
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                if (EDGES && tinv[(size_t)pass * ncell + j]) continue;           // dmt:1372
+#pragma unroll
+                for (int eye = 0; eye < 2; ++eye) {
+                    TriSetup t; uint32_t col[3];
+                    if (!mesh_tri_pure(t, col, rv, j, pass, eye, gy0, gy1, fp)) continue;
+                    i64 minX = t.X0 < t.X1 ? t.X0 : t.X1; if (t.X2 < minX) minX = t.X2;
+                    i64 maxX = t.X0 > t.X1 ? t.X0 : t.X1; if (t.X2 > maxX) maxX = t.X2;
+                    i64 px0 = floordiv_subpix(minX - kSubpix / 2 + kSubpix - 1);
+                    i64 px1 = floordiv_subpix(maxX - kSubpix / 2);
+                    if (px0 < 0) px0 = 0;
+                    if (px1 > W - 1) px1 = W - 1;
+                    const uint32_t lowkey = ((uint32_t)pass << 17) | ((uint32_t)rs << 16) | (uint32_t)j;
+                    for (i64 px = px0; px <= px1; ++px) {
+                        float q0, q1, q2;
+                        if (!tri_sample(t, px, k, q0, q1, q2)) continue;
+                        const float iz = (q0 + q1) + q2;
+                        const u64 key = ((u64)(~__float_as_uint(iz)) << 32) | lowkey;
+                        atomicMin(&zb[(size_t)eye * W + (int)px], key);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- edge points of source row k (sr:589-606, 745-781): vertices of removed triangles ----
+    const uint8_t* crow_k = a.color + (size_t)f * a.color_stride + (size_t)k * a.color_pitch;
+    if (EDGEPTS) {
+        const uint8_t* drow_k = a.depth + (size_t)f * a.depth_stride + (size_t)k * a.depth_pitch;
+        const uint8_t* urow = a.unused + (size_t)fr * a.ws_stride_px + (size_t)k * W;
+        const float fW = (float)W;
+        for (int j = tid; j < W; j += blockDim.x) {
+            if (!urow[j]) continue;
+            const uint32_t code = code16_of(load_px_bytes(drow_k, j));
+            const float z = decode_z(code, fp.mult, fp.scale);
+            if (!(z > kNear)) continue;
+            const float d = fp.dl / z;
+            const float gx = (float)j * fp.sx;
+            const float ex = ((gx - fp.cx) * fp.sW) + fp.cx;
+            const uint32_t ekey = (code << 16) | (uint32_t)j;
+            const float uL = ex + d, uR = ex - d;
+            if (uL > -1.0f && uL < fW + 1.0f) {
+                const int x = (int)rintf(uL);
+                if (x >= 0 && x < W) atomicMin(&eb[x], ekey);
+            }
+            if (uR > -1.0f && uR < fW + 1.0f) {
+                const int x = (int)rintf(uR);
+                if (x >= 0 && x < W) atomicMin(&eb[W + x], ekey);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- resolve ----
+    const int ngroups = W / PX;
+#pragma unroll
+    for (int eye = 0; eye < 2; ++eye) {
+        uint8_t* orow = a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)k * a.rgb_pitch;
+        uint8_t* mrow = a.mask[eye] + (size_t)f * a.mask_stride + (size_t)k * a.mask_pitch;
+        float* zrow = ZOUT && a.zout[eye]
+                          ? (float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)k * a.zout_pitch)
+                          : nullptr;
+        for (int g = tid; g < ngroups; g += blockDim.x) {
+            uint32_t opx[PX], om[PX];
+            float oz[PX];
+#pragma unroll
+            for (int q = 0; q < PX; ++q) {
+                const int x = g * PX + q;
+                const u64 key = zb[(size_t)eye * W + x];
+                const bool covered = key != kEmpty64;
+                uint32_t rgb = 0;
+                float zval = 0.0f;
+                if (covered) {
+                    const uint32_t low = (uint32_t)key;
+                    const int pass = (low >> 17) & 1, rs = (low >> 16) & 1, j = (int)(low & 0xFFFFu);
+                    const int c = c_first + rs;
+                    RowVerts rv;
+                    rv.d0 = raw + (size_t)rs * rowbytes;        rv.d1 = raw + (size_t)(rs + 1) * rowbytes;
+                    rv.c0 = raw + (size_t)(3 + rs) * rowbytes;  rv.c1 = raw + (size_t)(4 + rs) * rowbytes;
+                    TriSetup t; uint32_t col[3];
+                    mesh_tri_pure(t, col, rv, j, pass, eye, (float)c * fp.sy, (float)(c + 1) * fp.sy, fp);
+                    float q0, q1, q2;
+                    tri_sample(t, x, k, q0, q1, q2);
+                    const float iz = (q0 + q1) + q2;
+                    rgb = shade_px(q0, q1, q2, iz, col[0], col[1], col[2]);
+                    zval = 1.0f / iz;
+                }
+                const bool hole = !covered || rgb == a.key_rgb;
+                uint32_t out = hole ? 0u : rgb;
+                if (EDGEPTS && hole) {
+                    const uint32_t ek = eb[(size_t)eye * W + x];
+                    if (ek != kEmpty32) out = load_px_bytes(crow_k, (int)(ek & 0xFFFFu));
+                }
+                opx[q] = out;
+                om[q] = hole ? 255u : 0u;
+                if (ZOUT) oz[q] = zval;
+            }
+            RowIO<PX>::store_rgb(orow, g, opx);
+            RowIO<PX>::store_mask(mrow, g, om);
+            if (ZOUT && zrow) RowIO<PX>::store_z(zrow, g, oz);
+        }
+    }
+}
+
+// =================================================================================================
+// MESH MODE, general (pose / convergence): triangles rasterised into global 64-bit z keys
+// =================================================================================================
+//   key = ~bits(1/Z') << 32 | pass << 30 | i << 15 | j        (cell row i, column j; i, j < 32768)
+
+__device__ __forceinline__ bool mesh_tri_general(TriSetup& t, uint32_t (&col)[3], const RenderArgs& a, const FrameDev& fp,
+                                                 int f, int i, int j, int pass, int eye)
+{
+    const int ii[3] = {i, i + 1, pass == 0 ? i + 1 : i};
+    const int jj[3] = {j, pass == 0 ? j : j + 1, j + 1};
+    Vert v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)ii[k] * a.depth_pitch;
+        const uint8_t* crow = a.color + (size_t)f * a.color_stride + (size_t)ii[k] * a.color_pitch;
+        const float z = decode_z(code16_of(load_px_bytes(drow, jj[k])), fp.mult, fp.scale);
+        float xc, yc;
+        camera_point(fp, (float)jj[k] * fp.sx, (float)ii[k] * fp.sy, z, xc, yc);
+        v[k] = vertex_general(fp, fp.M[eye], xc, yc, z);
+        col[k] = load_px_bytes(crow, jj[k]);
+    }
+    return tri_setup(t, v[0], v[1], v[2]);
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
+{
+    constexpr bool EDGES = FLAGS & 2;
+    const int W = a.W, H = a.H;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    const int fr = blockIdx.z;
+    if (j >= W - 1) return;
+    const int f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const size_t ncell = (size_t)(W - 1) * (H - 1);
+    const uint8_t* tinv = EDGES ? a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j : nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (EDGES && tinv[(size_t)pass * ncell]) continue;
+        const uint32_t lowkey = ((uint32_t)pass << 30) | ((uint32_t)i << 15) | (uint32_t)j;
+        for (int eye = 0; eye < 2; ++eye) {
+            TriSetup t; uint32_t col[3];
+            if (!mesh_tri_general(t, col, a, fp, f, i, j, pass, eye)) continue;
+            i64 minX = t.X0 < t.X1 ? t.X0 : t.X1; if (t.X2 < minX) minX = t.X2;
+            i64 maxX = t.X0 > t.X1 ? t.X0 : t.X1; if (t.X2 > maxX) maxX = t.X2;
+            i64 minY = t.Y0 < t.Y1 ? t.Y0 : t.Y1; if (t.Y2 < minY) minY = t.Y2;
+            i64 maxY = t.Y0 > t.Y1 ? t.Y0 : t.Y1; if (t.Y2 > maxY) maxY = t.Y2;
+            i64 px0 = floordiv_subpix(minX - kSubpix / 2 + kSubpix - 1), px1 = floordiv_subpix(maxX - kSubpix / 2);
+            i64 py0 = floordiv_subpix(minY - kSubpix / 2 + kSubpix - 1), py1 = floordiv_subpix(maxY - kSubpix / 2);
+            if (px0 < 0) px0 = 0;
+            if (py0 < 0) py0 = 0;
+            if (px1 > W - 1) px1 = W - 1;
+            if (py1 > H - 1) py1 = H - 1;
+            u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
+            for (i64 py = py0; py <= py1; ++py)
+                for (i64 px = px0; px <= px1; ++px) {
+                    float q0, q1, q2;
+                    if (!tri_sample(t, px, py, q0, q1, q2)) continue;
+                    const float iz = (q0 + q1) + q2;
+                    atomicMin(&keys[(size_t)py * W + (size_t)px], ((u64)(~__float_as_uint(iz)) << 32) | lowkey);
+                }
+        }
+    }
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(256) k_mesh_resolve_general(RenderArgs a)
+{
+    constexpr bool ZOUT = FLAGS & 1, EDGEPTS = FLAGS & 4;
+    const int W = a.W;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int fr = blockIdx.z >> 1, eye = blockIdx.z & 1;
+    if (x >= W) return;
+    const int f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const size_t o = (size_t)fr * a.ws_stride_px + (size_t)y * W + x;
+    const u64 key = a.keys[eye][o];
+    const bool covered = key != kEmpty64;
+    uint32_t rgb = 0;
+    float zval = 0.0f;
+    if (covered) {
+        const uint32_t low = (uint32_t)key;
+        const int pass = (int)(low >> 30) & 1, i = (int)(low >> 15) & 0x7FFF, j = (int)(low & 0x7FFFu);
+        TriSetup t; uint32_t col[3];
+        mesh_tri_general(t, col, a, fp, f, i, j, pass, eye);
+        float q0, q1, q2;
+        tri_sample(t, x, y, q0, q1, q2);
+        const float iz = (q0 + q1) + q2;
+        rgb = shade_px(q0, q1, q2, iz, col[0], col[1], col[2]);
+        zval = 1.0f / iz;
+    }
+    const bool hole = !covered || rgb == a.key_rgb;
+    uint32_t out = hole ? 0u : rgb;
+    if (EDGEPTS && hole) {
+        const u64 ek = a.ekeys[eye][o];
+        if (ek != kEmpty64) {
+            const uint32_t src = (uint32_t)ek;
+            out = load_px_bytes(a.color + (size_t)f * a.color_stride + (size_t)(src >> 16) * a.color_pitch, (int)(src & 0xFFFFu));
+        }
+    }
+    store_px_bytes(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)y * a.rgb_pitch, x, out);
+    (a.mask[eye] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch)[x] = hole ? 255 : 0;
+    if (ZOUT && a.zout[eye]) {
+        float* zrow = (float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)y * a.zout_pitch);
+        zrow[x] = zval;
+    }
+}
+
+// =================================================================================================
 // launch plumbing
 // =================================================================================================
 
@@ -431,7 +757,9 @@ size_t render_lds_bytes(const RenderPlan& plan, int W)
         if (plan.edge_points) b += 2 * (size_t)W * sizeof(uint32_t);
         return b;
     }
-    return 0;
+    size_t b = 2 * (size_t)W * sizeof(u64) + 6 * (size_t)(((3 * W + 3) & ~3) + 8);
+    if (plan.edge_points) b += 2 * (size_t)W * sizeof(uint32_t);
+    return b;
 }
 
 template <int PX>
@@ -485,13 +813,63 @@ static hipError_t launch_points_general(const RenderPlan& plan, const RenderArgs
     return hipGetLastError();
 }
 
+template <int PX>
+static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+{
+    const size_t lds = render_lds_bytes(plan, a.W);
+    const dim3 grid((unsigned)(plan.n * a.H)), block(256);
+    const bool zout = a.zout[0] || a.zout[1];
+    const int flags = (zout ? 1 : 0) | (plan.remove_edges ? 2 : 0) | (plan.remove_edges && plan.edge_points ? 4 : 0);
+#define MDVT_CASE(F)                                                                                   \
+    case F:                                                                                            \
+        (void)hipFuncSetAttribute((const void*)k_mesh_rows<PX, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_mesh_rows<PX, F>), grid, block, lds, s, a);                              \
+        break;
+    switch (flags) {
+        MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(2) MDVT_CASE(3) MDVT_CASE(6) MDVT_CASE(7)
+        default: return hipErrorInvalidValue;
+    }
+#undef MDVT_CASE
+    return hipGetLastError();
+}
+
+static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+{
+    const bool zout = a.zout[0] || a.zout[1];
+    const bool edge = plan.remove_edges && plan.edge_points;
+    hipError_t e;
+    for (int eye = 0; eye < 2; ++eye) {
+        if ((e = hipMemsetAsync(a.keys[eye], 0xFF, (size_t)plan.n * a.ws_stride_px * sizeof(u64), s)) != hipSuccess) return e;
+        if (edge && (e = hipMemsetAsync(a.ekeys[eye], 0xFF, (size_t)plan.n * a.ws_stride_px * sizeof(u64), s)) != hipSuccess) return e;
+    }
+    const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
+    if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_general<2>), grid_c, dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((k_mesh_raster_general<0>), grid_c, dim3(128), 0, s, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (edge) {
+        const dim3 grid_s((a.W + 255) / 256, a.H, plan.n);
+        hipLaunchKernelGGL((k_points_splat_general<14>), grid_s, dim3(256), 0, s, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    const dim3 grid_r((a.W + 255) / 256, a.H, plan.n * 2);
+    const int rflags = (zout ? 1 : 0) | (edge ? 4 : 0);
+    switch (rflags) {
+        case 0: hipLaunchKernelGGL((k_mesh_resolve_general<0>), grid_r, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_mesh_resolve_general<1>), grid_r, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_mesh_resolve_general<4>), grid_r, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_mesh_resolve_general<5>), grid_r, dim3(256), 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_render(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     if (plan.mode == MDVT_MODE_POINTS) {
         if (plan.general) return launch_points_general(plan, a, s);
         return plan.vec4 ? launch_points_rows<4>(plan, a, s) : launch_points_rows<1>(plan, a, s);
     }
-    return hipErrorNotSupported;
+    if (plan.general) return launch_mesh_general(plan, a, s);
+    return plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);
 }
 
 }  // namespace mdvt

@@ -153,6 +153,73 @@ def test_full_hd_single_frame_matches_oracle(mods, orc):
     r.close()
 
 
+# ----------------------------------------------------------------------------------------------- mesh mode
+@pytest.mark.parametrize("W,H", [(64, 48), (96, 64), (250, 37), (33, 17), (320, 240)])
+@pytest.mark.parametrize("infill_mask", [False, True])
+def test_mesh_pure_shift(mods, orc, W, H, infill_mask):
+    """Default mode of the reference (grid mesh).  infill_mask=True is the product default of
+    movie_2_3D.py: 89-degree edge filter + green key + edge points (m23d:441, sr:568-570)."""
+    _lib, sr, synthetic = mods
+    depth_rgb, color = _scene(synthetic, W, H, seed=W * 7 + H)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=infill_mask)
+    p = r.frame_params(xfov=45.0)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"mesh {W}x{H} infill={infill_mask}")
+    assert (got["mask"] > 0).any() and not (got["mask"] > 0).all()
+    r.close()
+
+
+@pytest.mark.parametrize("flags", [dict(remove_edges=True, dont_place_points_in_edges=True), dict(remove_edges=True)])
+def test_mesh_remove_edges_variants(mods, orc, flags):
+    _lib, sr, synthetic = mods
+    W, H = 160, 96
+    depth_rgb, color = _scene(synthetic, W, H, seed=21)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, **flags)
+    p = r.frame_params(xfov=60.0)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"mesh {flags}")
+    r.close()
+
+
+@pytest.mark.parametrize("case", ["convergence", "pose", "both"])
+@pytest.mark.parametrize("infill_mask", [False, True])
+def test_mesh_general_path(mods, orc, case, infill_mask):
+    _lib, sr, synthetic = mods
+    W, H = 96, 64
+    depth_rgb, color = _scene(synthetic, W, H, seed=41)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=infill_mask)
+    T = synthetic.synthetic_pose_track(40)[33] if case in ("pose", "both") else None
+    p = r.frame_params(xfov=45.0, convergence_distance=2.5 if case != "pose" else None, transformation=T)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color, T=T), W, f"mesh general/{case}")
+    r.close()
+
+
+def test_mesh_batch(mods, orc):
+    _lib, sr, synthetic = mods
+    W, H, N = 128, 80, 10
+    d, c = synthetic.SyntheticScene(W, H, seed=4, n_fg=5).clip(N)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
+    params = [r.frame_params(xfov=42.0 + k) for k in range(N)]
+    got = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), params)
+    for k in range(N):
+        one = {key: v[k] for key, v in got.items()}
+        _compare(one, _oracle(orc, r, params[k], d[k], c[k], want_depth=False), W, f"mesh batch frame {k}")
+    r.close()
+
+
+def test_mesh_full_hd_product_default(mods, orc):
+    """1920x1080 through the product-default variant (mesh + edge filter + edge points)."""
+    _lib, sr, synthetic = mods
+    W, H = 1920, 1080
+    depth_rgb, color = synthetic.SyntheticScene(W, H, config_id=2).frame(0)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
+    p = r.frame_params(xfov=45.0)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, "mesh C2")
+    r.close()
+
+
 def test_codec_on_device(mods, orc, golden):
     from metric_depth_video_toolbox_amd import depth_frames_helper as dfh
     g = golden("codec")
@@ -209,7 +276,7 @@ def test_edge_filter_full_size_matches_oracle(mods, orc):
 def test_errors_are_reported_not_swallowed(mods):
     _lib, sr, synthetic = mods
     with pytest.raises(_lib.MdvtError) as e:
-        _lib.Context(0, 1, 1)
+        _lib.Context(0, 0, 1)
     assert e.value.code == -1
     r = sr.StereoRerenderer(64, 48, render_as_pointcloud=True)
     with pytest.raises(ValueError):
