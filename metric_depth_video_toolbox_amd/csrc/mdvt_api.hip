@@ -39,6 +39,10 @@ struct mdvt_ctx {
     std::string err;
     ParamSlot slots[kParamSlots];
     int next_slot = 0;
+    // the most recently staged parameter block: clips with constant parameters re-use the device copy
+    std::vector<FrameDev> last_staged;
+    ParamSlot* last_slot = nullptr;
+    hipStream_t last_stream = nullptr;
     // workspace for the general path / edge filter, sized for ws_frames frames
     int ws_frames = 0;
     bool ws_keys = false, ws_ekeys = false, ws_edges = false;
@@ -127,6 +131,13 @@ int fill_frame_dev(mdvt_ctx* c, const mdvt_frame_params& p, FrameDev& f)
 // Stage n FrameDev records to the device through the pinned ring; returns the device pointer.
 int stage_params(mdvt_ctx* c, const std::vector<FrameDev>& v, hipStream_t s, const FrameDev** dev, ParamSlot** slot_out)
 {
+    if (c->last_slot && c->last_stream == s && c->last_staged.size() == v.size() &&
+        memcmp(c->last_staged.data(), v.data(), v.size() * sizeof(FrameDev)) == 0) {
+        // identical to what already sits on the device (stream order keeps the earlier copy ahead of us)
+        *dev = c->last_slot->dev;
+        *slot_out = c->last_slot;
+        return MDVT_OK;
+    }
     ParamSlot& sl = c->slots[c->next_slot];
     c->next_slot = (c->next_slot + 1) % kParamSlots;
     if (sl.used) MDVT_HIP(c, hipEventSynchronize(sl.done));     // slot is being reused: its last user must be done
@@ -144,6 +155,9 @@ int stage_params(mdvt_ctx* c, const std::vector<FrameDev>& v, hipStream_t s, con
     memcpy(sl.host, v.data(), v.size() * sizeof(FrameDev));
     MDVT_HIP(c, hipMemcpyAsync(sl.dev, sl.host, v.size() * sizeof(FrameDev), hipMemcpyHostToDevice, s));
     sl.used = true;
+    c->last_staged = v;
+    c->last_slot = &sl;
+    c->last_stream = s;
     *dev = sl.dev;
     *slot_out = &sl;
     return MDVT_OK;

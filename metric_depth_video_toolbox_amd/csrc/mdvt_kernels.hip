@@ -13,6 +13,10 @@
 // Compiled with -ffp-contract=off: see the arithmetic decree in mdvt_device.h / DESIGN.md.
 #include "mdvt_device.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 namespace mdvt {
 
 // =================================================================================================
@@ -231,10 +235,58 @@ struct RowIO<1> {
     static __device__ __forceinline__ void load_u8(const uint8_t* row, int g, uint32_t (&v)[1]) { v[0] = row[g]; }
 };
 
+// LDS z-buffer slot of target pixel x.  With 4 pixels per lane, lane l's q-th atomic goes to pixel
+// ~4l+q+disparity: a linear layout would put lanes 32 B apart (8-way bank conflict on 8-byte keys).
+// Splitting the row into 4 residue classes (x mod 4) makes consecutive lanes hit consecutive slots
+// both in the splat phase (locally constant disparity) and in the resolve phase.
+template <int SWZ>
+__device__ __forceinline__ int zslot(int x, int W4) { return SWZ ? (x & 3) * W4 + (x >> 2) : x; }
+
 // FLAGS bit 0: optional depth planes, bit 1: `unused` vertices are not drawn (remove_edges),
 // bit 2: edge points splatted into holes.
-template <int PX, int FLAGS>
-__global__ void __launch_bounds__(256) k_points_rows(RenderArgs a)
+template <int PX, int FLAGS, int SWZ>
+__device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[PX], const uint32_t (&cpx)[PX],
+                                                   const uint32_t (&un)[PX], u64* zb, uint32_t* eb, int W,
+                                                   float mult, float scale, float dl, float ecx, float esW)
+{
+    constexpr bool UNUSED = FLAGS & 2, EDGE = FLAGS & 4;
+    const float fW = (float)W;
+    const int W4 = W >> 2;
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+        const int j = g * PX + q;
+        const uint32_t code = code16_of(dpx[q]);
+        const float z = decode_z(code, mult, scale);
+        if (!(z > kNear)) continue;
+        const float d = dl / z;
+        const float fj = (float)j;
+        if (!(UNUSED && un[q])) {
+            const u64 key = ((u64)code << 40) | ((u64)(uint32_t)j << 24) | (u64)cpx[q];
+            const float uL = fj + d, uR = fj - d;
+            if (uL >= 0.0f && uL < fW) atomicMin(&zb[zslot<SWZ>((int)floorf(uL), W4)], key);
+            if (uR >= 0.0f && uR < fW) atomicMin(&zb[W + zslot<SWZ>((int)floorf(uR), W4)], key);
+        } else if (EDGE) {
+            // sr:599-600, 746: undo the off-by-one scale on X, project, round half-even.
+            const float ex = ((fj - ecx) * esW) + ecx;
+            const uint32_t ekey = (code << 16) | (uint32_t)j;
+            const float uL = ex + d, uR = ex - d;
+            if (uL > -1.0f && uL < fW + 1.0f) {
+                const int x = (int)rintf(uL);
+                if (x >= 0 && x < W) atomicMin(&eb[zslot<SWZ>(x, W4)], ekey);
+            }
+            if (uR > -1.0f && uR < fW + 1.0f) {
+                const int x = (int)rintf(uR);
+                if (x >= 0 && x < W) atomicMin(&eb[W + zslot<SWZ>(x, W4)], ekey);
+            }
+        }
+    }
+}
+
+// TPB threads; ITERS > 0: every thread owns exactly ITERS groups (ngroups <= TPB*ITERS) whose HBM
+// loads are all issued before the LDS clear, so 2*ITERS 768-byte wave loads are in flight per wave
+// while the z-buffer is initialised.  ITERS == 0: plain strided loop (any W).
+template <int PX, int FLAGS, int TPB, int ITERS, int SWZ>
+__global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
 {
     constexpr bool ZOUT = FLAGS & 1, UNUSED = FLAGS & 2, EDGE = FLAGS & 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -250,48 +302,47 @@ __global__ void __launch_bounds__(256) k_points_rows(RenderArgs a)
     const int tid = threadIdx.x;
     const int ngroups = W / PX;
 
-    for (int x = tid; x < 2 * W; x += blockDim.x) zb[x] = kEmpty64;
-    if (EDGE) for (int x = tid; x < 2 * W; x += blockDim.x) eb[x] = kEmpty32;
-    __syncthreads();
-
     const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
     const uint8_t* crow = a.color + (size_t)f * a.color_stride + (size_t)i * a.color_pitch;
     const uint8_t* urow = UNUSED ? a.unused + (size_t)fr * a.ws_stride_px + (size_t)i * W : nullptr;
-    const float fW = (float)W;
     const float ecx = fp.cx, esW = fp.sW;
 
-    for (int g = tid; g < ngroups; g += blockDim.x) {
-        uint32_t dpx[PX], cpx[PX], un[PX];
-        RowIO<PX>::load(drow, g, dpx);
-        RowIO<PX>::load(crow, g, cpx);
-        if (UNUSED) RowIO<PX>::load_u8(urow, g, un);
+    constexpr int NIT = ITERS > 0 ? ITERS : 1;
+    uint32_t dpx[NIT][PX], cpx[NIT][PX], un[NIT][PX];
+    if (ITERS > 0) {
 #pragma unroll
-        for (int q = 0; q < PX; ++q) {
-            const int j = g * PX + q;
-            const uint32_t code = code16_of(dpx[q]);
-            const float z = decode_z(code, mult, scale);
-            if (!(z > kNear)) continue;
-            const float d = dl / z;
-            const float fj = (float)j;
-            if (!(UNUSED && un[q])) {
-                const u64 key = ((u64)code << 40) | ((u64)(uint32_t)j << 24) | (u64)cpx[q];
-                const float uL = fj + d, uR = fj - d;
-                if (uL >= 0.0f && uL < fW) atomicMin(&zb[(int)floorf(uL)], key);
-                if (uR >= 0.0f && uR < fW) atomicMin(&zb[W + (int)floorf(uR)], key);
-            } else if (EDGE) {
-                // sr:599-600, 746: undo the off-by-one scale on X, project, round half-even.
-                const float ex = ((fj - ecx) * esW) + ecx;
-                const uint32_t ekey = (code << 16) | (uint32_t)j;
-                const float uL = ex + d, uR = ex - d;
-                if (uL > -1.0f && uL < fW + 1.0f) {
-                    const int x = (int)rintf(uL);
-                    if (x >= 0 && x < W) atomicMin(&eb[x], ekey);
-                }
-                if (uR > -1.0f && uR < fW + 1.0f) {
-                    const int x = (int)rintf(uR);
-                    if (x >= 0 && x < W) atomicMin(&eb[W + x], ekey);
-                }
+        for (int it = 0; it < NIT; ++it) {
+            const int g = tid + it * TPB;
+            if (g < ngroups) {
+                RowIO<PX>::load(drow, g, dpx[it]);
+                RowIO<PX>::load(crow, g, cpx[it]);
+                if (UNUSED) RowIO<PX>::load_u8(urow, g, un[it]);
             }
+        }
+    }
+
+    // clear the z-buffers (16 B per store where the layout allows)
+    {
+        uint4* z4 = (uint4*)zb;
+        const int n4 = W;                        // 2*W u64 = W uint4
+        for (int x = tid; x < n4; x += TPB) z4[x] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (EDGE) for (int x = tid; x < 2 * W; x += TPB) eb[x] = kEmpty32;
+    }
+    __syncthreads();
+
+    if (ITERS > 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int g = tid + it * TPB;
+            if (g < ngroups)
+                points_splat_group<PX, FLAGS, SWZ>(g, dpx[it], cpx[it], un[it], zb, eb, W, mult, scale, dl, ecx, esW);
+        }
+    } else {
+        for (int g = tid; g < ngroups; g += TPB) {
+            RowIO<PX>::load(drow, g, dpx[0]);
+            RowIO<PX>::load(crow, g, cpx[0]);
+            if (UNUSED) RowIO<PX>::load_u8(urow, g, un[0]);
+            points_splat_group<PX, FLAGS, SWZ>(g, dpx[0], cpx[0], un[0], zb, eb, W, mult, scale, dl, ecx, esW);
         }
     }
     __syncthreads();
@@ -304,19 +355,20 @@ __global__ void __launch_bounds__(256) k_points_rows(RenderArgs a)
                           ? (float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)i * a.zout_pitch)
                           : nullptr;
         const u64* zrow_lds = zb + (size_t)eye * W;
-        for (int g = tid; g < ngroups; g += blockDim.x) {
+        for (int g = tid; g < ngroups; g += TPB) {
             uint32_t opx[PX], om[PX];
             float oz[PX];
 #pragma unroll
             for (int q = 0; q < PX; ++q) {
                 const int x = g * PX + q;
-                const u64 key = zrow_lds[x];
+                const int slot = SWZ ? q * (W >> 2) + g : x;              // == zslot<SWZ>(x, W/4)
+                const u64 key = zrow_lds[slot];
                 const uint32_t rgb = (uint32_t)key & 0xFFFFFFu;
                 const bool covered = key != kEmpty64;
                 const bool hole = !covered || rgb == a.key_rgb;       // sr:740 colour-key compare
                 uint32_t out = hole ? 0u : rgb;                       // sr:793
                 if (EDGE && hole) {
-                    const uint32_t ek = eb[(size_t)eye * W + x];
+                    const uint32_t ek = eb[(size_t)eye * W + slot];
                     if (ek != kEmpty32) {
                         // colour of source column (ek & 0xFFFF) of this row (sr:813-814)
                         out = load_px_bytes(crow, (int)(ek & 0xFFFFu));
@@ -762,17 +814,19 @@ size_t render_lds_bytes(const RenderPlan& plan, int W)
     return b;
 }
 
-template <int PX>
-static hipError_t launch_points_rows(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+template <int PX, int TPB, int ITERS, int SWZ>
+static hipError_t launch_points_rows_cfg(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const size_t lds = render_lds_bytes(plan, a.W);
-    const dim3 grid((unsigned)(plan.n * a.H)), block(256);
+    const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
     const bool zout = a.zout[0] || a.zout[1];
     const int flags = (zout ? 1 : 0) | (plan.remove_edges ? 2 : 0) | (plan.remove_edges && plan.edge_points ? 4 : 0);
 #define MDVT_CASE(F)                                                                                   \
     case F:                                                                                            \
-        (void)hipFuncSetAttribute((const void*)k_points_rows<PX, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_points_rows<PX, F>), grid, block, lds, s, a);                            \
+        if (lds > 48 * 1024)                                                                           \
+            (void)hipFuncSetAttribute((const void*)k_points_rows<PX, F, TPB, ITERS, SWZ>,                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        hipLaunchKernelGGL((k_points_rows<PX, F, TPB, ITERS, SWZ>), grid, block, lds, s, a);                \
         break;
     switch (flags) {
         MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(2) MDVT_CASE(3) MDVT_CASE(6) MDVT_CASE(7)
@@ -780,6 +834,40 @@ static hipError_t launch_points_rows(const RenderPlan& plan, const RenderArgs& a
     }
 #undef MDVT_CASE
     return hipGetLastError();
+}
+
+// Tuning override for experiments: MDVT_POINTS_CFG = "<TPB>x<ITERS>[s]" (e.g. 512x1, 256x2s; s = swizzled
+// LDS slots).  Re-read on every launch so one process can A/B configurations.
+static int points_cfg_override()
+{
+    const char* e = getenv("MDVT_POINTS_CFG");
+    int t = 0, it = 0;
+    if (e && sscanf(e, "%dx%d", &t, &it) == 2) return (t * 16 + it) * 2 + (strchr(e, 's') ? 1 : 0);
+    return 0;
+}
+
+static hipError_t launch_points_rows_vec4(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+{
+    const int ngroups = a.W / 4;
+    int cfg = points_cfg_override();
+    if (cfg == 0 || ((cfg / 2) % 16 != 0 && ((cfg / 2) / 16) * ((cfg / 2) % 16) < ngroups)) {
+        int c;
+        if (ngroups <= 256) c = 256 * 16 + 1;
+        else if (ngroups <= 512) c = 512 * 16 + 1;        // 1080p: measured best (tools/kbench.py)
+        else if (ngroups <= 1024) c = 512 * 16 + 2;
+        else if (ngroups <= 2048) c = 1024 * 16 + 2;
+        else c = 256 * 16 + 0;
+        cfg = c * 2 + 0;
+    }
+#define MDVT_CFG(T, I)                                                                         \
+    case (T * 16 + I) * 2: return launch_points_rows_cfg<4, T, I, 0>(plan, a, s);              \
+    case (T * 16 + I) * 2 + 1: return launch_points_rows_cfg<4, T, I, 1>(plan, a, s);
+    switch (cfg) {
+        MDVT_CFG(128, 4) MDVT_CFG(256, 1) MDVT_CFG(256, 2) MDVT_CFG(512, 1) MDVT_CFG(512, 2) MDVT_CFG(1024, 2)
+        MDVT_CFG(256, 0)
+        default: return launch_points_rows_cfg<4, 256, 0, 0>(plan, a, s);
+    }
+#undef MDVT_CFG
 }
 
 static hipError_t launch_points_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
@@ -866,7 +954,7 @@ hipError_t launch_render(const RenderPlan& plan, const RenderArgs& a, hipStream_
 {
     if (plan.mode == MDVT_MODE_POINTS) {
         if (plan.general) return launch_points_general(plan, a, s);
-        return plan.vec4 ? launch_points_rows<4>(plan, a, s) : launch_points_rows<1>(plan, a, s);
+        return plan.vec4 ? launch_points_rows_vec4(plan, a, s) : launch_points_rows_cfg<1, 256, 0, 0>(plan, a, s);
     }
     if (plan.general) return launch_mesh_general(plan, a, s);
     return plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);

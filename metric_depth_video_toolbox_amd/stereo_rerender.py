@@ -96,6 +96,25 @@ def make_frame_params(W, H, xfov=None, yfov=None, *, master_xfov=45.0, pupillary
 # ------------------------------------------------------------------------------------------------
 # renderer
 # ------------------------------------------------------------------------------------------------
+class PreparedRender:
+    """One pre-validated submission: launch() = one mdvt_render_stereo_batch call on a stream."""
+
+    def __init__(self, renderer, n, params_arr, io, results, keepalive, device):
+        self._fn = renderer._L.mdvt_render_stereo_batch
+        self._check = renderer.ctx.check
+        self._h = renderer.ctx.handle
+        self._n, self._arr, self._io, self._ioref = n, params_arr, io, C.byref(io)
+        self.results = results
+        self._keep = keepalive
+        self._device = device
+        self._torch = renderer.torch
+
+    def launch(self, stream=None):
+        s = stream if stream is not None else self._torch.cuda.current_stream(self._device)
+        self._check(self._fn(self._h, self._n, self._arr, self._ioref, C.c_void_p(s.cuda_stream)))
+        return self.results
+
+
 class StereoRerenderer:
     """One render context for W x H frames on one GPU.
 
@@ -149,11 +168,11 @@ class StereoRerenderer:
                                  convergence_distance=convergence_distance, transformation=transformation)
 
     # -- the per-frame loop body, batched -----------------------------------------------------
-    def render(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
-               out_depth=None, stream=None):
-        """depth_rgb, color_rgb: uint8 device tensors [N,H,W,3] (or [H,W,3]); params: one
-        MdvtFrameParams or a sequence of N.  Returns dict(sbs=[N,H,2W,3] u8 (left | right, sr:918),
-        mask=[N,H,2W] u8 (255 = hole), depth=[N,H,2W] f32 (optional; 0 = background))."""
+    def prepare(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
+                out_depth=None):
+        """Validate once and pack everything one submission needs (buffer table, parameter records).
+        Returns a PreparedRender whose launch() is a single C-ABI call -- use it when the same buffers
+        are rendered into repeatedly (streaming loops, benchmarks)."""
         torch = self.torch
         single = depth_rgb.dim() == 3
         if single:
@@ -163,13 +182,11 @@ class StereoRerenderer:
             "color image and depth image need to have same width and height"          # sr:507
         assert depth_rgb.dtype == torch.uint8 and color_rgb.dtype == torch.uint8
         assert depth_rgb.is_cuda and color_rgb.is_cuda and depth_rgb.is_contiguous() and color_rgb.is_contiguous()
-        if isinstance(params, _lib.MdvtFrameParams):
-            params = [params] * N
-        if len(params) != N:
-            raise ValueError(f"need {N} frame parameter records, got {len(params)}")
+        arr = self.pack_params(params, N)
         dev = depth_rgb.device
         sbs = out_sbs if out_sbs is not None else torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=dev)
         mask = out_mask if out_mask is not None else torch.empty((N, H, 2 * W), dtype=torch.uint8, device=dev)
+        assert tuple(sbs.shape[-3:]) == (H, 2 * W, 3) and tuple(mask.shape[-2:]) == (H, 2 * W)
         zout = None
         if want_depth:
             zout = out_depth if out_depth is not None else torch.empty((N, H, 2 * W), dtype=torch.float32, device=dev)
@@ -184,13 +201,32 @@ class StereoRerenderer:
         if zout is not None:
             io.left_depth, io.right_depth = zout.data_ptr(), zout.data_ptr() + 4 * W
             io.zout_pitch, io.zout_stride = 8 * W, 8 * W * H
-        arr = (_lib.MdvtFrameParams * N)(*params)
-        s = stream if stream is not None else torch.cuda.current_stream(dev)
-        self.ctx.check(self._L.mdvt_render_stereo_batch(self.ctx.handle, N, arr, C.byref(io), C.c_void_p(s.cuda_stream)))
         res = {"sbs": sbs[0] if single else sbs, "mask": mask[0] if single else mask}
         if zout is not None:
             res["depth"] = zout[0] if single else zout
-        return res
+        return PreparedRender(self, N, arr, io, res, (depth_rgb, color_rgb, sbs, mask, zout), dev)
+
+    def render(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
+               out_depth=None, stream=None):
+        """depth_rgb, color_rgb: uint8 device tensors [N,H,W,3] (or [H,W,3]); params: one
+        MdvtFrameParams or a sequence of N.  Returns dict(sbs=[N,H,2W,3] u8 (left | right, sr:918),
+        mask=[N,H,2W] u8 (255 = hole), depth=[N,H,2W] f32 (optional; 0 = background))."""
+        return self.prepare(depth_rgb, color_rgb, params, out_sbs=out_sbs, out_mask=out_mask,
+                            want_depth=want_depth, out_depth=out_depth).launch(stream)
+
+    @staticmethod
+    def pack_params(params, n_frames: int):
+        """One record, a sequence of N records, or an already packed ctypes array -> ctypes array of N.
+        Pack once and pass the array to render() to keep the per-call host cost off the launch path."""
+        if isinstance(params, C.Array):
+            if len(params) != n_frames:
+                raise ValueError(f"need {n_frames} frame parameter records, got {len(params)}")
+            return params
+        if isinstance(params, _lib.MdvtFrameParams):
+            params = [params] * n_frames
+        if len(params) != n_frames:
+            raise ValueError(f"need {n_frames} frame parameter records, got {len(params)}")
+        return (_lib.MdvtFrameParams * n_frames)(*params)
 
     def edge_filter(self, depth_rgb, params, of_by_one: Optional[bool] = None, stream=None):
         """The filter part of dmt.get_mesh_from_depth_map(remove_edges=True) for one frame:

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""In-process A/B timing of kernel configurations (env MDVT_POINTS_CFG is re-read per launch).
+usage: python tools/kbench.py cfgA cfgB ... [--rounds R] [--calls C] [--mode points|mesh]"""
+import os, sys, argparse, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+if os.environ.get('KB_DIST'):
+    import torch.distributed as dist
+    print('dist imported', dist.is_available())
+if os.environ.get('KB_SETDEV'):
+    torch.cuda.set_device(0)
+from metric_depth_video_toolbox_amd.stereo_rerender import StereoRerenderer
+from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
+
+ap = argparse.ArgumentParser()
+ap.add_argument("cfgs", nargs="+")
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--calls", type=int, default=10)
+ap.add_argument("--frames", type=int, default=32)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--env", default="MDVT_POINTS_CFG")
+ap.add_argument("--mesh", action="store_true")
+ap.add_argument("--infill", action="store_true")
+ap.add_argument("--zout", action="store_true")
+a = ap.parse_args()
+W, H, N = a.width, a.height, a.frames
+if os.environ.get('KB_ORDER'):
+    r = StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not a.mesh, infill_mask=a.infill)
+    d, c = SyntheticScene(W, H, config_id=2).clip(N)
+    d, c = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+else:
+    d, c = SyntheticScene(W, H, config_id=2).clip(N)
+    d, c = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    r = StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not a.mesh, infill_mask=a.infill)
+p = [r.frame_params(xfov=45.0)] * N
+sbs = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device="cuda")
+mask = torch.empty((N, H, 2 * W), dtype=torch.uint8, device="cuda")
+zo = torch.empty((N, H, 2 * W), dtype=torch.float32, device="cuda") if a.zout else None
+job = r.prepare(d, c, p, out_sbs=sbs, out_mask=mask, want_depth=a.zout, out_depth=zo)
+stream = torch.cuda.current_stream()
+def run():
+    job.launch(stream)
+res = {k: [] for k in a.cfgs}
+for k in a.cfgs:
+    os.environ[a.env] = k; run()
+torch.cuda.synchronize()
+for _ in range(a.rounds):
+    for k in a.cfgs:
+        os.environ[a.env] = k
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.calls): run()
+        e1.record(); torch.cuda.synchronize()
+        res[k].append(e0.elapsed_time(e1) / a.calls * 1e3)
+bpp = 14 + (8 if a.zout else 0)
+for k in a.cfgs:
+    med = statistics.median(res[k])
+    print(f"{k:>10s}: median {med:7.1f} us  min {min(res[k]):7.1f}  ->  {bpp*W*H*N/med/1e6:.2f} TB/s  ({N*1e6/med:.0f} fps)")
