@@ -1,0 +1,240 @@
+"""Clip-level driver: the counterpart of the reference's whole `stereo_rerender.py` run (sr:318-968)
+for frame dumps, with frames streamed through the GPU in batches and sharded over ranks.
+
+On-disk formats.  The reference reads/writes FFV1-in-MKV through OpenCV (sr:327-341, 435-444, 941);
+a device-side FFV1 codec is out of scope, so this driver works on raw frame dumps:
+
+  <name>.npy            uint8 [N, H, W, 3]  RGB frames (np.load(..., mmap_mode="r") compatible)
+  depth dump            the same layout holding the 16-bit RGB depth code of dfh:48-61 (RGB order)
+  <depth>_stereo.npy    uint8 [N, H, 2W, 3] left | right (sr:918), written as <depth>_tmp_stereo.npy and
+                        renamed only when every frame was written (the reference's verify_and_move,
+                        dfh:163-179)
+  <depth>_stereo.npy_holemask.npy   uint8 [N, H, 2W]   255 = hole (sr:740 / 854)
+  <depth>_stereo.npy_depth.npy      uint8 [N, H, 2W, 3] B,G,R 16-bit depth code of both eyes (sr:930-939)
+
+Side-cars are the reference's own JSON formats: xfov list (sr:351-359), convergence list with NaNs
+(sr:343-349), transformations list of 4x4 (sr:362-373).
+
+Pipelining: per batch, H2D on a copy stream from pinned staging -> render on the compute stream ->
+D2H on a second copy stream into pinned staging; two staging sets alternate, HIP events order them.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import distributed as D
+from .stereo_rerender import StereoRerenderer, curve_fit, fill_nan_with_closest
+
+
+def load_clip_parameters(n_frames: int, W: int, H: int, *, xfov=None, xfov_file=None, convergence_file=None,
+                         transformation_file=None, transformation_lock_frame: int = 0, pupillary_distance=63,
+                         max_depth=100, master_xfov: float = 45.0, render_as_pointcloud=False, remove_edges=False,
+                         infill_mask=False, dont_place_points_in_edges=False) -> D.ClipParameters:
+    """What sr:318-373 does before the loop, on rank 0."""
+    if xfov is None and xfov_file is None:
+        raise ValueError("Error: Either --xfov_file, --xfov or --yfov must be provided.")            # sr:319-320
+    if xfov_file is not None:
+        if not os.path.isfile(xfov_file):
+            raise FileNotFoundError(f"XFOV file not found: {xfov_file}")
+        with open(xfov_file) as fh:
+            xf = json.load(fh)
+        if not isinstance(xf, list) or not all(isinstance(x, (int, float)) for x in xf):
+            raise ValueError("XFOV file must contain a list of numbers.")                             # sr:358-359
+        if len(xf) != n_frames:
+            raise ValueError(f"XFOV file must have the same number of frames as the input video ({n_frames} vs xfov={len(xf)}).")
+        xfovs = np.asarray(xf, np.float64)
+    else:
+        xfovs = np.full(n_frames, float(xfov))
+    conv = np.zeros(n_frames)
+    if convergence_file is not None:
+        if not os.path.isfile(convergence_file):
+            raise FileNotFoundError(f"Convergence file not found: {convergence_file}")
+        with open(convergence_file) as fh:
+            vals = fill_nan_with_closest([float(v) for v in json.load(fh)])                            # sr:348
+        conv = np.asarray(curve_fit(vals), np.float64)                                                 # sr:349
+        if len(conv) != n_frames:
+            raise ValueError("convergence file must have one value per frame")
+    T = None
+    if transformation_file is not None:
+        if not os.path.isfile(transformation_file):
+            raise Exception("input transformation_file does not exist")                                # sr:364-365
+        with open(transformation_file) as fh:
+            T = D.rebase_on_lock_frame(json.load(fh), transformation_lock_frame)                        # sr:369-373
+        if len(T) < n_frames:
+            raise ValueError("transformation file has fewer entries than frames")
+        T = T[:n_frames]
+    rm = bool(infill_mask or remove_edges)
+    flags = (1 if render_as_pointcloud else 0) | (2 if rm else 0) | (4 if (rm and not dont_place_points_in_edges) else 0) \
+        | (8 if infill_mask else 0)
+    return D.ClipParameters(W, H, n_frames, pupillary_distance / 1000, float(max_depth), float(master_xfov), flags,
+                            xfovs, conv, T)
+
+
+def renderer_for(clip: D.ClipParameters, device: Optional[int] = None) -> StereoRerenderer:
+    f = clip.mode_flags
+    pd = clip.ipd_m * 1000
+    if abs(pd - round(pd)) < 1e-9:
+        pd = int(round(pd))                     # --pupillary_distance is an int in mm (sr:288)
+    return StereoRerenderer(clip.W, clip.H, device=device, pupillary_distance=pd,
+                            max_depth=clip.max_depth, master_xfov=clip.master_xfov,
+                            render_as_pointcloud=bool(f & 1), remove_edges=bool(f & 2) and not bool(f & 8),
+                            infill_mask=bool(f & 8), dont_place_points_in_edges=not bool(f & 4))
+
+
+def frame_param_records(r: StereoRerenderer, clip: D.ClipParameters, lo: int, hi: int):
+    out = []
+    for t in range(lo, hi):
+        cd = float(clip.convergence[t])
+        out.append(r.frame_params(xfov=float(clip.xfov[t]),
+                                  convergence_distance=None if (cd == 0.0 or math.isnan(cd)) else cd,
+                                  transformation=None if clip.transformations is None else clip.transformations[t]))
+    return out
+
+
+def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParameters, *, lo: int = 0,
+                hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, device: Optional[int] = None):
+    """Render frames [lo, hi) of a clip.  depth_frames / color_frames / out_*: array-likes indexed
+    [frame] (NumPy arrays or memmaps, uint8).  Returns (frames, seconds, hole_pixels)."""
+    import time
+    import torch
+    from . import depth_frames_helper as dfh
+
+    hi = clip.n_frames if hi is None else hi
+    W, H = clip.W, clip.H
+    r = renderer_for(clip, device)
+    dev = torch.device("cuda", r.device)
+    recs = frame_param_records(r, clip, lo, hi)
+    B = max(1, min(batch, hi - lo))
+    want_z = out_depth_rgb is not None
+
+    def pinned(shape, dtype):
+        return torch.empty(shape, dtype=dtype, pin_memory=True)
+
+    sets = []
+    for _ in range(2):
+        sets.append({
+            "h_d": pinned((B, H, W, 3), torch.uint8), "h_c": pinned((B, H, W, 3), torch.uint8),
+            "h_sbs": pinned((B, H, 2 * W, 3), torch.uint8), "h_mask": pinned((B, H, 2 * W), torch.uint8),
+            "h_zrgb": pinned((B, H, 2 * W, 3), torch.uint8) if want_z else None,
+            "d_d": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
+            "d_c": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
+            "d_sbs": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev),
+            "d_mask": torch.empty((B, H, 2 * W), dtype=torch.uint8, device=dev),
+            "d_z": torch.empty((B, H, 2 * W), dtype=torch.float32, device=dev) if want_z else None,
+            "d_zrgb": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if want_z else None,
+            "in_done": torch.cuda.Event(), "render_done": torch.cuda.Event(), "out_done": torch.cuda.Event(),
+            "pending": None,
+        })
+    s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    s_cmp = torch.cuda.current_stream(dev)
+    holes = 0
+
+    def drain(st):
+        nonlocal holes
+        if st["pending"] is None:
+            return
+        a, n = st["pending"]
+        st["out_done"].synchronize()
+        out_sbs[a:a + n] = st["h_sbs"][:n].numpy()
+        m = st["h_mask"][:n].numpy()
+        out_mask[a:a + n] = m
+        holes += int(np.count_nonzero(m))
+        if want_z:
+            out_depth_rgb[a:a + n] = st["h_zrgb"][:n].numpy()
+        st["pending"] = None
+
+    t0 = time.perf_counter()
+    k = 0
+    for a in range(lo, hi, B):
+        n = min(B, hi - a)
+        st = sets[k % 2]
+        k += 1
+        drain(st)                                   # this staging set's previous batch must have left
+        st["h_d"][:n].numpy()[...] = depth_frames[a:a + n]
+        st["h_c"][:n].numpy()[...] = color_frames[a:a + n]
+        with torch.cuda.stream(s_in):
+            s_in.wait_event(st["render_done"])      # device inputs free again
+            st["d_d"][:n].copy_(st["h_d"][:n], non_blocking=True)
+            st["d_c"][:n].copy_(st["h_c"][:n], non_blocking=True)
+            st["in_done"].record(s_in)
+        s_cmp.wait_event(st["in_done"])
+        s_cmp.wait_event(st["out_done"])            # device outputs free again
+        r.render(st["d_d"][:n], st["d_c"][:n], recs[a - lo:a - lo + n], out_sbs=st["d_sbs"][:n],
+                 out_mask=st["d_mask"][:n], want_depth=want_z, out_depth=st["d_z"][:n] if want_z else None)
+        if want_z:                                  # sr:930-939: both eyes through the 16-bit code, B,G,R
+            for f in range(n):
+                dfh.encode_depth_frame(st["d_z"][f], clip.max_depth, bgr=True, out=st["d_zrgb"][f])
+        st["render_done"].record(s_cmp)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(st["render_done"])
+            st["h_sbs"][:n].copy_(st["d_sbs"][:n], non_blocking=True)
+            st["h_mask"][:n].copy_(st["d_mask"][:n], non_blocking=True)
+            if want_z:
+                st["h_zrgb"][:n].copy_(st["d_zrgb"][:n], non_blocking=True)
+            st["out_done"].record(s_out)
+        st["pending"] = (a, n)
+    for st in sets:
+        drain(st)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    r.close()
+    return hi - lo, dt, holes
+
+
+def verify_and_move(tmp_path: str, expected_frames: int, final_path: str):
+    """The reference's tmp -> final protocol (dfh:163-179): rename only if the frame count matches."""
+    arr = np.load(tmp_path, mmap_mode="r")
+    if arr.shape[0] != expected_frames:
+        raise RuntimeError(f"{tmp_path}: {arr.shape[0]} frames written, expected {expected_frames}; left in place")
+    del arr
+    os.replace(tmp_path, final_path)
+
+
+def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_sbs_depth_video: bool = False,
+        max_frames: int = -1, **clip_kwargs):
+    """File-level entry (what `python stereo_rerender.py --depth_video ...` is to the reference).
+    Multi-process aware: under torchrun every rank renders its own contiguous frame range."""
+    rank, world = D.init_process_group()
+    depth = np.load(depth_path, mmap_mode="r")
+    color = depth if color_path is None else np.load(color_path, mmap_mode="r")                        # sr:508-509
+    if depth.ndim != 4 or depth.shape[3] != 3 or depth.dtype != np.uint8:
+        raise ValueError("depth dump must be uint8 [N, H, W, 3]")
+    if color.shape != depth.shape:
+        raise ValueError(f"Depth video and Color video must have the same dimensions "
+                         f"(Depth: {depth.shape[2]}x{depth.shape[1]} vs Color {color.shape[2]}x{color.shape[1]}).")   # sr:387-388
+    N, H, W = depth.shape[:3]
+    if max_frames >= 0:
+        N = min(N, max_frames)      # the reference processes max_frames+1 and then fails its own check: dropped
+    clip = load_clip_parameters(N, W, H, **clip_kwargs) if rank == 0 else None
+    clip = D.broadcast_clip_parameters(clip, src=0)
+    final = depth_path + "_stereo.npy"
+    tmp = depth_path + "_tmp_stereo.npy"
+    names = {"sbs": (tmp, final, (N, H, 2 * W, 3)),
+             "mask": (tmp + "_holemask.npy", final + "_holemask.npy", (N, H, 2 * W))}
+    if create_sbs_depth_video:
+        names["depth"] = (tmp + "_depth.npy", final + "_depth.npy", (N, H, 2 * W, 3))
+    if rank == 0:
+        for t, _, shape in names.values():
+            np.lib.format.open_memmap(t, mode="w+", dtype=np.uint8, shape=shape).flush()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    outs = {k: np.load(v[0], mmap_mode="r+") for k, v in names.items()}
+    lo, hi = D.frame_range(rank, world, N)
+    frames, secs, holes = render_clip(depth, color, outs["sbs"], outs["mask"], clip, lo=lo, hi=hi, batch=batch,
+                                      out_depth_rgb=outs.get("depth"))
+    for o in outs.values():
+        o.flush()
+    stats = D.gather_rank_stats(frames, secs, holes)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    if rank == 0:
+        for t, f, _ in names.values():
+            verify_and_move(t, N, f)
+    return stats, final

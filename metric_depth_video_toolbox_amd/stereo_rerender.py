@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -248,3 +249,71 @@ class StereoRerenderer:
 
     def close(self):
         self.ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# command line (the reference's flags, sr:273-316, for raw frame dumps -- see clip.py)
+# ------------------------------------------------------------------------------------------------
+def build_arg_parser():
+    import argparse
+    ap = argparse.ArgumentParser(description="Convert an RGB-encoded depth frame dump and optional colour frame dump "
+                                             "into a stereoscopic side-by-side output on MI355X GPUs.")
+    ap.add_argument("--master_xfov", type=float, default=45.0)
+    ap.add_argument("--depth_video", type=str, required=True, help="uint8 [N,H,W,3] .npy dump of the RGB-coded depth frames")
+    ap.add_argument("--color_video", type=str, required=False, help="uint8 [N,H,W,3] .npy dump of the colour frames")
+    ap.add_argument("--xfov", type=float, required=False)
+    ap.add_argument("--yfov", type=float, required=False)
+    ap.add_argument("--xfov_file", type=str, required=False)
+    ap.add_argument("--max_depth", default=100, type=int)
+    ap.add_argument("--transformation_file", type=str, required=False)
+    ap.add_argument("--transformation_lock_frame", default=0, type=int)
+    ap.add_argument("--pupillary_distance", default=63, type=int)
+    ap.add_argument("--max_frames", default=-1, type=int)
+    ap.add_argument("--render_as_pointcloud", action="store_true")
+    ap.add_argument("--convergence_file", type=str, required=False)
+    ap.add_argument("--dont_place_points_in_edges", action="store_true")
+    ap.add_argument("--dont_remove_edges", action="store_true")
+    ap.add_argument("--infill_mask", action="store_true")
+    ap.add_argument("--remove_edges", action="store_true")
+    ap.add_argument("--create_sbs_depth_video", action="store_true")
+    ap.add_argument("--batch", default=16, type=int, help="frames per GPU submission")
+    for flag in ("--touchly0", "--touchly1", "--vr180", "--do_basic_infill", "--compressed", "--mask_video",
+                 "--save_background", "--load_background", "--green_and_black_infill_mask"):
+        ap.add_argument(flag, nargs="?", const=True, default=None, help="reference flag outside the built hot path")
+    return ap
+
+
+def main(argv=None):
+    from . import clip
+    args = build_arg_parser().parse_args(argv)
+    for flag in ("touchly0", "touchly1", "vr180", "do_basic_infill", "compressed", "mask_video", "save_background",
+                 "load_background"):
+        if getattr(args, flag) is not None:
+            raise NotImplementedError(f"--{flag} is outside the hot path this build covers (DESIGN.md section 1)")
+    if args.xfov is None and args.yfov is None and args.xfov_file is None:
+        raise ValueError("Error: Either --xfov_file, --xfov or --yfov must be provided.")       # sr:319-320
+    if args.xfov is None and args.xfov_file is None:
+        raise NotImplementedError("--yfov without --xfov: the reference itself fails at sr:537 in this case")
+    if not os.path.isfile(args.depth_video):
+        raise FileNotFoundError(f"Depth video not found: {args.depth_video}")                  # sr:326
+    if args.color_video and not os.path.isfile(args.color_video):
+        raise FileNotFoundError(f"Color video not found: {args.color_video}")                  # sr:331
+    stats, final = clip.run(args.depth_video, args.color_video, batch=args.batch,
+                            create_sbs_depth_video=args.create_sbs_depth_video, max_frames=args.max_frames,
+                            xfov=args.xfov, xfov_file=args.xfov_file, convergence_file=args.convergence_file,
+                            transformation_file=args.transformation_file,
+                            transformation_lock_frame=args.transformation_lock_frame,
+                            pupillary_distance=args.pupillary_distance, max_depth=args.max_depth,
+                            master_xfov=args.master_xfov, render_as_pointcloud=args.render_as_pointcloud,
+                            remove_edges=(args.remove_edges and not args.dont_remove_edges),
+                            infill_mask=(args.infill_mask and not args.dont_remove_edges),
+                            dont_place_points_in_edges=args.dont_place_points_in_edges)
+    if int(os.environ.get("RANK", "0")) == 0:
+        frames, secs = float(stats[:, 0].sum()), float(stats[:, 1].max())
+        print(f"Processing complete. Output saved to: {final}  ({frames:.0f} frames, {frames / secs:.1f} frames/s incl. host I/O)")
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

@@ -1,0 +1,108 @@
+"""GPU tests of the clip-level driver (BASELINE configs C3 / C4 shapes at test sizes + one 4K frame):
+streamed batches, per-frame side-car parameters, SBS depth dump, z-buffer contention stressor."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def mods():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from metric_depth_video_toolbox_amd import clip, stereo_rerender, synthetic
+    return clip, stereo_rerender, synthetic
+
+
+def _oracle_frame(orc, clipp, r, rec, d, c, T):
+    K = np.array([rec.K[k] for k in range(9)]).reshape(3, 3)
+    op = orc.make_params(clipp.W, clipp.H, K, ipd_m=clipp.ipd_m, max_depth=clipp.max_depth, depth_scale=rec.depth_scale,
+                         mode=orc.MODE_POINTS if r.mode == 0 else orc.MODE_MESH, remove_edges=r.remove_edges,
+                         edge_points=r.edge_points, conv_angle=rec.convergence_angle, T=T, key_rgb=r.key_rgb)
+    return orc.render_stereo(op, d, c, want_depth=True)
+
+
+@pytest.mark.parametrize("variant", ["plain_points", "mesh_infill_sidecars"])
+def test_clip_through_files(mods, orc, tmp_path, variant):
+    clip, sr, synthetic = mods
+    W, H, N = 192, 108, 23
+    d, c = synthetic.SyntheticScene(W, H, config_id=3, n_fg=6).clip(N)
+    dp, cp = str(tmp_path / "clip_depth.npy"), str(tmp_path / "clip_color.npy")
+    np.save(dp, d); np.save(cp, c)
+    kw = dict(pupillary_distance=65, render_as_pointcloud=True, xfov=45.0)
+    if variant == "mesh_infill_sidecars":
+        xf = [44.0 + 0.25 * k for k in range(N)]
+        conv = [2.0 + 0.05 * k for k in range(N)]
+        conv[0] = conv[5] = conv[6] = float("nan")
+        T = synthetic.synthetic_pose_track(N)
+        (tmp_path / "xfov.json").write_text(json.dumps(xf))
+        (tmp_path / "conv.json").write_text(json.dumps(conv))
+        (tmp_path / "T.json").write_text(json.dumps(T.tolist()))
+        kw = dict(pupillary_distance=63, xfov_file=str(tmp_path / "xfov.json"), convergence_file=str(tmp_path / "conv.json"),
+                  transformation_file=str(tmp_path / "T.json"), transformation_lock_frame=4, infill_mask=True)
+    stats, final = clip.run(dp, cp, batch=5, create_sbs_depth_video=True, **kw)
+    assert final == dp + "_stereo.npy" and os.path.exists(final) and not os.path.exists(dp + "_tmp_stereo.npy")
+    assert stats.shape == (1, 3) and stats[0, 0] == N
+    sbs, mask, zrgb = np.load(final), np.load(final + "_holemask.npy"), np.load(final + "_depth.npy")
+    assert sbs.shape == (N, H, 2 * W, 3) and mask.shape == (N, H, 2 * W) and zrgb.shape == (N, H, 2 * W, 3)
+    cl = clip.load_clip_parameters(N, W, H, **kw)
+    r = clip.renderer_for(cl)
+    recs = clip.frame_param_records(r, cl, 0, N)
+    for t in range(N):
+        T = None if cl.transformations is None else cl.transformations[t]
+        want = _oracle_frame(orc, cl, r, recs[t], d[t], c[t], T)
+        assert np.array_equal(mask[t][:, :W], want["left_mask"]) and np.array_equal(mask[t][:, W:], want["right_mask"]), t
+        assert np.array_equal(sbs[t][:, :W], want["left_rgb"]) and np.array_equal(sbs[t][:, W:], want["right_rgb"]), t
+        for sl, key in ((slice(0, W), "left_depth"), (slice(W, 2 * W), "right_depth")):
+            assert np.array_equal(zrgb[t][:, sl][..., ::-1], orc.encode_depth(want[key], cl.max_depth)), t   # sr:930-936, B,G,R
+    assert int(stats[0, 2]) == int(np.count_nonzero(mask))
+    r.close()
+
+
+def test_4k_pose_driven_with_contention_band(mods, orc):
+    """BASELINE config C4's shape: 3840x2160, pose-driven novel view, a band where ~512 sources fold onto
+    one or two target pixels (z-buffer atomic contention)."""
+    clip, sr, synthetic = mods
+    W, H = 3840, 2160
+    sc = synthetic.SyntheticScene(W, H, config_id=4)
+    from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
+    K = compute_camera_matrix(45.0, None, W, H)
+    z = synthetic.contention_band(sc.depth_m(0), K[0, 0], 0.065, row0=1000, rows=64)
+    depth_rgb = synthetic.quantise_depth_to_rgb(z)
+    _, color = sc.frame(0)
+    T = synthetic.synthetic_pose_track(60)[50]
+    for pose in (None, T):
+        r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True)
+        p = r.frame_params(xfov=45.0, transformation=pose)
+        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+        op = orc.make_params(W, H, K, ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_POINTS, T=pose)
+        want = orc.render_stereo(op, depth_rgb, color, want_depth=True)
+        sbs, mask, zz = got["sbs"].cpu().numpy(), got["mask"].cpu().numpy(), got["depth"].cpu().numpy()
+        assert np.array_equal(mask[:, :W], want["left_mask"]) and np.array_equal(mask[:, W:], want["right_mask"])
+        assert np.array_equal(sbs[:, :W], want["left_rgb"]) and np.array_equal(sbs[:, W:], want["right_rgb"])
+        assert np.array_equal(zz[:, :W], want["left_depth"]) and np.array_equal(zz[:, W:], want["right_depth"])
+        if pose is None:    # the stressor really folds: in the band, one left-eye column wins over hundreds of sources
+            band_holes = (mask[1000:1064, :W] > 0).sum(axis=1)
+            assert band_holes.min() > 300
+        r.close()
+
+
+def test_4k_mesh_pose_single_frame(mods, orc):
+    clip, sr, synthetic = mods
+    W, H = 3840, 2160
+    depth_rgb, color = synthetic.SyntheticScene(W, H, config_id=4).frame(0)
+    T = synthetic.synthetic_pose_track(60)[25]
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65)
+    p = r.frame_params(xfov=45.0, transformation=T)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p)
+    K = np.array([p.K[k] for k in range(9)]).reshape(3, 3)
+    op = orc.make_params(W, H, K, ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_MESH, T=T)
+    want = orc.render_stereo(op, depth_rgb, color)
+    sbs, mask = got["sbs"].cpu().numpy(), got["mask"].cpu().numpy()
+    assert np.array_equal(mask[:, :W], want["left_mask"]) and np.array_equal(mask[:, W:], want["right_mask"])
+    assert np.array_equal(sbs[:, :W], want["left_rgb"]) and np.array_equal(sbs[:, W:], want["right_rgb"])
+    r.close()

@@ -23,6 +23,8 @@ ap.add_argument("--env", default="MDVT_POINTS_CFG")
 ap.add_argument("--mesh", action="store_true")
 ap.add_argument("--infill", action="store_true")
 ap.add_argument("--zout", action="store_true")
+ap.add_argument("--conv", type=float, default=None)
+ap.add_argument("--pose", action="store_true")
 a = ap.parse_args()
 W, H, N = a.width, a.height, a.frames
 if os.environ.get('KB_ORDER'):
@@ -33,7 +35,9 @@ else:
     d, c = SyntheticScene(W, H, config_id=2).clip(N)
     d, c = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
     r = StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not a.mesh, infill_mask=a.infill)
-p = [r.frame_params(xfov=45.0)] * N
+from metric_depth_video_toolbox_amd.synthetic import synthetic_pose_track
+Ts = synthetic_pose_track(N) if a.pose else [None] * N
+p = [r.frame_params(xfov=45.0, convergence_distance=a.conv, transformation=Ts[k]) for k in range(N)]
 sbs = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device="cuda")
 mask = torch.empty((N, H, 2 * W), dtype=torch.uint8, device="cuda")
 zo = torch.empty((N, H, 2 * W), dtype=torch.float32, device="cuda") if a.zout else None
