@@ -1,0 +1,40 @@
+"""BASELINE config C5's plumbing: Depth-Anything-V2 (transformers class, seeded random weights -- no
+checkpoint is downloadable here) -> on-device 16-bit quantisation -> HIP reproject kernels, one stream."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_depth_model_feeds_the_render_kernels_on_one_stream(orc):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    pytest.importorskip("transformers")
+    from metric_depth_video_toolbox_amd import model_hop, stereo_rerender as sr, synthetic
+    W, H, N = 448, 252, 2
+    _, color = synthetic.SyntheticScene(W, H, config_id=5, n_fg=6).clip(N)
+    color_t = torch.from_numpy(color).cuda()
+    model = model_hop.build_depth_anything_v2("vits", max_depth=20, seed=7, num_layers=4)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, max_depth=20, render_as_pointcloud=True)
+    p = r.frame_params(xfov=45.0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                       # everything is enqueued on ONE (non-default) stream
+        res, depth_rgb = model_hop.color_to_stereo(model, color_t, r, p, input_height=252, want_depth=True)
+    side.synchronize()
+    code = depth_rgb.cpu().numpy()
+    assert code.shape == (N, H, W, 3) and np.array_equal(code[..., 0], code[..., 1])      # R == G (dfh:53-54)
+    # the quantiser is the reference codec: decode(encode(model depth)) is within one 16-bit LSB, one-sided
+    depth = model_hop.infer_depth(model, color_t, 252).cpu().numpy()
+    assert np.array_equal(code, np.stack([orc.encode_depth(depth[k], 20) for k in range(N)]))
+    back = np.stack([orc.decode_depth(code[k], 20) for k in range(N)])
+    err = depth.astype(np.float64) - back
+    assert err.min() > -1e-6 and err.max() < 20 * 65536 / 255 ** 4 + 1e-6
+    K = np.array([p.K[k] for k in range(9)]).reshape(3, 3)
+    op = orc.make_params(W, H, K, ipd_m=0.065, max_depth=20, depth_scale=p.depth_scale, mode=orc.MODE_POINTS)
+    for k in range(N):
+        want = orc.render_stereo(op, code[k], color[k], want_depth=True)
+        sbs, mask = res["sbs"][k].cpu().numpy(), res["mask"][k].cpu().numpy()
+        assert np.array_equal(mask[:, :W], want["left_mask"]) and np.array_equal(mask[:, W:], want["right_mask"])
+        assert np.array_equal(sbs[:, :W], want["left_rgb"]) and np.array_equal(sbs[:, W:], want["right_rgb"])
+    r.close()
