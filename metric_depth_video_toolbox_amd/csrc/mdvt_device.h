@@ -90,87 +90,103 @@ __device__ __forceinline__ Vert vertex_general(const FrameDev& f, const float* M
 }
 
 // ---- rasteriser pieces --------------------------------------------------------------------
-__device__ __forceinline__ i64 snap(float x)
+// Snapped coordinates are int32 (|x| <= 2^21 px * 256 = 2^29), so every coordinate difference fits
+// int32 and every product below is one 32x32->64 multiply (v_mad_i64_i32).
+__device__ __forceinline__ int snap(float x)
 {
     x = fminf(fmaxf(x, -kSnapLimit), kSnapLimit);
-    return (i64)rintf(x * (float)kSubpix);
-}
-
-__device__ __forceinline__ i64 floordiv_pos(i64 a, i64 b)   // b > 0
-{
-    i64 q = a / b;
-    if ((a % b) < 0) --q;
-    return q;
+    return (int)rintf(x * (float)kSubpix);
 }
 
 // floor division by the sub-pixel grid (power of two): arithmetic shift.
-__device__ __forceinline__ i64 floordiv_subpix(i64 a) { return a >> 8; }
+__device__ __forceinline__ int floordiv_subpix(int a) { return a >> 8; }
 static_assert(kSubpix == 256, "floordiv_subpix assumes a 1/256 grid");
 
-__device__ __forceinline__ bool edge_in(i64 w, i64 dx, i64 dy)
+__device__ __forceinline__ bool edge_in(i64 w, int dx, int dy)
 {
     if (w > 0) return true;
     if (w < 0) return false;
     return (dy < 0) || (dy == 0 && dx > 0);     // top-left rule, clockwise (y down)
 }
 
-// One triangle prepared for point-in-triangle queries on the sub-pixel grid.
+// One triangle prepared for point-in-triangle queries on the sub-pixel grid.  The three edge
+// functions are kept in the form  w_k(X, Y) = dx_k * (Y - Yk) - dy_k * (X - Xk)  with orientation-
+// normalised deltas (clockwise, y down), so a query is three 32x32->64 multiply-adds.
 struct TriSetup {
-    i64 X0, Y0, X1, Y1, X2, Y2;
-    i64 s;           // orientation sign; 0 = degenerate
-    float fa;        // (float)|area2|
+    int dx0, dy0, dx1, dy1, dx2, dy2;   // v1->v2 (weight of v0), v2->v0 (v1), v0->v1 (v2)
+    int bx0, by0, bx1, by1, bx2, by2;   // base point of each edge: v1, v2, v0
+    int minX, maxX, minY, maxY;         // snapped bounding box
+    i64 area2;                          // |area2|; 0 = degenerate / dropped
     float iz0, iz1, iz2;
 };
 
-__device__ __forceinline__ bool tri_setup(TriSetup& t, const Vert& a, const Vert& b, const Vert& c)
+__device__ __forceinline__ i64 mul64(int a, int b) { return (i64)a * (i64)b; }
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
+
+// iz_k = 1/Z_k of the three vertices; a vertex behind the near plane is flagged by iz == 0.
+__device__ __forceinline__ bool tri_setup_snapped(TriSetup& t, int X0, int Y0, float iz0, int X1, int Y1, float iz1,
+                                                  int X2, int Y2, float iz2)
 {
-    t.s = 0;
-    if (!(a.ok && b.ok && c.ok)) return false;          // near plane: whole triangle dropped
-    t.X0 = snap(a.u); t.Y0 = snap(a.v);
-    t.X1 = snap(b.u); t.Y1 = snap(b.v);
-    t.X2 = snap(c.u); t.Y2 = snap(c.v);
-    i64 area2 = (t.X1 - t.X0) * (t.Y2 - t.Y0) - (t.Y1 - t.Y0) * (t.X2 - t.X0);
-    if (area2 == 0) return false;
-    t.s = area2 > 0 ? 1 : -1;
-    area2 *= t.s;
-    t.fa = (float)area2;
-    t.iz0 = 1.0f / a.z; t.iz1 = 1.0f / b.z; t.iz2 = 1.0f / c.z;
+    t.area2 = 0;
+    if (!(iz0 > 0.0f && iz1 > 0.0f && iz2 > 0.0f)) return false;    // near plane: whole triangle dropped
+    const i64 a2 = mul64(X1 - X0, Y2 - Y0) - mul64(Y1 - Y0, X2 - X0);
+    if (a2 == 0) return false;
+    const bool neg = a2 < 0;
+    t.area2 = neg ? -a2 : a2;
+    t.dx0 = neg ? X1 - X2 : X2 - X1; t.dy0 = neg ? Y1 - Y2 : Y2 - Y1;
+    t.dx1 = neg ? X2 - X0 : X0 - X2; t.dy1 = neg ? Y2 - Y0 : Y0 - Y2;
+    t.dx2 = neg ? X0 - X1 : X1 - X0; t.dy2 = neg ? Y0 - Y1 : Y1 - Y0;
+    t.bx0 = X1; t.by0 = Y1; t.bx1 = X2; t.by1 = Y2; t.bx2 = X0; t.by2 = Y0;
+    t.minX = min3i(X0, X1, X2); t.maxX = max3i(X0, X1, X2);
+    t.minY = min3i(Y0, Y1, Y2); t.maxY = max3i(Y0, Y1, Y2);
+    t.iz0 = iz0; t.iz1 = iz1; t.iz2 = iz2;
     return true;
 }
 
-// Pixel (px,py) centre against the triangle: returns true and the three q = lambda*invz weights.
-__device__ __forceinline__ bool tri_sample(const TriSetup& t, i64 px, i64 py, float& q0, float& q1, float& q2)
+__device__ __forceinline__ bool tri_setup(TriSetup& t, const Vert& a, const Vert& b, const Vert& c)
 {
-    const i64 Xc = px * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
-    const i64 w0 = t.s * ((t.X2 - t.X1) * (Yc - t.Y1) - (t.Y2 - t.Y1) * (Xc - t.X1));
-    const i64 w1 = t.s * ((t.X0 - t.X2) * (Yc - t.Y2) - (t.Y0 - t.Y2) * (Xc - t.X2));
-    const i64 w2 = t.s * ((t.X1 - t.X0) * (Yc - t.Y0) - (t.Y1 - t.Y0) * (Xc - t.X0));
-    if (!(edge_in(w0, t.s * (t.X2 - t.X1), t.s * (t.Y2 - t.Y1)) &&
-          edge_in(w1, t.s * (t.X0 - t.X2), t.s * (t.Y0 - t.Y2)) &&
-          edge_in(w2, t.s * (t.X1 - t.X0), t.s * (t.Y1 - t.Y0))))
-        return false;
-    const float l0 = (float)w0 / t.fa, l1 = (float)w1 / t.fa, l2 = (float)w2 / t.fa;
+    return tri_setup_snapped(t, snap(a.u), snap(a.v), a.ok ? 1.0f / a.z : 0.0f, snap(b.u), snap(b.v),
+                             b.ok ? 1.0f / b.z : 0.0f, snap(c.u), snap(c.v), c.ok ? 1.0f / c.z : 0.0f);
+}
+
+// i64 -> f32, round to nearest even.  When the value fits int32 the single-instruction conversion
+// gives the same correctly rounded result.
+__device__ __forceinline__ float i64_to_f32(i64 w, bool fits32) { return fits32 ? (float)(int)w : (float)w; }
+
+// Pixel (px,py) centre against the triangle: returns true and the three q = lambda*invz weights.
+// lambda_k = f32(w_k) * (1/f32(area2)) (one division per call, only on covered pixels).
+__device__ __forceinline__ bool tri_sample(const TriSetup& t, int px, int py, float& q0, float& q1, float& q2)
+{
+    const int Xc = px * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
+    const i64 w0 = mul64(t.dx0, Yc - t.by0) - mul64(t.dy0, Xc - t.bx0);
+    const i64 w1 = mul64(t.dx1, Yc - t.by1) - mul64(t.dy1, Xc - t.bx1);
+    const i64 w2 = mul64(t.dx2, Yc - t.by2) - mul64(t.dy2, Xc - t.bx2);
+    if (!(edge_in(w0, t.dx0, t.dy0) && edge_in(w1, t.dx1, t.dy1) && edge_in(w2, t.dx2, t.dy2))) return false;
+    const bool small = t.area2 < 0x7FFFFFFFll;                            // 0 <= w_k <= area2 inside
+    const float ra = 1.0f / i64_to_f32(t.area2, small);
+    const float l0 = i64_to_f32(w0, small) * ra, l1 = i64_to_f32(w1, small) * ra, l2 = i64_to_f32(w2, small) * ra;
     q0 = l0 * t.iz0; q1 = l1 * t.iz1; q2 = l2 * t.iz2;
     return true;
 }
 
-// Perspective-correct colour of one channel, rounded half-even to u8 (decree).
-__device__ __forceinline__ uint32_t shade_channel(float q0, float q1, float q2, float iz,
+// Perspective-correct colour, rounded half-even to u8 (decree): rint(((q0 c0 + q1 c1) + q2 c2) * (1/iz)).
+__device__ __forceinline__ uint32_t shade_channel(float q0, float q1, float q2, float riz,
                                                   uint32_t c0, uint32_t c1, uint32_t c2)
 {
     const float num = (q0 * (float)c0 + q1 * (float)c1) + q2 * (float)c2;
-    float val = rintf(num / iz);
+    float val = rintf(num * riz);
     if (!(val >= 0.0f)) val = 0.0f;
     if (val > 255.0f) val = 255.0f;
     return (uint32_t)val;
 }
 
-__device__ __forceinline__ uint32_t shade_px(float q0, float q1, float q2, float iz,
+__device__ __forceinline__ uint32_t shade_px(float q0, float q1, float q2, float riz,
                                              uint32_t p0, uint32_t p1, uint32_t p2)
 {
-    const uint32_t r = shade_channel(q0, q1, q2, iz, p0 & 0xFF, p1 & 0xFF, p2 & 0xFF);
-    const uint32_t g = shade_channel(q0, q1, q2, iz, (p0 >> 8) & 0xFF, (p1 >> 8) & 0xFF, (p2 >> 8) & 0xFF);
-    const uint32_t b = shade_channel(q0, q1, q2, iz, p0 >> 16, p1 >> 16, p2 >> 16);
+    const uint32_t r = shade_channel(q0, q1, q2, riz, p0 & 0xFF, p1 & 0xFF, p2 & 0xFF);
+    const uint32_t g = shade_channel(q0, q1, q2, riz, (p0 >> 8) & 0xFF, (p1 >> 8) & 0xFF, (p2 >> 8) & 0xFF);
+    const uint32_t b = shade_channel(q0, q1, q2, riz, p0 >> 16, p1 >> 16, p2 >> 16);
     return r | (g << 8) | (b << 16);
 }
 

@@ -14,7 +14,7 @@ namespace mdvt {
 constexpr float kNear = 1e-4f;
 // Rasteriser sub-pixel grid and the clamp applied before snapping (DESIGN.md "Arithmetic decree").
 constexpr int kSubpix = 256;
-constexpr float kSnapLimit = 4194304.0f;
+constexpr float kSnapLimit = 2097152.0f;   // 2^21 px: snapped coordinates fit int32, differences too
 
 // Per-frame constants, derived on the host in f64 and rounded once (see fill_frame_dev()).
 struct FrameDev {

@@ -477,206 +477,250 @@ __global__ void __launch_bounds__(256) k_points_resolve_general(RenderArgs a)
 // =================================================================================================
 //
 // With v = grid_y (depth independent) every vertex row is a horizontal line on screen, so an output
-// scanline is covered by ONE row of grid cells (two when the scanline passes exactly through a vertex
-// row): the 2-D rasterisation collapses to interval coverage along x.  One thread per cell walks the
-// pixel centres inside the cell's two triangles for both eyes and posts
-//        key = ~bits(1/Z interpolated) << 32 | pass << 17 | rowsel << 16 | j
-// to the LDS z-buffer (min == nearest, ties to the earlier triangle in the reference's draw order:
-// all tri1 before all tri2, row-major inside, dmt:1243-1254).  The resolve phase re-evaluates the
-// winning triangle at the pixel centre and shades it perspective-correctly.
+// scanline k is covered by exactly ONE row of grid cells: the row c whose snapped span [Yt, Yb)
+// contains the scanline (a scanline lying exactly on a vertex row belongs to the cells below it: the
+// row above touches it only with bottom edges / a bottom vertex, which the top-left rule excludes
+// for either orientation).  The 2-D rasterisation collapses to interval coverage along x.
+//
+//   stage    the two vertex rows c, c+1 once per workgroup: decode, d = dl/Z, 1/Z, snapped x for BOTH
+//            eyes, packed colour -> 16 B per vertex in LDS (coalesced 12 B/lane HBM reads)
+//   raster   per eye: one thread per cell walks the pixel centres inside its two triangles, shades each
+//            covered fragment perspective-correctly and posts
+//               key = ~bits(1/Z interpolated) << 32 | R | G<<8 | B<<16
+//            with ds_min_u64 (min == nearest; an exact 1/Z tie between overlapping triangles goes to the
+//            smaller packed colour -- the decree's order-free stand-in for draw order, which lets the
+//            fragment travel in one LDS word).  Spans longer than kShortSpan (rubber-sheet triangles
+//            across depth edges) are handed to the whole wave: one lane's triangle is broadcast with
+//            v_readlane and 64 lanes test 64 pixel centres at a time.
+//   resolve  per eye: plain LDS reads -> colour-key hole test -> coalesced dwordx3 / dword stores.
+// The z-buffer holds one eye at a time (the resolve of the left eye resets it), so LDS is
+// 2*16*W + 8*W (+4*W with edge points) bytes: 77 KB at 1080p -> two workgroups per CU.
 
-struct RowVerts {            // the two vertex rows of one cell row, staged as raw RGB bytes in LDS
-    const uint8_t* d0; const uint8_t* d1;    // depth rows c, c+1
-    const uint8_t* c0; const uint8_t* c1;    // colour rows c, c+1
+// One covered fragment -> z-buffer word.
+__device__ __forceinline__ u64 mesh_fragment_key(float q0, float q1, float q2, uint32_t c0, uint32_t c1, uint32_t c2)
+{
+    const float iz = (q0 + q1) + q2;
+    const float riz = 1.0f / iz;
+    return ((u64)(~__float_as_uint(iz)) << 32) | shade_px(q0, q1, q2, riz, c0, c1, c2);
+}
+
+struct MeshVert { int XL, XR; float iz; uint32_t rgb; };
+static_assert(sizeof(MeshVert) == 16, "MeshVert is one ds_read_b128");
+constexpr int kShortSpan = 4;
+
+__device__ __forceinline__ MeshVert mesh_vertex(uint32_t dpx, uint32_t cpx, int j, const FrameDev& fp)
+{
+    MeshVert v;
+    const float z = decode_z(code16_of(dpx), fp.mult, fp.scale);
+    const bool ok = z > kNear;
+    const float d = fp.dl / z;
+    const float gx = (float)j * fp.sx;
+    v.XL = snap(gx + d);
+    v.XR = snap(gx - d);
+    v.iz = ok ? 1.0f / z : 0.0f;            // iz == 0 flags a vertex behind the near plane
+    v.rgb = cpx;
+    return v;
+}
+
+// Triangle `pass` (0: tri1 = A,B,C; 1: tri2 = A,C,D) of cell column j for one eye from the LDS vertices.
+__device__ __forceinline__ bool mesh_tri_lds(TriSetup& t, const MeshVert& A, const MeshVert& B, const MeshVert& Cv,
+                                             const MeshVert& D, int pass, int eye, int Yt, int Yb)
+{
+    const int XA = eye == 0 ? A.XL : A.XR, XB = eye == 0 ? B.XL : B.XR;
+    const int XC = eye == 0 ? Cv.XL : Cv.XR, XD = eye == 0 ? D.XL : D.XR;
+    // vertex order of the reference: tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]); tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
+    if (pass == 0) return tri_setup_snapped(t, XA, Yt, A.iz, XB, Yb, B.iz, XC, Yb, Cv.iz);
+    return tri_setup_snapped(t, XA, Yt, A.iz, XC, Yb, Cv.iz, XD, Yt, D.iz);
+}
+
+// LDS vertex array with 16-byte (colour inside) or 12-byte (colour re-read from the frame in the
+// resolve phase; for wide frames whose 16-byte rows would not fit the 160 KB LDS) records.
+template <bool VRGB>
+struct VertStore {
+    static constexpr int kDwords = VRGB ? 4 : 3;
+    int* base;
+    __device__ __forceinline__ void put(int idx, const MeshVert& v) const
+    {
+        int* p = base + (size_t)idx * kDwords;
+        if (VRGB) *(int4*)p = make_int4(v.XL, v.XR, __float_as_int(v.iz), (int)v.rgb);
+        else { p[0] = v.XL; p[1] = v.XR; p[2] = __float_as_int(v.iz); }
+    }
+    __device__ __forceinline__ MeshVert get(int idx) const
+    {
+        const int* p = base + (size_t)idx * kDwords;
+        MeshVert v;
+        if (VRGB) { const int4 q = *(const int4*)p; v.XL = q.x; v.XR = q.y; v.iz = __int_as_float(q.z); v.rgb = (uint32_t)q.w; }
+        else { v.XL = p[0]; v.XR = p[1]; v.iz = __int_as_float(p[2]); v.rgb = 0; }
+        return v;
+    }
 };
 
-__device__ __forceinline__ uint32_t lds_px(const uint8_t* row, int j)
-{
-    // unaligned 3-byte pixel from a dword-aligned LDS row: two aligned dwords + funnel shift
-    const uint32_t off = 3u * (uint32_t)j;
-    const uint32_t* p = (const uint32_t*)(row + (off & ~3u));
-    const uint32_t lo = p[0], hi = p[1];
-    return __builtin_amdgcn_alignbyte(hi, lo, off & 3u) & 0xFFFFFFu;
-}
-
-// Triangle `pass` (0: tri1 = A,B,C; 1: tri2 = A,C,D) of cell column j for one eye, pure shift.
-__device__ __forceinline__ bool mesh_tri_pure(TriSetup& t, uint32_t (&col)[3], const RowVerts& rv, int j, int pass,
-                                              int eye, float gy0, float gy1, const FrameDev& fp)
-{
-    const float gx0 = (float)j * fp.sx, gx1 = (float)(j + 1) * fp.sx;
-    // vertex order of the reference: tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]); tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
-    const uint8_t* dr[3] = {rv.d0, pass == 0 ? rv.d1 : rv.d1, pass == 0 ? rv.d1 : rv.d0};
-    const uint8_t* cr[3] = {rv.c0, pass == 0 ? rv.c1 : rv.c1, pass == 0 ? rv.c1 : rv.c0};
-    const int jj[3] = {j, pass == 0 ? j : j + 1, j + 1};
-    const float gxs[3] = {gx0, pass == 0 ? gx0 : gx1, gx1};
-    const float gys[3] = {gy0, gy1, pass == 0 ? gy1 : gy0};
-    Vert v[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float z = decode_z(code16_of(lds_px(dr[k], jj[k])), fp.mult, fp.scale);
-        const float d = fp.dl / z;
-        v[k] = vertex_pure(gxs[k], gys[k], z, d, eye);
-        col[k] = lds_px(cr[k], jj[k]);
-    }
-    return tri_setup(t, v[0], v[1], v[2]);
-}
-
-template <int PX, int FLAGS>
-__global__ void __launch_bounds__(256) k_mesh_rows(RenderArgs a)
+template <int PX, int FLAGS, int TPB, bool VRGB>
+__global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 {
     constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = a.W, H = a.H;
-    const int rowbytes = ((3 * W + 3) & ~3) + 8;       // dword rows with slack for the two-dword pixel read
-    u64* zb = (u64*)smem;                              // [2][W]
-    uint8_t* raw = (uint8_t*)(zb + 2 * (size_t)W);     // [2 images][3 rows][rowbytes]
-    uint32_t* eb = (uint32_t*)(raw + 6 * (size_t)rowbytes);   // [2][W] edge-point keys (EDGEPTS)
+    u64* zb = (u64*)smem;                              // [W] z keys of the eye being rendered
+    VertStore<VRGB> verts{(int*)(zb + W)};             // [2][W]: vertex rows c and c+1
+    uint32_t* eb = (uint32_t*)(verts.base + 2 * (size_t)W * VertStore<VRGB>::kDwords);   // [W] edge-point keys (EDGEPTS)
 
     const int fr = blockIdx.x / H;
     const int k = blockIdx.x - fr * H;                 // output row
     const int f = a.frame0 + fr;
     const FrameDev& fp = a.fp[f];
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
 
-    // ---- which cell rows can cover scanline k (uniform) ----
-    const i64 Yc = (i64)k * kSubpix + kSubpix / 2;
+    // ---- the cell row covering scanline k (uniform) ----
+    const int Yc = k * kSubpix + kSubpix / 2;
     int ilo = (int)(((float)k + 0.5f) / fp.sy);
     ilo = ilo < 0 ? 0 : (ilo > H - 1 ? H - 1 : ilo);
     while (ilo > 0 && snap((float)ilo * fp.sy) > Yc) --ilo;
     while (ilo + 1 <= H - 1 && snap((float)(ilo + 1) * fp.sy) <= Yc) ++ilo;
-    const bool on_row = snap((float)ilo * fp.sy) == Yc;
-    const int cand_hi = (ilo <= H - 2) ? ilo : -1;
-    const int cand_lo = (on_row && ilo >= 1) ? ilo - 1 : -1;
-    const int c_first = cand_lo >= 0 ? cand_lo : cand_hi;     // first cell row (rowsel 0)
-    const int ncand = (cand_lo >= 0 ? 1 : 0) + (cand_hi >= 0 ? 1 : 0);
-    const int nvrows = ncand == 0 ? 0 : ncand + 1;            // vertex rows c_first .. c_first+ncand
+    const int c = (ilo <= H - 2) ? ilo : -1;           // largest i with Ys(i) <= Yc; -1: below the last vertex row
+    const int Yt = c >= 0 ? snap((float)c * fp.sy) : 0;
+    const int Yb = c >= 0 ? snap((float)(c + 1) * fp.sy) : 0;
 
-    for (int x = tid; x < 2 * W; x += blockDim.x) zb[x] = kEmpty64;
-    if (EDGEPTS) for (int x = tid; x < 2 * W; x += blockDim.x) eb[x] = kEmpty32;
-    // ---- stage the vertex rows (raw bytes, coalesced dwords) ----
-    {
-        const int ndw = (3 * W + 3) / 4;
-        for (int r = 0; r < nvrows; ++r) {
-            const uint8_t* dsrc = a.depth + (size_t)f * a.depth_stride + (size_t)(c_first + r) * a.depth_pitch;
-            const uint8_t* csrc = a.color + (size_t)f * a.color_stride + (size_t)(c_first + r) * a.color_pitch;
-            uint8_t* ddst = raw + (size_t)r * rowbytes;
-            uint8_t* cdst = raw + (size_t)(3 + r) * rowbytes;
-            if (PX == 4) {
-                for (int x = tid; x < ndw; x += blockDim.x) {
-                    ((uint32_t*)ddst)[x] = ((const uint32_t*)dsrc)[x];
-                    ((uint32_t*)cdst)[x] = ((const uint32_t*)csrc)[x];
-                }
-            } else {
-                for (int x = tid; x < 3 * W; x += blockDim.x) { ddst[x] = dsrc[x]; cdst[x] = csrc[x]; }
+    // ---- stage the two vertex rows, clear the z-buffer ----
+    if (c >= 0) {
+        const int ngroups = W / PX;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)(c + r) * a.depth_pitch;
+            const uint8_t* crow = a.color + (size_t)f * a.color_stride + (size_t)(c + r) * a.color_pitch;
+            for (int g = tid; g < ngroups; g += TPB) {
+                uint32_t dpx[PX], cpx[PX];
+                RowIO<PX>::load(drow, g, dpx);
+                RowIO<PX>::load(crow, g, cpx);
+#pragma unroll
+                for (int q = 0; q < PX; ++q) verts.put(r * W + g * PX + q, mesh_vertex(dpx[q], cpx[q], g * PX + q, fp));
             }
         }
     }
+    for (int x = tid; x < W; x += TPB) zb[x] = kEmpty64;
+    if (EDGEPTS) for (int x = tid; x < W; x += TPB) eb[x] = kEmpty32;
     __syncthreads();
 
-    // ---- rasterise: one thread per cell of each candidate cell row ----
-    for (int rs = 0; rs < ncand; ++rs) {
-        const int c = c_first + rs;
-        RowVerts rv;
-        rv.d0 = raw + (size_t)rs * rowbytes;        rv.d1 = raw + (size_t)(rs + 1) * rowbytes;
-        rv.c0 = raw + (size_t)(3 + rs) * rowbytes;  rv.c1 = raw + (size_t)(4 + rs) * rowbytes;
-        const float gy0 = (float)c * fp.sy, gy1 = (float)(c + 1) * fp.sy;
-        const uint8_t* tinv = EDGES ? a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)c * (W - 1) : nullptr;
-        const size_t ncell = (size_t)(W - 1) * (H - 1);
-        for (int j = tid; j < W - 1; j += blockDim.x) {
+    const uint8_t* crow_k = a.color + (size_t)f * a.color_stride + (size_t)k * a.color_pitch;
+    const size_t ncell = (size_t)(W - 1) * (H - 1);
+    const uint8_t* tinv = (EDGES && c >= 0) ? a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)c * (W - 1) : nullptr;
+
+#pragma unroll 1
+    for (int eye = 0; eye < 2; ++eye) {
+        // ---- rasterise this eye ----
+        if (c >= 0) {
+            for (int j0 = 0; j0 < W - 1; j0 += TPB) {
+                const int j = j0 + tid;
+                TriSetup t[2];
+                int px0[2], px1[2];
+                uint32_t col[2][3];
+                bool lng[2] = {false, false};
+                if (j < W - 1) {
+                    const MeshVert A = verts.get(j), D = verts.get(j + 1), B = verts.get(W + j), Cv = verts.get(W + j + 1);
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                if (EDGES && tinv[(size_t)pass * ncell + j]) continue;           // dmt:1372
+                    for (int pass = 0; pass < 2; ++pass) {
+                        if (EDGES && tinv[(size_t)pass * ncell + j]) continue;            // dmt:1372
+                        if (!mesh_tri_lds(t[pass], A, B, Cv, D, pass, eye, Yt, Yb)) continue;
+                        const TriSetup& tt = t[pass];
+                        int p0 = floordiv_subpix(tt.minX - kSubpix / 2 + kSubpix - 1), p1 = floordiv_subpix(tt.maxX - kSubpix / 2);
+                        if (p0 < 0) p0 = 0;
+                        if (p1 > W - 1) p1 = W - 1;
+                        px0[pass] = p0; px1[pass] = p1;
+                        col[pass][0] = A.rgb; col[pass][1] = pass == 0 ? B.rgb : Cv.rgb; col[pass][2] = pass == 0 ? Cv.rgb : D.rgb;
+                        if (!VRGB) {
+                            const uint8_t* cr0 = a.color + (size_t)f * a.color_stride + (size_t)c * a.color_pitch;
+                            const uint8_t* cr1 = cr0 + a.color_pitch;
+                            col[pass][0] = load_px_bytes(cr0, j);
+                            col[pass][1] = load_px_bytes(cr1, pass == 0 ? j : j + 1);
+                            col[pass][2] = pass == 0 ? load_px_bytes(cr1, j + 1) : load_px_bytes(cr0, j + 1);
+                        }
+                        if (p1 - p0 >= kShortSpan) { lng[pass] = true; continue; }
+                        for (int px = p0; px <= p1; ++px) {
+                            float q0, q1, q2;
+                            if (!tri_sample(tt, px, k, q0, q1, q2)) continue;
+                            atomicMin(&zb[px], mesh_fragment_key(q0, q1, q2, col[pass][0], col[pass][1], col[pass][2]));
+                        }
+                    }
+                }
+                // long spans: the whole wave works on one lane's triangle at a time
 #pragma unroll
-                for (int eye = 0; eye < 2; ++eye) {
-                    TriSetup t; uint32_t col[3];
-                    if (!mesh_tri_pure(t, col, rv, j, pass, eye, gy0, gy1, fp)) continue;
-                    i64 minX = t.X0 < t.X1 ? t.X0 : t.X1; if (t.X2 < minX) minX = t.X2;
-                    i64 maxX = t.X0 > t.X1 ? t.X0 : t.X1; if (t.X2 > maxX) maxX = t.X2;
-                    i64 px0 = floordiv_subpix(minX - kSubpix / 2 + kSubpix - 1);
-                    i64 px1 = floordiv_subpix(maxX - kSubpix / 2);
-                    if (px0 < 0) px0 = 0;
-                    if (px1 > W - 1) px1 = W - 1;
-                    const uint32_t lowkey = ((uint32_t)pass << 17) | ((uint32_t)rs << 16) | (uint32_t)j;
-                    for (i64 px = px0; px <= px1; ++px) {
-                        float q0, q1, q2;
-                        if (!tri_sample(t, px, k, q0, q1, q2)) continue;
-                        const float iz = (q0 + q1) + q2;
-                        const u64 key = ((u64)(~__float_as_uint(iz)) << 32) | lowkey;
-                        atomicMin(&zb[(size_t)eye * W + (int)px], key);
+                for (int pass = 0; pass < 2; ++pass) {
+                    u64 m = __ballot(lng[pass]);
+                    while (m) {
+                        const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        TriSetup b;
+#define MDVT_BCAST(fld) b.fld = __builtin_amdgcn_readlane(t[pass].fld, l)
+                        MDVT_BCAST(dx0); MDVT_BCAST(dy0); MDVT_BCAST(dx1); MDVT_BCAST(dy1); MDVT_BCAST(dx2); MDVT_BCAST(dy2);
+                        MDVT_BCAST(bx0); MDVT_BCAST(by0); MDVT_BCAST(bx1); MDVT_BCAST(by1); MDVT_BCAST(bx2); MDVT_BCAST(by2);
+#undef MDVT_BCAST
+                        const uint32_t alo = __builtin_amdgcn_readlane((int)(uint32_t)t[pass].area2, l);
+                        const uint32_t ahi = __builtin_amdgcn_readlane((int)(uint32_t)((u64)t[pass].area2 >> 32), l);
+                        b.area2 = (i64)(((u64)ahi << 32) | alo);
+                        b.iz0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t[pass].iz0), l));
+                        b.iz1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t[pass].iz1), l));
+                        b.iz2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t[pass].iz2), l));
+                        const int bp0 = __builtin_amdgcn_readlane(px0[pass], l), bp1 = __builtin_amdgcn_readlane(px1[pass], l);
+                        const uint32_t bc0 = __builtin_amdgcn_readlane((int)col[pass][0], l);
+                        const uint32_t bc1 = __builtin_amdgcn_readlane((int)col[pass][1], l);
+                        const uint32_t bc2 = __builtin_amdgcn_readlane((int)col[pass][2], l);
+                        for (int px = bp0 + lane; px <= bp1; px += 64) {
+                            float q0, q1, q2;
+                            if (!tri_sample(b, px, k, q0, q1, q2)) continue;
+                            atomicMin(&zb[px], mesh_fragment_key(q0, q1, q2, bc0, bc1, bc2));
+                        }
                     }
                 }
             }
         }
-    }
-
-    // ---- edge points of source row k (sr:589-606, 745-781): vertices of removed triangles ----
-    const uint8_t* crow_k = a.color + (size_t)f * a.color_stride + (size_t)k * a.color_pitch;
-    if (EDGEPTS) {
-        const uint8_t* drow_k = a.depth + (size_t)f * a.depth_stride + (size_t)k * a.depth_pitch;
-        const uint8_t* urow = a.unused + (size_t)fr * a.ws_stride_px + (size_t)k * W;
-        const float fW = (float)W;
-        for (int j = tid; j < W; j += blockDim.x) {
-            if (!urow[j]) continue;
-            const uint32_t code = code16_of(load_px_bytes(drow_k, j));
-            const float z = decode_z(code, fp.mult, fp.scale);
-            if (!(z > kNear)) continue;
-            const float d = fp.dl / z;
-            const float gx = (float)j * fp.sx;
-            const float ex = ((gx - fp.cx) * fp.sW) + fp.cx;
-            const uint32_t ekey = (code << 16) | (uint32_t)j;
-            const float uL = ex + d, uR = ex - d;
-            if (uL > -1.0f && uL < fW + 1.0f) {
-                const int x = (int)rintf(uL);
-                if (x >= 0 && x < W) atomicMin(&eb[x], ekey);
-            }
-            if (uR > -1.0f && uR < fW + 1.0f) {
-                const int x = (int)rintf(uR);
-                if (x >= 0 && x < W) atomicMin(&eb[W + x], ekey);
+        // ---- edge points of source row k (sr:589-606, 745-781): vertices of removed triangles ----
+        if (EDGEPTS) {
+            const uint8_t* drow_k = a.depth + (size_t)f * a.depth_stride + (size_t)k * a.depth_pitch;
+            const uint8_t* urow = a.unused + (size_t)fr * a.ws_stride_px + (size_t)k * W;
+            const float fW = (float)W;
+            for (int j = tid; j < W; j += TPB) {
+                if (!urow[j]) continue;
+                const uint32_t code = code16_of(load_px_bytes(drow_k, j));
+                const float z = decode_z(code, fp.mult, fp.scale);
+                if (!(z > kNear)) continue;
+                const float d = fp.dl / z;
+                const float gx = (float)j * fp.sx;
+                const float ex = ((gx - fp.cx) * fp.sW) + fp.cx;
+                const float u = eye == 0 ? ex + d : ex - d;
+                if (u > -1.0f && u < fW + 1.0f) {
+                    const int x = (int)rintf(u);
+                    if (x >= 0 && x < W) atomicMin(&eb[x], (code << 16) | (uint32_t)j);
+                }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- resolve ----
-    const int ngroups = W / PX;
-#pragma unroll
-    for (int eye = 0; eye < 2; ++eye) {
+        // ---- resolve this eye ----
         uint8_t* orow = a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)k * a.rgb_pitch;
         uint8_t* mrow = a.mask[eye] + (size_t)f * a.mask_stride + (size_t)k * a.mask_pitch;
         float* zrow = ZOUT && a.zout[eye]
                           ? (float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)k * a.zout_pitch)
                           : nullptr;
-        for (int g = tid; g < ngroups; g += blockDim.x) {
+        for (int g = tid; g < W / PX; g += TPB) {
             uint32_t opx[PX], om[PX];
             float oz[PX];
 #pragma unroll
             for (int q = 0; q < PX; ++q) {
                 const int x = g * PX + q;
-                const u64 key = zb[(size_t)eye * W + x];
+                const u64 key = zb[x];
                 const bool covered = key != kEmpty64;
-                uint32_t rgb = 0;
+                const uint32_t rgb = covered ? (uint32_t)key & 0xFFFFFFu : 0u;
                 float zval = 0.0f;
-                if (covered) {
-                    const uint32_t low = (uint32_t)key;
-                    const int pass = (low >> 17) & 1, rs = (low >> 16) & 1, j = (int)(low & 0xFFFFu);
-                    const int c = c_first + rs;
-                    RowVerts rv;
-                    rv.d0 = raw + (size_t)rs * rowbytes;        rv.d1 = raw + (size_t)(rs + 1) * rowbytes;
-                    rv.c0 = raw + (size_t)(3 + rs) * rowbytes;  rv.c1 = raw + (size_t)(4 + rs) * rowbytes;
-                    TriSetup t; uint32_t col[3];
-                    mesh_tri_pure(t, col, rv, j, pass, eye, (float)c * fp.sy, (float)(c + 1) * fp.sy, fp);
-                    float q0, q1, q2;
-                    tri_sample(t, x, k, q0, q1, q2);
-                    const float iz = (q0 + q1) + q2;
-                    rgb = shade_px(q0, q1, q2, iz, col[0], col[1], col[2]);
-                    zval = 1.0f / iz;
-                }
+                if (ZOUT && covered) zval = 1.0f / __uint_as_float(~(uint32_t)(key >> 32));
                 const bool hole = !covered || rgb == a.key_rgb;
                 uint32_t out = hole ? 0u : rgb;
-                if (EDGEPTS && hole) {
-                    const uint32_t ek = eb[(size_t)eye * W + x];
-                    if (ek != kEmpty32) out = load_px_bytes(crow_k, (int)(ek & 0xFFFFu));
+                if (EDGEPTS) {
+                    const uint32_t ek = eb[x];
+                    if (hole && ek != kEmpty32) out = load_px_bytes(crow_k, (int)(ek & 0xFFFFu));
+                    if (eye == 0) eb[x] = kEmpty32;
                 }
+                if (eye == 0) zb[x] = kEmpty64;               // ready for the right eye
                 opx[q] = out;
                 om[q] = hole ? 255u : 0u;
                 if (ZOUT) oz[q] = zval;
@@ -685,13 +729,14 @@ __global__ void __launch_bounds__(256) k_mesh_rows(RenderArgs a)
             RowIO<PX>::store_mask(mrow, g, om);
             if (ZOUT && zrow) RowIO<PX>::store_z(zrow, g, oz);
         }
+        if (eye == 0) __syncthreads();
     }
 }
 
 // =================================================================================================
 // MESH MODE, general (pose / convergence): triangles rasterised into global 64-bit z keys
 // =================================================================================================
-//   key = ~bits(1/Z') << 32 | pass << 30 | i << 15 | j        (cell row i, column j; i, j < 32768)
+//   key = ~bits(1/Z') << 32 | R | G<<8 | B<<16     (the shaded fragment travels in the key, see above)
 
 __device__ __forceinline__ bool mesh_tri_general(TriSetup& t, uint32_t (&col)[3], const RenderArgs& a, const FrameDev& fp,
                                                  int f, int i, int j, int pass, int eye)
@@ -727,27 +772,21 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
     const uint8_t* tinv = EDGES ? a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j : nullptr;
     for (int pass = 0; pass < 2; ++pass) {
         if (EDGES && tinv[(size_t)pass * ncell]) continue;
-        const uint32_t lowkey = ((uint32_t)pass << 30) | ((uint32_t)i << 15) | (uint32_t)j;
         for (int eye = 0; eye < 2; ++eye) {
             TriSetup t; uint32_t col[3];
             if (!mesh_tri_general(t, col, a, fp, f, i, j, pass, eye)) continue;
-            i64 minX = t.X0 < t.X1 ? t.X0 : t.X1; if (t.X2 < minX) minX = t.X2;
-            i64 maxX = t.X0 > t.X1 ? t.X0 : t.X1; if (t.X2 > maxX) maxX = t.X2;
-            i64 minY = t.Y0 < t.Y1 ? t.Y0 : t.Y1; if (t.Y2 < minY) minY = t.Y2;
-            i64 maxY = t.Y0 > t.Y1 ? t.Y0 : t.Y1; if (t.Y2 > maxY) maxY = t.Y2;
-            i64 px0 = floordiv_subpix(minX - kSubpix / 2 + kSubpix - 1), px1 = floordiv_subpix(maxX - kSubpix / 2);
-            i64 py0 = floordiv_subpix(minY - kSubpix / 2 + kSubpix - 1), py1 = floordiv_subpix(maxY - kSubpix / 2);
+            int px0 = floordiv_subpix(t.minX - kSubpix / 2 + kSubpix - 1), px1 = floordiv_subpix(t.maxX - kSubpix / 2);
+            int py0 = floordiv_subpix(t.minY - kSubpix / 2 + kSubpix - 1), py1 = floordiv_subpix(t.maxY - kSubpix / 2);
             if (px0 < 0) px0 = 0;
             if (py0 < 0) py0 = 0;
             if (px1 > W - 1) px1 = W - 1;
             if (py1 > H - 1) py1 = H - 1;
             u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
-            for (i64 py = py0; py <= py1; ++py)
-                for (i64 px = px0; px <= px1; ++px) {
+            for (int py = py0; py <= py1; ++py)
+                for (int px = px0; px <= px1; ++px) {
                     float q0, q1, q2;
                     if (!tri_sample(t, px, py, q0, q1, q2)) continue;
-                    const float iz = (q0 + q1) + q2;
-                    atomicMin(&keys[(size_t)py * W + (size_t)px], ((u64)(~__float_as_uint(iz)) << 32) | lowkey);
+                    atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, col[0], col[1], col[2]));
                 }
         }
     }
@@ -763,23 +802,11 @@ __global__ void __launch_bounds__(256) k_mesh_resolve_general(RenderArgs a)
     const int fr = blockIdx.z >> 1, eye = blockIdx.z & 1;
     if (x >= W) return;
     const int f = a.frame0 + fr;
-    const FrameDev& fp = a.fp[f];
     const size_t o = (size_t)fr * a.ws_stride_px + (size_t)y * W + x;
     const u64 key = a.keys[eye][o];
     const bool covered = key != kEmpty64;
-    uint32_t rgb = 0;
-    float zval = 0.0f;
-    if (covered) {
-        const uint32_t low = (uint32_t)key;
-        const int pass = (int)(low >> 30) & 1, i = (int)(low >> 15) & 0x7FFF, j = (int)(low & 0x7FFFu);
-        TriSetup t; uint32_t col[3];
-        mesh_tri_general(t, col, a, fp, f, i, j, pass, eye);
-        float q0, q1, q2;
-        tri_sample(t, x, y, q0, q1, q2);
-        const float iz = (q0 + q1) + q2;
-        rgb = shade_px(q0, q1, q2, iz, col[0], col[1], col[2]);
-        zval = 1.0f / iz;
-    }
+    const uint32_t rgb = covered ? (uint32_t)key & 0xFFFFFFu : 0u;
+    const float zval = (ZOUT && covered) ? 1.0f / __uint_as_float(~(uint32_t)(key >> 32)) : 0.0f;
     const bool hole = !covered || rgb == a.key_rgb;
     uint32_t out = hole ? 0u : rgb;
     if (EDGEPTS && hole) {
@@ -801,6 +828,8 @@ __global__ void __launch_bounds__(256) k_mesh_resolve_general(RenderArgs a)
 // launch plumbing
 // =================================================================================================
 
+constexpr size_t kMaxLds = 160 * 1024;
+
 size_t render_lds_bytes(const RenderPlan& plan, int W)
 {
     if (plan.general) return 0;
@@ -809,8 +838,9 @@ size_t render_lds_bytes(const RenderPlan& plan, int W)
         if (plan.edge_points) b += 2 * (size_t)W * sizeof(uint32_t);
         return b;
     }
-    size_t b = 2 * (size_t)W * sizeof(u64) + 6 * (size_t)(((3 * W + 3) & ~3) + 8);
-    if (plan.edge_points) b += 2 * (size_t)W * sizeof(uint32_t);
+    const size_t extra = (size_t)W * sizeof(u64) + (plan.edge_points ? (size_t)W * sizeof(uint32_t) : 0);
+    size_t b = 2 * (size_t)W * 16 + extra;              // 16-byte vertices (colour in LDS)
+    if (b > kMaxLds) b = 2 * (size_t)W * 12 + extra;    // 12-byte vertices (colour re-read in the resolve)
     return b;
 }
 
@@ -904,14 +934,25 @@ static hipError_t launch_points_general(const RenderPlan& plan, const RenderArgs
 template <int PX>
 static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
+    constexpr int TPB = 512;
     const size_t lds = render_lds_bytes(plan, a.W);
-    const dim3 grid((unsigned)(plan.n * a.H)), block(256);
+    if (lds > kMaxLds) return hipErrorNotSupported;         // W > 4551 with edge points (5120 without)
+    const bool vrgb = lds == 2 * (size_t)a.W * 16 + (size_t)a.W * 8 + (plan.edge_points ? (size_t)a.W * 4 : 0);
+    const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
     const bool zout = a.zout[0] || a.zout[1];
     const int flags = (zout ? 1 : 0) | (plan.remove_edges ? 2 : 0) | (plan.remove_edges && plan.edge_points ? 4 : 0);
 #define MDVT_CASE(F)                                                                                   \
     case F:                                                                                            \
-        (void)hipFuncSetAttribute((const void*)k_mesh_rows<PX, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_mesh_rows<PX, F>), grid, block, lds, s, a);                              \
+        if (vrgb) {                                                                                    \
+            if (lds > 48 * 1024)                                                                       \
+                (void)hipFuncSetAttribute((const void*)k_mesh_rows<PX, F, TPB, true>,                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            hipLaunchKernelGGL((k_mesh_rows<PX, F, TPB, true>), grid, block, lds, s, a);               \
+        } else {                                                                                       \
+            (void)hipFuncSetAttribute((const void*)k_mesh_rows<PX, F, TPB, false>,                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            hipLaunchKernelGGL((k_mesh_rows<PX, F, TPB, false>), grid, block, lds, s, a);              \
+        }                                                                                              \
         break;
     switch (flags) {
         MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(2) MDVT_CASE(3) MDVT_CASE(6) MDVT_CASE(7)

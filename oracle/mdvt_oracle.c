@@ -17,7 +17,7 @@
 
 #define ORC_NEAR 1e-4f            /* ctr.set_constant_z_near(0.0001), dmt:1520 */
 #define ORC_SUBPIX 256            /* raster sub-pixel grid (decree)            */
-#define ORC_SNAP_LIMIT 4194304.0f /* |u|,|v| clamp before snapping (2^22 px)   */
+#define ORC_SNAP_LIMIT 2097152.0f /* |u|,|v| clamp before snapping (2^21 px)   */
 
 /* ------------------------------------------------------------------------------------------ */
 /* codec                                                                                      */
@@ -305,6 +305,7 @@ static inline int64_t orc_floordiv(int64_t a, int64_t b) /* b > 0 */
 typedef struct {
     int W, H;
     float* zbuf;        /* mesh: interpolated 1/Z (bigger = nearer), 0 = empty; points: Z, INF = empty */
+    float* zinv;        /* mesh: 1/zbuf of the winning fragment (the depth plane) */
     uint8_t* rgb;       /* H*W*3 */
     uint8_t* covered;   /* H*W   */
 } orc_target;
@@ -345,7 +346,7 @@ static void orc_raster_tri(orc_target* t, const orc_vert* a, const orc_vert* b, 
     const int64_t dx1 = s * (X0 - X2), dy1 = s * (Y0 - Y2);   /* v2 -> v0, weight of v1 */
     const int64_t dx2 = s * (X1 - X0), dy2 = s * (Y1 - Y0);   /* v0 -> v1, weight of v2 */
     const float iz0 = 1.0f / a->z, iz1 = 1.0f / b->z, iz2 = 1.0f / c->z;
-    const float fa = (float)area2;
+    const float ra = 1.0f / (float)area2;        /* one division per triangle; lambda_k = f32(w_k) * ra */
     for (int64_t py = py0; py <= py1; ++py) {
         const int64_t Yc = py * ORC_SUBPIX + half;
         for (int64_t px = px0; px <= px1; ++px) {
@@ -355,20 +356,33 @@ static void orc_raster_tri(orc_target* t, const orc_vert* a, const orc_vert* b, 
             const int64_t w2 = s * ((X1 - X0) * (Yc - Y0) - (Y1 - Y0) * (Xc - X0));
             if (!(orc_edge_in(w0, dx0, dy0) && orc_edge_in(w1, dx1, dy1) && orc_edge_in(w2, dx2, dy2)))
                 continue;
-            const float l0 = (float)w0 / fa, l1 = (float)w1 / fa, l2 = (float)w2 / fa;
+            const float l0 = (float)w0 * ra, l1 = (float)w1 * ra, l2 = (float)w2 * ra;
             const float q0 = l0 * iz0, q1 = l1 * iz1, q2 = l2 * iz2;
             const float iz = (q0 + q1) + q2;
             const size_t o = (size_t)py * t->W + (size_t)px;
-            if (!(iz > t->zbuf[o])) continue;          /* GL_LESS on depth == GREATER on 1/Z; first drawn wins ties */
-            t->zbuf[o] = iz;
-            t->covered[o] = 1;
+            if (iz < t->zbuf[o]) continue;             /* GL_LESS on depth == GREATER on 1/Z */
+            const float riz = 1.0f / iz;               /* one division per fragment; also the depth plane value */
+            uint8_t frag[3];
             for (int ch = 0; ch < 3; ++ch) {
                 const float num = (q0 * (float)ca[ch] + q1 * (float)cb[ch]) + q2 * (float)cc[ch];
-                float val = rintf(num / iz);
+                float val = rintf(num * riz);
                 if (!(val >= 0.0f)) val = 0.0f;
                 if (val > 255.0f) val = 255.0f;
-                t->rgb[3 * o + ch] = (uint8_t)val;
+                frag[ch] = (uint8_t)val;
             }
+            if (iz == t->zbuf[o]) {
+                /* exact tie in interpolated 1/Z between overlapping triangles (decree): the fragment with
+                 * the smaller packed colour R | G<<8 | B<<16 wins -- a deterministic, order-free stand-in
+                 * for GL's draw order that lets the z-buffer word carry the colour. */
+                const uint32_t mine = frag[0] | ((uint32_t)frag[1] << 8) | ((uint32_t)frag[2] << 16);
+                const uint8_t* cur = t->rgb + 3 * o;
+                const uint32_t theirs = cur[0] | ((uint32_t)cur[1] << 8) | ((uint32_t)cur[2] << 16);
+                if (!t->covered[o] || !(mine < theirs)) continue;
+            }
+            t->zbuf[o] = iz;
+            t->covered[o] = 1;
+            t->zinv[o] = riz;
+            memcpy(t->rgb + 3 * o, frag, 3);
         }
     }
 }
@@ -389,6 +403,7 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
     orc_target t;
     t.W = W; t.H = H;
     t.zbuf = (float*)malloc(n * sizeof(float));
+    t.zinv = (float*)calloc(n, sizeof(float));
     t.rgb = (uint8_t*)calloc(n, 3);
     t.covered = (uint8_t*)calloc(n, 1);
 
@@ -430,7 +445,7 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
                     orc_raster_tri(&t, &V[v0], &V[v1], &V[v2], color + 3 * v0, color + 3 * v1, color + 3 * v2);
                 }
         if (out_depth)
-            for (size_t k = 0; k < n; ++k) out_depth[k] = t.covered[k] ? 1.0f / t.zbuf[k] : 0.0f;
+            for (size_t k = 0; k < n; ++k) out_depth[k] = t.covered[k] ? t.zinv[k] : 0.0f;
     }
 
     /* hole mask (sr:740): colour-key compare against the background colour. */
@@ -462,7 +477,7 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
         free(ez);
     }
 
-    free(V); free(t.covered); free(t.rgb); free(t.zbuf);
+    free(V); free(t.covered); free(t.rgb); free(t.zinv); free(t.zbuf);
 }
 
 int orc_render_stereo(const orc_params* p, const uint8_t* depth_rgb, const uint8_t* color_rgb,

@@ -291,3 +291,20 @@ def test_errors_are_reported_not_swallowed(mods):
         r.render(ok, ok, p)
     assert e.value.code == -3
     r.close()
+
+
+@pytest.mark.parametrize("W,H,infill", [(3840, 40, True), (3840, 40, False), (4600, 24, True), (5000, 24, False)])
+def test_mesh_wide_frames_use_compact_lds_vertices(mods, orc, W, H, infill):
+    """Row widths whose 16-byte LDS vertex rows would exceed 160 KB take the 12-byte variant."""
+    _lib, sr, synthetic = mods
+    depth_rgb, color = _scene(synthetic, W, H, seed=W + H, n_fg=10)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=infill)
+    p = r.frame_params(xfov=45.0)
+    if W * 36 > 160 * 1024 and infill:
+        with pytest.raises(_lib.MdvtError) as e:
+            r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p)
+        assert e.value.code == -3
+    else:
+        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+        _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"wide mesh {W}")
+    r.close()
