@@ -170,7 +170,7 @@ def main():
         fps = total_frames / wall
         bytes_per_launch = BYTES_PER_PX * W * H * n_local
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        kname = "k_points_rows<4, " if args.mode == "points" else "k_mesh_rows<4, "
+        kname = ("k_points_rows<4, " if args.remove_edges else "k_points_rows_fast<") if args.mode == "points" else "k_mesh_rows<4, "
         tr = pmc_traffic(kname, n_local, W, H)
         out = {
             "metric": "stereo frames/sec at 1920x1080 (+ achieved HBM GB/s vs roofline)",

@@ -385,6 +385,104 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Hand-scheduled variant of the row kernel for the headline case (4 px/lane, one group per thread, no
+// edge filter): byte shuffles are single v_perm_b32 ops, out-of-range fragments are steered to a trash
+// LDS word instead of branching (no exec-mask traffic), float->int uses truncation (== floor for the
+// non-negative values that pass the range test).  Same arithmetic, same results as k_points_rows.
+// -------------------------------------------------------------------------------------------------
+template <int TPB, bool ZOUT>
+__global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = a.W, W4 = W >> 2;
+    u64* zb = (u64*)smem;                        // [2W] keys (left, right) + [1] trash word
+    const int fr = blockIdx.x / a.H;
+    const int i = blockIdx.x - fr * a.H;
+    const int f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const float mult = fp.mult, scale = fp.scale, dl = fp.dl;
+    const int g = threadIdx.x;
+    const bool act = g < W4;
+
+    uint32_t d0 = 0, d1 = 0, d2 = 0, c0 = 0, c1 = 0, c2 = 0;
+    if (act) {
+        const uint32_t* dp = (const uint32_t*)(a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch) + 3 * g;
+        const uint32_t* cp = (const uint32_t*)(a.color + (size_t)f * a.color_stride + (size_t)i * a.color_pitch) + 3 * g;
+        d0 = dp[0]; d1 = dp[1]; d2 = dp[2];
+        c0 = cp[0]; c1 = cp[1]; c2 = cp[2];
+    }
+    {
+        uint4* z4 = (uint4*)zb;
+        for (int x = g; x < W; x += TPB) z4[x] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    }
+    __syncthreads();
+
+    if (act) {
+        // R<<24 | B<<16 of each pixel (dfh:67-69): one byte permute each
+        uint32_t c32[4], cpx[4];
+        c32[0] = __builtin_amdgcn_perm(d0, d0, 0x00020c0cu);
+        c32[1] = __builtin_amdgcn_perm(d1, d0, 0x03050c0cu);
+        c32[2] = __builtin_amdgcn_perm(d2, d1, 0x02040c0cu);
+        c32[3] = __builtin_amdgcn_perm(d2, d2, 0x01030c0cu);
+        cpx[0] = c0 & 0xFFFFFFu;
+        cpx[1] = __builtin_amdgcn_perm(c1, c0, 0x0c050403u);
+        cpx[2] = __builtin_amdgcn_perm(c2, c1, 0x0c040302u);
+        cpx[3] = c2 >> 8;
+        const float fW = (float)W;
+        const float fj0 = (float)(g << 2);
+        const uint32_t jhi = (uint32_t)g >> 6, jlo = ((uint32_t)g << 2) & 0xFFu;
+        const int trash = 2 * W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float z = ((float)c32[q] * mult) * scale;
+            const bool ok = z > kNear;
+            const float d = dl / z;
+            const float fj = fj0 + (float)q;
+            const float uL = fj + d, uR = fj - d;
+            const bool okL = ok && (uL < fW);
+            const bool okR = ok && (uR >= 0.0f);
+            const int sL = okL ? (int)uL : trash;
+            const int sR = okR ? W + (int)uR : trash;
+            const uint32_t hi = __builtin_amdgcn_perm(c32[q], jhi, 0x0c070600u);      // code16 << 8 | j >> 8
+            const uint32_t lo = __builtin_amdgcn_perm(jlo + (uint32_t)q, cpx[q], 0x04020100u);   // (j & 255) << 24 | rgb
+            const u64 key = ((u64)hi << 32) | lo;
+            atomicMin(&zb[sL], key);
+            atomicMin(&zb[sR], key);
+        }
+    }
+    __syncthreads();
+
+    if (act) {
+#pragma unroll
+        for (int eye = 0; eye < 2; ++eye) {
+            const uint4* zq = (const uint4*)(zb + (size_t)eye * W) + 2 * g;
+            const uint4 k01 = zq[0], k23 = zq[1];
+            const uint32_t hi[4] = {k01.y, k01.w, k23.y, k23.w};
+            const uint32_t lo[4] = {k01.x, k01.z, k23.x, k23.z};
+            uint32_t o[4], mw = 0;
+            float oz[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool covered = hi[q] != ~0u;                 // code16<<8 | j>>8 < 2^24 when covered
+                const uint32_t rgb = lo[q] & 0xFFFFFFu;
+                const bool hole = !covered || rgb == a.key_rgb;    // sr:740
+                o[q] = hole ? 0u : rgb;                            // sr:793
+                mw |= hole ? (0xFFu << (8 * q)) : 0u;
+                if (ZOUT) oz[q] = covered ? decode_z(hi[q] >> 8, mult, scale) : 0.0f;
+            }
+            uint32_t* op = (uint32_t*)(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)i * a.rgb_pitch) + 3 * g;
+            op[0] = __builtin_amdgcn_perm(o[1], o[0], 0x04020100u);
+            op[1] = __builtin_amdgcn_perm(o[2], o[1], 0x05040201u);
+            op[2] = __builtin_amdgcn_perm(o[3], o[2], 0x06050402u);
+            ((uint32_t*)(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch))[g] = mw;
+            if (ZOUT && a.zout[eye])
+                ((float4*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)i * a.zout_pitch))[g] =
+                    make_float4(oz[0], oz[1], oz[2], oz[3]);
+        }
+    }
+}
+
 // =================================================================================================
 // POINT MODE, general (pose / convergence / K != Krender): global 64-bit z keys
 // =================================================================================================
@@ -876,9 +974,30 @@ static int points_cfg_override()
     return 0;
 }
 
+template <int TPB>
+static hipError_t launch_points_rows_fast(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+{
+    const size_t lds = (2 * (size_t)a.W + 2) * sizeof(u64);
+    const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
+    if (a.zout[0] || a.zout[1]) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_points_rows_fast<TPB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_points_rows_fast<TPB, true>), grid, block, lds, s, a);
+    } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_points_rows_fast<TPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_points_rows_fast<TPB, false>), grid, block, lds, s, a);
+    }
+    return hipGetLastError();
+}
+
 static hipError_t launch_points_rows_vec4(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const int ngroups = a.W / 4;
+    const char* env = getenv("MDVT_POINTS_CFG");       // experiments only: "<TPB>x<ITERS>[s]" selects the template kernel
+    if (!(env && env[0]) && !plan.remove_edges) {
+        if (ngroups <= 256) return launch_points_rows_fast<256>(plan, a, s);
+        if (ngroups <= 512) return launch_points_rows_fast<512>(plan, a, s);
+        if (ngroups <= 1024) return launch_points_rows_fast<1024>(plan, a, s);
+    }
     int cfg = points_cfg_override();
     if (cfg == 0 || ((cfg / 2) % 16 != 0 && ((cfg / 2) / 16) * ((cfg / 2) % 16) < ngroups)) {
         int c;
