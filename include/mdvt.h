@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 1
+#define MDVT_VERSION_MINOR 2
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -80,6 +80,11 @@ typedef struct mdvt_io {
     uint8_t* left_rgb; uint8_t* right_rgb; size_t rgb_pitch;  size_t rgb_stride;    /* sr:819, 907           */
     uint8_t* left_mask; uint8_t* right_mask; size_t mask_pitch; size_t mask_stride; /* 255 = hole (sr:740, 854) */
     float* left_depth; float* right_depth; size_t zout_pitch; size_t zout_stride;   /* optional; 0 = background (dmt:1563) */
+    /* optional compacted hole mask: 1 bit per pixel, bit k of byte b = pixel 8b+k (np.packbits(mask > 0,
+     * bitorder="little")), rows padded to whole dwords: maskbits_pitch >= 4*ceil(W/32) */
+    uint8_t* left_maskbits; uint8_t* right_maskbits; size_t maskbits_pitch; size_t maskbits_stride;
+    /* optional: hole_counts[2*frame + eye] = number of hole pixels (uint32, overwritten) */
+    uint32_t* hole_counts;
 } mdvt_io;
 
 int mdvt_version(void);

@@ -46,7 +46,9 @@ class MdvtIO(C.Structure):
                 ("color_rgb", C.c_void_p), ("color_pitch", C.c_size_t), ("color_stride", C.c_size_t),
                 ("left_rgb", C.c_void_p), ("right_rgb", C.c_void_p), ("rgb_pitch", C.c_size_t), ("rgb_stride", C.c_size_t),
                 ("left_mask", C.c_void_p), ("right_mask", C.c_void_p), ("mask_pitch", C.c_size_t), ("mask_stride", C.c_size_t),
-                ("left_depth", C.c_void_p), ("right_depth", C.c_void_p), ("zout_pitch", C.c_size_t), ("zout_stride", C.c_size_t)]
+                ("left_depth", C.c_void_p), ("right_depth", C.c_void_p), ("zout_pitch", C.c_size_t), ("zout_stride", C.c_size_t),
+                ("left_maskbits", C.c_void_p), ("right_maskbits", C.c_void_p), ("maskbits_pitch", C.c_size_t),
+                ("maskbits_stride", C.c_size_t), ("hole_counts", C.c_void_p)]
 
 
 _lib = None

@@ -278,6 +278,13 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         return fail(c, MDVT_ERR_INVALID_ARG, "a pitch is smaller than one row");   // sr:507 shape assert
     const bool zout = io->left_depth || io->right_depth;
     if (zout && io->zout_pitch < (size_t)4 * W) return fail(c, MDVT_ERR_INVALID_ARG, "zout_pitch smaller than one row");
+    const bool want_bits = io->left_maskbits || io->right_maskbits;
+    if (want_bits) {
+        if (!io->left_maskbits || !io->right_maskbits) return fail(c, MDVT_ERR_INVALID_ARG, "maskbits need both eyes");
+        if (io->maskbits_pitch < (size_t)4 * (((size_t)W + 31) / 32) || io->maskbits_pitch % 4 != 0 || io->maskbits_stride % 4 != 0 ||
+            ((uintptr_t)io->left_maskbits % 4) || ((uintptr_t)io->right_maskbits % 4))
+            return fail(c, MDVT_ERR_INVALID_ARG, "maskbits rows must be dword aligned and at least 4*ceil(W/32) bytes");
+    }
     DeviceGuard g(c->device);
     hipStream_t s = (hipStream_t)stream;
 
@@ -319,6 +326,10 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.rgb[0] = io->left_rgb; a.rgb[1] = io->right_rgb; a.rgb_pitch = io->rgb_pitch; a.rgb_stride = io->rgb_stride;
     a.mask[0] = io->left_mask; a.mask[1] = io->right_mask; a.mask_pitch = io->mask_pitch; a.mask_stride = io->mask_stride;
     a.zout[0] = io->left_depth; a.zout[1] = io->right_depth; a.zout_pitch = io->zout_pitch; a.zout_stride = io->zout_stride;
+    a.maskbits[0] = io->left_maskbits; a.maskbits[1] = io->right_maskbits;
+    a.maskbits_pitch = io->maskbits_pitch; a.maskbits_stride = io->maskbits_stride;
+    a.hole_counts = io->hole_counts;
+    if (io->hole_counts) MDVT_HIP(c, hipMemsetAsync(io->hole_counts, 0, (size_t)n_frames * 2 * sizeof(uint32_t), s));
     a.fp = dfp;
     a.W = W; a.H = H;
     a.key_rgb = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
@@ -340,6 +351,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         hipError_t e = launch_render(plan, a, s);
         if (e == hipErrorNotSupported) return fail(c, MDVT_ERR_UNSUPPORTED, "render mode %d is not built yet", plan.mode);
         if (e != hipSuccess) return fail(c, MDVT_ERR_HIP, "render launch failed: %s", hipGetErrorString(e));
+        if ((want_bits || io->hole_counts) && !plan.fused_bits) MDVT_HIP(c, launch_pack_mask(a, plan.n, s));
     }
     MDVT_HIP(c, hipEventRecord(slot->done, s));
     return MDVT_OK;

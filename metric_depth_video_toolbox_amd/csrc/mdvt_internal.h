@@ -36,6 +36,8 @@ struct RenderArgs {
     uint8_t* rgb[2];  size_t rgb_pitch, rgb_stride;
     uint8_t* mask[2]; size_t mask_pitch, mask_stride;
     float* zout[2];   size_t zout_pitch, zout_stride;
+    uint8_t* maskbits[2]; size_t maskbits_pitch, maskbits_stride;   // optional 1 bit/px hole mask
+    uint32_t* hole_counts;       // optional [n_frames][2]
     const FrameDev* fp;          // device array, one per frame of the batch
     int32_t W, H;
     int32_t frame0;              // first frame of this launch within the batch
@@ -64,9 +66,11 @@ struct RenderPlan {
     int edge_points;
     int general;         // any frame of the launch needs the general path
     int vec4;            // W%4==0 and every pointer/pitch 4-byte aligned
+    int fused_bits;      // set by launch_render when the render kernel itself produced maskbits / hole_counts
     int n;               // frames in this launch
 };
-hipError_t launch_render(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 size_t render_lds_bytes(const RenderPlan& plan, int W);
 
 }  // namespace mdvt

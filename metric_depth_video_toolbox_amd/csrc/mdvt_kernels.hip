@@ -385,13 +385,59 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
     }
 }
 
+// Wavefront hole-mask compaction.  Each lane holds the hole flags of 4 consecutive pixels (nib, LSB = lowest
+// x).  Eight lanes' nibbles are OR-combined with three cross-lane exchanges into one dword of the packed
+// 1-bit/px mask; the per-(frame,eye) hole count is the popcount of four 64-lane ballots, one atomic per wave.
+__device__ __forceinline__ void compact_hole_nibble(uint32_t nib, int g, bool act, uint8_t* bits_row, uint32_t* count)
+{
+    if (bits_row) {
+        uint32_t v = nib << (4 * (g & 7));
+        v |= __shfl_xor((int)v, 1);
+        v |= __shfl_xor((int)v, 2);
+        v |= __shfl_xor((int)v, 4);
+        if (act && (g & 7) == 0) ((uint32_t*)bits_row)[g >> 3] = v;
+    }
+    if (count) {
+        const int c = __popcll(__ballot(nib & 1)) + __popcll(__ballot(nib & 2)) + __popcll(__ballot(nib & 4)) +
+                      __popcll(__ballot(nib & 8));
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (uint32_t)c);
+    }
+}
+
+// Post-pass for the kernels that do not compact in place: byte mask -> packed bits + counts.
+__global__ void __launch_bounds__(256) k_pack_mask(RenderArgs a)
+{
+    const int W = a.W;
+    const int ngroups = (W + 3) / 4;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    const int fr = blockIdx.z >> 1, eye = blockIdx.z & 1;
+    const int f = a.frame0 + fr;
+    const bool act = g < ngroups;
+    uint32_t nib = 0;
+    if (act) {
+        const uint8_t* mrow = a.mask[eye] + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch;
+        for (int q = 0; q < 4; ++q) if (4 * g + q < W && mrow[4 * g + q]) nib |= 1u << q;
+    }
+    uint8_t* brow = a.maskbits[eye] ? a.maskbits[eye] + (size_t)f * a.maskbits_stride + (size_t)i * a.maskbits_pitch : nullptr;
+    compact_hole_nibble(nib, g, act, brow, a.hole_counts ? a.hole_counts + 2 * (size_t)f + eye : nullptr);
+}
+
+hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s)
+{
+    const int ngroups = (a.W + 3) / 4;
+    dim3 grid((ngroups + 255) / 256, a.H, n * 2);
+    hipLaunchKernelGGL(k_pack_mask, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // -------------------------------------------------------------------------------------------------
 // Hand-scheduled variant of the row kernel for the headline case (4 px/lane, one group per thread, no
 // edge filter): byte shuffles are single v_perm_b32 ops, out-of-range fragments are steered to a trash
 // LDS word instead of branching (no exec-mask traffic), float->int uses truncation (== floor for the
 // non-negative values that pass the range test).  Same arithmetic, same results as k_points_rows.
 // -------------------------------------------------------------------------------------------------
-template <int TPB, bool ZOUT>
+template <int TPB, bool ZOUT, bool BITS>
 __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -453,11 +499,14 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
     }
     __syncthreads();
 
-    if (act) {
+    if (act || BITS) {
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
-            const uint4* zq = (const uint4*)(zb + (size_t)eye * W) + 2 * g;
-            const uint4 k01 = zq[0], k23 = zq[1];
+            uint4 k01 = make_uint4(0, 0, 0, 0), k23 = make_uint4(0, 0, 0, 0);     // inactive lanes: "covered, not key"
+            if (act) {
+                const uint4* zq = (const uint4*)(zb + (size_t)eye * W) + 2 * g;
+                k01 = zq[0]; k23 = zq[1];
+            }
             const uint32_t hi[4] = {k01.y, k01.w, k23.y, k23.w};
             const uint32_t lo[4] = {k01.x, k01.z, k23.x, k23.z};
             uint32_t o[4], mw = 0;
@@ -471,14 +520,21 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
                 mw |= hole ? (0xFFu << (8 * q)) : 0u;
                 if (ZOUT) oz[q] = covered ? decode_z(hi[q] >> 8, mult, scale) : 0.0f;
             }
-            uint32_t* op = (uint32_t*)(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)i * a.rgb_pitch) + 3 * g;
-            op[0] = __builtin_amdgcn_perm(o[1], o[0], 0x04020100u);
-            op[1] = __builtin_amdgcn_perm(o[2], o[1], 0x05040201u);
-            op[2] = __builtin_amdgcn_perm(o[3], o[2], 0x06050402u);
-            ((uint32_t*)(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch))[g] = mw;
-            if (ZOUT && a.zout[eye])
-                ((float4*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)i * a.zout_pitch))[g] =
-                    make_float4(oz[0], oz[1], oz[2], oz[3]);
+            if (act) {
+                uint32_t* op = (uint32_t*)(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)i * a.rgb_pitch) + 3 * g;
+                op[0] = __builtin_amdgcn_perm(o[1], o[0], 0x04020100u);
+                op[1] = __builtin_amdgcn_perm(o[2], o[1], 0x05040201u);
+                op[2] = __builtin_amdgcn_perm(o[3], o[2], 0x06050402u);
+                ((uint32_t*)(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch))[g] = mw;
+                if (ZOUT && a.zout[eye])
+                    ((float4*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)i * a.zout_pitch))[g] =
+                        make_float4(oz[0], oz[1], oz[2], oz[3]);
+            }
+            if (BITS) {
+                const uint32_t nib = act ? ((mw & 1u) | ((mw >> 7) & 2u) | ((mw >> 14) & 4u) | ((mw >> 21) & 8u)) : 0u;
+                uint8_t* brow = a.maskbits[eye] ? a.maskbits[eye] + (size_t)f * a.maskbits_stride + (size_t)i * a.maskbits_pitch : nullptr;
+                compact_hole_nibble(nib, g, act, brow, a.hole_counts ? a.hole_counts + 2 * (size_t)f + eye : nullptr);
+            }
         }
     }
 }
@@ -974,22 +1030,28 @@ static int points_cfg_override()
     return 0;
 }
 
-template <int TPB>
-static hipError_t launch_points_rows_fast(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+template <int TPB, bool ZOUT, bool BITS>
+static hipError_t launch_points_rows_fast_cfg(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const size_t lds = (2 * (size_t)a.W + 2) * sizeof(u64);
     const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
-    if (a.zout[0] || a.zout[1]) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_points_rows_fast<TPB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_points_rows_fast<TPB, true>), grid, block, lds, s, a);
-    } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_points_rows_fast<TPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_points_rows_fast<TPB, false>), grid, block, lds, s, a);
-    }
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_points_rows_fast<TPB, ZOUT, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_points_rows_fast<TPB, ZOUT, BITS>), grid, block, lds, s, a);
     return hipGetLastError();
 }
 
-static hipError_t launch_points_rows_vec4(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+template <int TPB>
+static hipError_t launch_points_rows_fast(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+{
+    const bool zout = a.zout[0] || a.zout[1];
+    const bool bits = a.maskbits[0] || a.maskbits[1] || a.hole_counts;
+    plan.fused_bits = bits;
+    if (zout) return bits ? launch_points_rows_fast_cfg<TPB, true, true>(plan, a, s) : launch_points_rows_fast_cfg<TPB, true, false>(plan, a, s);
+    return bits ? launch_points_rows_fast_cfg<TPB, false, true>(plan, a, s) : launch_points_rows_fast_cfg<TPB, false, false>(plan, a, s);
+}
+
+static hipError_t launch_points_rows_vec4(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const int ngroups = a.W / 4;
     const char* env = getenv("MDVT_POINTS_CFG");       // experiments only: "<TPB>x<ITERS>[s]" selects the template kernel
@@ -1110,8 +1172,9 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
     return hipGetLastError();
 }
 
-hipError_t launch_render(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
+    plan.fused_bits = 0;
     if (plan.mode == MDVT_MODE_POINTS) {
         if (plan.general) return launch_points_general(plan, a, s);
         return plan.vec4 ? launch_points_rows_vec4(plan, a, s) : launch_points_rows_cfg<1, 256, 0, 0>(plan, a, s);

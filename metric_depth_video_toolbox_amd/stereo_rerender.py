@@ -170,7 +170,7 @@ class StereoRerenderer:
 
     # -- the per-frame loop body, batched -----------------------------------------------------
     def prepare(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
-                out_depth=None):
+                out_depth=None, want_maskbits: bool = False, want_hole_counts: bool = False):
         """Validate once and pack everything one submission needs (buffer table, parameter records).
         Returns a PreparedRender whose launch() is a single C-ABI call -- use it when the same buffers
         are rendered into repeatedly (streaming loops, benchmarks)."""
@@ -205,15 +205,27 @@ class StereoRerenderer:
         res = {"sbs": sbs[0] if single else sbs, "mask": mask[0] if single else mask}
         if zout is not None:
             res["depth"] = zout[0] if single else zout
-        return PreparedRender(self, N, arr, io, res, (depth_rgb, color_rgb, sbs, mask, zout), dev)
+        bits = counts = None
+        if want_maskbits:       # [N, H, 2, 4*ceil(W/32)] u8: packed 1 bit/px rows, left then right eye
+            rowb = 4 * ((W + 31) // 32)
+            bits = torch.zeros((N, H, 2, rowb), dtype=torch.uint8, device=dev)
+            io.left_maskbits, io.right_maskbits = bits.data_ptr(), bits.data_ptr() + rowb
+            io.maskbits_pitch, io.maskbits_stride = 2 * rowb, 2 * rowb * H
+            res["maskbits"] = bits[0] if single else bits
+        if want_hole_counts:    # [N, 2] int32 (left, right)
+            counts = torch.zeros((N, 2), dtype=torch.int32, device=dev)
+            io.hole_counts = counts.data_ptr()
+            res["hole_counts"] = counts[0] if single else counts
+        return PreparedRender(self, N, arr, io, res, (depth_rgb, color_rgb, sbs, mask, zout, bits, counts), dev)
 
     def render(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
-               out_depth=None, stream=None):
+               out_depth=None, stream=None, want_maskbits: bool = False, want_hole_counts: bool = False):
         """depth_rgb, color_rgb: uint8 device tensors [N,H,W,3] (or [H,W,3]); params: one
         MdvtFrameParams or a sequence of N.  Returns dict(sbs=[N,H,2W,3] u8 (left | right, sr:918),
         mask=[N,H,2W] u8 (255 = hole), depth=[N,H,2W] f32 (optional; 0 = background))."""
         return self.prepare(depth_rgb, color_rgb, params, out_sbs=out_sbs, out_mask=out_mask,
-                            want_depth=want_depth, out_depth=out_depth).launch(stream)
+                            want_depth=want_depth, out_depth=out_depth, want_maskbits=want_maskbits,
+                            want_hole_counts=want_hole_counts).launch(stream)
 
     @staticmethod
     def pack_params(params, n_frames: int):

@@ -308,3 +308,25 @@ def test_mesh_wide_frames_use_compact_lds_vertices(mods, orc, W, H, infill):
         got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
         _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"wide mesh {W}")
     r.close()
+
+
+@pytest.mark.parametrize("kind", ["points_fast", "points_edges", "mesh", "points_general", "odd_width"])
+def test_compacted_hole_mask_and_counts(mods, orc, kind):
+    """1 bit/px hole mask (wavefront compaction) and per-eye hole counts agree with the byte mask."""
+    _lib, sr, synthetic = mods
+    W, H, N = (250, 37, 3) if kind == "odd_width" else (192, 108, 3)
+    d, c = synthetic.SyntheticScene(W, H, seed=17, n_fg=6).clip(N)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=kind != "mesh", infill_mask=kind == "points_edges")
+    p = r.frame_params(xfov=45.0, convergence_distance=2.0 if kind == "points_general" else None)
+    got = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), p, want_maskbits=True, want_hole_counts=True)
+    mask = got["mask"].cpu().numpy() > 0
+    bits = got["maskbits"].cpu().numpy()
+    counts = got["hole_counts"].cpu().numpy()
+    for k in range(N):
+        for eye, sl in ((0, slice(0, W)), (1, slice(W, 2 * W))):
+            want = np.packbits(mask[k][:, sl], axis=1, bitorder="little")
+            assert np.array_equal(bits[k, :, eye, :want.shape[1]], want), (kind, k, eye)
+            assert counts[k, eye] == mask[k][:, sl].sum()
+    one = {key: v[0] for key, v in got.items() if key in ("sbs", "mask")}
+    _compare(one, _oracle(orc, r, p, d[0], c[0], want_depth=False), W, kind)
+    r.close()

@@ -24,14 +24,14 @@ def test_library_exports_every_declared_symbol(lib):
     declared = sorted(set(re.findall(r"\b(mdvt_[a-z_]+)\s*\(", hdr)))
     assert declared == sorted(lib.SYMBOLS), "keep _lib.SYMBOLS in step with include/mdvt.h"
     assert lib.exported_symbols() == list(lib.SYMBOLS)
-    assert lib.load().mdvt_version() == (0 << 16) | 1
+    assert lib.load().mdvt_version() == (0 << 16) | 2
 
 
 def test_struct_layouts_match_the_header(lib):
     import ctypes as C
     assert C.sizeof(lib.MdvtConfig) == 40
     assert C.sizeof(lib.MdvtFrameParams) == 8 * (9 + 9 + 2 + 16) + 8
-    assert C.sizeof(lib.MdvtIO) == 8 * 18
+    assert C.sizeof(lib.MdvtIO) == 8 * 23
 
 
 def test_no_device_fails_loudly(lib):

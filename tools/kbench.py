@@ -25,6 +25,7 @@ ap.add_argument("--infill", action="store_true")
 ap.add_argument("--zout", action="store_true")
 ap.add_argument("--conv", type=float, default=None)
 ap.add_argument("--pose", action="store_true")
+ap.add_argument("--bits", action="store_true")
 a = ap.parse_args()
 W, H, N = a.width, a.height, a.frames
 if os.environ.get('KB_ORDER'):
@@ -41,17 +42,17 @@ p = [r.frame_params(xfov=45.0, convergence_distance=a.conv, transformation=Ts[k]
 sbs = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device="cuda")
 mask = torch.empty((N, H, 2 * W), dtype=torch.uint8, device="cuda")
 zo = torch.empty((N, H, 2 * W), dtype=torch.float32, device="cuda") if a.zout else None
-job = r.prepare(d, c, p, out_sbs=sbs, out_mask=mask, want_depth=a.zout, out_depth=zo)
+job = r.prepare(d, c, p, out_sbs=sbs, out_mask=mask, want_depth=a.zout, out_depth=zo, want_maskbits=a.bits, want_hole_counts=a.bits)
 stream = torch.cuda.current_stream()
 def run():
     job.launch(stream)
 res = {k: [] for k in a.cfgs}
 for k in a.cfgs:
-    os.environ[a.env] = k; run()
+    os.environ[a.env] = '' if k == 'default' else k; run()
 torch.cuda.synchronize()
 for _ in range(a.rounds):
     for k in a.cfgs:
-        os.environ[a.env] = k
+        os.environ[a.env] = '' if k == 'default' else k
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.calls): run()
