@@ -50,6 +50,8 @@ struct mdvt_ctx {
     unsigned long long* ekeys[2] = {nullptr, nullptr};
     uint8_t* tri_invalid = nullptr;
     uint8_t* unused = nullptr;
+    uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
+    int row_counts_frames = 0;
 };
 
 namespace {
@@ -248,6 +250,7 @@ int mdvt_destroy(mdvt_ctx* c)
     for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); }
     if (c->tri_invalid) (void)hipFree(c->tri_invalid);
     if (c->unused) (void)hipFree(c->unused);
+    if (c->row_counts) (void)hipFree(c->row_counts);
     delete c;
     return MDVT_OK;
 }
@@ -329,7 +332,15 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.maskbits[0] = io->left_maskbits; a.maskbits[1] = io->right_maskbits;
     a.maskbits_pitch = io->maskbits_pitch; a.maskbits_stride = io->maskbits_stride;
     a.hole_counts = io->hole_counts;
-    if (io->hole_counts) MDVT_HIP(c, hipMemsetAsync(io->hole_counts, 0, (size_t)n_frames * 2 * sizeof(uint32_t), s));
+    if (io->hole_counts) {
+        if (c->row_counts_frames < chunk) {
+            if (c->row_counts) (void)hipFree(c->row_counts);
+            c->row_counts = nullptr; c->row_counts_frames = 0;
+            MDVT_HIP(c, hipMalloc((void**)&c->row_counts, (size_t)chunk * 2 * H * sizeof(uint32_t)));
+            c->row_counts_frames = chunk;
+        }
+        a.row_counts = c->row_counts;
+    }
     a.fp = dfp;
     a.W = W; a.H = H;
     a.key_rgb = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
@@ -352,6 +363,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         if (e == hipErrorNotSupported) return fail(c, MDVT_ERR_UNSUPPORTED, "render mode %d is not built yet", plan.mode);
         if (e != hipSuccess) return fail(c, MDVT_ERR_HIP, "render launch failed: %s", hipGetErrorString(e));
         if ((want_bits || io->hole_counts) && !plan.fused_bits) MDVT_HIP(c, launch_pack_mask(a, plan.n, s));
+        if (io->hole_counts) MDVT_HIP(c, launch_reduce_counts(a, plan.n, s));
     }
     MDVT_HIP(c, hipEventRecord(slot->done, s));
     return MDVT_OK;

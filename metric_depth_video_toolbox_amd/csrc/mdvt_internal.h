@@ -38,6 +38,7 @@ struct RenderArgs {
     float* zout[2];   size_t zout_pitch, zout_stride;
     uint8_t* maskbits[2]; size_t maskbits_pitch, maskbits_stride;   // optional 1 bit/px hole mask
     uint32_t* hole_counts;       // optional [n_frames][2]
+    uint32_t* row_counts;        // workspace [frames in launch][2][H], zeroed per launch (when hole_counts)
     const FrameDev* fp;          // device array, one per frame of the batch
     int32_t W, H;
     int32_t frame0;              // first frame of this launch within the batch
@@ -71,6 +72,7 @@ struct RenderPlan {
 };
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
+hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 size_t render_lds_bytes(const RenderPlan& plan, int W);
 
 }  // namespace mdvt

@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
 // Wavefront hole-mask compaction.  Each lane holds the hole flags of 4 consecutive pixels (nib, LSB = lowest
 // x).  Eight lanes' nibbles are OR-combined with three cross-lane exchanges into one dword of the packed
 // 1-bit/px mask; the per-(frame,eye) hole count is the popcount of four 64-lane ballots, one atomic per wave.
-__device__ __forceinline__ void compact_hole_nibble(uint32_t nib, int g, bool act, uint8_t* bits_row, uint32_t* count)
+__device__ __forceinline__ int compact_hole_nibble(uint32_t nib, int g, bool act, uint8_t* bits_row, bool want_count)
 {
     if (bits_row) {
         uint32_t v = nib << (4 * (g & 7));
@@ -397,37 +397,62 @@ __device__ __forceinline__ void compact_hole_nibble(uint32_t nib, int g, bool ac
         v |= __shfl_xor((int)v, 4);
         if (act && (g & 7) == 0) ((uint32_t*)bits_row)[g >> 3] = v;
     }
-    if (count) {
-        const int c = __popcll(__ballot(nib & 1)) + __popcll(__ballot(nib & 2)) + __popcll(__ballot(nib & 4)) +
-                      __popcll(__ballot(nib & 8));
-        if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (uint32_t)c);
-    }
+    if (!want_count) return 0;
+    return __popcll(__ballot(nib & 1)) + __popcll(__ballot(nib & 2)) + __popcll(__ballot(nib & 4)) + __popcll(__ballot(nib & 8));
 }
 
-// Post-pass for the kernels that do not compact in place: byte mask -> packed bits + counts.
+// row_counts[(2*frame + eye)*H + row] -> hole_counts[2*frame + eye]
+__global__ void __launch_bounds__(256) k_reduce_counts(const uint32_t* __restrict__ row_counts, uint32_t* __restrict__ hole_counts,
+                                                       int H, int frame0)
+{
+    __shared__ uint32_t part[4];
+    const int fe = blockIdx.x;                       // 2*fr + eye within this launch
+    uint32_t c = 0;
+    for (int i = threadIdx.x; i < H; i += 256) c += row_counts[(size_t)fe * H + i];
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down((int)c, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) hole_counts[2 * (size_t)frame0 + fe] = part[0] + part[1] + part[2] + part[3];
+}
+
+// Post-pass for the kernels that do not compact in place: byte mask -> packed bits + per-row counts.
+// One workgroup per (row, frame, eye).
 __global__ void __launch_bounds__(256) k_pack_mask(RenderArgs a)
 {
+    __shared__ uint32_t wcount[4];
     const int W = a.W;
     const int ngroups = (W + 3) / 4;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    const int fr = blockIdx.z >> 1, eye = blockIdx.z & 1;
+    const int i = blockIdx.x;
+    const int fr = blockIdx.y >> 1, eye = blockIdx.y & 1;
     const int f = a.frame0 + fr;
-    const bool act = g < ngroups;
-    uint32_t nib = 0;
-    if (act) {
-        const uint8_t* mrow = a.mask[eye] + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch;
-        for (int q = 0; q < 4; ++q) if (4 * g + q < W && mrow[4 * g + q]) nib |= 1u << q;
-    }
+    const uint8_t* mrow = a.mask[eye] + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch;
     uint8_t* brow = a.maskbits[eye] ? a.maskbits[eye] + (size_t)f * a.maskbits_stride + (size_t)i * a.maskbits_pitch : nullptr;
-    compact_hole_nibble(nib, g, act, brow, a.hole_counts ? a.hole_counts + 2 * (size_t)f + eye : nullptr);
+    int cnt = 0;
+    for (int g0 = 0; g0 < ngroups; g0 += 256) {
+        const int g = g0 + threadIdx.x;
+        const bool act = g < ngroups;
+        uint32_t nib = 0;
+        if (act)
+            for (int q = 0; q < 4; ++q) if (4 * g + q < W && mrow[4 * g + q]) nib |= 1u << q;
+        cnt += compact_hole_nibble(nib, g, act, brow, a.hole_counts != nullptr);
+    }
+    if (a.hole_counts) {
+        if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = (uint32_t)cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) a.row_counts[(2 * (size_t)fr + eye) * a.H + i] = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    }
 }
 
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s)
 {
-    const int ngroups = (a.W + 3) / 4;
-    dim3 grid((ngroups + 255) / 256, a.H, n * 2);
+    dim3 grid(a.H, n * 2);
     hipLaunchKernelGGL(k_pack_mask, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_reduce_counts, dim3(2 * n), dim3(256), 0, s, a.row_counts, a.hole_counts, a.H, a.frame0);
     return hipGetLastError();
 }
 
@@ -533,8 +558,21 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
             if (BITS) {
                 const uint32_t nib = act ? ((mw & 1u) | ((mw >> 7) & 2u) | ((mw >> 14) & 4u) | ((mw >> 21) & 8u)) : 0u;
                 uint8_t* brow = a.maskbits[eye] ? a.maskbits[eye] + (size_t)f * a.maskbits_stride + (size_t)i * a.maskbits_pitch : nullptr;
-                compact_hole_nibble(nib, g, act, brow, a.hole_counts ? a.hole_counts + 2 * (size_t)f + eye : nullptr);
+                const int c = compact_hole_nibble(nib, g, act, brow, a.hole_counts != nullptr);
+                // the z keys of this eye have been consumed by every wave only after the barrier below;
+                // wave totals go to a few LDS words past the trash slot
+                if (a.hole_counts && (g & 63) == 0) ((uint32_t*)(zb + 2 * (size_t)W + 1))[eye * (TPB / 64) + (g >> 6)] = (uint32_t)c;
             }
+        }
+    }
+    if (BITS && a.hole_counts) {
+        __syncthreads();
+        if (g < 2) {
+            const uint32_t* wc = (const uint32_t*)(zb + 2 * (size_t)W + 1) + g * (TPB / 64);
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < TPB / 64; ++w) tot += wc[w];
+            a.row_counts[(2 * (size_t)fr + g) * a.H + i] = tot;
         }
     }
 }
@@ -1033,7 +1071,7 @@ static int points_cfg_override()
 template <int TPB, bool ZOUT, bool BITS>
 static hipError_t launch_points_rows_fast_cfg(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
-    const size_t lds = (2 * (size_t)a.W + 2) * sizeof(u64);
+    const size_t lds = (2 * (size_t)a.W + 2) * sizeof(u64) + (BITS ? 2 * (TPB / 64) * sizeof(uint32_t) + 8 : 0);
     const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)k_points_rows_fast<TPB, ZOUT, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

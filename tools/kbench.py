@@ -26,6 +26,7 @@ ap.add_argument("--zout", action="store_true")
 ap.add_argument("--conv", type=float, default=None)
 ap.add_argument("--pose", action="store_true")
 ap.add_argument("--bits", action="store_true")
+ap.add_argument("--counts", action="store_true")
 a = ap.parse_args()
 W, H, N = a.width, a.height, a.frames
 if os.environ.get('KB_ORDER'):
@@ -42,7 +43,7 @@ p = [r.frame_params(xfov=45.0, convergence_distance=a.conv, transformation=Ts[k]
 sbs = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device="cuda")
 mask = torch.empty((N, H, 2 * W), dtype=torch.uint8, device="cuda")
 zo = torch.empty((N, H, 2 * W), dtype=torch.float32, device="cuda") if a.zout else None
-job = r.prepare(d, c, p, out_sbs=sbs, out_mask=mask, want_depth=a.zout, out_depth=zo, want_maskbits=a.bits, want_hole_counts=a.bits)
+job = r.prepare(d, c, p, out_sbs=sbs, out_mask=mask, want_depth=a.zout, out_depth=zo, want_maskbits=a.bits, want_hole_counts=a.counts)
 stream = torch.cuda.current_stream()
 def run():
     job.launch(stream)
