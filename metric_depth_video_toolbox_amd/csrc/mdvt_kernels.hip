@@ -125,6 +125,36 @@ __device__ __forceinline__ void vertex_f64(const FrameDev& f, int i, int j, int 
     p[2] = (double)z;
 }
 
+// Division-free screening of the same test.  cos < c0  <=>  dot < c0 * (|n||v| + 1e-15); with the
+// unnormalised view vector vs = a+b+c (v = -vs/3) this is  -n.vs < c0 * |n| |vs|  up to the 1e-15 term.
+// Squaring removes the square roots.  The screening value carries ~1e-15 relative rounding error and
+// ignores the 1e-15 term (<= 1e-8 relative for any triangle bigger than a few square microns), so a
+// triangle whose margin is below kScreenMargin is NOT decided here and goes through the exact formula;
+// everything else provably gets the decision the exact formula would give.
+constexpr double kScreenMargin = 1e-6;
+
+// returns 0 = valid, 1 = oblique (removed), 2 = undecided
+__device__ __forceinline__ int tri_oblique_screen(const double (&a)[3], const double (&b)[3], const double (&c)[3])
+{
+    const double e1x = b[0] - a[0], e1y = b[1] - a[1], e1z = b[2] - a[2];
+    const double e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
+    const double nx = e1y * e2z - e1z * e2y;
+    const double ny = e1z * e2x - e1x * e2z;
+    const double nz = e1x * e2y - e1y * e2x;
+    const double sx = (a[0] + b[0]) + c[0], sy = (a[1] + b[1]) + c[1], sz = (a[2] + b[2]) + c[2];
+    const double d = -((nx * sx + ny * sy) + nz * sz);                 // 3 * dot
+    const double nn = (nx * nx + ny * ny) + nz * nz;
+    const double ss = (sx * sx + sy * sy) + sz * sz;                   // 9 * |v|^2
+    const double c0 = 0x1.1df0b2b89dd37p-6;
+    const double rhs = (c0 * c0) * (nn * ss);                          // (c0 |n| |vs|)^2
+    if (!(rhs > 1e-60)) return 2;                                      // degenerate / zero depth: exact path
+    const double lhs = d * fabs(d);                                    // signed square
+    const double tol = kScreenMargin * rhs;
+    if (lhs < rhs - tol) return 1;
+    if (lhs > rhs + tol) return 0;
+    return 2;
+}
+
 // One thread per grid cell: both triangles of the cell.  `unused` must be zeroed beforehand.
 // NOTE f.sx / f.sy hold the mesh grid scale only when the frame was prepared for mesh mode; the host
 // passes scale factors explicitly so the filter can be run standalone for either grid.
@@ -146,13 +176,29 @@ __global__ void k_edge_filter(const uint8_t* __restrict__ depth_rgb, size_t pitc
     const float zD = decode_z(code16_of(load_px_bytes(r0, j + 1)), f.mult, f.scale);
     const float zB = decode_z(code16_of(load_px_bytes(r1, j)), f.mult, f.scale);
     const float zC = decode_z(code16_of(load_px_bytes(r1, j + 1)), f.mult, f.scale);
-    double A[3], B[3], Cc[3], D[3];
-    vertex_f64(f, i, j, of_by_one, zA, A);
-    vertex_f64(f, i + 1, j, of_by_one, zB, B);
-    vertex_f64(f, i + 1, j + 1, of_by_one, zC, Cc);
-    vertex_f64(f, i, j + 1, of_by_one, zD, D);
-    const bool inv1 = tri_oblique(A, B, Cc);     // tri1 = (v[i,j], v[i+1,j], v[i+1,j+1])
-    const bool inv2 = tri_oblique(A, Cc, D);     // tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
+    // screening vertices: the same unprojection with a reciprocal instead of the two divisions
+    const double rfx = 1.0 / f.Kd[0], rfy = 1.0 / f.Kd[1];
+    const double x0 = (of_by_one ? (double)((float)j * f.sx) : (double)j) - f.Kd[2];
+    const double x1 = (of_by_one ? (double)((float)(j + 1) * f.sx) : (double)(j + 1)) - f.Kd[2];
+    const double y0 = (of_by_one ? (double)((float)i * f.sy) : (double)i) - f.Kd[3];
+    const double y1 = (of_by_one ? (double)((float)(i + 1) * f.sy) : (double)(i + 1)) - f.Kd[3];
+    const double A[3] = {x0 * (double)zA * rfx, y0 * (double)zA * rfy, (double)zA};
+    const double B[3] = {x0 * (double)zB * rfx, y1 * (double)zB * rfy, (double)zB};
+    const double Cc[3] = {x1 * (double)zC * rfx, y1 * (double)zC * rfy, (double)zC};
+    const double D[3] = {x1 * (double)zD * rfx, y0 * (double)zD * rfy, (double)zD};
+    int s1 = tri_oblique_screen(A, B, Cc);      // tri1 = (v[i,j], v[i+1,j], v[i+1,j+1])
+    int s2 = tri_oblique_screen(A, Cc, D);      // tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
+    if (s1 == 2 || s2 == 2) {
+        // exact path: the reference's own evaluation order (dmt:1127-1128, 1283-1294)
+        double Ae[3], Be[3], Ce[3], De[3];
+        vertex_f64(f, i, j, of_by_one, zA, Ae);
+        vertex_f64(f, i + 1, j, of_by_one, zB, Be);
+        vertex_f64(f, i + 1, j + 1, of_by_one, zC, Ce);
+        vertex_f64(f, i, j + 1, of_by_one, zD, De);
+        if (s1 == 2) s1 = tri_oblique(Ae, Be, Ce) ? 1 : 0;
+        if (s2 == 2) s2 = tri_oblique(Ae, Ce, De) ? 1 : 0;
+    }
+    const bool inv1 = s1 == 1, inv2 = s2 == 1;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     const size_t cell = (size_t)i * (W - 1) + j;
     if (tri_invalid) {
