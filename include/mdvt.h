@@ -118,6 +118,16 @@ int mdvt_encode_depth(mdvt_ctx* ctx, const float* d_depth, size_t depth_pitch, u
 int mdvt_edge_filter(mdvt_ctx* ctx, const uint8_t* d_depth_rgb, size_t depth_pitch, const double K[9],
                      double depth_scale, int of_by_one, uint8_t* d_tri_invalid, uint8_t* d_unused, void* stream);
 
+/* stereo_rerender.infill_using_normals (sr:155-240; --do_basic_infill at sr:810-812, and
+ * basic_nomal_infill.py:103): every hole pixel marches from its position along the XY direction of its
+ * normal until it meets a non-hole pixel (at most max_steps pixels; the sample two, then one, step further
+ * in is preferred) and takes that pixel's colour.  d_color / d_out: u8 RGB rows; d_hole: u8, nonzero = hole;
+ * d_normal: f32 x 3 per pixel (XY = march direction; a pixel whose normal is exactly (0,1,0) or whose XY
+ * length is <= 1e-6 is left alone).  d_out may not alias d_color. */
+int mdvt_infill_using_normals(mdvt_ctx* ctx, const uint8_t* d_color, size_t color_pitch, const uint8_t* d_hole,
+                              size_t hole_pitch, const float* d_normal, size_t normal_pitch, uint8_t* d_out,
+                              size_t out_pitch, int max_steps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -425,4 +425,21 @@ int mdvt_edge_filter(mdvt_ctx* c, const uint8_t* d_depth_rgb, size_t depth_pitch
     return MDVT_OK;
 }
 
+int mdvt_infill_using_normals(mdvt_ctx* c, const uint8_t* d_color, size_t color_pitch, const uint8_t* d_hole,
+                              size_t hole_pitch, const float* d_normal, size_t normal_pitch, uint8_t* d_out,
+                              size_t out_pitch, int max_steps, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_color || !d_hole || !d_normal || !d_out) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (d_out == d_color) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias d_color (sources are read from the input image)");
+    if (color_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W || hole_pitch < (size_t)c->W ||
+        normal_pitch < (size_t)12 * c->W || normal_pitch % 4 != 0)
+        return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (max_steps < 0) return fail(c, MDVT_ERR_INVALID_ARG, "max_steps must be >= 0");
+    DeviceGuard g(c->device);
+    MDVT_HIP(c, launch_infill_normals(d_color, color_pitch, d_hole, hole_pitch, d_normal, normal_pitch, d_out, out_pitch,
+                                      c->W, c->H, max_steps, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
 }  // extern "C"

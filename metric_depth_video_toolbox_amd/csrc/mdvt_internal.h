@@ -71,6 +71,9 @@ struct RenderPlan {
     int n;               // frames in this launch
 };
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const uint8_t* hole, size_t hole_pitch,
+                                 const float* normal, size_t normal_pitch, uint8_t* out, size_t out_pitch, int W, int H,
+                                 int max_steps, hipStream_t s);
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 size_t render_lds_bytes(const RenderPlan& plan, int W);

@@ -62,6 +62,28 @@ def master_fov_scale_depth(xfov, master_xfov):
     return 1.0 / scale_disp
 
 
+def infill_using_normals(color_img, hole_mask, normal_map, max_steps=400, out=None):
+    """Device version of the reference's infill_using_normals (sr:155-240), same argument meaning:
+    color_img uint8 [H,W,3], hole_mask bool/uint8 [H,W] (True = fill), normal_map float32 [H,W,3] whose XY
+    components give the march direction.  All CUDA tensors; returns a new uint8 [H,W,3] tensor."""
+    import torch
+    from .depth_frames_helper import _ctx
+    assert color_img.is_cuda and color_img.dtype == torch.uint8 and color_img.dim() == 3 and color_img.shape[2] == 3
+    H, W = int(color_img.shape[0]), int(color_img.shape[1])
+    color_img = color_img.contiguous()
+    hole = hole_mask.to(torch.uint8).contiguous()
+    normal = normal_map.to(torch.float32).contiguous()
+    assert tuple(hole.shape) == (H, W) and tuple(normal.shape) == (H, W, 3)
+    if out is None:
+        out = torch.empty_like(color_img)
+    ctx = _ctx(color_img.device.index or 0, W, H)
+    s = torch.cuda.current_stream(color_img.device)
+    ctx.check(_lib.load().mdvt_infill_using_normals(ctx.handle, color_img.data_ptr(), 3 * W, hole.data_ptr(), W,
+                                                    normal.data_ptr(), 12 * W, out.data_ptr(), 3 * W, int(max_steps),
+                                                    C.c_void_p(s.cuda_stream)))
+    return out
+
+
 def make_frame_params(W, H, xfov=None, yfov=None, *, master_xfov=45.0, pupillary_distance=63,
                       convergence_distance=None, transformation=None):
     """The per-frame scalars the reference computes before its render calls (sr:515-541, 563-566,

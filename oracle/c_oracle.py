@@ -60,6 +60,8 @@ def lib():
         L.orc_convergence_angle.restype = C.c_double
         L.orc_render_stereo.argtypes = [C.POINTER(OrcParams), u8p, u8p, u8p, u8p, u8p, u8p, f32p, f32p]
         L.orc_render_stereo.restype = C.c_int
+        L.orc_infill_using_normals.argtypes = [u8p, u8p, f32p, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_infill_using_normals.restype = None
         _lib = L
     return _lib
 
@@ -173,4 +175,15 @@ def render_stereo(p: OrcParams, depth_rgb: np.ndarray, color_rgb: np.ndarray, wa
                                  _p(out["left_mask"], C.c_uint8), _p(out["right_mask"], C.c_uint8), ld, rd)
     if rc != 0:
         raise ValueError(f"orc_render_stereo failed: {rc}")
+    return out
+
+
+def infill_using_normals(color: np.ndarray, hole_mask: np.ndarray, normal_map: np.ndarray, max_steps: int = 400) -> np.ndarray:
+    color = np.ascontiguousarray(color, np.uint8)
+    hole = np.ascontiguousarray(hole_mask, np.uint8)
+    normal = np.ascontiguousarray(normal_map, np.float32)
+    H, W = hole.shape
+    out = np.empty_like(color)
+    lib().orc_infill_using_normals(_p(color, C.c_uint8), _p(hole, C.c_uint8), _p(normal, C.c_float), W, H, int(max_steps),
+                                   _p(out, C.c_uint8))
     return out

@@ -502,3 +502,45 @@ int orc_render_stereo(const orc_params* p, const uint8_t* depth_rgb, const uint8
     free(tri_invalid); free(unused); free(depth);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* infill_using_normals (sr:155-240)                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_infill_using_normals(const uint8_t* color, const uint8_t* hole, const float* normal, int W, int H,
+                              int max_steps, uint8_t* out)
+{
+    const size_t n = (size_t)W * H;
+    memcpy(out, color, n * 3);
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+            const size_t k = (size_t)y * W + x;
+            if (!hole[k]) continue;
+            const float nx = normal[3 * k], ny = normal[3 * k + 1], nz = normal[3 * k + 2];
+            /* sr:176-179: dirs = normal[..., :2] (f32); norms = np.linalg.norm -> sqrt(x*x + y*y) in f32 */
+            const float len = sqrtf(nx * nx + ny * ny);
+            if (!(len > 1e-6f)) continue;                       /* valid = norms > 1e-6 */
+            if (nx == 0.0f && ny == 1.0f && nz == 0.0f) continue;   /* sr:182: green-coded normals are skipped */
+            const float dx = nx / len, dy = ny / len;
+            const float px = (float)x, py = (float)y;
+            for (int t = 1; t <= max_steps; ++t) {
+                const float sx = px + dx * (float)t, sy = py + dy * (float)t;    /* sr:205 (f32) */
+                const float rx = rintf(sx), ry = rintf(sy);
+                if (!(rx >= 0.0f && rx < (float)W && ry >= 0.0f && ry < (float)H)) break;   /* left the image: ray dies */
+                const int xi = (int)rx, yi = (int)ry;
+                if (hole[(size_t)yi * W + xi]) continue;
+                /* sr:220-228: prefer t+2, then t+1, then t */
+                for (int dt = 2; dt >= 0; --dt) {
+                    const float off = (float)(t + dt);
+                    const float qx = rintf(px + dx * off), qy = rintf(py + dy * off);
+                    if (!(qx >= 0.0f && qx < (float)W && qy >= 0.0f && qy < (float)H)) continue;
+                    const size_t s = (size_t)(int)qy * W + (int)qx;
+                    if (hole[s]) continue;
+                    memcpy(out + 3 * k, color + 3 * s, 3);
+                    break;
+                }
+                break;
+            }
+        }
+    }
+}

@@ -159,7 +159,31 @@ def main():
     geo["scale_60_to_45"] = np.array([scale], np.float64)
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), meta=json.dumps(meta), **geo)
 
-    for f in ("codec.npz", "camera.npz", "geometry.npz"):
+    # ------------------------------------------------------------------ infill_using_normals (sr:155-240)
+    inf = {}
+    for name, (W, H, seed) in {"a": (64, 40, 1), "b": (96, 64, 2)}.items():
+        r2 = np.random.default_rng(900 + seed)
+        color = r2.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        hole = np.zeros((H, W), bool)
+        for _ in range(6):                                   # rectangular holes, some touching the border
+            x0, y0 = int(r2.integers(0, W - 4)), int(r2.integers(0, H - 4))
+            hole[y0:y0 + int(r2.integers(3, H // 3)), x0:x0 + int(r2.integers(3, W // 4))] = True
+        hole[:, 0] = True; hole[0, W // 2:] = True
+        ang = r2.uniform(0, 2 * np.pi, (H, W))
+        mag = r2.uniform(0.2, 1.0, (H, W))
+        normal = np.stack([np.cos(ang) * mag, np.sin(ang) * mag, r2.uniform(-1, 1, (H, W))], -1).astype(np.float32)
+        normal[hole & (r2.uniform(size=(H, W)) < 0.1)] = (0.0, 1.0, 0.0)      # green-coded: skipped (sr:182)
+        normal[hole & (r2.uniform(size=(H, W)) < 0.05)] = (0.0, 0.0, 1.0)     # zero XY direction: invalid (sr:178)
+        normal[2, :] = (1.0, 0.0, 0.0)                                         # axis-aligned marches
+        normal[:, 3] = (0.0, -1.0, 0.0)
+        inf[f"{name}_color"] = color
+        inf[f"{name}_hole"] = hole
+        inf[f"{name}_normal"] = normal
+        inf[f"{name}_out"] = sr.infill_using_normals(color.copy(), hole.copy(), normal.copy())
+        inf[f"{name}_out_12"] = sr.infill_using_normals(color.copy(), hole.copy(), normal.copy(), max_steps=12)
+    np.savez_compressed(os.path.join(HERE, "infill.npz"), meta=json.dumps(meta), **inf)
+
+    for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -330,3 +330,23 @@ def test_compacted_hole_mask_and_counts(mods, orc, kind):
     one = {key: v[0] for key, v in got.items() if key in ("sbs", "mask")}
     _compare(one, _oracle(orc, r, p, d[0], c[0], want_depth=False), W, kind)
     r.close()
+
+
+def test_infill_using_normals_on_device(mods, orc, golden):
+    """The HIP kernel against the reference's own outputs (golden) and against the oracle on a big case."""
+    _lib, sr, synthetic = mods
+    g = golden("infill")
+    for scene in ("a", "b"):
+        c, h, n = (torch.from_numpy(np.ascontiguousarray(g[f"{scene}_{k}"])).cuda() for k in ("color", "hole", "normal"))
+        assert np.array_equal(sr.infill_using_normals(c, h, n).cpu().numpy(), g[f"{scene}_out"])
+        assert np.array_equal(sr.infill_using_normals(c, h, n, max_steps=12).cpu().numpy(), g[f"{scene}_out_12"])
+    rng = np.random.default_rng(5)
+    W, H = 1283, 517
+    color = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    hole = rng.uniform(size=(H, W)) < 0.02
+    for _ in range(40):
+        x0, y0 = int(rng.integers(0, W - 80)), int(rng.integers(0, H - 60))
+        hole[y0:y0 + int(rng.integers(5, 60)), x0:x0 + int(rng.integers(5, 80))] = True
+    normal = rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)
+    got = sr.infill_using_normals(torch.from_numpy(color).cuda(), torch.from_numpy(hole).cuda(), torch.from_numpy(normal).cuda())
+    assert np.array_equal(got.cpu().numpy(), orc.infill_using_normals(color, hole, normal))

@@ -163,3 +163,15 @@ def test_master_scale_golden(orc, golden):
     got = orc.decode_depth(g["a_depth_rgb"], 100, scale)
     assert np.array_equal(bits(got), bits(g["a_depth_scaled_60_to_45"]))
     assert np.array_equal(bits(onp.decode_rgb_depth_frame(g["a_depth_rgb"], 100, scale)), bits(g["a_depth_scaled_60_to_45"]))
+
+
+# ------------------------------------------------------------------------------- infill_using_normals
+@pytest.mark.parametrize("scene", ["a", "b"])
+def test_infill_using_normals_golden(orc, golden, scene):
+    """orc_infill_using_normals against the reference's own infill_using_normals (sr:155-240)."""
+    g = golden("infill")
+    for key, steps in (("out", 400), ("out_12", 12)):
+        got = orc.infill_using_normals(g[f"{scene}_color"], g[f"{scene}_hole"], g[f"{scene}_normal"], steps)
+        assert np.array_equal(got, g[f"{scene}_{key}"])
+    changed = np.any(g[f"{scene}_out"] != g[f"{scene}_color"], axis=-1)
+    assert changed.sum() > 100 and not changed[~g[f"{scene}_hole"]].any()      # only holes are touched
