@@ -29,8 +29,8 @@ BYTES_PER_PX = 14              # 3 depth-RGB + 3 colour read, 2 x (3 RGB + 1 mas
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed spin of the same step before the W warm-up steps: the GPU leaves its idle "
                          "power state over tens of ms (measured: the first ~100 launches after idle run ~15%% slower)")
@@ -145,7 +145,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     # HIP events on the stream the kernel is launched on (torch's current stream), bracketing the timed
     # region: K back-to-back launches of the one kernel a step consists of -> average launch duration.
@@ -157,7 +157,7 @@ def main():
         step()
     ev1.record()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     wall = time.perf_counter() - t0
     wall = D.max_over_ranks(wall, device=dev)
@@ -194,7 +194,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     r.close()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -76,7 +76,8 @@ def init_process_group(backend: Optional[str] = None):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # torchrun: join even with one rank
+    if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -90,7 +91,7 @@ def broadcast_clip_parameters(params: Optional[ClipParameters], src: int = 0, de
     With a single process this is the identity."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         assert params is not None
         return params
     if device is None:
@@ -109,7 +110,7 @@ def gather_rank_stats(frames: float, seconds: float, hole_px: float, device=None
     import torch
     import torch.distributed as dist
     mine = np.array([frames, seconds, hole_px], np.float64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return mine[None]
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -122,7 +123,7 @@ def gather_rank_stats(frames: float, seconds: float, hole_px: float, device=None
 def max_over_ranks(value: float, device=None) -> float:
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
