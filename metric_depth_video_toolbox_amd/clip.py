@@ -11,6 +11,9 @@ a device-side FFV1 codec is out of scope, so this driver works on raw frame dump
                         dfh:163-179)
   <depth>_stereo.npy_holemask.npy   uint8 [N, H, 2W]   255 = hole (sr:740 / 854)
   <depth>_stereo.npy_depth.npy      uint8 [N, H, 2W, 3] B,G,R 16-bit depth code of both eyes (sr:930-939)
+  <depth>_stereo.npy_infillmask.npy uint8 [N, H, 2W, 3] only with --infill_mask --green_and_black_infill_mask:
+                        the key colour (0,255,0) at holes, black elsewhere (sr:787-793, 921-928; RGB order).
+                        The normal-coloured variant needs cv2.inpaint (TELEA) and is not built.
 
 Side-cars are the reference's own JSON formats: xfov list (sr:351-359), convergence list with NaNs
 (sr:343-349), transformations list of 4x4 (sr:362-373).
@@ -196,7 +199,7 @@ def verify_and_move(tmp_path: str, expected_frames: int, final_path: str):
 
 
 def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_sbs_depth_video: bool = False,
-        max_frames: int = -1, **clip_kwargs):
+        max_frames: int = -1, green_and_black_infill_mask: bool = False, **clip_kwargs):
     """File-level entry (what `python stereo_rerender.py --depth_video ...` is to the reference).
     Multi-process aware: under torchrun every rank renders its own contiguous frame range."""
     rank, world = D.init_process_group()
@@ -218,6 +221,8 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
              "mask": (tmp + "_holemask.npy", final + "_holemask.npy", (N, H, 2 * W))}
     if create_sbs_depth_video:
         names["depth"] = (tmp + "_depth.npy", final + "_depth.npy", (N, H, 2 * W, 3))
+    if green_and_black_infill_mask and clip_kwargs.get("infill_mask"):
+        names["infill"] = (tmp + "_infillmask.npy", final + "_infillmask.npy", (N, H, 2 * W, 3))
     if rank == 0:
         for t, _, shape in names.values():
             np.lib.format.open_memmap(t, mode="w+", dtype=np.uint8, shape=shape).flush()
@@ -228,6 +233,11 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     lo, hi = D.frame_range(rank, world, N)
     frames, secs, holes = render_clip(depth, color, outs["sbs"], outs["mask"], clip, lo=lo, hi=hi, batch=batch,
                                       out_depth_rgb=outs.get("depth"))
+    if "infill" in outs:        # sr:787-793 with --green_and_black_infill_mask: bg_color at holes, black elsewhere
+        key = np.array([0, 255, 0], np.uint8)
+        for a in range(lo, hi, 8):
+            b = min(hi, a + 8)
+            outs["infill"][a:b] = (outs["mask"][a:b] > 0)[..., None] * key
     for o in outs.values():
         o.flush()
     stats = D.gather_rank_stats(frames, secs, holes)

@@ -311,8 +311,9 @@ def build_arg_parser():
     ap.add_argument("--remove_edges", action="store_true")
     ap.add_argument("--create_sbs_depth_video", action="store_true")
     ap.add_argument("--batch", default=16, type=int, help="frames per GPU submission")
+    ap.add_argument("--green_and_black_infill_mask", action="store_true")
     for flag in ("--touchly0", "--touchly1", "--vr180", "--do_basic_infill", "--compressed", "--mask_video",
-                 "--save_background", "--load_background", "--green_and_black_infill_mask"):
+                 "--save_background", "--load_background"):
         ap.add_argument(flag, nargs="?", const=True, default=None, help="reference flag outside the built hot path")
     return ap
 
@@ -334,6 +335,7 @@ def main(argv=None):
         raise FileNotFoundError(f"Color video not found: {args.color_video}")                  # sr:331
     stats, final = clip.run(args.depth_video, args.color_video, batch=args.batch,
                             create_sbs_depth_video=args.create_sbs_depth_video, max_frames=args.max_frames,
+                            green_and_black_infill_mask=args.green_and_black_infill_mask,
                             xfov=args.xfov, xfov_file=args.xfov_file, convergence_file=args.convergence_file,
                             transformation_file=args.transformation_file,
                             transformation_lock_frame=args.transformation_lock_frame,

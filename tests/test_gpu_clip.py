@@ -44,11 +44,16 @@ def test_clip_through_files(mods, orc, tmp_path, variant):
         (tmp_path / "T.json").write_text(json.dumps(T.tolist()))
         kw = dict(pupillary_distance=63, xfov_file=str(tmp_path / "xfov.json"), convergence_file=str(tmp_path / "conv.json"),
                   transformation_file=str(tmp_path / "T.json"), transformation_lock_frame=4, infill_mask=True)
-    stats, final = clip.run(dp, cp, batch=5, create_sbs_depth_video=True, **kw)
+    stats, final = clip.run(dp, cp, batch=5, create_sbs_depth_video=True, green_and_black_infill_mask=True, **kw)
     assert final == dp + "_stereo.npy" and os.path.exists(final) and not os.path.exists(dp + "_tmp_stereo.npy")
     assert stats.shape == (1, 3) and stats[0, 0] == N
     sbs, mask, zrgb = np.load(final), np.load(final + "_holemask.npy"), np.load(final + "_depth.npy")
     assert sbs.shape == (N, H, 2 * W, 3) and mask.shape == (N, H, 2 * W) and zrgb.shape == (N, H, 2 * W, 3)
+    if kw.get("infill_mask"):
+        im = np.load(final + "_infillmask.npy")
+        assert np.array_equal(im, (mask > 0)[..., None] * np.array([0, 255, 0], np.uint8))
+    else:
+        assert not os.path.exists(final + "_infillmask.npy")
     cl = clip.load_clip_parameters(N, W, H, **kw)
     r = clip.renderer_for(cl)
     recs = clip.frame_param_records(r, cl, 0, N)
