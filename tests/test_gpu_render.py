@@ -350,3 +350,96 @@ def test_infill_using_normals_on_device(mods, orc, golden):
     normal = rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)
     got = sr.infill_using_normals(torch.from_numpy(color).cuda(), torch.from_numpy(hole).cuda(), torch.from_numpy(normal).cuda())
     assert np.array_equal(got.cpu().numpy(), orc.infill_using_normals(color, hole, normal))
+
+
+# ----------------------------------------------------------------------------------------------- raw ABI use
+def _raw_io(_lib, **kw):
+    io = _lib.MdvtIO()
+    for k, v in kw.items():
+        setattr(io, k, v)
+    return io
+
+
+@pytest.mark.parametrize("mode", ["points", "mesh"])
+def test_raw_abi_with_padded_pitches_and_separate_eye_buffers(mods, orc, mode):
+    """The C ABI takes arbitrary pitches: padded input rows, separate (non side-by-side) eye buffers, an
+    unaligned pitch (-> the byte path), the single-frame entry point and a non-default stream."""
+    import ctypes as C
+    _lib, sr, synthetic = mods
+    W, H = 120, 66
+    depth_rgb, color = _scene(synthetic, W, H, seed=99)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=mode == "points", infill_mask=True)
+    p = r.frame_params(xfov=45.0)
+    want = _oracle(orc, r, p, depth_rgb, color)
+    L = _lib.load()
+    for in_pitch, out_pitch, m_pitch in ((3 * W, 3 * W, W), (3 * W + 20, 3 * W + 36, W + 8), (3 * W + 5, 3 * W + 7, W + 3)):
+        dbuf = torch.zeros((H, in_pitch), dtype=torch.uint8, device="cuda")
+        cbuf = torch.zeros((H, in_pitch), dtype=torch.uint8, device="cuda")
+        dbuf[:, :3 * W] = torch.from_numpy(depth_rgb.reshape(H, 3 * W)).cuda()
+        cbuf[:, :3 * W] = torch.from_numpy(color.reshape(H, 3 * W)).cuda()
+        outs = {k: torch.full((H, out_pitch), 7, dtype=torch.uint8, device="cuda") for k in ("l", "r")}
+        masks = {k: torch.full((H, m_pitch), 7, dtype=torch.uint8, device="cuda") for k in ("l", "r")}
+        zl = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+        zr = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+        io = _raw_io(_lib, depth_rgb=dbuf.data_ptr(), depth_pitch=in_pitch, color_rgb=cbuf.data_ptr(), color_pitch=in_pitch,
+                     left_rgb=outs["l"].data_ptr(), right_rgb=outs["r"].data_ptr(), rgb_pitch=out_pitch,
+                     left_mask=masks["l"].data_ptr(), right_mask=masks["r"].data_ptr(), mask_pitch=m_pitch,
+                     left_depth=zl.data_ptr(), right_depth=zr.data_ptr(), zout_pitch=4 * W)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        r.ctx.check(L.mdvt_render_stereo(r.ctx.handle, C.byref(p), C.byref(io), C.c_void_p(side.cuda_stream)))
+        side.synchronize()
+        for eye, k in (("left", "l"), ("right", "r")):
+            assert np.array_equal(outs[k][:, :3 * W].cpu().numpy().reshape(H, W, 3), want[eye + "_rgb"]), (mode, in_pitch, eye)
+            assert np.array_equal(masks[k][:, :W].cpu().numpy(), want[eye + "_mask"])
+            assert (outs[k][:, 3 * W:] == 7).all() and (masks[k][:, W:] == 7).all(), "padding must stay untouched"
+        assert np.array_equal(zl.cpu().numpy(), want["left_depth"]) and np.array_equal(zr.cpu().numpy(), want["right_depth"])
+    r.close()
+
+
+def test_parameter_cache_respects_changes_and_streams(mods, orc):
+    """The library re-uses the device copy of identical parameter blocks; changing them (or the stream) must
+    re-upload."""
+    _lib, sr, synthetic = mods
+    W, H = 128, 72
+    depth_rgb, color = _scene(synthetic, W, H, seed=123)
+    d, c = torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda()
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True)
+    for xfov in (45.0, 45.0, 50.0, 45.0):
+        p = r.frame_params(xfov=xfov)
+        _compare(r.render(d, c, p, want_depth=True), _oracle(orc, r, p, depth_rgb, color), W, f"cache xfov={xfov}")
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    p = r.frame_params(xfov=45.0)
+    got = r.render(d, c, p, want_depth=True, stream=s2)
+    s2.synchronize()
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, "cache other stream")
+    r.close()
+
+
+def test_invalid_arguments_return_codes(mods):
+    import ctypes as C
+    _lib, sr, synthetic = mods
+    L = _lib.load()
+    r = sr.StereoRerenderer(64, 48, render_as_pointcloud=True)
+    p = r.frame_params(xfov=45.0)
+    buf = torch.zeros((48, 64 * 6), dtype=torch.uint8, device="cuda")
+    ok = dict(depth_rgb=buf.data_ptr(), depth_pitch=192, color_rgb=buf.data_ptr(), color_pitch=192,
+              left_rgb=buf.data_ptr(), right_rgb=buf.data_ptr() + 192, rgb_pitch=384,
+              left_mask=buf.data_ptr(), right_mask=buf.data_ptr() + 64, mask_pitch=128)
+    for bad in (dict(depth_rgb=None), dict(left_mask=None), dict(depth_pitch=100), dict(rgb_pitch=64), dict(mask_pitch=10)):
+        io = _raw_io(_lib, **{**ok, **bad})
+        assert L.mdvt_render_stereo(r.ctx.handle, C.byref(p), C.byref(io), None) == -1, bad
+        assert len(L.mdvt_last_error(r.ctx.handle)) > 0
+    io = _raw_io(_lib, **ok)
+    assert L.mdvt_render_stereo_batch(r.ctx.handle, 0, C.byref(p), C.byref(io), None) == -1
+    p2 = r.frame_params(xfov=45.0)
+    p2.depth_scale = 0.0
+    assert L.mdvt_render_stereo(r.ctx.handle, C.byref(p2), C.byref(io), None) == -1
+    p3 = r.frame_params(xfov=45.0, transformation=np.arange(16.0).reshape(4, 4))       # not affine
+    assert L.mdvt_render_stereo(r.ctx.handle, C.byref(p3), C.byref(io), None) == -3
+    cfg = _lib.MdvtConfig(mode=7)
+    assert L.mdvt_set_config(r.ctx.handle, C.byref(cfg)) == -1
+    cfg = _lib.MdvtConfig(mode=0, edge_points=1, remove_edges=0, ipd_m=0.065, max_depth=100.0)
+    assert L.mdvt_set_config(r.ctx.handle, C.byref(cfg)) == -1
+    r.close()
