@@ -154,8 +154,17 @@ __device__ __forceinline__ bool tri_setup(TriSetup& t, const Vert& a, const Vert
 // gives the same correctly rounded result.
 __device__ __forceinline__ float i64_to_f32(i64 w, bool fits32) { return fits32 ? (float)(int)w : (float)w; }
 
+// q_k = lambda_k * (1/Z_k) with lambda_k = f32(w_k) * (1/f32(area2)): one division per covered pixel.
+__device__ __forceinline__ void tri_weights(i64 area2, float iz0, float iz1, float iz2, i64 w0, i64 w1, i64 w2,
+                                            float& q0, float& q1, float& q2)
+{
+    const bool small = area2 < 0x7FFFFFFFll;                              // 0 <= w_k <= area2 inside
+    const float ra = 1.0f / i64_to_f32(area2, small);
+    const float l0 = i64_to_f32(w0, small) * ra, l1 = i64_to_f32(w1, small) * ra, l2 = i64_to_f32(w2, small) * ra;
+    q0 = l0 * iz0; q1 = l1 * iz1; q2 = l2 * iz2;
+}
+
 // Pixel (px,py) centre against the triangle: returns true and the three q = lambda*invz weights.
-// lambda_k = f32(w_k) * (1/f32(area2)) (one division per call, only on covered pixels).
 __device__ __forceinline__ bool tri_sample(const TriSetup& t, int px, int py, float& q0, float& q1, float& q2)
 {
     const int Xc = px * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
@@ -163,10 +172,7 @@ __device__ __forceinline__ bool tri_sample(const TriSetup& t, int px, int py, fl
     const i64 w1 = mul64(t.dx1, Yc - t.by1) - mul64(t.dy1, Xc - t.bx1);
     const i64 w2 = mul64(t.dx2, Yc - t.by2) - mul64(t.dy2, Xc - t.bx2);
     if (!(edge_in(w0, t.dx0, t.dy0) && edge_in(w1, t.dx1, t.dy1) && edge_in(w2, t.dx2, t.dy2))) return false;
-    const bool small = t.area2 < 0x7FFFFFFFll;                            // 0 <= w_k <= area2 inside
-    const float ra = 1.0f / i64_to_f32(t.area2, small);
-    const float l0 = i64_to_f32(w0, small) * ra, l1 = i64_to_f32(w1, small) * ra, l2 = i64_to_f32(w2, small) * ra;
-    q0 = l0 * t.iz0; q1 = l1 * t.iz1; q2 = l2 * t.iz2;
+    tri_weights(t.area2, t.iz0, t.iz1, t.iz2, w0, w1, w2, q0, q1, q2);
     return true;
 }
 

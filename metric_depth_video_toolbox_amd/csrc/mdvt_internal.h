@@ -50,6 +50,7 @@ struct RenderArgs {
     uint8_t* unused;             // [slot][H*W]
     size_t ws_stride_px;         // H*W (elements) between slots
     size_t ws_stride_tri;        // 2*(H-1)*(W-1)
+    int32_t debug_skip;          // ablation hook for tools/kbench.py (env MDVT_DEBUG_SKIP): 1 raster, 2 resolve, 4 staging
 };
 
 // launchers implemented in mdvt_kernels.hip; all return hipError_t from hipGetLastError()

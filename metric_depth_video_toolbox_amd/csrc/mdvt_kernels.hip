@@ -793,6 +793,36 @@ struct VertStore {
     }
 };
 
+// Regular cell (both triangles in the grid's own orientation): on the scanline the cell is the interval
+// between its two column edges, split by the diagonal A-C.  With
+//   E_col_j(X) = h (X - XA) - (XB - XA) t,   E_diag(X) = h (X - XA) - (XC - XA) t
+// tri1 = {E_col_j >= 0, E_diag < 0}, tri2 = {E_diag >= 0, E_col_j+1 < 0} (top-left rule), and the integer
+// barycentric weights are these same edge values -- identical to the generic edge functions, three 64-bit
+// subtractions per pixel instead of two triangle set-ups.
+struct RegularCell {
+    int XA, XB, XC, XD;
+    float izA, izB, izC, izD;
+    uint32_t cA, cB, cC, cD;
+    int flags;              // bit0: tri1 removed, bit1: tri2 removed (dmt:1372)
+};
+
+__device__ __forceinline__ void regular_cell_pixel(const RegularCell& r, int px, int tt, int bb, int hh,
+                                                   i64 kcol0, i64 kcol1, i64 kdiag, u64* zb)
+{
+    const i64 hX = mul64(hh, px * kSubpix + kSubpix / 2);
+    const i64 e0 = hX - kcol0, e1 = hX - kcol1, ed = hX - kdiag;
+    const bool in1 = e0 >= 0 && ed < 0 && !(r.flags & 1);
+    const bool in2 = ed >= 0 && e1 < 0 && !(r.flags & 2);
+    if (!(in1 || in2)) return;
+    const i64 area2 = in1 ? mul64(hh, r.XC - r.XB) : mul64(hh, r.XD - r.XA);
+    const i64 w0 = in1 ? mul64(r.XC - r.XB, bb) : -e1;
+    const i64 w1 = in1 ? -ed : mul64(r.XD - r.XA, tt);
+    const i64 w2 = in1 ? e0 : ed;
+    float q0, q1, q2;
+    tri_weights(area2, r.izA, in1 ? r.izB : r.izC, in1 ? r.izC : r.izD, w0, w1, w2, q0, q1, q2);
+    atomicMin(&zb[px], mesh_fragment_key(q0, q1, q2, r.cA, in1 ? r.cB : r.cC, in1 ? r.cC : r.cD));
+}
+
 template <int PX, int FLAGS, int TPB, bool VRGB>
 __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 {
@@ -802,6 +832,8 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
     u64* zb = (u64*)smem;                              // [W] z keys of the eye being rendered
     VertStore<VRGB> verts{(int*)(zb + W)};             // [2][W]: vertex rows c and c+1
     uint32_t* eb = (uint32_t*)(verts.base + 2 * (size_t)W * VertStore<VRGB>::kDwords);   // [W] edge-point keys (EDGEPTS)
+    uint8_t* cfl = (uint8_t*)(eb + (EDGEPTS ? W : 0));  // [W] per-column flags (EDGES): bit0 tri1 removed, bit1 tri2 removed, bit2 vertex (k,j) unused
+    uint16_t* kcode = (uint16_t*)(cfl + (((size_t)W + 15) & ~(size_t)15));   // [W] 16-bit depth codes of source row k (EDGEPTS)
 
     const int fr = blockIdx.x / H;
     const int k = blockIdx.x - fr * H;                 // output row
@@ -819,9 +851,10 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
     const int c = (ilo <= H - 2) ? ilo : -1;           // largest i with Ys(i) <= Yc; -1: below the last vertex row
     const int Yt = c >= 0 ? snap((float)c * fp.sy) : 0;
     const int Yb = c >= 0 ? snap((float)(c + 1) * fp.sy) : 0;
+    const int tt = Yc - Yt, bb = Yb - Yc, hh = Yb - Yt;     // scanline position inside the cell row (sub-pixels)
 
     // ---- stage the two vertex rows, clear the z-buffer ----
-    if (c >= 0) {
+    if (c >= 0 && !(a.debug_skip & 4)) {
         const int ngroups = W / PX;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -832,59 +865,137 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                 RowIO<PX>::load(drow, g, dpx);
                 RowIO<PX>::load(crow, g, cpx);
 #pragma unroll
-                for (int q = 0; q < PX; ++q) verts.put(r * W + g * PX + q, mesh_vertex(dpx[q], cpx[q], g * PX + q, fp));
+                for (int q = 0; q < PX; ++q) {
+                    verts.put(r * W + g * PX + q, mesh_vertex(dpx[q], cpx[q], g * PX + q, fp));
+                    if (EDGEPTS && c + r == k) kcode[g * PX + q] = (uint16_t)code16_of(dpx[q]);
+                }
             }
         }
     }
     for (int x = tid; x < W; x += TPB) zb[x] = kEmpty64;
     if (EDGEPTS) for (int x = tid; x < W; x += TPB) eb[x] = kEmpty32;
+    if (EDGES) {
+        // removed-triangle flags of this cell row and unused-vertex flags of source row k: one coalesced pass
+        const size_t ncell_ = (size_t)(W - 1) * (H - 1);
+        const uint8_t* ti = c >= 0 ? a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)c * (W - 1) : nullptr;
+        const uint8_t* ur = a.unused + (size_t)fr * a.ws_stride_px + (size_t)k * W;
+        for (int x = tid; x < W; x += TPB) {
+            uint32_t fl = 0;
+            if (ti && x < W - 1) fl = (ti[x] ? 1u : 0u) | (ti[ncell_ + x] ? 2u : 0u);
+            if (EDGEPTS && ur[x]) fl |= 4u;
+            cfl[x] = (uint8_t)fl;
+        }
+    }
     __syncthreads();
 
     const uint8_t* crow_k = a.color + (size_t)f * a.color_stride + (size_t)k * a.color_pitch;
-    const size_t ncell = (size_t)(W - 1) * (H - 1);
-    const uint8_t* tinv = (EDGES && c >= 0) ? a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)c * (W - 1) : nullptr;
 
 #pragma unroll 1
     for (int eye = 0; eye < 2; ++eye) {
         // ---- rasterise this eye ----
-        if (c >= 0) {
+        if (c >= 0 && !(a.debug_skip & 1)) {
             for (int j0 = 0; j0 < W - 1; j0 += TPB) {
                 const int j = j0 + tid;
                 TriSetup t[2];
                 int px0[2], px1[2];
                 uint32_t col[2][3];
                 bool lng[2] = {false, false};
+                RegularCell rc;
+                int rp0 = 0, rp1 = -1;
+                bool lngcell = false;
                 if (j < W - 1) {
                     const MeshVert A = verts.get(j), D = verts.get(j + 1), B = verts.get(W + j), Cv = verts.get(W + j + 1);
-#pragma unroll
-                    for (int pass = 0; pass < 2; ++pass) {
-                        if (EDGES && tinv[(size_t)pass * ncell + j]) continue;            // dmt:1372
-                        if (!mesh_tri_lds(t[pass], A, B, Cv, D, pass, eye, Yt, Yb)) continue;
-                        const TriSetup& tt = t[pass];
-                        int p0 = floordiv_subpix(tt.minX - kSubpix / 2 + kSubpix - 1), p1 = floordiv_subpix(tt.maxX - kSubpix / 2);
-                        if (p0 < 0) p0 = 0;
-                        if (p1 > W - 1) p1 = W - 1;
-                        px0[pass] = p0; px1[pass] = p1;
-                        col[pass][0] = A.rgb; col[pass][1] = pass == 0 ? B.rgb : Cv.rgb; col[pass][2] = pass == 0 ? Cv.rgb : D.rgb;
-                        if (!VRGB) {
-                            const uint8_t* cr0 = a.color + (size_t)f * a.color_stride + (size_t)c * a.color_pitch;
-                            const uint8_t* cr1 = cr0 + a.color_pitch;
-                            col[pass][0] = load_px_bytes(cr0, j);
-                            col[pass][1] = load_px_bytes(cr1, pass == 0 ? j : j + 1);
-                            col[pass][2] = pass == 0 ? load_px_bytes(cr1, j + 1) : load_px_bytes(cr0, j + 1);
+                    const int XA = eye == 0 ? A.XL : A.XR, XB = eye == 0 ? B.XL : B.XR;
+                    const int XC = eye == 0 ? Cv.XL : Cv.XR, XD = eye == 0 ? D.XL : D.XR;
+                    const uint32_t fl = EDGES ? cfl[j] : 0u;
+                    const bool inv1 = fl & 1u, inv2 = fl & 2u;                                       // dmt:1372
+                    uint32_t cA = A.rgb, cB = B.rgb, cC = Cv.rgb, cD = D.rgb;
+                    if (!VRGB) {
+                        const uint8_t* cr0 = a.color + (size_t)f * a.color_stride + (size_t)c * a.color_pitch;
+                        const uint8_t* cr1 = cr0 + a.color_pitch;
+                        cA = load_px_bytes(cr0, j); cD = load_px_bytes(cr0, j + 1);
+                        cB = load_px_bytes(cr1, j); cC = load_px_bytes(cr1, j + 1);
+                    }
+                    col[0][0] = cA; col[0][1] = cB; col[0][2] = cC;
+                    col[1][0] = cA; col[1][1] = cC; col[1][2] = cD;
+                    const bool allok = A.iz > 0.0f && B.iz > 0.0f && Cv.iz > 0.0f && D.iz > 0.0f;
+                    int p0 = floordiv_subpix(min(XA, XB) - kSubpix / 2 + kSubpix - 1);
+                    int p1 = floordiv_subpix(max(XC, XD) - kSubpix / 2);
+                    if (p0 < 0) p0 = 0;
+                    if (p1 > W - 1) p1 = W - 1;
+                    rc.XA = XA; rc.XB = XB; rc.XC = XC; rc.XD = XD;
+                    rc.izA = A.iz; rc.izB = B.iz; rc.izC = Cv.iz; rc.izD = D.iz;
+                    rc.cA = cA; rc.cB = cB; rc.cC = cC; rc.cD = cD;
+                    rc.flags = (inv1 ? 1 : 0) | (inv2 ? 2 : 0);
+                    if (allok && XC > XB && XD > XA) {
+                        if (rc.flags != 3) {
+                            const i64 kcol0 = mul64(XB - XA, tt) + mul64(hh, XA);
+                            const i64 kcol1 = mul64(XC - XD, tt) + mul64(hh, XD);
+                            // The cell meets the scanline in [kcol0/h, kcol1/h) -- for a cell sheared across a
+                            // horizontal depth edge that is ~1 px although its bounding box spans the whole
+                            // disparity jump.  Candidate pixels from a float estimate of the two crossings,
+                            // widened by one pixel (the estimate is good to ~0.1 px inside the snap range); the
+                            // exact integer tests in regular_cell_pixel decide.
+                            const float rh = 1.0f / (float)hh;
+                            int q0 = (int)floorf(((float)kcol0 * rh - 128.0f) * (1.0f / 256.0f));
+                            int q1 = (int)floorf(((float)kcol1 * rh - 128.0f) * (1.0f / 256.0f)) + 1;
+                            if (q0 < p0) q0 = p0;
+                            if (q1 > p1) q1 = p1;
+                            rp0 = q0; rp1 = q1;
+                            if (q1 - q0 >= kShortSpan) {
+                                lngcell = true;           // rubber-sheet cell across a vertical depth edge: whole-wave path below
+                            } else if (!(a.debug_skip & 16)) {
+                                const i64 kdiag = mul64(XC - XA, tt) + mul64(hh, XA);
+                                for (int px = q0; px <= q1; ++px) regular_cell_pixel(rc, px, tt, bb, hh, kcol0, kcol1, kdiag, zb);
+                            }
                         }
-                        if (p1 - p0 >= kShortSpan) { lng[pass] = true; continue; }
-                        for (int px = p0; px <= p1; ++px) {
-                            float q0, q1, q2;
-                            if (!tri_sample(tt, px, k, q0, q1, q2)) continue;
-                            atomicMin(&zb[px], mesh_fragment_key(q0, q1, q2, col[pass][0], col[pass][1], col[pass][2]));
+                    } else {
+                        // folded / degenerate / near-plane / long-span cells: the generic triangle path
+#pragma unroll
+                        for (int pass = 0; pass < 2; ++pass) {
+                            if (pass == 0 ? inv1 : inv2) continue;
+                            if (!mesh_tri_lds(t[pass], A, B, Cv, D, pass, eye, Yt, Yb)) continue;
+                            const TriSetup& tr = t[pass];
+                            int q0p = floordiv_subpix(tr.minX - kSubpix / 2 + kSubpix - 1), q1p = floordiv_subpix(tr.maxX - kSubpix / 2);
+                            if (q0p < 0) q0p = 0;
+                            if (q1p > W - 1) q1p = W - 1;
+                            px0[pass] = q0p; px1[pass] = q1p;
+                            if (q1p - q0p >= kShortSpan) { lng[pass] = true; continue; }
+                            for (int px = q0p; px <= q1p; ++px) {
+                                float q0, q1, q2;
+                                if (!tri_sample(tr, px, k, q0, q1, q2)) continue;
+                                atomicMin(&zb[px], mesh_fragment_key(q0, q1, q2, col[pass][0], col[pass][1], col[pass][2]));
+                            }
                         }
                     }
                 }
-                // long spans: the whole wave works on one lane's triangle at a time
+                // long regular cells: the whole wave works on one lane's cell at a time (64 pixel centres per step)
+                {
+                    u64 m = (a.debug_skip & 8) ? 0ull : __ballot(lngcell);
+                    while (m) {
+                        const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        RegularCell b;
+#define MDVT_BI(fld) b.fld = __builtin_amdgcn_readlane(rc.fld, l)
+#define MDVT_BF(fld) b.fld = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rc.fld), l))
+#define MDVT_BU(fld) b.fld = (uint32_t)__builtin_amdgcn_readlane((int)rc.fld, l)
+                        MDVT_BI(XA); MDVT_BI(XB); MDVT_BI(XC); MDVT_BI(XD); MDVT_BI(flags);
+                        MDVT_BF(izA); MDVT_BF(izB); MDVT_BF(izC); MDVT_BF(izD);
+                        MDVT_BU(cA); MDVT_BU(cB); MDVT_BU(cC); MDVT_BU(cD);
+#undef MDVT_BI
+#undef MDVT_BF
+#undef MDVT_BU
+                        const int bp0 = __builtin_amdgcn_readlane(rp0, l), bp1 = __builtin_amdgcn_readlane(rp1, l);
+                        const i64 kcol0 = mul64(b.XB - b.XA, tt) + mul64(hh, b.XA);
+                        const i64 kcol1 = mul64(b.XC - b.XD, tt) + mul64(hh, b.XD);
+                        const i64 kdiag = mul64(b.XC - b.XA, tt) + mul64(hh, b.XA);
+                        for (int px = bp0 + lane; px <= bp1; px += 64) regular_cell_pixel(b, px, tt, bb, hh, kcol0, kcol1, kdiag, zb);
+                    }
+                }
+                // long spans of irregular cells: the whole wave works on one lane's triangle at a time
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
-                    u64 m = __ballot(lng[pass]);
+                    u64 m = (a.debug_skip & 8) ? 0ull : __ballot(lng[pass]);
                     while (m) {
                         const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
                         m &= m - 1;
@@ -915,11 +1026,11 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
         // ---- edge points of source row k (sr:589-606, 745-781): vertices of removed triangles ----
         if (EDGEPTS) {
             const uint8_t* drow_k = a.depth + (size_t)f * a.depth_stride + (size_t)k * a.depth_pitch;
-            const uint8_t* urow = a.unused + (size_t)fr * a.ws_stride_px + (size_t)k * W;
+            const bool k_staged = c >= 0 && (k == c || k == c + 1) && !(a.debug_skip & 4);
             const float fW = (float)W;
             for (int j = tid; j < W; j += TPB) {
-                if (!urow[j]) continue;
-                const uint32_t code = code16_of(load_px_bytes(drow_k, j));
+                if (!(cfl[j] & 4u)) continue;
+                const uint32_t code = k_staged ? (uint32_t)kcode[j] : code16_of(load_px_bytes(drow_k, j));
                 const float z = decode_z(code, fp.mult, fp.scale);
                 if (!(z > kNear)) continue;
                 const float d = fp.dl / z;
@@ -940,7 +1051,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
         float* zrow = ZOUT && a.zout[eye]
                           ? (float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)k * a.zout_pitch)
                           : nullptr;
-        for (int g = tid; g < W / PX; g += TPB) {
+        for (int g = tid; g < W / PX && !(a.debug_skip & 2); g += TPB) {
             uint32_t opx[PX], om[PX];
             float oz[PX];
 #pragma unroll
@@ -1135,7 +1246,8 @@ size_t render_lds_bytes(const RenderPlan& plan, int W)
         if (plan.edge_points) b += 2 * (size_t)W * sizeof(uint32_t);
         return b;
     }
-    const size_t extra = (size_t)W * sizeof(u64) + (plan.edge_points ? (size_t)W * sizeof(uint32_t) : 0);
+    const size_t extra = (size_t)W * sizeof(u64) + (plan.edge_points ? (size_t)W * sizeof(uint32_t) + 2 * (size_t)W + 16 : 0) +
+                         (plan.remove_edges ? (((size_t)W + 15) & ~(size_t)15) : 0);
     size_t b = 2 * (size_t)W * 16 + extra;              // 16-byte vertices (colour in LDS)
     if (b > kMaxLds) b = 2 * (size_t)W * 12 + extra;    // 12-byte vertices (colour re-read in the resolve)
     return b;
@@ -1255,13 +1367,9 @@ static hipError_t launch_points_general(const RenderPlan& plan, const RenderArgs
     return hipGetLastError();
 }
 
-template <int PX>
-static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+template <int PX, int TPB>
+static hipError_t launch_mesh_rows_tpb(const RenderPlan& plan, const RenderArgs& a, size_t lds, bool vrgb, hipStream_t s)
 {
-    constexpr int TPB = 512;
-    const size_t lds = render_lds_bytes(plan, a.W);
-    if (lds > kMaxLds) return hipErrorNotSupported;         // W > 4551 with edge points (5120 without)
-    const bool vrgb = lds == 2 * (size_t)a.W * 16 + (size_t)a.W * 8 + (plan.edge_points ? (size_t)a.W * 4 : 0);
     const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
     const bool zout = a.zout[0] || a.zout[1];
     const int flags = (zout ? 1 : 0) | (plan.remove_edges ? 2 : 0) | (plan.remove_edges && plan.edge_points ? 4 : 0);
@@ -1284,6 +1392,23 @@ static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a, 
     }
 #undef MDVT_CASE
     return hipGetLastError();
+}
+
+template <int PX>
+static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
+{
+    RenderArgs a = a_in;
+    if (const char* e = getenv("MDVT_DEBUG_SKIP")) a.debug_skip = atoi(e);
+    const size_t lds = render_lds_bytes(plan, a.W);
+    if (lds > kMaxLds) return hipErrorNotSupported;         // W > ~4300 with edge points (5120 without)
+    const bool vrgb = lds == 2 * (size_t)a.W * 16 + (size_t)a.W * 8 + (plan.edge_points ? (size_t)a.W * 4 + 2 * (size_t)a.W + 16 : 0) +
+                             (plan.remove_edges ? (((size_t)a.W + 15) & ~(size_t)15) : 0);
+    // two 512-thread workgroups per CU when two fit in the 160 KB LDS, otherwise one 1024-thread workgroup:
+    // either way 16 waves per CU
+    int tpb = (2 * lds <= kMaxLds) ? 512 : 1024;
+    if (const char* e = getenv("MDVT_MESH_TPB")) tpb = atoi(e);
+    if (tpb == 1024) return launch_mesh_rows_tpb<PX, 1024>(plan, a, lds, vrgb, s);
+    return launch_mesh_rows_tpb<PX, 512>(plan, a, lds, vrgb, s);
 }
 
 static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
