@@ -48,6 +48,8 @@ struct mdvt_ctx {
     bool ws_keys = false, ws_ekeys = false, ws_edges = false;
     unsigned long long* keys[2] = {nullptr, nullptr};
     unsigned long long* ekeys[2] = {nullptr, nullptr};
+    uint4* gverts[2] = {nullptr, nullptr};
+    bool ws_gverts = false;
     uint8_t* tri_invalid = nullptr;
     uint8_t* unused = nullptr;
     uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
@@ -165,7 +167,7 @@ int stage_params(mdvt_ctx* c, const std::vector<FrameDev>& v, hipStream_t s, con
     return MDVT_OK;
 }
 
-int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, bool need_edges)
+int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, bool need_edges, bool need_gverts)
 {
     const size_t npx = (size_t)c->W * c->H;
     const size_t ntri = 2 * (size_t)(c->W - 1) * (c->H - 1);
@@ -183,6 +185,10 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         if (c->unused) (void)hipFree(c->unused);
         c->tri_invalid = nullptr; c->unused = nullptr; c->ws_edges = false;
     }
+    if (grow || (need_gverts && !c->ws_gverts)) {
+        for (int e = 0; e < 2; ++e) { if (c->gverts[e]) (void)hipFree(c->gverts[e]); c->gverts[e] = nullptr; }
+        c->ws_gverts = false;
+    }
     if (grow) c->ws_frames = frames;
     const size_t nf = (size_t)c->ws_frames;
     if (need_keys && !c->ws_keys) {
@@ -192,6 +198,10 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     if (need_ekeys && !c->ws_ekeys) {
         for (int e = 0; e < 2; ++e) MDVT_HIP(c, hipMalloc((void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long)));
         c->ws_ekeys = true;
+    }
+    if (need_gverts && !c->ws_gverts) {
+        for (int e = 0; e < 2; ++e) MDVT_HIP(c, hipMalloc((void**)&c->gverts[e], nf * npx * sizeof(uint4)));
+        c->ws_gverts = true;
     }
     if (need_edges && !c->ws_edges) {
         MDVT_HIP(c, hipMalloc((void**)&c->tri_invalid, nf * ntri));
@@ -247,7 +257,7 @@ int mdvt_destroy(mdvt_ctx* c)
         if (sl.dev) (void)hipFree(sl.dev);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
-    for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); }
+    for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); if (c->gverts[e]) (void)hipFree(c->gverts[e]); }
     if (c->tri_invalid) (void)hipFree(c->tri_invalid);
     if (c->unused) (void)hipFree(c->unused);
     if (c->row_counts) (void)hipFree(c->row_counts);
@@ -321,7 +331,8 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     const bool need_keys = plan.general;
     const bool need_ekeys = plan.general && plan.edge_points;
     const int chunk = need_ws ? (n_frames < kWorkspaceChunk ? n_frames : kWorkspaceChunk) : n_frames;
-    if (need_ws && (rc = ensure_workspace(c, chunk, need_keys, need_ekeys, plan.remove_edges)) != MDVT_OK) return rc;
+    const bool need_gverts = plan.general && plan.mode == MDVT_MODE_MESH;
+    if (need_ws && (rc = ensure_workspace(c, chunk, need_keys, need_ekeys, plan.remove_edges, need_gverts)) != MDVT_OK) return rc;
 
     RenderArgs a{};
     a.depth = io->depth_rgb; a.depth_pitch = io->depth_pitch; a.depth_stride = io->depth_stride;
@@ -346,6 +357,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.key_rgb = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     a.keys[0] = c->keys[0]; a.keys[1] = c->keys[1];
     a.ekeys[0] = c->ekeys[0]; a.ekeys[1] = c->ekeys[1];
+    a.gverts[0] = c->gverts[0]; a.gverts[1] = c->gverts[1];
     a.tri_invalid = c->tri_invalid; a.unused = c->unused;
     a.ws_stride_px = (size_t)W * H;
     a.ws_stride_tri = 2 * (size_t)(W - 1) * (H - 1);

@@ -46,6 +46,7 @@ struct RenderArgs {
     // workspace (general path / edge filter); per frame-in-flight slices
     unsigned long long* keys[2]; // [slot][H*W] 64-bit z keys per eye
     unsigned long long* ekeys[2];// edge-point keys per eye
+    uint4* gverts[2];            // general mesh path: per-eye projected vertices {X, Y (snapped), 1/Z', rgb}, [slot][H*W]
     uint8_t* tri_invalid;        // [slot][2*(H-1)*(W-1)]
     uint8_t* unused;             // [slot][H*W]
     size_t ws_stride_px;         // H*W (elements) between slots

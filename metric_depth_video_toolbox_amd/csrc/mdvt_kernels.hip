@@ -1087,25 +1087,37 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 // =================================================================================================
 //   key = ~bits(1/Z') << 32 | R | G<<8 | B<<16     (the shaded fragment travels in the key, see above)
 
-__device__ __forceinline__ bool mesh_tri_general(TriSetup& t, uint32_t (&col)[3], const RenderArgs& a, const FrameDev& fp,
-                                                 int f, int i, int j, int pass, int eye)
+// Stage 1: every vertex is projected ONCE per eye (decode, unproject, 3x4 transform, pinhole, snap, 1/Z')
+// into a 16-byte record; the rasteriser then reads four records per cell instead of recomputing each
+// vertex for all six triangles that share it.
+__global__ void __launch_bounds__(256) k_mesh_vertices_general(RenderArgs a)
 {
-    const int ii[3] = {i, i + 1, pass == 0 ? i + 1 : i};
-    const int jj[3] = {j, pass == 0 ? j : j + 1, j + 1};
-    Vert v[3];
+    const int W = a.W;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    const int fr = blockIdx.z;
+    if (j >= W) return;
+    const int f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
+    const uint8_t* crow = a.color + (size_t)f * a.color_stride + (size_t)i * a.color_pitch;
+    const float z = decode_z(code16_of(load_px_bytes(drow, j)), fp.mult, fp.scale);
+    const uint32_t rgb = load_px_bytes(crow, j);
+    float xc, yc;
+    camera_point(fp, (float)j * fp.sx, (float)i * fp.sy, z, xc, yc);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)ii[k] * a.depth_pitch;
-        const uint8_t* crow = a.color + (size_t)f * a.color_stride + (size_t)ii[k] * a.color_pitch;
-        const float z = decode_z(code16_of(load_px_bytes(drow, jj[k])), fp.mult, fp.scale);
-        float xc, yc;
-        camera_point(fp, (float)jj[k] * fp.sx, (float)ii[k] * fp.sy, z, xc, yc);
-        v[k] = vertex_general(fp, fp.M[eye], xc, yc, z);
-        col[k] = load_px_bytes(crow, jj[k]);
+    for (int eye = 0; eye < 2; ++eye) {
+        const Vert v = vertex_general(fp, fp.M[eye], xc, yc, z);
+        const float iz = v.ok ? 1.0f / v.z : 0.0f;          // 0 flags a vertex behind the near plane
+        a.gverts[eye][(size_t)fr * a.ws_stride_px + (size_t)i * W + j] =
+            make_uint4((uint32_t)snap(v.u), (uint32_t)snap(v.v), __float_as_uint(iz), rgb);
     }
-    return tri_setup(t, v[0], v[1], v[2]);
 }
 
+constexpr int kSmallBox = 12;      // bounding boxes up to this many pixel centres are walked by the owning lane
+
+// Stage 2: one thread per cell, both triangles, both eyes.  Triangles with a large bounding box (rubber
+// sheet across depth edges, sheared cells) are broadcast lane by lane and rasterised by the whole wave.
 template <int FLAGS>
 __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
 {
@@ -1114,29 +1126,81 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     const int fr = blockIdx.z;
-    if (j >= W - 1) return;
-    const int f = a.frame0 + fr;
-    const FrameDev& fp = a.fp[f];
+    const int lane = threadIdx.x & 63;
+    const bool act = j < W - 1;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
-    const uint8_t* tinv = EDGES ? a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j : nullptr;
-    for (int pass = 0; pass < 2; ++pass) {
-        if (EDGES && tinv[(size_t)pass * ncell]) continue;
-        for (int eye = 0; eye < 2; ++eye) {
-            TriSetup t; uint32_t col[3];
-            if (!mesh_tri_general(t, col, a, fp, f, i, j, pass, eye)) continue;
-            int px0 = floordiv_subpix(t.minX - kSubpix / 2 + kSubpix - 1), px1 = floordiv_subpix(t.maxX - kSubpix / 2);
-            int py0 = floordiv_subpix(t.minY - kSubpix / 2 + kSubpix - 1), py1 = floordiv_subpix(t.maxY - kSubpix / 2);
-            if (px0 < 0) px0 = 0;
-            if (py0 < 0) py0 = 0;
-            if (px1 > W - 1) px1 = W - 1;
-            if (py1 > H - 1) py1 = H - 1;
-            u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
-            for (int py = py0; py <= py1; ++py)
-                for (int px = px0; px <= px1; ++px) {
-                    float q0, q1, q2;
-                    if (!tri_sample(t, px, py, q0, q1, q2)) continue;
-                    atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, col[0], col[1], col[2]));
+    bool inv[2] = {false, false};
+    if (EDGES && act) {
+        const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
+        inv[0] = tinv[0]; inv[1] = tinv[ncell];
+    }
+#pragma unroll 1
+    for (int eye = 0; eye < 2; ++eye) {
+        u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
+        uint4 A = make_uint4(0, 0, 0, 0), B = A, Cv = A, D = A;
+        if (act) {
+            const uint4* v = a.gverts[eye] + (size_t)fr * a.ws_stride_px + (size_t)i * W + j;
+            A = v[0]; D = v[1]; B = v[W]; Cv = v[W + 1];
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            // tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]); tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])   (dmt:1243-1254)
+            const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
+            TriSetup t;
+            bool big = false;
+            int px0 = 0, px1 = -1, py0 = 0, py1 = -1;
+            if (act && !inv[pass] &&
+                tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
+                                  (int)v2.x, (int)v2.y, __uint_as_float(v2.z))) {
+                px0 = floordiv_subpix(t.minX - kSubpix / 2 + kSubpix - 1); px1 = floordiv_subpix(t.maxX - kSubpix / 2);
+                py0 = floordiv_subpix(t.minY - kSubpix / 2 + kSubpix - 1); py1 = floordiv_subpix(t.maxY - kSubpix / 2);
+                if (px0 < 0) px0 = 0;
+                if (py0 < 0) py0 = 0;
+                if (px1 > W - 1) px1 = W - 1;
+                if (py1 > H - 1) py1 = H - 1;
+                if (px1 >= px0 && py1 >= py0) {
+                    if ((px1 - px0 + 1) * (i64)(py1 - py0 + 1) > kSmallBox) big = true;
+                    else
+                        for (int py = py0; py <= py1; ++py)
+                            for (int px = px0; px <= px1; ++px) {
+                                float q0, q1, q2;
+                                if (!tri_sample(t, px, py, q0, q1, q2)) continue;
+                                atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, A.w, v1.w, v2.w));
+                            }
                 }
+            }
+            u64 m = __ballot(big);
+            while (m) {
+                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                m &= m - 1;
+                TriSetup b;
+#define MDVT_BCAST(fld) b.fld = __builtin_amdgcn_readlane(t.fld, l)
+                MDVT_BCAST(dx0); MDVT_BCAST(dy0); MDVT_BCAST(dx1); MDVT_BCAST(dy1); MDVT_BCAST(dx2); MDVT_BCAST(dy2);
+                MDVT_BCAST(bx0); MDVT_BCAST(by0); MDVT_BCAST(bx1); MDVT_BCAST(by1); MDVT_BCAST(bx2); MDVT_BCAST(by2);
+#undef MDVT_BCAST
+                const uint32_t alo = __builtin_amdgcn_readlane((int)(uint32_t)t.area2, l);
+                const uint32_t ahi = __builtin_amdgcn_readlane((int)(uint32_t)((u64)t.area2 >> 32), l);
+                b.area2 = (i64)(((u64)ahi << 32) | alo);
+                b.iz0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.iz0), l));
+                b.iz1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.iz1), l));
+                b.iz2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.iz2), l));
+                const int bx0 = __builtin_amdgcn_readlane(px0, l), bx1 = __builtin_amdgcn_readlane(px1, l);
+                const int by0 = __builtin_amdgcn_readlane(py0, l), by1 = __builtin_amdgcn_readlane(py1, l);
+                const uint32_t c0 = __builtin_amdgcn_readlane((int)A.w, l), c1 = __builtin_amdgcn_readlane((int)v1.w, l);
+                const uint32_t c2 = __builtin_amdgcn_readlane((int)v2.w, l);
+                const int bw = bx1 - bx0 + 1;
+                const i64 total = (i64)bw * (by1 - by0 + 1);
+                // lanes walk the box in row-major order, 64 pixel centres per step
+                int px = bx0 + lane % bw, py = by0 + lane / bw;
+                const int sx = 64 % bw, sy = 64 / bw;
+                for (i64 idx = lane; idx < total; idx += 64) {
+                    float q0, q1, q2;
+                    if (tri_sample(b, px, py, q0, q1, q2))
+                        atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, c0, c1, c2));
+                    px += sx; py += sy;
+                    if (px > bx1) { px -= bw; ++py; }
+                }
+            }
         }
     }
 }
@@ -1420,6 +1484,9 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
         if ((e = hipMemsetAsync(a.keys[eye], 0xFF, (size_t)plan.n * a.ws_stride_px * sizeof(u64), s)) != hipSuccess) return e;
         if (edge && (e = hipMemsetAsync(a.ekeys[eye], 0xFF, (size_t)plan.n * a.ws_stride_px * sizeof(u64), s)) != hipSuccess) return e;
     }
+    const dim3 grid_v((a.W + 255) / 256, a.H, plan.n);
+    hipLaunchKernelGGL(k_mesh_vertices_general, grid_v, dim3(256), 0, s, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
     if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_general<2>), grid_c, dim3(128), 0, s, a);
     else hipLaunchKernelGGL((k_mesh_raster_general<0>), grid_c, dim3(128), 0, s, a);
