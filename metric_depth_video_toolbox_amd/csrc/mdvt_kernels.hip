@@ -281,23 +281,15 @@ struct RowIO<1> {
     static __device__ __forceinline__ void load_u8(const uint8_t* row, int g, uint32_t (&v)[1]) { v[0] = row[g]; }
 };
 
-// LDS z-buffer slot of target pixel x.  With 4 pixels per lane, lane l's q-th atomic goes to pixel
-// ~4l+q+disparity: a linear layout would put lanes 32 B apart (8-way bank conflict on 8-byte keys).
-// Splitting the row into 4 residue classes (x mod 4) makes consecutive lanes hit consecutive slots
-// both in the splat phase (locally constant disparity) and in the resolve phase.
-template <int SWZ>
-__device__ __forceinline__ int zslot(int x, int W4) { return SWZ ? (x & 3) * W4 + (x >> 2) : x; }
-
 // FLAGS bit 0: optional depth planes, bit 1: `unused` vertices are not drawn (remove_edges),
 // bit 2: edge points splatted into holes.
-template <int PX, int FLAGS, int SWZ>
+template <int PX, int FLAGS>
 __device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[PX], const uint32_t (&cpx)[PX],
                                                    const uint32_t (&un)[PX], u64* zb, uint32_t* eb, int W,
                                                    float mult, float scale, float dl, float ecx, float esW)
 {
     constexpr bool UNUSED = FLAGS & 2, EDGE = FLAGS & 4;
     const float fW = (float)W;
-    const int W4 = W >> 2;
 #pragma unroll
     for (int q = 0; q < PX; ++q) {
         const int j = g * PX + q;
@@ -309,8 +301,8 @@ __device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[
         if (!(UNUSED && un[q])) {
             const u64 key = ((u64)code << 40) | ((u64)(uint32_t)j << 24) | (u64)cpx[q];
             const float uL = fj + d, uR = fj - d;
-            if (uL >= 0.0f && uL < fW) atomicMin(&zb[zslot<SWZ>((int)floorf(uL), W4)], key);
-            if (uR >= 0.0f && uR < fW) atomicMin(&zb[W + zslot<SWZ>((int)floorf(uR), W4)], key);
+            if (uL >= 0.0f && uL < fW) atomicMin(&zb[(int)floorf(uL)], key);
+            if (uR >= 0.0f && uR < fW) atomicMin(&zb[W + (int)floorf(uR)], key);
         } else if (EDGE) {
             // sr:599-600, 746: undo the off-by-one scale on X, project, round half-even.
             const float ex = ((fj - ecx) * esW) + ecx;
@@ -318,11 +310,11 @@ __device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[
             const float uL = ex + d, uR = ex - d;
             if (uL > -1.0f && uL < fW + 1.0f) {
                 const int x = (int)rintf(uL);
-                if (x >= 0 && x < W) atomicMin(&eb[zslot<SWZ>(x, W4)], ekey);
+                if (x >= 0 && x < W) atomicMin(&eb[x], ekey);
             }
             if (uR > -1.0f && uR < fW + 1.0f) {
                 const int x = (int)rintf(uR);
-                if (x >= 0 && x < W) atomicMin(&eb[W + zslot<SWZ>(x, W4)], ekey);
+                if (x >= 0 && x < W) atomicMin(&eb[W + x], ekey);
             }
         }
     }
@@ -331,7 +323,7 @@ __device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[
 // TPB threads; ITERS > 0: every thread owns exactly ITERS groups (ngroups <= TPB*ITERS) whose HBM
 // loads are all issued before the LDS clear, so 2*ITERS 768-byte wave loads are in flight per wave
 // while the z-buffer is initialised.  ITERS == 0: plain strided loop (any W).
-template <int PX, int FLAGS, int TPB, int ITERS, int SWZ>
+template <int PX, int FLAGS, int TPB, int ITERS>
 __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
 {
     constexpr bool ZOUT = FLAGS & 1, UNUSED = FLAGS & 2, EDGE = FLAGS & 4;
@@ -381,14 +373,14 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
         for (int it = 0; it < NIT; ++it) {
             const int g = tid + it * TPB;
             if (g < ngroups)
-                points_splat_group<PX, FLAGS, SWZ>(g, dpx[it], cpx[it], un[it], zb, eb, W, mult, scale, dl, ecx, esW);
+                points_splat_group<PX, FLAGS>(g, dpx[it], cpx[it], un[it], zb, eb, W, mult, scale, dl, ecx, esW);
         }
     } else {
         for (int g = tid; g < ngroups; g += TPB) {
             RowIO<PX>::load(drow, g, dpx[0]);
             RowIO<PX>::load(crow, g, cpx[0]);
             if (UNUSED) RowIO<PX>::load_u8(urow, g, un[0]);
-            points_splat_group<PX, FLAGS, SWZ>(g, dpx[0], cpx[0], un[0], zb, eb, W, mult, scale, dl, ecx, esW);
+            points_splat_group<PX, FLAGS>(g, dpx[0], cpx[0], un[0], zb, eb, W, mult, scale, dl, ecx, esW);
         }
     }
     __syncthreads();
@@ -407,14 +399,13 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
 #pragma unroll
             for (int q = 0; q < PX; ++q) {
                 const int x = g * PX + q;
-                const int slot = SWZ ? q * (W >> 2) + g : x;              // == zslot<SWZ>(x, W/4)
-                const u64 key = zrow_lds[slot];
+                const u64 key = zrow_lds[x];
                 const uint32_t rgb = (uint32_t)key & 0xFFFFFFu;
                 const bool covered = key != kEmpty64;
                 const bool hole = !covered || rgb == a.key_rgb;       // sr:740 colour-key compare
                 uint32_t out = hole ? 0u : rgb;                       // sr:793
                 if (EDGE && hole) {
-                    const uint32_t ek = eb[(size_t)eye * W + slot];
+                    const uint32_t ek = eb[(size_t)eye * W + x];
                     if (ek != kEmpty32) {
                         // colour of source column (ek & 0xFFFF) of this row (sr:813-814)
                         out = load_px_bytes(crow, (int)(ek & 0xFFFFu));
@@ -1317,7 +1308,7 @@ size_t render_lds_bytes(const RenderPlan& plan, int W)
     return b;
 }
 
-template <int PX, int TPB, int ITERS, int SWZ>
+template <int PX, int TPB, int ITERS>
 static hipError_t launch_points_rows_cfg(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const size_t lds = render_lds_bytes(plan, a.W);
@@ -1327,9 +1318,9 @@ static hipError_t launch_points_rows_cfg(const RenderPlan& plan, const RenderArg
 #define MDVT_CASE(F)                                                                                   \
     case F:                                                                                            \
         if (lds > 48 * 1024)                                                                           \
-            (void)hipFuncSetAttribute((const void*)k_points_rows<PX, F, TPB, ITERS, SWZ>,                   \
+            (void)hipFuncSetAttribute((const void*)k_points_rows<PX, F, TPB, ITERS>,                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-        hipLaunchKernelGGL((k_points_rows<PX, F, TPB, ITERS, SWZ>), grid, block, lds, s, a);                \
+        hipLaunchKernelGGL((k_points_rows<PX, F, TPB, ITERS>), grid, block, lds, s, a);                \
         break;
     switch (flags) {
         MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(2) MDVT_CASE(3) MDVT_CASE(6) MDVT_CASE(7)
@@ -1339,13 +1330,13 @@ static hipError_t launch_points_rows_cfg(const RenderPlan& plan, const RenderArg
     return hipGetLastError();
 }
 
-// Tuning override for experiments: MDVT_POINTS_CFG = "<TPB>x<ITERS>[s]" (e.g. 512x1, 256x2s; s = swizzled
-// LDS slots).  Re-read on every launch so one process can A/B configurations.
+// Tuning override for experiments (tools/kbench.py): MDVT_POINTS_CFG = "<TPB>x<ITERS>" (e.g. 512x1) selects the
+// templated kernel with that geometry instead of the defaults.  Re-read on every launch.
 static int points_cfg_override()
 {
     const char* e = getenv("MDVT_POINTS_CFG");
     int t = 0, it = 0;
-    if (e && sscanf(e, "%dx%d", &t, &it) == 2) return (t * 16 + it) * 2 + (strchr(e, 's') ? 1 : 0);
+    if (e && sscanf(e, "%dx%d", &t, &it) == 2) return t * 16 + it;
     return 0;
 }
 
@@ -1373,29 +1364,23 @@ static hipError_t launch_points_rows_fast(RenderPlan& plan, const RenderArgs& a,
 static hipError_t launch_points_rows_vec4(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const int ngroups = a.W / 4;
-    const char* env = getenv("MDVT_POINTS_CFG");       // experiments only: "<TPB>x<ITERS>[s]" selects the template kernel
-    if (!(env && env[0]) && !plan.remove_edges) {
+    int cfg = points_cfg_override();
+    if (cfg == 0 && !plan.remove_edges) {          // the headline kernel
         if (ngroups <= 256) return launch_points_rows_fast<256>(plan, a, s);
         if (ngroups <= 512) return launch_points_rows_fast<512>(plan, a, s);
         if (ngroups <= 1024) return launch_points_rows_fast<1024>(plan, a, s);
     }
-    int cfg = points_cfg_override();
-    if (cfg == 0 || ((cfg / 2) % 16 != 0 && ((cfg / 2) / 16) * ((cfg / 2) % 16) < ngroups)) {
-        int c;
-        if (ngroups <= 256) c = 256 * 16 + 1;
-        else if (ngroups <= 512) c = 512 * 16 + 1;        // 1080p: measured best (tools/kbench.py)
-        else if (ngroups <= 1024) c = 512 * 16 + 2;
-        else if (ngroups <= 2048) c = 1024 * 16 + 2;
-        else c = 256 * 16 + 0;
-        cfg = c * 2 + 0;
+    if (cfg == 0 || (cfg % 16 != 0 && (cfg / 16) * (cfg % 16) < ngroups)) {
+        if (ngroups <= 256) cfg = 256 * 16 + 1;
+        else if (ngroups <= 512) cfg = 512 * 16 + 1;        // 1080p: measured best (tools/kbench.py)
+        else if (ngroups <= 1024) cfg = 512 * 16 + 2;
+        else if (ngroups <= 2048) cfg = 1024 * 16 + 2;
+        else cfg = 256 * 16 + 0;
     }
-#define MDVT_CFG(T, I)                                                                         \
-    case (T * 16 + I) * 2: return launch_points_rows_cfg<4, T, I, 0>(plan, a, s);              \
-    case (T * 16 + I) * 2 + 1: return launch_points_rows_cfg<4, T, I, 1>(plan, a, s);
+#define MDVT_CFG(T, I) case T * 16 + I: return launch_points_rows_cfg<4, T, I>(plan, a, s);
     switch (cfg) {
         MDVT_CFG(128, 4) MDVT_CFG(256, 1) MDVT_CFG(256, 2) MDVT_CFG(512, 1) MDVT_CFG(512, 2) MDVT_CFG(1024, 2)
-        MDVT_CFG(256, 0)
-        default: return launch_points_rows_cfg<4, 256, 0, 0>(plan, a, s);
+        default: return launch_points_rows_cfg<4, 256, 0>(plan, a, s);
     }
 #undef MDVT_CFG
 }
@@ -1512,7 +1497,7 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
     plan.fused_bits = 0;
     if (plan.mode == MDVT_MODE_POINTS) {
         if (plan.general) return launch_points_general(plan, a, s);
-        return plan.vec4 ? launch_points_rows_vec4(plan, a, s) : launch_points_rows_cfg<1, 256, 0, 0>(plan, a, s);
+        return plan.vec4 ? launch_points_rows_vec4(plan, a, s) : launch_points_rows_cfg<1, 256, 0>(plan, a, s);
     }
     if (plan.general) return launch_mesh_general(plan, a, s);
     return plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);
