@@ -475,3 +475,50 @@ def test_render_is_hip_graph_capturable(mods, orc):
             one = {key: v[k] for key, v in job.results.items()}
             _compare(one, _oracle(orc, r, p, dd[k], cc[k], want_depth=False), W, f"graph replay frame {k}")
     r.close()
+
+
+def test_randomised_parity_sweep(mods, orc):
+    """Seeded random sweep over sizes (incl. tiny / odd), camera scalars, modes, flags, poses and
+    degenerate depth content; every output plane must equal the oracle bit for bit."""
+    _lib, sr, synthetic = mods
+    rng = np.random.default_rng(20260927)
+    sizes = [(2, 2), (3, 2), (4, 4), (5, 3), (8, 8), (17, 9), (36, 20), (61, 33), (64, 32), (100, 31), (128, 16), (200, 12)]
+    n_cases = 60
+    for case in range(n_cases):
+        W, H = sizes[int(rng.integers(len(sizes)))]
+        mesh = bool(rng.integers(2))
+        infill = bool(rng.integers(2))
+        no_pts = bool(rng.integers(4) == 0)
+        ipd = int(rng.choice([0, 1, 30, 63, 65, 120, 400]))
+        xfov = float(rng.choice([20.0, 45.0, 60.0, 90.0, 120.0]))
+        master = float(rng.choice([25.0, 45.0, 70.0]))
+        max_depth = int(rng.choice([5, 20, 100, 655]))
+        kind = int(rng.integers(4))                      # 0 pure, 1 convergence, 2 pose, 3 both
+        depth_rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        style = int(rng.integers(4))
+        if style == 0:                                   # smooth plane + a step
+            code = (2000 + 40 * np.arange(W)[None, :] + 7 * np.arange(H)[:, None]).astype(np.uint32)
+            code[:, W // 2:] //= 3
+            depth_rgb[..., 0] = (code >> 8) & 0xFF
+            depth_rgb[..., 2] = code & 0xFF
+        elif style == 1:                                 # very near content: huge disparities, near-plane rejects
+            depth_rgb[..., 0] = 0
+            depth_rgb[..., 2] = rng.integers(0, 4, (H, W))
+        elif style == 2:                                 # constant depth
+            depth_rgb[..., 0] = 3
+            depth_rgb[..., 2] = 77
+        color = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        if rng.integers(2):
+            color[rng.integers(H), rng.integers(W)] = (0, 255, 0) if infill else (0, 0, 0)
+        r = sr.StereoRerenderer(W, H, pupillary_distance=ipd, max_depth=max_depth, master_xfov=master,
+                                render_as_pointcloud=not mesh, infill_mask=infill, dont_place_points_in_edges=no_pts)
+        T = None
+        if kind >= 2:
+            T = synthetic.synthetic_pose_track(64)[int(rng.integers(1, 64))]
+            T[:3, 3] *= float(rng.choice([1.0, 20.0]))
+        p = r.frame_params(xfov=xfov, convergence_distance=float(rng.uniform(0.3, 8.0)) if kind in (1, 3) else None,
+                           transformation=T)
+        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+        tag = f"sweep#{case} {W}x{H} mesh={mesh} infill={infill} no_pts={no_pts} ipd={ipd} xfov={xfov} md={max_depth} kind={kind} style={style}"
+        _compare(got, _oracle(orc, r, p, depth_rgb, color, T=T), W, tag)
+        r.close()
