@@ -50,6 +50,7 @@ struct mdvt_ctx {
     unsigned long long* ekeys[2] = {nullptr, nullptr};
     uint4* gverts[2] = {nullptr, nullptr};
     bool ws_gverts = false;
+    bool keys_dirty = false;          // a general-path submission was interrupted between splat and resolve
     uint8_t* tri_invalid = nullptr;
     uint8_t* unused = nullptr;
     uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
@@ -192,11 +193,17 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     if (grow) c->ws_frames = frames;
     const size_t nf = (size_t)c->ws_frames;
     if (need_keys && !c->ws_keys) {
-        for (int e = 0; e < 2; ++e) MDVT_HIP(c, hipMalloc((void**)&c->keys[e], nf * npx * sizeof(unsigned long long)));
+        for (int e = 0; e < 2; ++e) {
+            MDVT_HIP(c, hipMalloc((void**)&c->keys[e], nf * npx * sizeof(unsigned long long)));
+            MDVT_HIP(c, hipMemset(c->keys[e], 0xFF, nf * npx * sizeof(unsigned long long)));     // EMPTY; resolve keeps them so
+        }
         c->ws_keys = true;
     }
     if (need_ekeys && !c->ws_ekeys) {
-        for (int e = 0; e < 2; ++e) MDVT_HIP(c, hipMalloc((void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long)));
+        for (int e = 0; e < 2; ++e) {
+            MDVT_HIP(c, hipMalloc((void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long)));
+            MDVT_HIP(c, hipMemset(c->ekeys[e], 0xFF, nf * npx * sizeof(unsigned long long)));
+        }
         c->ws_ekeys = true;
     }
     if (need_gverts && !c->ws_gverts) {
@@ -362,6 +369,16 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.ws_stride_px = (size_t)W * H;
     a.ws_stride_tri = 2 * (size_t)(W - 1) * (H - 1);
 
+    if (plan.general) {
+        if (c->keys_dirty) {        // re-establish the EMPTY invariant the resolve pass normally maintains
+            const size_t bytes = (size_t)c->ws_frames * a.ws_stride_px * sizeof(unsigned long long);
+            for (int e = 0; e < 2; ++e) {
+                if (c->keys[e]) MDVT_HIP(c, hipMemsetAsync(c->keys[e], 0xFF, bytes, s));
+                if (c->ekeys[e]) MDVT_HIP(c, hipMemsetAsync(c->ekeys[e], 0xFF, bytes, s));
+            }
+        }
+        c->keys_dirty = true;
+    }
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         plan.n = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
         a.frame0 = f0;
@@ -377,6 +394,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         if ((want_bits || io->hole_counts) && !plan.fused_bits) MDVT_HIP(c, launch_pack_mask(a, plan.n, s));
         if (io->hole_counts) MDVT_HIP(c, launch_reduce_counts(a, plan.n, s));
     }
+    if (plan.general) c->keys_dirty = false;
     MDVT_HIP(c, hipEventRecord(slot->done, s));
     return MDVT_OK;
 }

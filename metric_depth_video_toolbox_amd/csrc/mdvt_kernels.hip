@@ -665,40 +665,76 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
     }
 }
 
-template <int FLAGS>
-__global__ void __launch_bounds__(256) k_points_resolve_general(RenderArgs a)
+// Resolve of both general paths: PX pixels per thread, coalesced key reads, the keys are reset to EMPTY
+// on the way out (so the next submission needs no clearing pass), colour from the key (mesh) or gathered
+// from the source frame by the winning source index (points).
+template <int PX, int FLAGS, bool MESH>
+__global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
 {
     constexpr bool ZOUT = FLAGS & 1, EDGE = FLAGS & 4;
     const int W = a.W;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     const int fr = blockIdx.z >> 1, eye = blockIdx.z & 1;
-    if (x >= W) return;
+    if (g >= W / PX) return;
     const int f = a.frame0 + fr;
-    const size_t o = (size_t)fr * a.ws_stride_px + (size_t)y * W + x;
-    const u64 key = a.keys[eye][o];
-    const bool covered = key != kEmpty64;
-    uint32_t rgb = 0;
     const uint8_t* cbase = a.color + (size_t)f * a.color_stride;
-    if (covered) {
-        const uint32_t src = (uint32_t)key;
-        rgb = load_px_bytes(cbase + (size_t)(src >> 16) * a.color_pitch, (int)(src & 0xFFFFu));
-    }
-    const bool hole = !covered || rgb == a.key_rgb;
-    uint32_t out = hole ? 0u : rgb;
-    if (EDGE && hole) {
-        const u64 ek = a.ekeys[eye][o];
-        if (ek != kEmpty64) {
-            const uint32_t src = (uint32_t)ek;
+    u64* krow = a.keys[eye] + (size_t)fr * a.ws_stride_px + (size_t)y * W + (size_t)g * PX;
+    u64* erow = EDGE ? a.ekeys[eye] + (size_t)fr * a.ws_stride_px + (size_t)y * W + (size_t)g * PX : nullptr;
+    u64 key[PX], ek[PX];
+#pragma unroll
+    for (int q = 0; q < PX; ++q) { key[q] = krow[q]; if (EDGE) ek[q] = erow[q]; }
+#pragma unroll
+    for (int q = 0; q < PX; ++q) { krow[q] = kEmpty64; if (EDGE) erow[q] = kEmpty64; }
+    uint32_t opx[PX], om[PX];
+    float oz[PX];
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+        const bool covered = key[q] != kEmpty64;
+        uint32_t rgb = 0;
+        float zval = 0.0f;
+        if (covered) {
+            if (MESH) {
+                rgb = (uint32_t)key[q] & 0xFFFFFFu;
+                if (ZOUT) zval = 1.0f / __uint_as_float(~(uint32_t)(key[q] >> 32));
+            } else {
+                const uint32_t src = (uint32_t)key[q];
+                rgb = load_px_bytes(cbase + (size_t)(src >> 16) * a.color_pitch, (int)(src & 0xFFFFu));
+                if (ZOUT) zval = __uint_as_float((uint32_t)(key[q] >> 32));
+            }
+        }
+        const bool hole = !covered || rgb == a.key_rgb;
+        uint32_t out = hole ? 0u : rgb;
+        if (EDGE && hole && ek[q] != kEmpty64) {
+            const uint32_t src = (uint32_t)ek[q];
             out = load_px_bytes(cbase + (size_t)(src >> 16) * a.color_pitch, (int)(src & 0xFFFFu));
         }
+        opx[q] = out;
+        om[q] = hole ? 255u : 0u;
+        oz[q] = zval;
     }
-    store_px_bytes(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)y * a.rgb_pitch, x, out);
-    (a.mask[eye] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch)[x] = hole ? 255 : 0;
-    if (ZOUT && a.zout[eye]) {
-        float* zrow = (float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)y * a.zout_pitch);
-        zrow[x] = covered ? __uint_as_float((uint32_t)(key >> 32)) : 0.0f;
-    }
+    RowIO<PX>::store_rgb(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)y * a.rgb_pitch, g, opx);
+    RowIO<PX>::store_mask(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch, g, om);
+    if (ZOUT && a.zout[eye])
+        RowIO<PX>::store_z((float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)y * a.zout_pitch), g, oz);
+}
+
+template <bool MESH>
+static hipError_t launch_resolve_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+{
+    const bool zout = a.zout[0] || a.zout[1];
+    const bool edge = plan.remove_edges && plan.edge_points;
+    const int flags = (zout ? 1 : 0) | (edge ? 4 : 0);
+    const int px = plan.vec4 ? 4 : 1;
+    const dim3 grid((a.W / px + 255) / 256, a.H, plan.n * 2), block(256);
+#define MDVT_CASE(F)                                                                                  \
+    case F:                                                                                           \
+        if (px == 4) hipLaunchKernelGGL((k_resolve_general<4, F, MESH>), grid, block, 0, s, a);       \
+        else hipLaunchKernelGGL((k_resolve_general<1, F, MESH>), grid, block, 0, s, a);               \
+        break;
+    switch (flags) { MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(4) MDVT_CASE(5) }
+#undef MDVT_CASE
+    return hipGetLastError();
 }
 
 // =================================================================================================
@@ -1151,7 +1187,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                 if (py1 > H - 1) py1 = H - 1;
                 if (px1 >= px0 && py1 >= py0) {
                     if ((px1 - px0 + 1) * (i64)(py1 - py0 + 1) > kSmallBox) big = true;
-                    else
+                    else if (!(a.debug_skip & 16))
                         for (int py = py0; py <= py1; ++py)
                             for (int px = px0; px <= px1; ++px) {
                                 float q0, q1, q2;
@@ -1160,7 +1196,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                             }
                 }
             }
-            u64 m = __ballot(big);
+            u64 m = (a.debug_skip & 8) ? 0ull : __ballot(big);
             while (m) {
                 const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
                 m &= m - 1;
@@ -1193,38 +1229,6 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                 }
             }
         }
-    }
-}
-
-template <int FLAGS>
-__global__ void __launch_bounds__(256) k_mesh_resolve_general(RenderArgs a)
-{
-    constexpr bool ZOUT = FLAGS & 1, EDGEPTS = FLAGS & 4;
-    const int W = a.W;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int fr = blockIdx.z >> 1, eye = blockIdx.z & 1;
-    if (x >= W) return;
-    const int f = a.frame0 + fr;
-    const size_t o = (size_t)fr * a.ws_stride_px + (size_t)y * W + x;
-    const u64 key = a.keys[eye][o];
-    const bool covered = key != kEmpty64;
-    const uint32_t rgb = covered ? (uint32_t)key & 0xFFFFFFu : 0u;
-    const float zval = (ZOUT && covered) ? 1.0f / __uint_as_float(~(uint32_t)(key >> 32)) : 0.0f;
-    const bool hole = !covered || rgb == a.key_rgb;
-    uint32_t out = hole ? 0u : rgb;
-    if (EDGEPTS && hole) {
-        const u64 ek = a.ekeys[eye][o];
-        if (ek != kEmpty64) {
-            const uint32_t src = (uint32_t)ek;
-            out = load_px_bytes(a.color + (size_t)f * a.color_stride + (size_t)(src >> 16) * a.color_pitch, (int)(src & 0xFFFFu));
-        }
-    }
-    store_px_bytes(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)y * a.rgb_pitch, x, out);
-    (a.mask[eye] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch)[x] = hole ? 255 : 0;
-    if (ZOUT && a.zout[eye]) {
-        float* zrow = (float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)y * a.zout_pitch);
-        zrow[x] = zval;
     }
 }
 
@@ -1385,20 +1389,14 @@ static hipError_t launch_points_rows_vec4(RenderPlan& plan, const RenderArgs& a,
 #undef MDVT_CFG
 }
 
+// The global key buffers are EMPTY on entry: the host clears them when they are (re)allocated and every
+// resolve pass leaves them EMPTY again.
 static hipError_t launch_points_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
-    const size_t npx = (size_t)a.W * a.H;
-    const bool zout = a.zout[0] || a.zout[1];
     const bool edge = plan.remove_edges && plan.edge_points;
     hipError_t e;
-    for (int eye = 0; eye < 2; ++eye) {
-        if ((e = hipMemsetAsync(a.keys[eye], 0xFF, (size_t)plan.n * a.ws_stride_px * sizeof(u64), s)) != hipSuccess) return e;
-        if (edge && (e = hipMemsetAsync(a.ekeys[eye], 0xFF, (size_t)plan.n * a.ws_stride_px * sizeof(u64), s)) != hipSuccess) return e;
-    }
-    (void)npx;
     const dim3 block(256);
     const dim3 grid_s((a.W + 255) / 256, a.H, plan.n);
-    const dim3 grid_r((a.W + 255) / 256, a.H, plan.n * 2);
     const int sflags = (plan.remove_edges ? 2 : 0) | (edge ? 4 : 0);
     switch (sflags) {
         case 0: hipLaunchKernelGGL((k_points_splat_general<0>), grid_s, block, 0, s, a); break;
@@ -1406,14 +1404,7 @@ static hipError_t launch_points_general(const RenderPlan& plan, const RenderArgs
         default: hipLaunchKernelGGL((k_points_splat_general<6>), grid_s, block, 0, s, a); break;
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const int rflags = (zout ? 1 : 0) | (edge ? 4 : 0);
-    switch (rflags) {
-        case 0: hipLaunchKernelGGL((k_points_resolve_general<0>), grid_r, block, 0, s, a); break;
-        case 1: hipLaunchKernelGGL((k_points_resolve_general<1>), grid_r, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((k_points_resolve_general<4>), grid_r, block, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_points_resolve_general<5>), grid_r, block, 0, s, a); break;
-    }
-    return hipGetLastError();
+    return launch_resolve_general<false>(plan, a, s);
 }
 
 template <int PX, int TPB>
@@ -1460,15 +1451,12 @@ static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a_i
     return launch_mesh_rows_tpb<PX, 512>(plan, a, lds, vrgb, s);
 }
 
-static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
-    const bool zout = a.zout[0] || a.zout[1];
+    RenderArgs a = a_in;
+    if (const char* e = getenv("MDVT_DEBUG_SKIP")) a.debug_skip = atoi(e);
     const bool edge = plan.remove_edges && plan.edge_points;
     hipError_t e;
-    for (int eye = 0; eye < 2; ++eye) {
-        if ((e = hipMemsetAsync(a.keys[eye], 0xFF, (size_t)plan.n * a.ws_stride_px * sizeof(u64), s)) != hipSuccess) return e;
-        if (edge && (e = hipMemsetAsync(a.ekeys[eye], 0xFF, (size_t)plan.n * a.ws_stride_px * sizeof(u64), s)) != hipSuccess) return e;
-    }
     const dim3 grid_v((a.W + 255) / 256, a.H, plan.n);
     hipLaunchKernelGGL(k_mesh_vertices_general, grid_v, dim3(256), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1481,15 +1469,7 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
         hipLaunchKernelGGL((k_points_splat_general<14>), grid_s, dim3(256), 0, s, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    const dim3 grid_r((a.W + 255) / 256, a.H, plan.n * 2);
-    const int rflags = (zout ? 1 : 0) | (edge ? 4 : 0);
-    switch (rflags) {
-        case 0: hipLaunchKernelGGL((k_mesh_resolve_general<0>), grid_r, dim3(256), 0, s, a); break;
-        case 1: hipLaunchKernelGGL((k_mesh_resolve_general<1>), grid_r, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((k_mesh_resolve_general<4>), grid_r, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((k_mesh_resolve_general<5>), grid_r, dim3(256), 0, s, a); break;
-    }
-    return hipGetLastError();
+    return launch_resolve_general<true>(plan, a, s);
 }
 
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
