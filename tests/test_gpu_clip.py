@@ -111,3 +111,27 @@ def test_4k_mesh_pose_single_frame(mods, orc):
     assert np.array_equal(mask[:, :W], want["left_mask"]) and np.array_equal(mask[:, W:], want["right_mask"])
     assert np.array_equal(sbs[:, :W], want["left_rgb"]) and np.array_equal(sbs[:, W:], want["right_rgb"])
     r.close()
+
+
+def test_cli_end_to_end(mods, orc, tmp_path, capsys):
+    """`python -m metric_depth_video_toolbox_amd.stereo_rerender` with the reference's flag names."""
+    clip, sr, synthetic = mods
+    W, H, N = 160, 90, 7
+    d, c = synthetic.SyntheticScene(W, H, config_id=3, n_fg=5).clip(N)
+    dp, cp = str(tmp_path / "v_depth.npy"), str(tmp_path / "v.npy")
+    np.save(dp, d); np.save(cp, c)
+    rc = sr.main(["--depth_video", dp, "--color_video", cp, "--xfov", "50", "--pupillary_distance", "65",
+                  "--infill_mask", "--green_and_black_infill_mask", "--max_frames", "5", "--batch", "3"])
+    assert rc == 0 and "Processing complete" in capsys.readouterr().out
+    sbs, mask = np.load(dp + "_stereo.npy"), np.load(dp + "_stereo.npy_holemask.npy")
+    assert sbs.shape == (5, H, 2 * W, 3) and os.path.exists(dp + "_stereo.npy_infillmask.npy")
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
+    p = r.frame_params(xfov=50.0)
+    for t in range(5):
+        K = np.array([p.K[k] for k in range(9)]).reshape(3, 3)
+        op = orc.make_params(W, H, K, ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_MESH,
+                             remove_edges=True, edge_points=True, key_rgb=(0, 255, 0))
+        want = orc.render_stereo(op, d[t], c[t])
+        assert np.array_equal(sbs[t][:, :W], want["left_rgb"]) and np.array_equal(sbs[t][:, W:], want["right_rgb"])
+        assert np.array_equal(mask[t][:, :W], want["left_mask"]) and np.array_equal(mask[t][:, W:], want["right_mask"])
+    r.close()
