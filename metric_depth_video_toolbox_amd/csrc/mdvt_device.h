@@ -59,17 +59,6 @@ __device__ __forceinline__ void store_px_bytes(uint8_t* row, int j, uint32_t px)
 // ---- vertex programme (mirrors the decree, not the oracle's source) --------------------------
 struct Vert { float u, v, z; bool ok; };
 
-// Pure +-ipd/2 shift with K == Krender:  u = grid_x +- (fxr*ipd/2)/Z,  v = grid_y.
-__device__ __forceinline__ Vert vertex_pure(float gx, float gy, float z, float d, int eye)
-{
-    Vert o;
-    o.u = eye == 0 ? gx + d : gx - d;
-    o.v = gy;
-    o.z = z;
-    o.ok = z > kNear;
-    return o;
-}
-
 __device__ __forceinline__ void camera_point(const FrameDev& f, float gx, float gy, float z, float& xc, float& yc)
 {
     xc = ((gx - f.cx) * z) / f.fx;      // dmt:1127
