@@ -128,6 +128,13 @@ int mdvt_infill_using_normals(mdvt_ctx* ctx, const uint8_t* d_color, size_t colo
                               size_t hole_pitch, const float* d_normal, size_t normal_pitch, uint8_t* d_out,
                               size_t out_pitch, int max_steps, void* stream);
 
+/* infill_common.mark_lower_side (infill_common.py:4-49; used by basic_nomal_infill.py:111): every non-black
+ * pixel of the normal-coloured mask image marches along its encoded XY direction ((rg/255)*2-1); where it
+ * first steps onto a black pixel the previous sample position is painted (0,0,255) in d_out (all other
+ * pixels 0).  u8 RGB rows, max_steps as in the reference (march for t = 1 .. max_steps-1). */
+int mdvt_mark_lower_side(mdvt_ctx* ctx, const uint8_t* d_normals_img, size_t img_pitch, uint8_t* d_out,
+                         size_t out_pitch, int max_steps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -477,4 +477,17 @@ int mdvt_infill_using_normals(mdvt_ctx* c, const uint8_t* d_color, size_t color_
     return MDVT_OK;
 }
 
+int mdvt_mark_lower_side(mdvt_ctx* c, const uint8_t* d_normals_img, size_t img_pitch, uint8_t* d_out, size_t out_pitch,
+                         int max_steps, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_normals_img || !d_out) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (d_out == d_normals_img) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias the input image");
+    if (img_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (max_steps < 0) return fail(c, MDVT_ERR_INVALID_ARG, "max_steps must be >= 0");
+    DeviceGuard g(c->device);
+    MDVT_HIP(c, launch_mark_lower_side(d_normals_img, img_pitch, d_out, out_pitch, c->W, c->H, max_steps, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
 }  // extern "C"

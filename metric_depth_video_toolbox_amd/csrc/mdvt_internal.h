@@ -76,6 +76,8 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const uint8_t* hole, size_t hole_pitch,
                                  const float* normal, size_t normal_pitch, uint8_t* out, size_t out_pitch, int W, int H,
                                  int max_steps, hipStream_t s);
+hipError_t launch_mark_lower_side(const uint8_t* img, size_t img_pitch, uint8_t* out, size_t out_pitch, int W, int H,
+                                  int max_steps, hipStream_t s);
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 size_t render_lds_bytes(const RenderPlan& plan, int W);

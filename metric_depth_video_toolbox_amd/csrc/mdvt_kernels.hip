@@ -1291,6 +1291,42 @@ hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const
     return hipGetLastError();
 }
 
+// mark_lower_side (infill_common.py:4-49): one thread per pixel of the normal-coloured mask image.
+// `out` is zeroed beforehand; every hit writes the same (0,0,255), so concurrent writers agree.
+__global__ void __launch_bounds__(256) k_mark_lower_side(const uint8_t* __restrict__ img, size_t img_pitch,
+                                                         uint8_t* __restrict__ out, size_t out_pitch, int W, int H, int max_steps)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const uint32_t px = load_px_bytes(img + (size_t)y * img_pitch, x);
+    if (px == 0) return;                                               // ic:7: only non-black pixels march
+    const float dx0 = ((float)(px & 0xFF) / 255.0f) * 2.0f - 1.0f;     // ic:10
+    const float dy0 = ((float)((px >> 8) & 0xFF) / 255.0f) * 2.0f - 1.0f;
+    const float len = sqrtf(dx0 * dx0 + dy0 * dy0);
+    if (!(len > 1e-6f)) return;                                        // ic:12
+    const float dx = dx0 / len, dy = dy0 / len;
+    const float fx = (float)x, fy = (float)y;
+    for (int t = 1; t < max_steps; ++t) {
+        const float rx = rintf(fx + dx * (float)t), ry = rintf(fy + dy * (float)t);
+        if (!in_image(rx, ry, W, H)) return;                           // ic:41-42
+        if (load_px_bytes(img + (size_t)(int)ry * img_pitch, (int)rx) != 0) continue;
+        const float bx = rintf(fx + dx * (float)(t - 1)), by = rintf(fy + dy * (float)(t - 1));   // ic:35-39
+        if (bx >= 0.0f && by >= 0.0f) store_px_bytes(out + (size_t)(int)by * out_pitch, (int)bx, 0xFF0000u);
+        return;
+    }
+}
+
+hipError_t launch_mark_lower_side(const uint8_t* img, size_t img_pitch, uint8_t* out, size_t out_pitch, int W, int H,
+                                  int max_steps, hipStream_t s)
+{
+    hipError_t e = hipMemset2DAsync(out, out_pitch, 0, (size_t)3 * W, (size_t)H, s);
+    if (e != hipSuccess) return e;
+    dim3 grid((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_mark_lower_side, grid, dim3(256), 0, s, img, img_pitch, out, out_pitch, W, H, max_steps);
+    return hipGetLastError();
+}
+
 // =================================================================================================
 // launch plumbing
 // =================================================================================================

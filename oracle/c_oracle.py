@@ -62,6 +62,8 @@ def lib():
         L.orc_render_stereo.restype = C.c_int
         L.orc_infill_using_normals.argtypes = [u8p, u8p, f32p, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_infill_using_normals.restype = None
+        L.orc_mark_lower_side.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_mark_lower_side.restype = None
         _lib = L
     return _lib
 
@@ -186,4 +188,12 @@ def infill_using_normals(color: np.ndarray, hole_mask: np.ndarray, normal_map: n
     out = np.empty_like(color)
     lib().orc_infill_using_normals(_p(color, C.c_uint8), _p(hole, C.c_uint8), _p(normal, C.c_float), W, H, int(max_steps),
                                    _p(out, C.c_uint8))
+    return out
+
+
+def mark_lower_side(normals_img: np.ndarray, max_steps: int = 30) -> np.ndarray:
+    img = np.ascontiguousarray(normals_img, np.uint8)
+    H, W = img.shape[:2]
+    out = np.empty_like(img)
+    lib().orc_mark_lower_side(_p(img, C.c_uint8), W, H, int(max_steps), _p(out, C.c_uint8))
     return out

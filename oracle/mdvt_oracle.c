@@ -544,3 +544,35 @@ void orc_infill_using_normals(const uint8_t* color, const uint8_t* hole, const f
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* mark_lower_side (infill_common.py:4-49)                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_mark_lower_side(const uint8_t* img, int W, int H, int max_steps, uint8_t* out)
+{
+    memset(out, 0, (size_t)W * H * 3);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const uint8_t* p = img + 3 * ((size_t)y * W + x);
+            if (p[0] == 0 && p[1] == 0 && p[2] == 0) continue;             /* ic:7 valid = non-black */
+            const float dx0 = ((float)p[0] / 255.0f) * 2.0f - 1.0f;        /* ic:10 (f32) */
+            const float dy0 = ((float)p[1] / 255.0f) * 2.0f - 1.0f;
+            const float len = sqrtf(dx0 * dx0 + dy0 * dy0);
+            if (!(len > 1e-6f)) continue;                                   /* ic:12 */
+            const float dx = dx0 / len, dy = dy0 / len;
+            const float fx = (float)x, fy = (float)y;
+            for (int t = 1; t < max_steps; ++t) {                           /* ic:20 range(1, max_steps) */
+                const float rx = rintf(fx + dx * (float)t), ry = rintf(fy + dy * (float)t);
+                if (!(rx >= 0.0f && rx < (float)W && ry >= 0.0f && ry < (float)H)) break;
+                const uint8_t* q = img + 3 * ((size_t)(int)ry * W + (int)rx);
+                if (!(q[0] == 0 && q[1] == 0 && q[2] == 0)) continue;
+                const float bx = rintf(fx + dx * (float)(t - 1)), by = rintf(fy + dy * (float)(t - 1));   /* ic:35-39 */
+                if (bx >= 0.0f && by >= 0.0f) {
+                    uint8_t* o = out + 3 * ((size_t)(int)by * W + (int)bx);
+                    o[0] = 0; o[1] = 0; o[2] = 255;
+                }
+                break;
+            }
+        }
+}

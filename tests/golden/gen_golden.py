@@ -181,6 +181,22 @@ def main():
         inf[f"{name}_normal"] = normal
         inf[f"{name}_out"] = sr.infill_using_normals(color.copy(), hole.copy(), normal.copy())
         inf[f"{name}_out_12"] = sr.infill_using_normals(color.copy(), hole.copy(), normal.copy(), max_steps=12)
+    # mark_lower_side (infill_common.py:4-49) on normal-coloured mask images
+    for name, (W, H, seed) in {"m1": (72, 48, 5), "m2": (120, 64, 6)}.items():
+        r2 = np.random.default_rng(700 + seed)
+        img = np.zeros((H, W, 3), np.uint8)
+        for _ in range(7):
+            x0, y0 = int(r2.integers(0, W - 6)), int(r2.integers(0, H - 6))
+            w, h = int(r2.integers(4, W // 3)), int(r2.integers(4, H // 3))
+            ang = r2.uniform(0, 2 * np.pi)
+            base = np.array([(np.cos(ang) + 1) / 2 * 255, (np.sin(ang) + 1) / 2 * 255, 128.0])
+            patch = np.clip(base[None, None, :] + r2.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+            img[y0:y0 + h, x0:x0 + w] = patch[:img[y0:y0 + h, x0:x0 + w].shape[0], :img[y0:y0 + h, x0:x0 + w].shape[1]]
+        img[3, 5] = (127, 127, 9)                    # |dir| ~ 0.004: still marches; and an exact-zero direction:
+        img[4, 5] = (128, 127, 200)
+        inf[f"{name}_img"] = img
+        inf[f"{name}_out"] = ic.mark_lower_side(img.copy())
+        inf[f"{name}_out_8"] = ic.mark_lower_side(img.copy(), max_steps=8)
     np.savez_compressed(os.path.join(HERE, "infill.npz"), meta=json.dumps(meta), **inf)
 
     for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz"):

@@ -522,3 +522,18 @@ def test_randomised_parity_sweep(mods, orc):
         tag = f"sweep#{case} {W}x{H} mesh={mesh} infill={infill} no_pts={no_pts} ipd={ipd} xfov={xfov} md={max_depth} kind={kind} style={style}"
         _compare(got, _oracle(orc, r, p, depth_rgb, color, T=T), W, tag)
         r.close()
+
+
+def test_mark_lower_side_on_device(mods, orc, golden):
+    from metric_depth_video_toolbox_amd import infill_common
+    g = golden("infill")
+    for scene in ("m1", "m2"):
+        img = torch.from_numpy(np.ascontiguousarray(g[f"{scene}_img"])).cuda()
+        assert np.array_equal(infill_common.mark_lower_side(img).cpu().numpy(), g[f"{scene}_out"])
+        assert np.array_equal(infill_common.mark_lower_side(img, max_steps=8).cpu().numpy(), g[f"{scene}_out_8"])
+    rng = np.random.default_rng(11)
+    big = np.zeros((300, 501, 3), np.uint8)
+    for _ in range(60):
+        x0, y0 = int(rng.integers(0, 460)), int(rng.integers(0, 270))
+        big[y0:y0 + int(rng.integers(3, 30)), x0:x0 + int(rng.integers(3, 40))] = rng.integers(1, 256, 3)
+    assert np.array_equal(infill_common.mark_lower_side(torch.from_numpy(big).cuda()).cpu().numpy(), orc.mark_lower_side(big))

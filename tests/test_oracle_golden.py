@@ -175,3 +175,12 @@ def test_infill_using_normals_golden(orc, golden, scene):
         assert np.array_equal(got, g[f"{scene}_{key}"])
     changed = np.any(g[f"{scene}_out"] != g[f"{scene}_color"], axis=-1)
     assert changed.sum() > 100 and not changed[~g[f"{scene}_hole"]].any()      # only holes are touched
+
+
+@pytest.mark.parametrize("scene", ["m1", "m2"])
+def test_mark_lower_side_golden(orc, golden, scene):
+    """orc_mark_lower_side against the reference's own infill_common.mark_lower_side."""
+    g = golden("infill")
+    assert np.array_equal(orc.mark_lower_side(g[f"{scene}_img"]), g[f"{scene}_out"])
+    assert np.array_equal(orc.mark_lower_side(g[f"{scene}_img"], 8), g[f"{scene}_out_8"])
+    assert np.all(g[f"{scene}_out"][..., :2] == 0) and (g[f"{scene}_out"][..., 2] == 255).sum() > 50
