@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 2
+#define MDVT_VERSION_MINOR 3
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -85,6 +85,12 @@ typedef struct mdvt_io {
     uint8_t* left_maskbits; uint8_t* right_maskbits; size_t maskbits_pitch; size_t maskbits_stride;
     /* optional: hole_counts[2*frame + eye] = number of hole pixels (uint32, overwritten) */
     uint32_t* hole_counts;
+    /* optional (needs remove_edges): the infill-mask SEED image of each eye, u8 RGB -- left_img_mask of
+     * sr:787-803 as (x*255).astype(uint8) just before cv2.inpaint: black outside holes; in holes the key
+     * colour, fixed inward normals on the image border (sr:796-799) and, at splatted edge points, the
+     * removed-vertex normal carried through the eye / pose transform, (n'+1)/2 (sr:596-606, 733, 802).
+     * cv2.inpaint(TELEA) + masked_blur (sr:804-808) are left to the caller. */
+    uint8_t* left_seed; uint8_t* right_seed; size_t seed_pitch; size_t seed_stride;
 } mdvt_io;
 
 int mdvt_version(void);

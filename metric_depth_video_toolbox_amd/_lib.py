@@ -48,7 +48,8 @@ class MdvtIO(C.Structure):
                 ("left_mask", C.c_void_p), ("right_mask", C.c_void_p), ("mask_pitch", C.c_size_t), ("mask_stride", C.c_size_t),
                 ("left_depth", C.c_void_p), ("right_depth", C.c_void_p), ("zout_pitch", C.c_size_t), ("zout_stride", C.c_size_t),
                 ("left_maskbits", C.c_void_p), ("right_maskbits", C.c_void_p), ("maskbits_pitch", C.c_size_t),
-                ("maskbits_stride", C.c_size_t), ("hole_counts", C.c_void_p)]
+                ("maskbits_stride", C.c_size_t), ("hole_counts", C.c_void_p),
+                ("left_seed", C.c_void_p), ("right_seed", C.c_void_p), ("seed_pitch", C.c_size_t), ("seed_stride", C.c_size_t)]
 
 
 _lib = None

@@ -13,7 +13,10 @@ a device-side FFV1 codec is out of scope, so this driver works on raw frame dump
   <depth>_stereo.npy_depth.npy      uint8 [N, H, 2W, 3] B,G,R 16-bit depth code of both eyes (sr:930-939)
   <depth>_stereo.npy_infillmask.npy uint8 [N, H, 2W, 3] only with --infill_mask --green_and_black_infill_mask:
                         the key colour (0,255,0) at holes, black elsewhere (sr:787-793, 921-928; RGB order).
-                        The normal-coloured variant needs cv2.inpaint (TELEA) and is not built.
+  <depth>_stereo.npy_infillmask_seed.npy  uint8 [N, H, 2W, 3] with --infill_mask (without the green/black flag):
+                        the normal-coloured mask as it stands just before cv2.inpaint (sr:803) -- key colour /
+                        border normals / removed-vertex normals.  stereo_rerender.finish_infill_mask() applies
+                        the remaining OpenCV steps (TELEA + masked blur) where cv2 is installed.
 
 Side-cars are the reference's own JSON formats: xfov list (sr:351-359), convergence list with NaNs
 (sr:343-349), transformations list of 4x4 (sr:362-373).
@@ -100,7 +103,7 @@ def frame_param_records(r: StereoRerenderer, clip: D.ClipParameters, lo: int, hi
 
 
 def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParameters, *, lo: int = 0,
-                hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, device: Optional[int] = None):
+                hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, out_seed=None, device: Optional[int] = None):
     """Render frames [lo, hi) of a clip.  depth_frames / color_frames / out_*: array-likes indexed
     [frame] (NumPy arrays or memmaps, uint8).  Returns (frames, seconds, hole_pixels)."""
     import time
@@ -114,6 +117,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     recs = frame_param_records(r, clip, lo, hi)
     B = max(1, min(batch, hi - lo))
     want_z = out_depth_rgb is not None
+    want_seed = out_seed is not None
 
     def pinned(shape, dtype):
         return torch.empty(shape, dtype=dtype, pin_memory=True)
@@ -124,6 +128,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             "h_d": pinned((B, H, W, 3), torch.uint8), "h_c": pinned((B, H, W, 3), torch.uint8),
             "h_sbs": pinned((B, H, 2 * W, 3), torch.uint8), "h_mask": pinned((B, H, 2 * W), torch.uint8),
             "h_zrgb": pinned((B, H, 2 * W, 3), torch.uint8) if want_z else None,
+            "h_seed": pinned((B, H, 2 * W, 3), torch.uint8) if want_seed else None,
             "d_d": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
             "d_c": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
             "d_sbs": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev),
@@ -149,6 +154,8 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         holes += int(np.count_nonzero(m))
         if want_z:
             out_depth_rgb[a:a + n] = st["h_zrgb"][:n].numpy()
+        if want_seed:
+            out_seed[a:a + n] = st["h_seed"][:n].numpy()
         st["pending"] = None
 
     t0 = time.perf_counter()
@@ -167,8 +174,9 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             st["in_done"].record(s_in)
         s_cmp.wait_event(st["in_done"])
         s_cmp.wait_event(st["out_done"])            # device outputs free again
-        r.render(st["d_d"][:n], st["d_c"][:n], recs[a - lo:a - lo + n], out_sbs=st["d_sbs"][:n],
-                 out_mask=st["d_mask"][:n], want_depth=want_z, out_depth=st["d_z"][:n] if want_z else None)
+        res = r.render(st["d_d"][:n], st["d_c"][:n], recs[a - lo:a - lo + n], out_sbs=st["d_sbs"][:n],
+                       out_mask=st["d_mask"][:n], want_depth=want_z, out_depth=st["d_z"][:n] if want_z else None,
+                       want_seed=want_seed)
         if want_z:                                  # sr:930-939: both eyes through the 16-bit code, B,G,R
             for f in range(n):
                 dfh.encode_depth_frame(st["d_z"][f], clip.max_depth, bgr=True, out=st["d_zrgb"][f])
@@ -179,6 +187,9 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             st["h_mask"][:n].copy_(st["d_mask"][:n], non_blocking=True)
             if want_z:
                 st["h_zrgb"][:n].copy_(st["d_zrgb"][:n], non_blocking=True)
+            if want_seed:
+                st["h_seed"][:n].copy_(res["seed"], non_blocking=True)
+                res["seed"].record_stream(s_out)
             st["out_done"].record(s_out)
         st["pending"] = (a, n)
     for st in sets:
@@ -223,6 +234,8 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
         names["depth"] = (tmp + "_depth.npy", final + "_depth.npy", (N, H, 2 * W, 3))
     if green_and_black_infill_mask and clip_kwargs.get("infill_mask"):
         names["infill"] = (tmp + "_infillmask.npy", final + "_infillmask.npy", (N, H, 2 * W, 3))
+    elif clip_kwargs.get("infill_mask"):
+        names["seed"] = (tmp + "_infillmask_seed.npy", final + "_infillmask_seed.npy", (N, H, 2 * W, 3))
     if rank == 0:
         for t, _, shape in names.values():
             np.lib.format.open_memmap(t, mode="w+", dtype=np.uint8, shape=shape).flush()
@@ -232,7 +245,7 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     outs = {k: np.load(v[0], mmap_mode="r+") for k, v in names.items()}
     lo, hi = D.frame_range(rank, world, N)
     frames, secs, holes = render_clip(depth, color, outs["sbs"], outs["mask"], clip, lo=lo, hi=hi, batch=batch,
-                                      out_depth_rgb=outs.get("depth"))
+                                      out_depth_rgb=outs.get("depth"), out_seed=outs.get("seed"))
     if "infill" in outs:        # sr:787-793 with --green_and_black_infill_mask: bg_color at holes, black elsewhere
         key = np.array([0, 255, 0], np.uint8)
         for a in range(lo, hi, 8):

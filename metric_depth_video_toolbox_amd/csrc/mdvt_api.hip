@@ -129,6 +129,9 @@ int fill_frame_dev(mdvt_ctx* c, const mdvt_frame_params& p, FrameDev& f)
             for (int col = 0; col < 3; ++col)
                 f.M[eye][4 * r + col] = (float)((R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col]);
             f.M[eye][4 * r + 3] = (float)(((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r]);
+            for (int col = 0; col < 3; ++col)
+                f.Md[eye][4 * r + col] = (R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col];
+            f.Md[eye][4 * r + 3] = ((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r];
         }
     }
     return MDVT_OK;
@@ -299,6 +302,11 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         return fail(c, MDVT_ERR_INVALID_ARG, "a pitch is smaller than one row");   // sr:507 shape assert
     const bool zout = io->left_depth || io->right_depth;
     if (zout && io->zout_pitch < (size_t)4 * W) return fail(c, MDVT_ERR_INVALID_ARG, "zout_pitch smaller than one row");
+    if (io->left_seed || io->right_seed) {
+        if (!io->left_seed || !io->right_seed) return fail(c, MDVT_ERR_INVALID_ARG, "seed images need both eyes");
+        if (!c->cfg.remove_edges) return fail(c, MDVT_ERR_INVALID_ARG, "seed images need remove_edges (the infill-mask mode of sr:568-570)");
+        if (io->seed_pitch < (size_t)3 * W) return fail(c, MDVT_ERR_INVALID_ARG, "seed_pitch smaller than one row");
+    }
     const bool want_bits = io->left_maskbits || io->right_maskbits;
     if (want_bits) {
         if (!io->left_maskbits || !io->right_maskbits) return fail(c, MDVT_ERR_INVALID_ARG, "maskbits need both eyes");
@@ -332,6 +340,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                 aligned(io->right_rgb, 4) && aligned(io->left_mask, 4) && aligned(io->right_mask, 4) &&
                 io->depth_pitch % 4 == 0 && io->color_pitch % 4 == 0 && io->rgb_pitch % 4 == 0 && io->mask_pitch % 4 == 0 &&
                 io->depth_stride % 4 == 0 && io->color_stride % 4 == 0 && io->rgb_stride % 4 == 0 && io->mask_stride % 4 == 0 &&
+                (!io->left_seed || (aligned(io->left_seed, 4) && aligned(io->right_seed, 4) && io->seed_pitch % 4 == 0 && io->seed_stride % 4 == 0)) &&
                 (!zout || ((!io->left_depth || aligned(io->left_depth, 16)) && (!io->right_depth || aligned(io->right_depth, 16)) &&
                            io->zout_pitch % 16 == 0 && io->zout_stride % 16 == 0));
 
@@ -355,6 +364,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.maskbits[0] = io->left_maskbits; a.maskbits[1] = io->right_maskbits;
     a.maskbits_pitch = io->maskbits_pitch; a.maskbits_stride = io->maskbits_stride;
     a.hole_counts = io->hole_counts;
+    a.seed[0] = io->left_seed; a.seed[1] = io->right_seed; a.seed_pitch = io->seed_pitch; a.seed_stride = io->seed_stride;
     if (io->hole_counts) {
         if (c->row_counts_frames < chunk) {
             if (c->row_counts) (void)hipFree(c->row_counts);

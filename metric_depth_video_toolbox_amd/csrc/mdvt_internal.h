@@ -28,6 +28,7 @@ struct FrameDev {
     int32_t general;     // 0: pure +-ipd/2 shift, 1: pose / convergence / K != Krender
     float M[2][12];      // per eye 3x4 = Translate(+-ipd/2) * Ry(-+a) * T, f32       sr:615-619, 724-725, 832-836
     double Kd[4];        // fx, fy, cx, cy in f64 for the 89-degree edge filter       dmt:1127-1128, 1283-1294
+    double Md[2][12];    // the per-eye 3x4 maps in f64 (infill-mask seed normals)       sr:727-733
 };
 
 struct RenderArgs {
@@ -38,6 +39,7 @@ struct RenderArgs {
     float* zout[2];   size_t zout_pitch, zout_stride;
     uint8_t* maskbits[2]; size_t maskbits_pitch, maskbits_stride;   // optional 1 bit/px hole mask
     uint32_t* hole_counts;       // optional [n_frames][2]
+    uint8_t* seed[2]; size_t seed_pitch, seed_stride;            // optional infill-mask seed images
     uint32_t* row_counts;        // workspace [frames in launch][2][H], zeroed per launch (when hole_counts)
     const FrameDev* fp;          // device array, one per frame of the batch
     int32_t W, H;

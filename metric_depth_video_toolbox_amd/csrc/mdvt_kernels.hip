@@ -229,6 +229,80 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
 }
 
 // =================================================================================================
+// infill-mask seed image (sr:787-803): colour of one hole pixel
+// =================================================================================================
+
+// Unit normal (f64) of the LAST triangle in the reference's draw order that contains vertex (i,j) -- what
+// the last-writer-wins scatter of dmt:1358-1364 leaves in normals_of_vertexes -- and the vertex itself.
+__device__ void removed_vertex_normal(const RenderArgs& a, const FrameDev& fp, int f, int i, int j, int of_by_one,
+                                      double (&n)[3], double (&p)[3])
+{
+    const int W = a.W, H = a.H;
+    int ci, cj, pass;
+    if (i <= H - 2 && j <= W - 2) { pass = 1; ci = i; cj = j; }               // tri2(i,j): vertex is A
+    else if (i <= H - 2 && j >= 1) { pass = 1; ci = i; cj = j - 1; }          // tri2(i,j-1): D
+    else if (i >= 1 && j >= 1) { pass = 1; ci = i - 1; cj = j - 1; }          // tri2(i-1,j-1): C
+    else { pass = 0; ci = i - 1; cj = j; }                                    // only (H-1, 0): tri1(H-2,0): B
+    const int vi[3] = {ci, ci + 1, pass == 0 ? ci + 1 : ci};
+    const int vj[3] = {cj, pass == 0 ? cj : cj + 1, cj + 1};
+    double v[3][3];
+    const uint8_t* dbase = a.depth + (size_t)f * a.depth_stride;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float z = decode_z(code16_of(load_px_bytes(dbase + (size_t)vi[k] * a.depth_pitch, vj[k])), fp.mult, fp.scale);
+        vertex_f64(fp, vi[k], vj[k], of_by_one, z, v[k]);
+    }
+    const double e1x = v[1][0] - v[0][0], e1y = v[1][1] - v[0][1], e1z = v[1][2] - v[0][2];
+    const double e2x = v[2][0] - v[0][0], e2y = v[2][1] - v[0][1], e2z = v[2][2] - v[0][2];
+    const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const double len = sqrt((nx * nx + ny * ny) + nz * nz);
+    if (len > 0.0) { n[0] = nx / len; n[1] = ny / len; n[2] = nz / len; }
+    else { n[0] = n[1] = n[2] = 1.0; }                                        // dmt:1348-1353
+    const float zp = decode_z(code16_of(load_px_bytes(dbase + (size_t)i * a.depth_pitch, j)), fp.mult, fp.scale);
+    vertex_f64(fp, i, j, of_by_one, zp, p);
+}
+
+// (n'+1)/2*255 truncated, n' = M(n + p) - M(S p) normalised (sr:596-600, 727-733, 777-802).
+__device__ uint32_t edge_normal_colour(const RenderArgs& a, const FrameDev& fp, int f, int eye, int i, int j, int of_by_one)
+{
+    double n[3], p[3];
+    removed_vertex_normal(a, fp, f, i, j, of_by_one, n, p);
+    const double sW = ((double)a.W - 1.0) / (double)a.W, sH = ((double)a.H - 1.0) / (double)a.H;
+    const double pa[3] = {n[0] + p[0], n[1] + p[1], n[2] + p[2]};
+    const double q[3] = {p[0] * sW, p[1] * sH, p[2]};
+    double d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double* M = fp.Md[eye] + 4 * r;
+        const double ar = ((M[0] * pa[0] + M[1] * pa[1]) + M[2] * pa[2]) + M[3];
+        const double qr = ((M[0] * q[0] + M[1] * q[1]) + M[2] * q[2]) + M[3];
+        d[r] = ar - qr;
+    }
+    const double len = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    uint32_t rgb = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double c = ((d[r] / len) + 1.0) / 2.0 * 255.0;
+        rgb |= ((c >= 0.0 && c < 256.0) ? (uint32_t)c : 0u) << (8 * r);
+    }
+    return rgb;
+}
+
+// Seed colour of output pixel (x,y): black outside holes; in holes the edge point's normal colour if one
+// was splatted there (esrc = i<<16 | j of the winning edge vertex, or ~0u), else border normals / key colour.
+__device__ __forceinline__ uint32_t seed_pixel(const RenderArgs& a, const FrameDev& fp, int f, int eye, int x, int y,
+                                               bool hole, uint32_t esrc, int of_by_one)
+{
+    if (!hole) return 0u;
+    if (esrc != ~0u) return edge_normal_colour(a, fp, f, eye, (int)(esrc >> 16), (int)(esrc & 0xFFFFu), of_by_one);
+    if (x == 0) return 255u | (127u << 8) | (127u << 16);             // sr:796 normal pointing right
+    if (x == a.W - 1) return 0u | (127u << 8) | (127u << 16);         // sr:797 pointing left
+    if (y == 0) return 127u | (127u << 8) | (0u << 16);               // sr:798 pointing down
+    if (y == a.H - 1) return 127u | (127u << 8) | (255u << 16);       // sr:799 pointing up
+    return a.key_rgb;
+}
+
+// =================================================================================================
 // POINT MODE, pure stereo shift: one workgroup per (frame,row), z-buffer in LDS
 // =================================================================================================
 //
@@ -326,7 +400,7 @@ __device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[
 template <int PX, int FLAGS, int TPB, int ITERS>
 __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
 {
-    constexpr bool ZOUT = FLAGS & 1, UNUSED = FLAGS & 2, EDGE = FLAGS & 4;
+    constexpr bool ZOUT = FLAGS & 1, UNUSED = FLAGS & 2, EDGE = FLAGS & 4, SEED = FLAGS & 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = a.W;
     u64* zb = (u64*)smem;                        // [2][W] main z keys, left then right eye
@@ -394,7 +468,7 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
                           : nullptr;
         const u64* zrow_lds = zb + (size_t)eye * W;
         for (int g = tid; g < ngroups; g += TPB) {
-            uint32_t opx[PX], om[PX];
+            uint32_t opx[PX], om[PX], spx[PX];
             float oz[PX];
 #pragma unroll
             for (int q = 0; q < PX; ++q) {
@@ -414,10 +488,16 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
                 opx[q] = out;
                 om[q] = hole ? 255u : 0u;
                 if (ZOUT) oz[q] = covered ? decode_z((uint32_t)(key >> 40), mult, scale) : 0.0f;
+                if (SEED && a.seed[eye]) {
+                    uint32_t esrc = ~0u;
+                    if (EDGE && hole) { const uint32_t ek = eb[(size_t)eye * W + x]; if (ek != kEmpty32) esrc = ((uint32_t)i << 16) | (ek & 0xFFFFu); }
+                    spx[q] = seed_pixel(a, fp, f, eye, x, i, hole, esrc, 0);
+                }
             }
             RowIO<PX>::store_rgb(orow, g, opx);
             RowIO<PX>::store_mask(mrow, g, om);
             if (ZOUT && zrow) RowIO<PX>::store_z(zrow, g, oz);
+            if (SEED && a.seed[eye]) RowIO<PX>::store_rgb(a.seed[eye] + (size_t)f * a.seed_stride + (size_t)i * a.seed_pitch, g, spx);
         }
     }
 }
@@ -671,7 +751,7 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
 template <int PX, int FLAGS, bool MESH>
 __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
 {
-    constexpr bool ZOUT = FLAGS & 1, EDGE = FLAGS & 4;
+    constexpr bool ZOUT = FLAGS & 1, EDGE = FLAGS & 4, SEED = FLAGS & 8;
     const int W = a.W;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -686,7 +766,7 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
     for (int q = 0; q < PX; ++q) { key[q] = krow[q]; if (EDGE) ek[q] = erow[q]; }
 #pragma unroll
     for (int q = 0; q < PX; ++q) { krow[q] = kEmpty64; if (EDGE) erow[q] = kEmpty64; }
-    uint32_t opx[PX], om[PX];
+    uint32_t opx[PX], om[PX], spx[PX];
     float oz[PX];
 #pragma unroll
     for (int q = 0; q < PX; ++q) {
@@ -705,14 +785,17 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
         }
         const bool hole = !covered || rgb == a.key_rgb;
         uint32_t out = hole ? 0u : rgb;
+        uint32_t esrc = ~0u;
         if (EDGE && hole && ek[q] != kEmpty64) {
-            const uint32_t src = (uint32_t)ek[q];
-            out = load_px_bytes(cbase + (size_t)(src >> 16) * a.color_pitch, (int)(src & 0xFFFFu));
+            esrc = (uint32_t)ek[q];
+            out = load_px_bytes(cbase + (size_t)(esrc >> 16) * a.color_pitch, (int)(esrc & 0xFFFFu));
         }
         opx[q] = out;
         om[q] = hole ? 255u : 0u;
         oz[q] = zval;
+        if (SEED && a.seed[eye]) spx[q] = seed_pixel(a, a.fp[f], f, eye, g * PX + q, y, hole, esrc, MESH ? 1 : 0);
     }
+    if (SEED && a.seed[eye]) RowIO<PX>::store_rgb(a.seed[eye] + (size_t)f * a.seed_stride + (size_t)y * a.seed_pitch, g, spx);
     RowIO<PX>::store_rgb(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)y * a.rgb_pitch, g, opx);
     RowIO<PX>::store_mask(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch, g, om);
     if (ZOUT && a.zout[eye])
@@ -724,7 +807,7 @@ static hipError_t launch_resolve_general(const RenderPlan& plan, const RenderArg
 {
     const bool zout = a.zout[0] || a.zout[1];
     const bool edge = plan.remove_edges && plan.edge_points;
-    const int flags = (zout ? 1 : 0) | (edge ? 4 : 0);
+    const int flags = (zout ? 1 : 0) | (edge ? 4 : 0) | (a.seed[0] ? 8 : 0);
     const int px = plan.vec4 ? 4 : 1;
     const dim3 grid((a.W / px + 255) / 256, a.H, plan.n * 2), block(256);
 #define MDVT_CASE(F)                                                                                  \
@@ -732,7 +815,9 @@ static hipError_t launch_resolve_general(const RenderPlan& plan, const RenderArg
         if (px == 4) hipLaunchKernelGGL((k_resolve_general<4, F, MESH>), grid, block, 0, s, a);       \
         else hipLaunchKernelGGL((k_resolve_general<1, F, MESH>), grid, block, 0, s, a);               \
         break;
-    switch (flags) { MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(4) MDVT_CASE(5) }
+    switch (flags) {
+        MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(4) MDVT_CASE(5) MDVT_CASE(8) MDVT_CASE(9) MDVT_CASE(12) MDVT_CASE(13)
+    }
 #undef MDVT_CASE
     return hipGetLastError();
 }
@@ -853,7 +938,7 @@ __device__ __forceinline__ void regular_cell_pixel(const RegularCell& r, int px,
 template <int PX, int FLAGS, int TPB, bool VRGB>
 __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 {
-    constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4;
+    constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4, SEED = FLAGS & 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = a.W, H = a.H;
     u64* zb = (u64*)smem;                              // [W] z keys of the eye being rendered
@@ -1079,7 +1164,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                           ? (float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)k * a.zout_pitch)
                           : nullptr;
         for (int g = tid; g < W / PX && !(a.debug_skip & 2); g += TPB) {
-            uint32_t opx[PX], om[PX];
+            uint32_t opx[PX], om[PX], spx[PX];
             float oz[PX];
 #pragma unroll
             for (int q = 0; q < PX; ++q) {
@@ -1091,11 +1176,13 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                 if (ZOUT && covered) zval = 1.0f / __uint_as_float(~(uint32_t)(key >> 32));
                 const bool hole = !covered || rgb == a.key_rgb;
                 uint32_t out = hole ? 0u : rgb;
+                uint32_t esrc = ~0u;
                 if (EDGEPTS) {
                     const uint32_t ek = eb[x];
-                    if (hole && ek != kEmpty32) out = load_px_bytes(crow_k, (int)(ek & 0xFFFFu));
+                    if (hole && ek != kEmpty32) { out = load_px_bytes(crow_k, (int)(ek & 0xFFFFu)); esrc = ((uint32_t)k << 16) | (ek & 0xFFFFu); }
                     if (eye == 0) eb[x] = kEmpty32;
                 }
+                if (SEED && a.seed[eye]) spx[q] = seed_pixel(a, fp, f, eye, x, k, hole, esrc, 1);
                 if (eye == 0) zb[x] = kEmpty64;               // ready for the right eye
                 opx[q] = out;
                 om[q] = hole ? 255u : 0u;
@@ -1104,6 +1191,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
             RowIO<PX>::store_rgb(orow, g, opx);
             RowIO<PX>::store_mask(mrow, g, om);
             if (ZOUT && zrow) RowIO<PX>::store_z(zrow, g, oz);
+            if (SEED && a.seed[eye]) RowIO<PX>::store_rgb(a.seed[eye] + (size_t)f * a.seed_stride + (size_t)k * a.seed_pitch, g, spx);
         }
         if (eye == 0) __syncthreads();
     }
@@ -1354,7 +1442,8 @@ static hipError_t launch_points_rows_cfg(const RenderPlan& plan, const RenderArg
     const size_t lds = render_lds_bytes(plan, a.W);
     const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
     const bool zout = a.zout[0] || a.zout[1];
-    const int flags = (zout ? 1 : 0) | (plan.remove_edges ? 2 : 0) | (plan.remove_edges && plan.edge_points ? 4 : 0);
+    const int flags = (zout ? 1 : 0) | (plan.remove_edges ? 2 : 0) | (plan.remove_edges && plan.edge_points ? 4 : 0) |
+                      (plan.remove_edges && a.seed[0] ? 8 : 0);
 #define MDVT_CASE(F)                                                                                   \
     case F:                                                                                            \
         if (lds > 48 * 1024)                                                                           \
@@ -1364,6 +1453,7 @@ static hipError_t launch_points_rows_cfg(const RenderPlan& plan, const RenderArg
         break;
     switch (flags) {
         MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(2) MDVT_CASE(3) MDVT_CASE(6) MDVT_CASE(7)
+        MDVT_CASE(10) MDVT_CASE(11) MDVT_CASE(14) MDVT_CASE(15)
         default: return hipErrorInvalidValue;
     }
 #undef MDVT_CASE
@@ -1448,7 +1538,8 @@ static hipError_t launch_mesh_rows_tpb(const RenderPlan& plan, const RenderArgs&
 {
     const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
     const bool zout = a.zout[0] || a.zout[1];
-    const int flags = (zout ? 1 : 0) | (plan.remove_edges ? 2 : 0) | (plan.remove_edges && plan.edge_points ? 4 : 0);
+    const int flags = (zout ? 1 : 0) | (plan.remove_edges ? 2 : 0) | (plan.remove_edges && plan.edge_points ? 4 : 0) |
+                      (plan.remove_edges && a.seed[0] ? 8 : 0);
 #define MDVT_CASE(F)                                                                                   \
     case F:                                                                                            \
         if (vrgb) {                                                                                    \
@@ -1464,6 +1555,7 @@ static hipError_t launch_mesh_rows_tpb(const RenderPlan& plan, const RenderArgs&
         break;
     switch (flags) {
         MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(2) MDVT_CASE(3) MDVT_CASE(6) MDVT_CASE(7)
+        MDVT_CASE(10) MDVT_CASE(11) MDVT_CASE(14) MDVT_CASE(15)
         default: return hipErrorInvalidValue;
     }
 #undef MDVT_CASE

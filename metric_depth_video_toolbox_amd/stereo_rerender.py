@@ -84,6 +84,34 @@ def infill_using_normals(color_img, hole_mask, normal_map, max_steps=400, out=No
     return out
 
 
+def finish_infill_mask(seed_rgb, key_rgb=(0, 255, 0)):
+    """Host-side completion of one eye's infill-mask image from the device-rendered SEED (the state of
+    left_img_mask at sr:803): cv2.inpaint(TELEA) over the still-green and black pixels, inpainted values
+    written back into the green ones, then the black-ignoring 6x6 Gaussian of masked_blur (sr:804-808,
+    114-153).  These two steps are OpenCV arithmetic (TELEA's fast-marching order is sequential) and stay
+    on the host; they need `cv2`, which is not part of this image -- without it this raises ImportError.
+    seed_rgb: uint8 [H,W,3] (NumPy).  Returns uint8 [H,W,3]."""
+    import cv2                                                          # noqa: F401  (ImportError if absent)
+    seed = np.ascontiguousarray(seed_rgb, np.uint8)
+    green = np.all(seed == np.array(key_rgb, np.uint8), axis=-1)
+    green_and_black = green | np.all(seed == 0, axis=-1)
+    inpainted = cv2.inpaint(seed, (green_and_black * 255).astype("uint8"), inpaintRadius=3, flags=cv2.INPAINT_TELEA)
+    img = seed.copy()
+    img[green] = inpainted[green]
+    # masked_blur (sr:114-153): Gaussian 6x6 that ignores pure black pixels
+    g1d = cv2.getGaussianKernel(6, 0)
+    kernel = g1d @ g1d.T
+    black = np.all(img == 0, axis=2)
+    valid = (~black).astype(np.float32)
+    bsum = cv2.filter2D(img.astype(np.float32), -1, kernel, borderType=cv2.BORDER_ISOLATED)
+    wsum = cv2.filter2D(valid, -1, kernel, borderType=cv2.BORDER_ISOLATED)
+    w = wsum[..., None]
+    out = bsum / np.where(w == 0, 1.0, w)
+    out[wsum == 0] = 0
+    out[black] = 0
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def make_frame_params(W, H, xfov=None, yfov=None, *, master_xfov=45.0, pupillary_distance=63,
                       convergence_distance=None, transformation=None):
     """The per-frame scalars the reference computes before its render calls (sr:515-541, 563-566,
@@ -192,7 +220,7 @@ class StereoRerenderer:
 
     # -- the per-frame loop body, batched -----------------------------------------------------
     def prepare(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
-                out_depth=None, want_maskbits: bool = False, want_hole_counts: bool = False):
+                out_depth=None, want_maskbits: bool = False, want_hole_counts: bool = False, want_seed: bool = False):
         """Validate once and pack everything one submission needs (buffer table, parameter records).
         Returns a PreparedRender whose launch() is a single C-ABI call -- use it when the same buffers
         are rendered into repeatedly (streaming loops, benchmarks)."""
@@ -238,16 +266,23 @@ class StereoRerenderer:
             counts = torch.zeros((N, 2), dtype=torch.int32, device=dev)
             io.hole_counts = counts.data_ptr()
             res["hole_counts"] = counts[0] if single else counts
-        return PreparedRender(self, N, arr, io, res, (depth_rgb, color_rgb, sbs, mask, zout, bits, counts), dev)
+        seed = None
+        if want_seed:           # [N, H, 2W, 3] u8: the infill-mask seed images, left | right (sr:787-803, 921-928)
+            seed = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=dev)
+            io.left_seed, io.right_seed = seed.data_ptr(), seed.data_ptr() + 3 * W
+            io.seed_pitch, io.seed_stride = 6 * W, 6 * W * H
+            res["seed"] = seed[0] if single else seed
+        return PreparedRender(self, N, arr, io, res, (depth_rgb, color_rgb, sbs, mask, zout, bits, counts, seed), dev)
 
     def render(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
-               out_depth=None, stream=None, want_maskbits: bool = False, want_hole_counts: bool = False):
+               out_depth=None, stream=None, want_maskbits: bool = False, want_hole_counts: bool = False,
+               want_seed: bool = False):
         """depth_rgb, color_rgb: uint8 device tensors [N,H,W,3] (or [H,W,3]); params: one
         MdvtFrameParams or a sequence of N.  Returns dict(sbs=[N,H,2W,3] u8 (left | right, sr:918),
         mask=[N,H,2W] u8 (255 = hole), depth=[N,H,2W] f32 (optional; 0 = background))."""
         return self.prepare(depth_rgb, color_rgb, params, out_sbs=out_sbs, out_mask=out_mask,
                             want_depth=want_depth, out_depth=out_depth, want_maskbits=want_maskbits,
-                            want_hole_counts=want_hole_counts).launch(stream)
+                            want_hole_counts=want_hole_counts, want_seed=want_seed).launch(stream)
 
     @staticmethod
     def pack_params(params, n_frames: int):

@@ -60,6 +60,8 @@ def lib():
         L.orc_convergence_angle.restype = C.c_double
         L.orc_render_stereo.argtypes = [C.POINTER(OrcParams), u8p, u8p, u8p, u8p, u8p, u8p, f32p, f32p]
         L.orc_render_stereo.restype = C.c_int
+        L.orc_render_stereo_seed.argtypes = [C.POINTER(OrcParams), u8p, u8p, u8p, u8p, u8p, u8p, f32p, f32p, u8p, u8p]
+        L.orc_render_stereo_seed.restype = C.c_int
         L.orc_infill_using_normals.argtypes = [u8p, u8p, f32p, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_infill_using_normals.restype = None
         L.orc_mark_lower_side.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
@@ -157,8 +159,8 @@ def make_params(W, H, K, *, Kr=None, ipd_m=0.065, max_depth=100.0, depth_scale=1
     return p
 
 
-def render_stereo(p: OrcParams, depth_rgb: np.ndarray, color_rgb: np.ndarray, want_depth: bool = False):
-    """-> dict(left_rgb, right_rgb, left_mask, right_mask[, left_depth, right_depth])"""
+def render_stereo(p: OrcParams, depth_rgb: np.ndarray, color_rgb: np.ndarray, want_depth: bool = False, want_seed: bool = False):
+    """-> dict(left_rgb, right_rgb, left_mask, right_mask[, left_depth, right_depth][, left_seed, right_seed])"""
     depth_rgb = np.ascontiguousarray(depth_rgb, np.uint8)
     color_rgb = np.ascontiguousarray(color_rgb, np.uint8)
     H, W = p.H, p.W
@@ -172,9 +174,14 @@ def render_stereo(p: OrcParams, depth_rgb: np.ndarray, color_rgb: np.ndarray, wa
         out["left_depth"] = np.empty((H, W), np.float32)
         out["right_depth"] = np.empty((H, W), np.float32)
         ld, rd = _p(out["left_depth"], C.c_float), _p(out["right_depth"], C.c_float)
-    rc = lib().orc_render_stereo(C.byref(p), _p(depth_rgb, C.c_uint8), _p(color_rgb, C.c_uint8),
-                                 _p(out["left_rgb"], C.c_uint8), _p(out["right_rgb"], C.c_uint8),
-                                 _p(out["left_mask"], C.c_uint8), _p(out["right_mask"], C.c_uint8), ld, rd)
+    ls = rs = None
+    if want_seed:
+        out["left_seed"] = np.empty((H, W, 3), np.uint8)
+        out["right_seed"] = np.empty((H, W, 3), np.uint8)
+        ls, rs = _p(out["left_seed"], C.c_uint8), _p(out["right_seed"], C.c_uint8)
+    rc = lib().orc_render_stereo_seed(C.byref(p), _p(depth_rgb, C.c_uint8), _p(color_rgb, C.c_uint8),
+                                      _p(out["left_rgb"], C.c_uint8), _p(out["right_rgb"], C.c_uint8),
+                                      _p(out["left_mask"], C.c_uint8), _p(out["right_mask"], C.c_uint8), ld, rd, ls, rs)
     if rc != 0:
         raise ValueError(f"orc_render_stereo failed: {rc}")
     return out

@@ -187,6 +187,7 @@ typedef struct {
     float dl;                   /* fxr * ipd/2 in f32: pure-shift disparity numerator */
     float sign;                 /* +1 left eye, -1 right eye (pure shift) */
     float M[12];                /* general: 3x4 eye*pose matrix, f32 */
+    double Md[12];              /* the same map in f64 (pure shift: identity + the +-ipd/2 translation) */
 } orc_eye;
 
 static void orc_eye_setup(const orc_params* p, int eye /*0 left, 1 right*/, orc_eye* e)
@@ -218,6 +219,9 @@ static void orc_eye_setup(const orc_params* p, int eye /*0 left, 1 right*/, orc_
         for (int col = 0; col < 3; ++col)
             e->M[4 * r + col] = (float)((R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col]);
         e->M[4 * r + 3] = (float)(((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r]);
+        for (int col = 0; col < 3; ++col)
+            e->Md[4 * r + col] = (R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col];
+        e->Md[4 * r + 3] = ((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r];
     }
 }
 
@@ -391,9 +395,32 @@ static void orc_raster_tri(orc_target* t, const orc_vert* a, const orc_vert* b, 
 /* one eye                                                                                    */
 /* ------------------------------------------------------------------------------------------ */
 
+/* Normal colour of an edge point for the infill-mask seed image (sr:596-606, 727-733, 777-802): the removed
+ * vertex normal n is carried as the point n + p, both it and the (undo-scaled, sr:599-600) edge point go
+ * through the eye / pose map, their difference is normalised and stored as (n'+1)/2 * 255, truncated. */
+static void orc_edge_normal_colour(const orc_eye* e, const double* p, const double* n, uint8_t* rgb)
+{
+    const double sW = ((double)e->W - 1.0) / (double)e->W, sH = ((double)e->H - 1.0) / (double)e->H;
+    const double a[3] = { n[0] + p[0], n[1] + p[1], n[2] + p[2] };
+    const double q[3] = { p[0] * sW, p[1] * sH, p[2] };
+    double d[3];
+    for (int r = 0; r < 3; ++r) {
+        const double* M = e->Md + 4 * r;
+        const double ar = ((M[0] * a[0] + M[1] * a[1]) + M[2] * a[2]) + M[3];
+        const double qr = ((M[0] * q[0] + M[1] * q[1]) + M[2] * q[2]) + M[3];
+        d[r] = ar - qr;
+    }
+    const double len = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    for (int r = 0; r < 3; ++r) {
+        const double c = ((d[r] / len) + 1.0) / 2.0 * 255.0;
+        rgb[r] = (c >= 0.0 && c < 256.0) ? (uint8_t)c : 0;            /* NaN (zero-length) -> 0 */
+    }
+}
+
 static void orc_render_eye(const orc_params* p, int eye, const float* depth, const uint8_t* color,
                            const uint8_t* tri_invalid, const uint8_t* unused,
-                           uint8_t* out_rgb, uint8_t* out_mask, float* out_depth)
+                           uint8_t* out_rgb, uint8_t* out_mask, float* out_depth,
+                           const double* P, const double* vnormals, uint8_t* out_seed)
 {
     const int W = p->W, H = p->H;
     const size_t n = (size_t)W * H;
@@ -458,6 +485,21 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
         else memcpy(out_rgb + 3 * k, c, 3);
     }
 
+    /* infill-mask seed (sr:787-799), before the edge normals: key colour in holes, black elsewhere, fixed
+     * inward normals on hole pixels of the image border (columns first, then rows). */
+    if (out_seed) {
+        for (size_t k = 0; k < n; ++k) {
+            uint8_t* s3 = out_seed + 3 * k;
+            if (!out_mask[k]) { s3[0] = s3[1] = s3[2] = 0; continue; }
+            const int x = (int)(k % (size_t)W), y = (int)(k / (size_t)W);
+            if (x == 0) { s3[0] = 255; s3[1] = 127; s3[2] = 127; }
+            else if (x == W - 1) { s3[0] = 0; s3[1] = 127; s3[2] = 127; }
+            else if (y == 0) { s3[0] = 127; s3[1] = 127; s3[2] = 0; }
+            else if (y == H - 1) { s3[0] = 127; s3[1] = 127; s3[2] = 255; }
+            else memcpy(s3, p->key_rgb, 3);
+        }
+    }
+
     /* edge points (sr:745-781, 813-814): far-to-near overwrite == nearest wins, only into holes. */
     if (p->edge_points && unused) {
         float* ez = (float*)malloc(n * sizeof(float));
@@ -473,6 +515,7 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
                 if (!(z < ez[o])) continue;                  /* ties: lower source index wins (decree) */
                 ez[o] = z;
                 memcpy(out_rgb + 3 * o, color + 3 * k, 3);
+                if (out_seed) orc_edge_normal_colour(&e, P + 3 * k, vnormals + 3 * k, out_seed + 3 * o);   /* sr:802 */
             }
         free(ez);
     }
@@ -480,27 +523,42 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
     free(V); free(t.covered); free(t.rgb); free(t.zinv); free(t.zbuf);
 }
 
-int orc_render_stereo(const orc_params* p, const uint8_t* depth_rgb, const uint8_t* color_rgb,
-                      uint8_t* left_rgb, uint8_t* right_rgb, uint8_t* left_mask, uint8_t* right_mask,
-                      float* left_depth, float* right_depth)
+int orc_render_stereo_seed(const orc_params* p, const uint8_t* depth_rgb, const uint8_t* color_rgb,
+                           uint8_t* left_rgb, uint8_t* right_rgb, uint8_t* left_mask, uint8_t* right_mask,
+                           float* left_depth, float* right_depth, uint8_t* left_seed, uint8_t* right_seed)
 {
     if (!p || p->W < 2 || p->H < 2) return -1;
     if (p->mode != ORC_MODE_POINTS && p->mode != ORC_MODE_MESH) return -1;
     const int W = p->W, H = p->H;
     const size_t n = (size_t)W * H;
+    const int want_seed = left_seed || right_seed;
     float* depth = (float*)malloc(n * sizeof(float));
     orc_decode_depth(depth_rgb, W, H, p->max_depth, p->depth_scale, depth);
 
     uint8_t* tri_invalid = NULL; uint8_t* unused = NULL;
+    double* P = NULL; double* vn = NULL;
     if (p->remove_edges) {
         tri_invalid = (uint8_t*)malloc(2 * (size_t)(W - 1) * (H - 1));
         unused = (uint8_t*)malloc(n);
-        orc_edge_filter(depth, W, H, p->K, p->mode == ORC_MODE_MESH, tri_invalid, unused, NULL);
+        if (want_seed) {
+            vn = (double*)malloc(n * 3 * sizeof(double));
+            P = (double*)malloc(n * 3 * sizeof(double));
+            orc_unproject_f64(depth, W, H, p->K, p->mode == ORC_MODE_MESH, P);
+        }
+        orc_edge_filter(depth, W, H, p->K, p->mode == ORC_MODE_MESH, tri_invalid, unused, vn);
     }
-    orc_render_eye(p, 0, depth, color_rgb, tri_invalid, unused, left_rgb, left_mask, left_depth);
-    orc_render_eye(p, 1, depth, color_rgb, tri_invalid, unused, right_rgb, right_mask, right_depth);
-    free(tri_invalid); free(unused); free(depth);
+    orc_render_eye(p, 0, depth, color_rgb, tri_invalid, unused, left_rgb, left_mask, left_depth, P, vn, left_seed);
+    orc_render_eye(p, 1, depth, color_rgb, tri_invalid, unused, right_rgb, right_mask, right_depth, P, vn, right_seed);
+    free(tri_invalid); free(unused); free(depth); free(P); free(vn);
     return 0;
+}
+
+int orc_render_stereo(const orc_params* p, const uint8_t* depth_rgb, const uint8_t* color_rgb,
+                      uint8_t* left_rgb, uint8_t* right_rgb, uint8_t* left_mask, uint8_t* right_mask,
+                      float* left_depth, float* right_depth)
+{
+    return orc_render_stereo_seed(p, depth_rgb, color_rgb, left_rgb, right_rgb, left_mask, right_mask,
+                                  left_depth, right_depth, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -121,6 +121,10 @@ def test_cli_end_to_end(mods, orc, tmp_path, capsys):
     dp, cp = str(tmp_path / "v_depth.npy"), str(tmp_path / "v.npy")
     np.save(dp, d); np.save(cp, c)
     rc = sr.main(["--depth_video", dp, "--color_video", cp, "--xfov", "50", "--pupillary_distance", "65",
+                  "--infill_mask", "--max_frames", "5", "--batch", "3"])
+    seed = np.load(dp + "_stereo.npy_infillmask_seed.npy")
+    os.remove(dp + "_stereo.npy")
+    rc = sr.main(["--depth_video", dp, "--color_video", cp, "--xfov", "50", "--pupillary_distance", "65",
                   "--infill_mask", "--green_and_black_infill_mask", "--max_frames", "5", "--batch", "3"])
     assert rc == 0 and "Processing complete" in capsys.readouterr().out
     sbs, mask = np.load(dp + "_stereo.npy"), np.load(dp + "_stereo.npy_holemask.npy")
@@ -131,7 +135,8 @@ def test_cli_end_to_end(mods, orc, tmp_path, capsys):
         K = np.array([p.K[k] for k in range(9)]).reshape(3, 3)
         op = orc.make_params(W, H, K, ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_MESH,
                              remove_edges=True, edge_points=True, key_rgb=(0, 255, 0))
-        want = orc.render_stereo(op, d[t], c[t])
+        want = orc.render_stereo(op, d[t], c[t], want_seed=True)
+        assert np.array_equal(seed[t][:, :W], want["left_seed"]) and np.array_equal(seed[t][:, W:], want["right_seed"])
         assert np.array_equal(sbs[t][:, :W], want["left_rgb"]) and np.array_equal(sbs[t][:, W:], want["right_rgb"])
         assert np.array_equal(mask[t][:, :W], want["left_mask"]) and np.array_equal(mask[t][:, W:], want["right_mask"])
     r.close()

@@ -537,3 +537,34 @@ def test_mark_lower_side_on_device(mods, orc, golden):
         x0, y0 = int(rng.integers(0, 460)), int(rng.integers(0, 270))
         big[y0:y0 + int(rng.integers(3, 30)), x0:x0 + int(rng.integers(3, 40))] = rng.integers(1, 256, 3)
     assert np.array_equal(infill_common.mark_lower_side(torch.from_numpy(big).cuda()).cpu().numpy(), orc.mark_lower_side(big))
+
+
+@pytest.mark.parametrize("mode", ["mesh", "points"])
+@pytest.mark.parametrize("kind", ["pure", "convergence", "pose", "no_edge_points"])
+def test_infill_mask_seed_image(mods, orc, mode, kind):
+    """The infill-mask seed (sr:787-803, just before cv2.inpaint): key colour / border normals / removed-vertex
+    normals carried through the eye transform, against the oracle (whose vertex normals are pinned bit-exactly
+    by the reference's get_mesh_from_depth_map goldens)."""
+    _lib, sr, synthetic = mods
+    W, H = 176, 100
+    depth_rgb, color = _scene(synthetic, W, H, seed=314, n_fg=7)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=mode == "points", infill_mask=True,
+                            dont_place_points_in_edges=kind == "no_edge_points")
+    T = synthetic.synthetic_pose_track(50)[41] if kind == "pose" else None
+    p = r.frame_params(xfov=45.0, convergence_distance=2.2 if kind == "convergence" else None, transformation=T)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_seed=True)
+    op = orc.make_params(W, H, _K(p), ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale,
+                         mode=orc.MODE_POINTS if mode == "points" else orc.MODE_MESH, remove_edges=True,
+                         edge_points=r.edge_points, conv_angle=p.convergence_angle, T=T, key_rgb=(0, 255, 0))
+    want = orc.render_stereo(op, depth_rgb, color, want_seed=True)
+    _compare({k: v for k, v in got.items() if k != "seed"}, want, W, f"seed {mode}/{kind}")
+    seed = got["seed"].cpu().numpy()
+    for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+        s, ws = seed[:, sl], want[eye + "_seed"]
+        assert np.array_equal(s, ws), f"{mode}/{kind} {eye} seed differs at {int(np.any(s != ws, axis=-1).sum())} px"
+        hole = want[eye + "_mask"] > 0
+        assert not s[~hole].any() and np.all(np.any(s[hole] != 0, axis=-1))       # black <=> not a hole
+        if kind != "no_edge_points":
+            is_key = np.all(s == np.array([0, 255, 0], np.uint8), axis=-1)
+            assert (hole & ~is_key).sum() > 20, "some holes must carry normals"
+    r.close()

@@ -24,14 +24,14 @@ def test_library_exports_every_declared_symbol(lib):
     declared = sorted(set(re.findall(r"\b(mdvt_[a-z_]+)\s*\(", hdr)))
     assert declared == sorted(lib.SYMBOLS), "keep _lib.SYMBOLS in step with include/mdvt.h"
     assert lib.exported_symbols() == list(lib.SYMBOLS)
-    assert lib.load().mdvt_version() == (0 << 16) | 2
+    assert lib.load().mdvt_version() == (0 << 16) | 3
 
 
 def test_struct_layouts_match_the_header(lib):
     import ctypes as C
     assert C.sizeof(lib.MdvtConfig) == 40
     assert C.sizeof(lib.MdvtFrameParams) == 8 * (9 + 9 + 2 + 16) + 8
-    assert C.sizeof(lib.MdvtIO) == 8 * 23
+    assert C.sizeof(lib.MdvtIO) == 8 * 27
 
 
 def test_no_device_fails_loudly(lib):
@@ -182,3 +182,18 @@ def test_cli_rejects_what_is_out_of_scope(tmp_path):
         sr.main(["--depth_video", d])
     with pytest.raises(FileNotFoundError):
         sr.main(["--depth_video", d + "x", "--xfov", "45"])
+
+
+def test_finish_infill_mask_needs_cv2():
+    from metric_depth_video_toolbox_amd import stereo_rerender as sr
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            sr.finish_infill_mask(np.zeros((8, 8, 3), np.uint8))
+    else:
+        seed = np.zeros((16, 16, 3), np.uint8)
+        seed[4:12, 4:12] = (0, 255, 0)
+        seed[4:12, 4] = (255, 127, 127)
+        out = sr.finish_infill_mask(seed)
+        assert out.shape == seed.shape and not out[0, 0].any() and out[8, 8].any()
