@@ -141,6 +141,13 @@ int mdvt_infill_using_normals(mdvt_ctx* ctx, const uint8_t* d_color, size_t colo
 int mdvt_mark_lower_side(mdvt_ctx* ctx, const uint8_t* d_normals_img, size_t img_pitch, uint8_t* d_out,
                          size_t out_pitch, int max_steps, void* stream);
 
+/* Touchly depth plane (sr:549-551 fast path, sr:689-691 / 825-829 after a render): f32 metres -> u8 RGB with
+ * all three channels = 255 - rint(max(0, min(depth, touchly_max) - touchly_min) * 255/(touchly_max-touchly_min))
+ * (f32 arithmetic as NumPy evaluates it).  zero_is_far != 0 applies sr:690 / 827 first: a quantised value of 0
+ * (render background) is treated as the far plane. */
+int mdvt_touchly_depth(mdvt_ctx* ctx, const float* d_depth, size_t depth_pitch, uint8_t* d_rgb, size_t rgb_pitch,
+                       double touchly_max_depth, double touchly_min_depth, int zero_is_far, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

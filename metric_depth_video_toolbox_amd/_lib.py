@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "MDVT_OK", -1: "MDVT_ERR_INVALID_ARG", -2: "MDVT_ERR_HIP", -3
 # every symbol include/mdvt.h declares
 SYMBOLS = ("mdvt_version", "mdvt_create", "mdvt_destroy", "mdvt_last_error", "mdvt_set_config",
            "mdvt_render_stereo", "mdvt_render_stereo_batch", "mdvt_decode_depth", "mdvt_encode_depth",
-           "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side")
+           "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side", "mdvt_touchly_depth")
 
 
 class MdvtError(RuntimeError):
@@ -91,6 +91,8 @@ def load():
     L.mdvt_infill_using_normals.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp]
     L.mdvt_mark_lower_side.restype = C.c_int
     L.mdvt_mark_lower_side.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp]
+    L.mdvt_touchly_depth.restype = C.c_int
+    L.mdvt_touchly_depth.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_double, C.c_double, C.c_int, vp]
     _lib = L
     return L
 

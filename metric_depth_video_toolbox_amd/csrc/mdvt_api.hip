@@ -500,4 +500,19 @@ int mdvt_mark_lower_side(mdvt_ctx* c, const uint8_t* d_normals_img, size_t img_p
     return MDVT_OK;
 }
 
+int mdvt_touchly_depth(mdvt_ctx* c, const float* d_depth, size_t depth_pitch, uint8_t* d_rgb, size_t rgb_pitch,
+                       double touchly_max_depth, double touchly_min_depth, int zero_is_far, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_depth || !d_rgb) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (depth_pitch < (size_t)4 * c->W || rgb_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (!(touchly_max_depth > touchly_min_depth)) return fail(c, MDVT_ERR_INVALID_ARG, "touchly_max_depth must exceed touchly_min_depth");
+    DeviceGuard g(c->device);
+    // NumPy: f32 array (op) python float -> the scalar is rounded to f32 first
+    MDVT_HIP(c, launch_touchly_depth(d_depth, depth_pitch, d_rgb, rgb_pitch, c->W, c->H, (float)touchly_max_depth,
+                                     (float)touchly_min_depth, (float)(255.0 / (touchly_max_depth - touchly_min_depth)),
+                                     zero_is_far, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
 }  // extern "C"

@@ -1415,6 +1415,30 @@ hipError_t launch_mark_lower_side(const uint8_t* img, size_t img_pitch, uint8_t*
     return hipGetLastError();
 }
 
+// Touchly inverse-depth plane (sr:549-551, 689-691, 825-829).
+__global__ void __launch_bounds__(256) k_touchly_depth(const float* __restrict__ depth, size_t depth_pitch,
+                                                       uint8_t* __restrict__ rgb, size_t rgb_pitch, int W, int H,
+                                                       float tmax, float tmin, float k, int zero_is_far)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const float d = ((const float*)((const uint8_t*)depth + (size_t)y * depth_pitch))[x];
+    const float v = rintf(fmaxf(0.0f, fminf(d, tmax) - tmin) * k);
+    uint32_t q = (uint32_t)v & 0xFFu;                       // .astype(np.uint8)
+    if (zero_is_far && q == 0) q = 255;                     // sr:690 / 827
+    q = 255u - q;                                           // Touchly uses reverse depth
+    store_px_bytes(rgb + (size_t)y * rgb_pitch, x, q | (q << 8) | (q << 16));
+}
+
+hipError_t launch_touchly_depth(const float* depth, size_t depth_pitch, uint8_t* rgb, size_t rgb_pitch, int W, int H,
+                                float tmax, float tmin, float k, int zero_is_far, hipStream_t s)
+{
+    dim3 grid((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_touchly_depth, grid, dim3(256), 0, s, depth, depth_pitch, rgb, rgb_pitch, W, H, tmax, tmin, k, zero_is_far);
+    return hipGetLastError();
+}
+
 // =================================================================================================
 // launch plumbing
 // =================================================================================================

@@ -84,6 +84,24 @@ def infill_using_normals(color_img, hole_mask, normal_map, max_steps=400, out=No
     return out
 
 
+def touchly_depth(depth, touchly_max_depth=5, touchly_min_depth=0, zero_is_far=False, out=None):
+    """float32 CUDA depth [H,W] -> uint8 [H,W,3] Touchly reverse-depth plane (sr:549-551; with zero_is_far the
+    variant used after a render, sr:689-691 / 825-829).  --touchly1 without a pose file is
+    vconcat([color_frame, touchly_depth(decode(depth_rgb) * scale)]) (sr:548-552)."""
+    import torch
+    from .depth_frames_helper import _ctx
+    assert depth.is_cuda and depth.dtype == torch.float32 and depth.dim() == 2 and depth.is_contiguous()
+    H, W = int(depth.shape[0]), int(depth.shape[1])
+    if out is None:
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device=depth.device)
+    ctx = _ctx(depth.device.index or 0, W, H)
+    s = torch.cuda.current_stream(depth.device)
+    ctx.check(_lib.load().mdvt_touchly_depth(ctx.handle, depth.data_ptr(), 4 * W, out.data_ptr(), 3 * W,
+                                             float(touchly_max_depth), float(touchly_min_depth), int(bool(zero_is_far)),
+                                             C.c_void_p(s.cuda_stream)))
+    return out
+
+
 def finish_infill_mask(seed_rgb, key_rgb=(0, 255, 0)):
     """Host-side completion of one eye's infill-mask image from the device-rendered SEED (the state of
     left_img_mask at sr:803): cv2.inpaint(TELEA) over the still-green and black pixels, inpainted values
