@@ -589,3 +589,33 @@ def test_touchly_depth_plane(mods, tmax, tmin):
         assert np.array_equal(got, want)
     frame = torch.cat([torch.from_numpy(color).cuda(), sr.touchly_depth(d_t, tmax, tmin)], dim=0)       # cv2.vconcat
     assert tuple(frame.shape) == (2 * H, W, 3)
+
+
+def test_bench_workload_is_bit_exact_and_deterministic(mods, orc):
+    """The exact workload bench.py times (32 distinct 1920x1080 frames, points mode, 65 mm, xfov 45, one
+    batched launch): every frame equals the oracle bit for bit, two launches agree (atomic order does not
+    matter), and a frame rendered inside the batch equals the same frame rendered alone."""
+    _lib, sr, synthetic = mods
+    W, H, N = 1920, 1080, 32
+    d, c = synthetic.SyntheticScene(W, H, config_id=2).clip(N)
+    dt, ct = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True)
+    p = r.frame_params(xfov=45.0)
+    a = r.render(dt, ct, p, want_hole_counts=True)
+    sbs1, mask1 = a["sbs"].clone(), a["mask"].clone()
+    b = r.render(dt, ct, p)
+    assert torch.equal(sbs1, b["sbs"]) and torch.equal(mask1, b["mask"])
+    counts = a["hole_counts"].cpu().numpy()
+    K = _K(p)
+    op = orc.make_params(W, H, K, ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_POINTS)
+    sbs, mask = sbs1.cpu().numpy(), mask1.cpu().numpy()
+    for k in range(N):
+        want = orc.render_stereo(op, d[k], c[k])
+        assert np.array_equal(mask[k][:, :W], want["left_mask"]) and np.array_equal(mask[k][:, W:], want["right_mask"]), k
+        assert np.array_equal(sbs[k][:, :W], want["left_rgb"]) and np.array_equal(sbs[k][:, W:], want["right_rgb"]), k
+        assert counts[k, 0] == (want["left_mask"] > 0).sum() and counts[k, 1] == (want["right_mask"] > 0).sum()
+        # a splat maps every source to at most one target per eye
+        assert (want["left_mask"] == 0).sum() <= W * H
+    one = r.render(dt[17], ct[17], p)
+    assert torch.equal(one["sbs"], sbs1[17]) and torch.equal(one["mask"], mask1[17])
+    r.close()
