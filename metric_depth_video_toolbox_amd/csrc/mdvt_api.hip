@@ -349,7 +349,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     const bool need_ekeys = plan.general && plan.edge_points;
     // general path: two frames per launch set keep the 64-bit key buffers (33 MB per 1080p frame) inside the
     // 256 MiB Infinity Cache between splat and resolve (measured +12 %); the edge filter alone streams, so 8.
-    int ws_chunk = plan.general ? 2 : kWorkspaceChunk;
+    int ws_chunk = (plan.general && plan.mode == MDVT_MODE_POINTS) ? 2 : kWorkspaceChunk;    // (mesh: rows with slivers need the slack)
     if (const char* e = getenv("MDVT_WS_CHUNK")) { const int v = atoi(e); if (v > 0) ws_chunk = v; }   // tuning hook
     const int chunk = need_ws ? (n_frames < ws_chunk ? n_frames : ws_chunk) : n_frames;
     const bool need_gverts = plan.general && plan.mode == MDVT_MODE_MESH;

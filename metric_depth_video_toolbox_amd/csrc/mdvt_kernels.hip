@@ -1229,6 +1229,29 @@ __global__ void __launch_bounds__(256) k_mesh_vertices_general(RenderArgs a)
     }
 }
 
+// Conservative pixel-column range [lo, hi] of a triangle on pixel row py: each orientation-normalised edge
+// w_k = A_k - dy_k * X >= 0 bounds X from above (dy_k > 0) or below (dy_k < 0); the crossings are estimated
+// in float and widened by one pixel (they are good to ~0.1 px inside the snap range), so the range is a
+// superset of the covered pixels and the exact integer test still decides.  Returns false for an empty row.
+__device__ __forceinline__ bool tri_row_range(const TriSetup& t, int py, int px0, int px1, int& lo, int& hi)
+{
+    const int Yc = py * kSubpix + kSubpix / 2;
+    float flo = -3.0e9f, fhi = 3.0e9f;
+    const int dxs[3] = {t.dx0, t.dx1, t.dx2}, dys[3] = {t.dy0, t.dy1, t.dy2};
+    const int bxs[3] = {t.bx0, t.bx1, t.bx2}, bys[3] = {t.by0, t.by1, t.by2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const i64 A = mul64(dxs[k], Yc - bys[k]) + mul64(dys[k], bxs[k]);
+        if (dys[k] == 0) { if (A < 0) return false; continue; }
+        const float x = (float)A / (float)dys[k];
+        if (dys[k] > 0) fhi = fminf(fhi, x); else flo = fmaxf(flo, x);
+    }
+    const float l = floorf((flo - 128.0f) * (1.0f / 256.0f)) - 1.0f, h = floorf((fhi - 128.0f) * (1.0f / 256.0f)) + 1.0f;
+    lo = l < (float)px0 ? px0 : (l > (float)px1 ? px1 + 1 : (int)l);
+    hi = h > (float)px1 ? px1 : (h < (float)px0 ? px0 - 1 : (int)h);
+    return lo <= hi;
+}
+
 constexpr int kSmallBox = 12;      // bounding boxes up to this many pixel centres are walked by the owning lane
 
 // Stage 2: one thread per cell, both triangles, both eyes.  Triangles with a large bounding box (rubber
@@ -1274,8 +1297,26 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                 if (px1 > W - 1) px1 = W - 1;
                 if (py1 > H - 1) py1 = H - 1;
                 if (px1 >= px0 && py1 >= py0) {
-                    if ((px1 - px0 + 1) * (i64)(py1 - py0 + 1) > kSmallBox) big = true;
-                    else if (!(a.debug_skip & 16))
+                    if ((px1 - px0 + 1) * (i64)(py1 - py0 + 1) > kSmallBox) {
+                        // large box: most are thin slivers (cells sheared across a depth edge) -- walk the rows by
+                        // their own x-range; only triangles that are large in area go to the whole-wave path
+                        int total = py1 - py0 > 8 ? kSmallBox + 1 : 0;
+                        for (int py = py0; py <= py1 && total <= kSmallBox; ++py) {
+                            int lo, hi;
+                            if (tri_row_range(t, py, px0, px1, lo, hi)) total += hi - lo + 1;
+                        }
+                        if (total > kSmallBox) big = true;
+                        else if (!(a.debug_skip & 16))
+                            for (int py = py0; py <= py1; ++py) {
+                                int lo, hi;
+                                if (!tri_row_range(t, py, px0, px1, lo, hi)) continue;
+                                for (int px = lo; px <= hi; ++px) {
+                                    float q0, q1, q2;
+                                    if (!tri_sample(t, px, py, q0, q1, q2)) continue;
+                                    atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, A.w, v1.w, v2.w));
+                                }
+                            }
+                    } else if (!(a.debug_skip & 16))
                         for (int py = py0; py <= py1; ++py)
                             for (int px = px0; px <= px1; ++px) {
                                 float q0, q1, q2;
