@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 3
+#define MDVT_VERSION_MINOR 4
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -147,6 +147,20 @@ int mdvt_mark_lower_side(mdvt_ctx* ctx, const uint8_t* d_normals_img, size_t img
  * (render background) is treated as the far plane. */
 int mdvt_touchly_depth(mdvt_ctx* ctx, const float* d_depth, size_t depth_pitch, uint8_t* d_rgb, size_t rgb_pitch,
                        double touchly_max_depth, double touchly_min_depth, int zero_is_far, void* stream);
+
+/* stereo_rerender.convert_to_equirectangular (sr:25-86; --vr180 / --touchly0 at sr:914-916): the rectilinear
+ * render (input_fov across the frame) placed in the centre of a 180-degree equirectangular image of the same
+ * size.  The reference's two H x W float32 maps are separable, so they are passed as lookup tables:
+ * map_x[W], map_y[H], -1 = angle outside the input fov (the pixel becomes black, like the (-1,-1) map entry
+ * with BORDER_CONSTANT).  mdvt_equirect_tables fills HOST arrays with the reference's f64 arithmetic
+ * (sr:41-78; no ctx, no device work); the caller uploads them once per (W, H, fov). */
+int mdvt_equirect_tables(int width, int height, double input_fov_deg, float* h_map_x, float* h_map_y);
+/* cv2.remap(image, map_x, map_y, INTER_LINEAR, BORDER_CONSTANT, 0) (sr:82-84) for n_images u8 RGB images of the
+ * ctx's W x H (stride = bytes between images): coordinates rounded to 1/32 px, integer bilinear weights with
+ * sum 2^15, result (sum + 2^14) >> 15 -- OpenCV's fixed-point path.  d_map_x / d_map_y: DEVICE tables. */
+int mdvt_equirect_remap(mdvt_ctx* ctx, const uint8_t* d_src, size_t src_pitch, size_t src_stride, uint8_t* d_dst,
+                        size_t dst_pitch, size_t dst_stride, int n_images, const float* d_map_x, const float* d_map_y,
+                        void* stream);
 
 #ifdef __cplusplus
 }

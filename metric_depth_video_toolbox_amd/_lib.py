@@ -22,7 +22,8 @@ STATUS_NAMES = {0: "MDVT_OK", -1: "MDVT_ERR_INVALID_ARG", -2: "MDVT_ERR_HIP", -3
 # every symbol include/mdvt.h declares
 SYMBOLS = ("mdvt_version", "mdvt_create", "mdvt_destroy", "mdvt_last_error", "mdvt_set_config",
            "mdvt_render_stereo", "mdvt_render_stereo_batch", "mdvt_decode_depth", "mdvt_encode_depth",
-           "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side", "mdvt_touchly_depth")
+           "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side", "mdvt_touchly_depth",
+           "mdvt_equirect_tables", "mdvt_equirect_remap")
 
 
 class MdvtError(RuntimeError):
@@ -93,6 +94,10 @@ def load():
     L.mdvt_mark_lower_side.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp]
     L.mdvt_touchly_depth.restype = C.c_int
     L.mdvt_touchly_depth.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_double, C.c_double, C.c_int, vp]
+    L.mdvt_equirect_tables.restype = C.c_int
+    L.mdvt_equirect_tables.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.mdvt_equirect_remap.restype = C.c_int
+    L.mdvt_equirect_remap.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_int, vp, vp, vp]
     _lib = L
     return L
 

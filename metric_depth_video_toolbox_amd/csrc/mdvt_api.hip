@@ -515,4 +515,39 @@ int mdvt_touchly_depth(mdvt_ctx* c, const float* d_depth, size_t depth_pitch, ui
     return MDVT_OK;
 }
 
+int mdvt_equirect_tables(int width, int height, double input_fov_deg, float* h_map_x, float* h_map_y)
+{
+    if (width < 2 || height < 2 || !h_map_x || !h_map_y) return MDVT_ERR_INVALID_ARG;
+    if (!(input_fov_deg > 0.0 && input_fov_deg < 180.0)) return MDVT_ERR_INVALID_ARG;
+    // f64 throughout, rounded to f32 at the end like map_x.astype(np.float32) (sr:77-78)
+    const double pi = 3.141592653589793;
+    const double cx = ((double)width - 1.0) / 2.0, cy = ((double)height - 1.0) / 2.0;
+    const double half = (input_fov_deg / 2.0) * (pi / 180.0);
+    const double fx = cx / tan(half), fy = cy / tan(half);
+    for (int x = 0; x < width; ++x) {
+        const double theta = ((double)x - cx) / cx * (pi / 2.0);
+        h_map_x[x] = fabs(theta) <= half ? (float)(fx * tan(theta) + cx) : -1.0f;
+    }
+    for (int y = 0; y < height; ++y) {
+        const double phi = ((double)y - cy) / cy * (pi / 2.0);
+        h_map_y[y] = fabs(phi) <= half ? (float)(fy * tan(phi) + cy) : -1.0f;
+    }
+    return MDVT_OK;
+}
+
+int mdvt_equirect_remap(mdvt_ctx* c, const uint8_t* d_src, size_t src_pitch, size_t src_stride, uint8_t* d_dst,
+                        size_t dst_pitch, size_t dst_stride, int n_images, const float* d_map_x, const float* d_map_y,
+                        void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_src || !d_dst || !d_map_x || !d_map_y) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (n_images < 1) return fail(c, MDVT_ERR_INVALID_ARG, "n_images must be >= 1");
+    if (src_pitch < (size_t)3 * c->W || dst_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (d_src == d_dst) return fail(c, MDVT_ERR_INVALID_ARG, "d_dst may not alias d_src");
+    DeviceGuard g(c->device);
+    MDVT_HIP(c, launch_equirect_remap(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_images, c->W, c->H,
+                                      d_map_x, d_map_y, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
 }  // extern "C"

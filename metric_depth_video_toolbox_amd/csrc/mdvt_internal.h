@@ -82,6 +82,8 @@ hipError_t launch_mark_lower_side(const uint8_t* img, size_t img_pitch, uint8_t*
                                   int max_steps, hipStream_t s);
 hipError_t launch_touchly_depth(const float* depth, size_t depth_pitch, uint8_t* rgb, size_t rgb_pitch, int W, int H,
                                 float tmax, float tmin, float k, int zero_is_far, hipStream_t s);
+hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst, size_t dst_pitch,
+                                 size_t dst_stride, int n, int W, int H, const float* mx, const float* my, hipStream_t s);
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 size_t render_lds_bytes(const RenderPlan& plan, int W);

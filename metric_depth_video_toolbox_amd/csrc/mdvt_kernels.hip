@@ -1481,6 +1481,76 @@ hipError_t launch_touchly_depth(const float* depth, size_t depth_pitch, uint8_t*
 }
 
 // =================================================================================================
+// VR180: convert_to_equirectangular (sr:25-86) = cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) through
+// separable lookup tables
+// =================================================================================================
+// One thread = PX output pixels of one row of one image.  Coordinates are rounded to 1/32 px (half to even),
+// the four taps get the integer weights (32-fx)(32-fy)*32 ... (sum 2^15), taps outside the image are 0, the
+// result is (sum + 2^14) >> 15.  A table entry of -1 marks an angle outside the input fov: the pixel is black.
+__device__ __forceinline__ uint32_t remap_tap4(const uint8_t* __restrict__ src, size_t pitch, int W, int H,
+                                               int ix, int iy, int fx, int fy)
+{
+    const int w00 = (32 - fx) * (32 - fy) * 32, w10 = fx * (32 - fy) * 32, w01 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W;
+    const bool y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+    const uint32_t p00 = (x0 && y0) ? load_px_bytes(src + (size_t)iy * pitch, ix) : 0u;
+    const uint32_t p10 = (x1 && y0 && w10) ? load_px_bytes(src + (size_t)iy * pitch, ix + 1) : 0u;
+    const uint32_t p01 = (x0 && y1 && w01) ? load_px_bytes(src + (size_t)(iy + 1) * pitch, ix) : 0u;
+    const uint32_t p11 = (x1 && y1 && w11) ? load_px_bytes(src + (size_t)(iy + 1) * pitch, ix + 1) : 0u;
+    uint32_t out = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int sh = 8 * c;
+        const int acc = w00 * (int)((p00 >> sh) & 0xFF) + w10 * (int)((p10 >> sh) & 0xFF) +
+                        w01 * (int)((p01 >> sh) & 0xFF) + w11 * (int)((p11 >> sh) & 0xFF);
+        out |= (uint32_t)((acc + (1 << 14)) >> 15) << sh;
+    }
+    return out;
+}
+
+template <int PX>
+__global__ void __launch_bounds__(256) k_equirect_remap(const uint8_t* __restrict__ src, size_t src_pitch, size_t src_stride,
+                                                        uint8_t* __restrict__ dst, size_t dst_pitch, size_t dst_stride,
+                                                        int W, int H, const float* __restrict__ mx, const float* __restrict__ my)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (g >= W / PX) return;
+    const uint8_t* simg = src + (size_t)blockIdx.z * src_stride;
+    uint8_t* drow = dst + (size_t)blockIdx.z * dst_stride + (size_t)y * dst_pitch;
+    const float fyv = my[y];
+    uint32_t out[PX];
+    if (fyv == -1.0f) {
+#pragma unroll
+        for (int q = 0; q < PX; ++q) out[q] = 0u;
+    } else {
+        const int sy = (int)rintf(fyv * 32.0f);
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            const float fxv = mx[g * PX + q];
+            if (fxv == -1.0f) { out[q] = 0u; continue; }
+            const int sx = (int)rintf(fxv * 32.0f);
+            out[q] = remap_tap4(simg, src_pitch, W, H, sx >> 5, sy >> 5, sx & 31, sy & 31);
+        }
+    }
+    RowIO<PX>::store_rgb(drow, g, out);
+}
+
+hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst, size_t dst_pitch,
+                                 size_t dst_stride, int n, int W, int H, const float* mx, const float* my, hipStream_t s)
+{
+    const bool vec4 = W % 4 == 0 && ((uintptr_t)dst % 4 == 0) && dst_pitch % 4 == 0 && dst_stride % 4 == 0;
+    if (vec4) {
+        dim3 grid((W / 4 + 255) / 256, H, n);
+        hipLaunchKernelGGL((k_equirect_remap<4>), grid, dim3(256), 0, s, src, src_pitch, src_stride, dst, dst_pitch, dst_stride, W, H, mx, my);
+    } else {
+        dim3 grid((W + 255) / 256, H, n);
+        hipLaunchKernelGGL((k_equirect_remap<1>), grid, dim3(256), 0, s, src, src_pitch, src_stride, dst, dst_pitch, dst_stride, W, H, mx, my);
+    }
+    return hipGetLastError();
+}
+
+// =================================================================================================
 // launch plumbing
 // =================================================================================================
 

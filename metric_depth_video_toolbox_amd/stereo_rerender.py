@@ -90,15 +90,59 @@ def touchly_depth(depth, touchly_max_depth=5, touchly_min_depth=0, zero_is_far=F
     vconcat([color_frame, touchly_depth(decode(depth_rgb) * scale)]) (sr:548-552)."""
     import torch
     from .depth_frames_helper import _ctx
-    assert depth.is_cuda and depth.dtype == torch.float32 and depth.dim() == 2 and depth.is_contiguous()
+    assert depth.is_cuda and depth.dtype == torch.float32 and depth.dim() == 2 and depth.stride(1) == 1   # rows may be strided
     H, W = int(depth.shape[0]), int(depth.shape[1])
     if out is None:
         out = torch.empty((H, W, 3), dtype=torch.uint8, device=depth.device)
+    assert out.is_contiguous()
     ctx = _ctx(depth.device.index or 0, W, H)
     s = torch.cuda.current_stream(depth.device)
-    ctx.check(_lib.load().mdvt_touchly_depth(ctx.handle, depth.data_ptr(), 4 * W, out.data_ptr(), 3 * W,
+    ctx.check(_lib.load().mdvt_touchly_depth(ctx.handle, depth.data_ptr(), 4 * depth.stride(0), out.data_ptr(), 3 * W,
                                              float(touchly_max_depth), float(touchly_min_depth), int(bool(zero_is_far)),
                                              C.c_void_p(s.cuda_stream)))
+    return out
+
+
+def equirect_tables(W, H, input_fov=100):
+    """The lookup tables of convert_to_equirectangular (sr:41-78) as float32 NumPy arrays (map_x[W], map_y[H];
+    -1 = outside the input fov).  Host arithmetic of the C library (mdvt_equirect_tables), no GPU needed."""
+    mx, my = np.empty(int(W), np.float32), np.empty(int(H), np.float32)
+    rc = _lib.load().mdvt_equirect_tables(int(W), int(H), float(input_fov), mx.ctypes.data_as(C.POINTER(C.c_float)),
+                                          my.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != _lib.MDVT_OK:
+        raise ValueError(f"bad equirect table request: W={W} H={H} input_fov={input_fov}")
+    return mx, my
+
+
+_equirect_cache = {}
+
+
+def convert_to_equirectangular(image, input_fov=100, out=None):
+    """Device version of the reference's convert_to_equirectangular (sr:25-86): uint8 CUDA image(s) [H,W,3] or
+    [N,H,W,3] rendered at `input_fov` -> 180-degree equirectangular image(s) of the same size, the valid region
+    centred and everything outside the input fov black.  Rows / images may be strided views (e.g. one eye of a
+    side-by-side buffer); pixels must be packed RGB."""
+    import torch
+    from .depth_frames_helper import _ctx
+    assert image.is_cuda and image.dtype == torch.uint8 and image.dim() in (3, 4) and image.shape[-1] == 3
+    assert image.stride(-1) == 1 and image.stride(-2) == 3, "pixels must be packed RGB"
+    batched = image.dim() == 4
+    N = int(image.shape[0]) if batched else 1
+    H, W = int(image.shape[-3]), int(image.shape[-2])
+    if out is None:
+        out = torch.empty(tuple(image.shape), dtype=torch.uint8, device=image.device)
+    assert out.shape == image.shape and out.stride(-1) == 1 and out.stride(-2) == 3 and out.data_ptr() != image.data_ptr()
+    dev = image.device.index or 0
+    key = (dev, W, H, float(input_fov))
+    if key not in _equirect_cache:
+        mx, my = equirect_tables(W, H, input_fov)
+        _equirect_cache[key] = (torch.from_numpy(mx).to(image.device), torch.from_numpy(my).to(image.device))
+    tx, ty = _equirect_cache[key]
+    ctx = _ctx(dev, W, H)
+    s = torch.cuda.current_stream(image.device)
+    ctx.check(_lib.load().mdvt_equirect_remap(ctx.handle, image.data_ptr(), image.stride(-3), image.stride(0) if batched else 0,
+                                              out.data_ptr(), out.stride(-3), out.stride(0) if batched else 0, N,
+                                              tx.data_ptr(), ty.data_ptr(), C.c_void_p(s.cuda_stream)))
     return out
 
 

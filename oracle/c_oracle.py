@@ -66,6 +66,10 @@ def lib():
         L.orc_infill_using_normals.restype = None
         L.orc_mark_lower_side.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_mark_lower_side.restype = None
+        L.orc_equirect_tables.argtypes = [C.c_int, C.c_int, C.c_double, f32p, f32p]
+        L.orc_equirect_tables.restype = None
+        L.orc_remap_linear.argtypes = [u8p, C.c_int, C.c_int, f32p, f32p, u8p]
+        L.orc_remap_linear.restype = None
         _lib = L
     return _lib
 
@@ -204,3 +208,35 @@ def mark_lower_side(normals_img: np.ndarray, max_steps: int = 30) -> np.ndarray:
     out = np.empty_like(img)
     lib().orc_mark_lower_side(_p(img, C.c_uint8), W, H, int(max_steps), _p(out, C.c_uint8))
     return out
+
+
+def equirect_tables(W: int, H: int, input_fov: float = 100.0):
+    """-> (mx f32[W], my f32[H]); -1 marks an angle outside the input fov (sr:25-78)."""
+    mx, my = np.empty(W, np.float32), np.empty(H, np.float32)
+    lib().orc_equirect_tables(int(W), int(H), float(input_fov), _p(mx, C.c_float), _p(my, C.c_float))
+    return mx, my
+
+
+def equirect_maps(W: int, H: int, input_fov: float = 100.0):
+    """The 2-D float32 maps the reference hands to cv2.remap (sr:77-78)."""
+    mx, my = equirect_tables(W, H, input_fov)
+    bad = (my == -1)[:, None] | (mx == -1)[None, :]
+    X = np.where(bad, np.float32(-1), np.broadcast_to(mx[None, :], (H, W))).astype(np.float32)
+    Y = np.where(bad, np.float32(-1), np.broadcast_to(my[:, None], (H, W))).astype(np.float32)
+    return np.ascontiguousarray(X), np.ascontiguousarray(Y)
+
+
+def remap_linear(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    H, W = src.shape[:2]
+    map_x, map_y = np.ascontiguousarray(map_x, np.float32), np.ascontiguousarray(map_y, np.float32)
+    assert map_x.shape == (H, W) and map_y.shape == (H, W)
+    out = np.empty_like(src)
+    lib().orc_remap_linear(_p(src, C.c_uint8), W, H, _p(map_x, C.c_float), _p(map_y, C.c_float), _p(out, C.c_uint8))
+    return out
+
+
+def convert_to_equirectangular(image: np.ndarray, input_fov: float = 100.0) -> np.ndarray:
+    H, W = image.shape[:2]
+    X, Y = equirect_maps(W, H, input_fov)
+    return remap_linear(image, X, Y)

@@ -634,3 +634,42 @@ void orc_mark_lower_side(const uint8_t* img, int W, int H, int max_steps, uint8_
             }
         }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* VR180: convert_to_equirectangular (sr:25-86)                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_equirect_tables(int W, int H, double input_fov_deg, float* mx, float* my)
+{
+    const double pi = 3.141592653589793;
+    const double cx = ((double)W - 1.0) / 2.0, cy = ((double)H - 1.0) / 2.0;      /* sr:41-42 */
+    const double half = (input_fov_deg / 2.0) * (pi / 180.0);                      /* np.radians, sr:57 */
+    const double fx = cx / tan(half), fy = cy / tan(half);                         /* sr:61-62 */
+    for (int x = 0; x < W; ++x) {
+        const double theta = ((double)x - cx) / cx * (pi / 2.0);                   /* sr:52 (linspace(0,W-1,W)[x] == x) */
+        mx[x] = fabs(theta) <= half ? (float)(fx * tan(theta) + cx) : -1.0f;       /* sr:65-74, 78 */
+    }
+    for (int y = 0; y < H; ++y) {
+        const double phi = ((double)y - cy) / cy * (pi / 2.0);                     /* sr:54 */
+        my[y] = fabs(phi) <= half ? (float)(fy * tan(phi) + cy) : -1.0f;
+    }
+}
+
+void orc_remap_linear(const uint8_t* src, int W, int H, const float* map_x, const float* map_y, uint8_t* dst)
+{
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const size_t o = (size_t)y * W + x;
+            const int sx = (int)lrintf(map_x[o] * 32.0f), sy = (int)lrintf(map_y[o] * 32.0f);   /* cvRound */
+            const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+            const int w[4] = { (32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32 };
+            int acc[3] = { 0, 0, 0 };
+            for (int t = 0; t < 4; ++t) {
+                const int tx = ix + (t & 1), ty = iy + (t >> 1);
+                if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;             /* BORDER_CONSTANT, value 0 */
+                const uint8_t* s = src + 3 * ((size_t)ty * W + tx);
+                for (int c = 0; c < 3; ++c) acc[c] += w[t] * s[c];
+            }
+            for (int c = 0; c < 3; ++c) dst[3 * o + c] = (uint8_t)((acc[c] + (1 << 14)) >> 15);
+        }
+}

@@ -199,7 +199,32 @@ def main():
         inf[f"{name}_out_8"] = ic.mark_lower_side(img.copy(), max_steps=8)
     np.savez_compressed(os.path.join(HERE, "infill.npz"), meta=json.dumps(meta), **inf)
 
-    for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz"):
+    # ------------------------------------------------------------------ convert_to_equirectangular maps (sr:25-86)
+    # cv2.remap is absent: a stub captures the float32 maps the reference hands to it (everything up to sr:82 is
+    # NumPy).  Small cases keep the full 2-D maps; the VR180 size keeps the centre row / column (the maps are
+    # separable: map_x depends on x only, map_y on y only, a pixel is invalid (-1,-1) if either angle is out of range).
+    import cv2 as cv2_stub
+    captured = {}
+
+    def _remap(image, map_x, map_y, **kw):
+        captured["x"], captured["y"] = map_x.copy(), map_y.copy()
+        return image
+    cv2_stub.remap = _remap
+    cv2_stub.INTER_LINEAR, cv2_stub.BORDER_CONSTANT = 1, 0
+    eq = {}
+    for name, (W, H, fov) in {"s0": (64, 48, 100), "s1": (33, 17, 120.5), "s2": (50, 50, 75), "s3": (40, 24, 179.0),
+                              "vr": (1920, 1920, 75), "vr100": (1920, 1920, 100), "hd": (1920, 1080, 90.0)}.items():
+        sr.convert_to_equirectangular(np.zeros((H, W, 3), np.uint8), input_fov=fov)
+        eq[f"{name}_whf"] = np.array([W, H, fov], np.float64)
+        if W * H <= 4096:
+            eq[f"{name}_map_x"], eq[f"{name}_map_y"] = captured["x"], captured["y"]
+        else:
+            eq[f"{name}_row_x"], eq[f"{name}_row_y"] = captured["x"][H // 2], captured["y"][H // 2]
+            eq[f"{name}_col_x"], eq[f"{name}_col_y"] = captured["x"][:, W // 2], captured["y"][:, W // 2]
+            eq[f"{name}_corner"] = np.array([captured["x"][0, 0], captured["y"][0, 0], captured["x"][-1, -1]], np.float32)
+    np.savez_compressed(os.path.join(HERE, "equirect.npz"), meta=json.dumps(meta), **eq)
+
+    for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz", "equirect.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -619,3 +619,38 @@ def test_bench_workload_is_bit_exact_and_deterministic(mods, orc):
     one = r.render(dt[17], ct[17], p)
     assert torch.equal(one["sbs"], sbs1[17]) and torch.equal(one["mask"], mask1[17])
     r.close()
+
+
+@pytest.mark.parametrize("W,H,fov", [(64, 48, 100), (33, 17, 120.5), (250, 61, 75), (640, 480, 90), (1920, 1920, 75)])
+def test_equirect_remap_matches_the_oracle(mods, orc, W, H, fov):
+    """convert_to_equirectangular (sr:25-86) on the device vs the oracle's cv2.remap restatement fed with the
+    reference's own float32 maps: bit-exact, batched and through strided side-by-side views."""
+    _lib, sr, synthetic = mods
+    rng = np.random.default_rng(W * 7 + H)
+    img = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    img[0, :, : W // 2] = np.linspace(0, 255, W // 2, dtype=np.uint8)[None, :, None]      # smooth part: weights matter
+    want = np.stack([orc.convert_to_equirectangular(img[k], fov) for k in range(2)])
+    t = torch.from_numpy(img).cuda()
+    assert np.array_equal(sr.convert_to_equirectangular(t, fov).cpu().numpy(), want)
+    assert np.array_equal(sr.convert_to_equirectangular(t[1], fov).cpu().numpy(), want[1])
+    # strided: the two images as the eyes of one side-by-side buffer, remapped in place of cv2.hconcat's inputs
+    sbs = torch.cat([t[0], t[1]], dim=1).contiguous()                                       # [H, 2W, 3]
+    out = torch.zeros_like(sbs)
+    sr.convert_to_equirectangular(sbs[:, :W], fov, out=out[:, :W])
+    sr.convert_to_equirectangular(sbs[:, W:], fov, out=out[:, W:])
+    assert np.array_equal(out.cpu().numpy(), np.concatenate([want[0], want[1]], axis=1))
+    valid = np.any(want[0] != 0, axis=-1)
+    assert valid[H // 2, W // 2] and not valid[0, 0]                                        # centred, black padding
+
+
+def test_equirect_remap_rejects_bad_arguments(mods):
+    _lib, sr, synthetic = mods
+    t = torch.zeros((16, 16, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        sr.convert_to_equirectangular(t, 180)
+    with pytest.raises(AssertionError):
+        sr.convert_to_equirectangular(t, 90, out=t)
+    ctx = _lib.Context(0, 16, 16)
+    tx = torch.zeros(16, device="cuda")
+    rc = _lib.load().mdvt_equirect_remap(ctx.handle, t.data_ptr(), 16, 0, t.data_ptr() + 1, 48, 0, 1, tx.data_ptr(), tx.data_ptr(), None)
+    assert rc == -1 and b"pitch" in _lib.load().mdvt_last_error(ctx.handle)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(lib):
     declared = sorted(set(re.findall(r"\b(mdvt_[a-z_]+)\s*\(", hdr)))
     assert declared == sorted(lib.SYMBOLS), "keep _lib.SYMBOLS in step with include/mdvt.h"
     assert lib.exported_symbols() == list(lib.SYMBOLS)
-    assert lib.load().mdvt_version() == (0 << 16) | 3
+    assert lib.load().mdvt_version() == (0 << 16) | 4
 
 
 def test_struct_layouts_match_the_header(lib):
@@ -182,6 +182,21 @@ def test_cli_rejects_what_is_out_of_scope(tmp_path):
         sr.main(["--depth_video", d])
     with pytest.raises(FileNotFoundError):
         sr.main(["--depth_video", d + "x", "--xfov", "45"])
+
+
+def test_equirect_tables_of_the_library_match_the_reference_maps(lib, golden):
+    """mdvt_equirect_tables is host arithmetic (no device): pinned against the maps the reference builds."""
+    from metric_depth_video_toolbox_amd import stereo_rerender as sr
+    from test_oracle_golden import _check_equirect_tables
+
+    def maps(W, H, fov):
+        mx, my = sr.equirect_tables(W, H, fov)
+        bad = (my == -1)[:, None] | (mx == -1)[None, :]
+        return (np.where(bad, np.float32(-1), mx[None, :]).astype(np.float32),
+                np.where(bad, np.float32(-1), my[:, None]).astype(np.float32))
+    _check_equirect_tables(golden("equirect"), sr.equirect_tables, maps)
+    with pytest.raises(ValueError):
+        sr.equirect_tables(64, 64, 180.0)
 
 
 def test_finish_infill_mask_needs_cv2():

@@ -184,3 +184,52 @@ def test_mark_lower_side_golden(orc, golden, scene):
     assert np.array_equal(orc.mark_lower_side(g[f"{scene}_img"]), g[f"{scene}_out"])
     assert np.array_equal(orc.mark_lower_side(g[f"{scene}_img"], 8), g[f"{scene}_out_8"])
     assert np.all(g[f"{scene}_out"][..., :2] == 0) and (g[f"{scene}_out"][..., 2] == 255).sum() > 50
+
+
+# ------------------------------------------------------------------------------- VR180 equirect maps
+def _check_equirect_tables(g, tables, maps):
+    for n in ("s0", "s1", "s2", "s3"):
+        W, H, fov = g[f"{n}_whf"]
+        X, Y = maps(int(W), int(H), float(fov))
+        assert np.array_equal(bits(X), bits(g[f"{n}_map_x"])) and np.array_equal(bits(Y), bits(g[f"{n}_map_y"]))
+    for n in ("vr", "vr100", "hd"):
+        W, H, fov = g[f"{n}_whf"]
+        W, H = int(W), int(H)
+        mx, my = tables(W, H, float(fov))
+        # centre row / column of the reference's 2-D maps == the separable tables
+        assert np.array_equal(bits(g[f"{n}_row_x"]), bits(mx)) and np.array_equal(bits(g[f"{n}_col_y"]), bits(my))
+        assert np.array_equal(bits(g[f"{n}_row_y"]), bits(np.where(mx == -1, np.float32(-1), my[H // 2])))
+        assert np.array_equal(bits(g[f"{n}_col_x"]), bits(np.where(my == -1, np.float32(-1), mx[W // 2])))
+        assert np.all(g[f"{n}_corner"] == -1) and mx[0] == -1 and my[-1] == -1
+
+
+def test_equirect_maps_golden(orc, golden):
+    """orc_equirect_tables against the float32 maps the reference's convert_to_equirectangular hands to
+    cv2.remap (sr:41-78): bit-exact, including the (-1,-1) entries outside the input fov."""
+    _check_equirect_tables(golden("equirect"), orc.equirect_tables, orc.equirect_maps)
+
+
+def test_remap_linear_known_answers(orc):
+    """The cv2.remap restatement on hand-computed cases: identity on grid points, 1/32-px rounding half to even,
+    integer weights, zero border."""
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (6, 7, 3), dtype=np.uint8)
+    H, W = src.shape[:2]
+    gx, gy = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    assert np.array_equal(orc.remap_linear(src, gx, gy), src)
+    # half-way between two pixels horizontally: (a + b + 1) >> 1 (round half up in the fixed-point sum)
+    out = orc.remap_linear(src, gx + np.float32(0.5), gy)
+    want = (src[:, :-1].astype(np.int32) + src[:, 1:].astype(np.int32) + 1) >> 1
+    assert np.array_equal(out[:, :-1], want)
+    assert np.array_equal(out[:, -1], (src[:, -1].astype(np.int32) + 1) >> 1)          # right tap is border 0
+    # 1/64 px is a rounding tie at 1/32 resolution: cvRound goes to the even count (0 -> fx 0; 3/64 -> fx 2)
+    assert np.array_equal(orc.remap_linear(src, gx + np.float32(1 / 64), gy), src)
+    out = orc.remap_linear(src, gx + np.float32(3 / 64), gy)
+    want = (src[:, :-1].astype(np.int32) * 30 * 32 * 32 + src[:, 1:].astype(np.int32) * 2 * 32 * 32 + (1 << 14)) >> 15
+    assert np.array_equal(out[:, :-1], want)
+    # (-1,-1) and far outside -> black
+    assert not orc.remap_linear(src, np.full_like(gx, -1), np.full_like(gy, -1)).any()
+    assert not orc.remap_linear(src, gx + 100, gy).any()
+    # negative fractional coordinate: floor semantics of >> 5 (x = -0.25 -> ix -1, fx 24)
+    out = orc.remap_linear(src, np.full_like(gx, -0.25), gy)
+    assert np.array_equal(out, np.broadcast_to(((src[:, :1].astype(np.int32) * 24 * 32 * 32 + (1 << 14)) >> 15), out.shape))
