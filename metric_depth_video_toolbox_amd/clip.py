@@ -18,6 +18,12 @@ a device-side FFV1 codec is out of scope, so this driver works on raw frame dump
                         border normals / removed-vertex normals.  stereo_rerender.finish_infill_mask() applies
                         the remaining OpenCV steps (TELEA + masked blur) where cv2 is installed.
 
+Output-format variants (sr:406-422, 548-552, 677-702, 825-829, 914-918); the VR180 ones need 1920x1920 inputs:
+  --vr180      both eyes rendered with the square VR180 camera, each put through convert_to_equirectangular
+  --touchly0   = --vr180 plus a third image, the left eye's Touchly reverse-depth plane: [N, H, 3W, 3]
+  --touchly1   colour over Touchly depth, [N, 2H, W, 3]; straight from the input without a pose file (sr:548-552),
+               else a mono render of the posed mesh (sr:673-691)
+
 Side-cars are the reference's own JSON formats: xfov list (sr:351-359), convergence list with NaNs
 (sr:343-349), transformations list of 4x4 (sr:362-373).
 
@@ -40,7 +46,8 @@ from .stereo_rerender import StereoRerenderer, curve_fit, fill_nan_with_closest
 def load_clip_parameters(n_frames: int, W: int, H: int, *, xfov=None, xfov_file=None, convergence_file=None,
                          transformation_file=None, transformation_lock_frame: int = 0, pupillary_distance=63,
                          max_depth=100, master_xfov: float = 45.0, render_as_pointcloud=False, remove_edges=False,
-                         infill_mask=False, dont_place_points_in_edges=False) -> D.ClipParameters:
+                         infill_mask=False, dont_place_points_in_edges=False, vr180=False, touchly0=False,
+                         touchly1=False, touchly_max_depth=5.0, touchly_min_depth=0.0) -> D.ClipParameters:
     """What sr:318-373 does before the loop, on rank 0."""
     if xfov is None and xfov_file is None:
         raise ValueError("Error: Either --xfov_file, --xfov or --yfov must be provided.")            # sr:319-320
@@ -77,13 +84,32 @@ def load_clip_parameters(n_frames: int, W: int, H: int, *, xfov=None, xfov_file=
     rm = bool(infill_mask or remove_edges)
     flags = (1 if render_as_pointcloud else 0) | (2 if rm else 0) | (4 if (rm and not dont_place_points_in_edges) else 0) \
         | (8 if infill_mask else 0)
+    if touchly0:
+        vr180 = True                                                                                   # sr:406-407
+    if touchly0 and touchly1:
+        raise ValueError("--touchly0 and --touchly1 are different output formats; pick one")
+    flags |= (16 if vr180 else 0) | (32 if touchly0 else 0) | (64 if touchly1 else 0)
+    if not float(touchly_max_depth) > float(touchly_min_depth):
+        raise ValueError("touchly_max_depth must exceed touchly_min_depth")
     return D.ClipParameters(W, H, n_frames, pupillary_distance / 1000, float(max_depth), float(master_xfov), flags,
-                            xfovs, conv, T)
+                            xfovs, conv, T, float(touchly_max_depth), float(touchly_min_depth))
+
+
+def output_shape(clip: D.ClipParameters):
+    """Frame shape (rows, cols) of the main output for the clip's format variant (sr:409-422)."""
+    f = clip.mode_flags
+    if f & 64:
+        return 2 * clip.H, clip.W           # touchly1: vconcat([colour, depth])
+    if f & 32:
+        return clip.H, 3 * clip.W           # touchly0: hconcat([left, right, left depth])
+    return clip.H, 2 * clip.W
 
 
 def renderer_for(clip: D.ClipParameters, device: Optional[int] = None) -> StereoRerenderer:
     f = clip.mode_flags
     pd = clip.ipd_m * 1000
+    if f & 64:
+        pd = 0                                  # touchly1 draws the posed mesh once, unshifted (sr:673-683)
     if abs(pd - round(pd)) < 1e-9:
         pd = int(round(pd))                     # --pupillary_distance is an int in mm (sr:288)
     return StereoRerenderer(clip.W, clip.H, device=device, pupillary_distance=pd,
@@ -96,10 +122,57 @@ def frame_param_records(r: StereoRerenderer, clip: D.ClipParameters, lo: int, hi
     out = []
     for t in range(lo, hi):
         cd = float(clip.convergence[t])
+        if clip.mode_flags & 64:
+            cd = 0.0                                # no toe-in in the touchly1 branch (sr:673-702)
         out.append(r.frame_params(xfov=float(clip.xfov[t]),
                                   convergence_distance=None if (cd == 0.0 or math.isnan(cd)) else cd,
-                                  transformation=None if clip.transformations is None else clip.transformations[t]))
+                                  transformation=None if clip.transformations is None else clip.transformations[t],
+                                  vr180=bool(clip.mode_flags & 16)))
     return out
+
+
+def _post_vr180(r, clip, recs, d_sbs, d_z, d_post, n):
+    """sr:914-918 on the device: every image of the frame through convert_to_equirectangular with that
+    frame's render fov, then hconcat.  d_post: [n, H, 2W or 3W, 3]."""
+    from .stereo_rerender import convert_to_equirectangular, touchly_depth, vr180_render_fov
+    W = clip.W
+    fovs = [vr180_render_fov(np.array([rec.K[k] for k in range(9)]).reshape(3, 3)) for rec in recs[:n]]
+    a = 0
+    while a < n:                                        # runs of equal fov share one remap call per eye
+        b = a + 1
+        while b < n and fovs[b] == fovs[a]:
+            b += 1
+        for eye in range(2):
+            convert_to_equirectangular(d_sbs[a:b, :, eye * W:(eye + 1) * W], fovs[a], out=d_post[a:b, :, eye * W:(eye + 1) * W])
+        a = b
+    if clip.mode_flags & 32:                            # touchly0: the left eye's depth plane (sr:825-829)
+        import torch
+        plane = torch.empty((clip.H, W, 3), dtype=torch.uint8, device=d_sbs.device)
+        for f in range(n):
+            touchly_depth(d_z[f, :, :W], clip.touchly_max_depth, clip.touchly_min_depth, zero_is_far=True, out=plane)
+            convert_to_equirectangular(plane, fovs[f], out=d_post[f, :, 2 * W:])
+    return d_post[:n]
+
+
+def _post_touchly1(r, clip, scales, d_depth_in, d_color_in, d_sbs, d_mask, d_z, d_post, n, posed):
+    """sr:548-552 (no pose file: colour over the decoded depth) / sr:673-691 (mono render of the posed mesh)."""
+    import torch
+    from . import depth_frames_helper as dfh
+    from .stereo_rerender import touchly_depth
+    W, H = clip.W, clip.H
+    for f in range(n):
+        if not posed:
+            d_post[f, :H] = d_color_in[f]
+            z = dfh.decode_rgb_depth_frame(d_depth_in[f], clip.max_depth, True, depth_scale=scales[f])
+            touchly_depth(z, clip.touchly_max_depth, clip.touchly_min_depth, out=d_post[f, H:])
+        else:
+            img = d_sbs[f, :, :W]
+            if r.key_rgb != (0, 0, 0):      # the reference keeps the raw render here: holes show the key colour (sr:683-684)
+                key = torch.tensor(r.key_rgb, dtype=torch.uint8, device=img.device)
+                img = torch.where((d_mask[f, :, :W] > 0)[..., None], key, img)
+            d_post[f, :H] = img
+            touchly_depth(d_z[f, :, :W], clip.touchly_max_depth, clip.touchly_min_depth, zero_is_far=True, out=d_post[f, H:])
+    return d_post[:n]
 
 
 def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParameters, *, lo: int = 0,
@@ -116,8 +189,14 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     dev = torch.device("cuda", r.device)
     recs = frame_param_records(r, clip, lo, hi)
     B = max(1, min(batch, hi - lo))
-    want_z = out_depth_rgb is not None
+    want_zrgb = out_depth_rgb is not None
+    vr180, touchly0, touchly1 = bool(clip.mode_flags & 16), bool(clip.mode_flags & 32), bool(clip.mode_flags & 64)
+    posed = clip.transformations is not None
+    skip_render = touchly1 and not posed                      # sr:548-552: "fast path we can skip the full render pass"
+    want_z = want_zrgb or touchly0 or (touchly1 and posed)
     want_seed = out_seed is not None
+    oH, oW = output_shape(clip)
+    post = vr180 or touchly1                                   # the main output is a post-processed image
 
     def pinned(shape, dtype):
         return torch.empty(shape, dtype=dtype, pin_memory=True)
@@ -126,15 +205,16 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     for _ in range(2):
         sets.append({
             "h_d": pinned((B, H, W, 3), torch.uint8), "h_c": pinned((B, H, W, 3), torch.uint8),
-            "h_sbs": pinned((B, H, 2 * W, 3), torch.uint8), "h_mask": pinned((B, H, 2 * W), torch.uint8),
-            "h_zrgb": pinned((B, H, 2 * W, 3), torch.uint8) if want_z else None,
+            "h_sbs": pinned((B, oH, oW, 3), torch.uint8), "h_mask": pinned((B, H, 2 * W), torch.uint8),
+            "h_zrgb": pinned((B, H, 2 * W, 3), torch.uint8) if want_zrgb else None,
             "h_seed": pinned((B, H, 2 * W, 3), torch.uint8) if want_seed else None,
             "d_d": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
             "d_c": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
             "d_sbs": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev),
             "d_mask": torch.empty((B, H, 2 * W), dtype=torch.uint8, device=dev),
             "d_z": torch.empty((B, H, 2 * W), dtype=torch.float32, device=dev) if want_z else None,
-            "d_zrgb": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if want_z else None,
+            "d_zrgb": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if want_zrgb else None,
+            "d_post": torch.zeros((B, oH, oW, 3), dtype=torch.uint8, device=dev) if post else None,
             "in_done": torch.cuda.Event(), "render_done": torch.cuda.Event(), "out_done": torch.cuda.Event(),
             "pending": None,
         })
@@ -152,7 +232,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         m = st["h_mask"][:n].numpy()
         out_mask[a:a + n] = m
         holes += int(np.count_nonzero(m))
-        if want_z:
+        if want_zrgb:
             out_depth_rgb[a:a + n] = st["h_zrgb"][:n].numpy()
         if want_seed:
             out_seed[a:a + n] = st["h_seed"][:n].numpy()
@@ -174,20 +254,30 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             st["in_done"].record(s_in)
         s_cmp.wait_event(st["in_done"])
         s_cmp.wait_event(st["out_done"])            # device outputs free again
-        res = r.render(st["d_d"][:n], st["d_c"][:n], recs[a - lo:a - lo + n], out_sbs=st["d_sbs"][:n],
-                       out_mask=st["d_mask"][:n], want_depth=want_z, out_depth=st["d_z"][:n] if want_z else None,
-                       want_seed=want_seed)
-        if want_z:                                  # sr:930-939: both eyes through the 16-bit code, B,G,R
+        brecs = recs[a - lo:a - lo + n]
+        res = None
+        if skip_render:
+            st["d_mask"][:n].zero_()
+        else:
+            res = r.render(st["d_d"][:n], st["d_c"][:n], brecs, out_sbs=st["d_sbs"][:n],
+                           out_mask=st["d_mask"][:n], want_depth=want_z, out_depth=st["d_z"][:n] if want_z else None,
+                           want_seed=want_seed)
+        if want_zrgb:                               # sr:930-939: both eyes through the 16-bit code, B,G,R
             for f in range(n):
                 dfh.encode_depth_frame(st["d_z"][f], clip.max_depth, bgr=True, out=st["d_zrgb"][f])
+        main = st["d_sbs"][:n]
+        if touchly1:
+            main = _post_touchly1(r, clip, [rec.depth_scale for rec in brecs], st["d_d"], st["d_c"], st["d_sbs"], st["d_mask"], st["d_z"], st["d_post"], n, posed)
+        elif vr180:
+            main = _post_vr180(r, clip, brecs, st["d_sbs"], st["d_z"], st["d_post"], n)
         st["render_done"].record(s_cmp)
         with torch.cuda.stream(s_out):
             s_out.wait_event(st["render_done"])
-            st["h_sbs"][:n].copy_(st["d_sbs"][:n], non_blocking=True)
+            st["h_sbs"][:n].copy_(main, non_blocking=True)
             st["h_mask"][:n].copy_(st["d_mask"][:n], non_blocking=True)
-            if want_z:
+            if want_zrgb:
                 st["h_zrgb"][:n].copy_(st["d_zrgb"][:n], non_blocking=True)
-            if want_seed:
+            if want_seed and res is not None:
                 st["h_seed"][:n].copy_(res["seed"], non_blocking=True)
                 res["seed"].record_stream(s_out)
             st["out_done"].record(s_out)
@@ -228,7 +318,8 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     clip = D.broadcast_clip_parameters(clip, src=0)
     final = depth_path + "_stereo.npy"
     tmp = depth_path + "_tmp_stereo.npy"
-    names = {"sbs": (tmp, final, (N, H, 2 * W, 3)),
+    oH, oW = output_shape(clip)
+    names = {"sbs": (tmp, final, (N, oH, oW, 3)),
              "mask": (tmp + "_holemask.npy", final + "_holemask.npy", (N, H, 2 * W))}
     if create_sbs_depth_video:
         names["depth"] = (tmp + "_depth.npy", final + "_depth.npy", (N, H, 2 * W, 3))

@@ -324,7 +324,14 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         if (rc != MDVT_OK) return rc;
         general |= fd[(size_t)k].general;
     }
-    if (general) for (auto& f : fd) f.general = 1;      // one code path per launch
+    // The arithmetic of a frame (pure shift or general) is its own property, never its batch
+    // neighbours': consecutive frames of one kind form a run, every run gets its own launches.
+    struct Run { int f0, f1, general; };
+    std::vector<Run> runs;
+    for (int k = 0; k < n_frames; ++k) {
+        if (runs.empty() || runs.back().general != fd[(size_t)k].general) runs.push_back({k, k + 1, fd[(size_t)k].general});
+        else runs.back().f1 = k + 1;
+    }
 
     const FrameDev* dfp = nullptr;
     ParamSlot* slot = nullptr;
@@ -344,16 +351,28 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                 (!zout || ((!io->left_depth || aligned(io->left_depth, 16)) && (!io->right_depth || aligned(io->right_depth, 16)) &&
                            io->zout_pitch % 16 == 0 && io->zout_stride % 16 == 0));
 
-    const bool need_ws = plan.general || plan.remove_edges;
-    const bool need_keys = plan.general;
-    const bool need_ekeys = plan.general && plan.edge_points;
-    // general path: two frames per launch set keep the 64-bit key buffers (33 MB per 1080p frame) inside the
-    // 256 MiB Infinity Cache between splat and resolve (measured +12 %); the edge filter alone streams, so 8.
-    int ws_chunk = (plan.general && plan.mode == MDVT_MODE_POINTS) ? 2 : kWorkspaceChunk;    // (mesh: rows with slivers need the slack)
-    if (const char* e = getenv("MDVT_WS_CHUNK")) { const int v = atoi(e); if (v > 0) ws_chunk = v; }   // tuning hook
-    const int chunk = need_ws ? (n_frames < ws_chunk ? n_frames : ws_chunk) : n_frames;
-    const bool need_gverts = plan.general && plan.mode == MDVT_MODE_MESH;
-    if (need_ws && (rc = ensure_workspace(c, chunk, need_keys, need_ekeys, plan.remove_edges, need_gverts)) != MDVT_OK) return rc;
+    const bool need_keys = general != 0;
+    const bool need_ekeys = general && plan.edge_points;
+    const bool need_gverts = general && plan.mode == MDVT_MODE_MESH;
+    // frames per launch set.  Point splat, general: two frames keep the 64-bit key buffers (33 MB per 1080p frame)
+    // inside the 256 MiB Infinity Cache between splat and resolve (measured +12 %); the mesh needs the slack of
+    // eight (rows full of slivers leave a long tail), and the edge filter alone streams, so 8 as well.
+    int tuned_chunk = 0;
+    if (const char* e = getenv("MDVT_WS_CHUNK")) { const int v = atoi(e); if (v > 0) tuned_chunk = v; }   // tuning hook
+    auto chunk_of = [&](const Run& r) {
+        const int n = r.f1 - r.f0;
+        if (!(r.general || plan.remove_edges)) return n;                  // no workspace: the whole run in one launch
+        int ws_chunk = (r.general && plan.mode == MDVT_MODE_POINTS) ? 2 : kWorkspaceChunk;
+        if (tuned_chunk) ws_chunk = tuned_chunk;
+        return n < ws_chunk ? n : ws_chunk;
+    };
+    int ws_frames = 0, count_frames = 0;
+    for (const Run& r : runs) {
+        const int ch = chunk_of(r);
+        if ((r.general || plan.remove_edges) && ch > ws_frames) ws_frames = ch;
+        if (ch > count_frames) count_frames = ch;
+    }
+    if (ws_frames && (rc = ensure_workspace(c, ws_frames, need_keys, need_ekeys, plan.remove_edges, need_gverts)) != MDVT_OK) return rc;
 
     RenderArgs a{};
     a.depth = io->depth_rgb; a.depth_pitch = io->depth_pitch; a.depth_stride = io->depth_stride;
@@ -366,11 +385,11 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.hole_counts = io->hole_counts;
     a.seed[0] = io->left_seed; a.seed[1] = io->right_seed; a.seed_pitch = io->seed_pitch; a.seed_stride = io->seed_stride;
     if (io->hole_counts) {
-        if (c->row_counts_frames < chunk) {
+        if (c->row_counts_frames < count_frames) {
             if (c->row_counts) (void)hipFree(c->row_counts);
             c->row_counts = nullptr; c->row_counts_frames = 0;
-            MDVT_HIP(c, hipMalloc((void**)&c->row_counts, (size_t)chunk * 2 * H * sizeof(uint32_t)));
-            c->row_counts_frames = chunk;
+            MDVT_HIP(c, hipMalloc((void**)&c->row_counts, (size_t)count_frames * 2 * H * sizeof(uint32_t)));
+            c->row_counts_frames = count_frames;
         }
         a.row_counts = c->row_counts;
     }
@@ -384,7 +403,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.ws_stride_px = (size_t)W * H;
     a.ws_stride_tri = 2 * (size_t)(W - 1) * (H - 1);
 
-    if (plan.general) {
+    if (general) {
         if (c->keys_dirty) {        // re-establish the EMPTY invariant the resolve pass normally maintains
             const size_t bytes = (size_t)c->ws_frames * a.ws_stride_px * sizeof(unsigned long long);
             for (int e = 0; e < 2; ++e) {
@@ -394,8 +413,11 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         }
         c->keys_dirty = true;
     }
-    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
-        plan.n = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
+    for (const Run& r : runs) {
+      plan.general = r.general;
+      const int chunk = chunk_of(r);
+      for (int f0 = r.f0; f0 < r.f1; f0 += chunk) {
+        plan.n = (r.f1 - f0 < chunk) ? r.f1 - f0 : chunk;
         a.frame0 = f0;
         if (plan.remove_edges) {
             MDVT_HIP(c, hipMemsetAsync(c->unused, 0, (size_t)plan.n * a.ws_stride_px, s));
@@ -408,8 +430,9 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         if (e != hipSuccess) return fail(c, MDVT_ERR_HIP, "render launch failed: %s", hipGetErrorString(e));
         if ((want_bits || io->hole_counts) && !plan.fused_bits) MDVT_HIP(c, launch_pack_mask(a, plan.n, s));
         if (io->hole_counts) MDVT_HIP(c, launch_reduce_counts(a, plan.n, s));
+      }
     }
-    if (plan.general) c->keys_dirty = false;
+    if (general) c->keys_dirty = false;
     MDVT_HIP(c, hipEventRecord(slot->done, s));
     return MDVT_OK;
 }

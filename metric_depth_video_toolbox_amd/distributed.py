@@ -3,7 +3,7 @@
 The reference's only parallelism is one OS process per scene with the parameters passed as argv
 (movie_2_3D.py:433-452).  Here: one process per GPU; rank 0 owns the clip-level parameters (per-frame
 xfov, the NaN-filled and smoothed convergence curve, the lock-frame re-based poses) and broadcasts
-them as ONE small block (24 + 144*N bytes) over RCCL/xGMI; every rank then renders its own contiguous
+them as ONE small block (80 + 144*N bytes) over RCCL/xGMI; every rank then renders its own contiguous
 frame range with no further exchange.  A final all-gather of three doubles per rank feeds the report.
 
 Backend "nccl" is RCCL on ROCm; the CPU tests run the same code over "gloo".
@@ -16,7 +16,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-HEADER_DOUBLES = 8     # W, H, N, ipd_m, max_depth, master_xfov, mode_flags, has_T
+HEADER_DOUBLES = 10    # W, H, N, ipd_m, max_depth, master_xfov, mode_flags, has_T, touchly_max_depth, touchly_min_depth
 PER_FRAME_DOUBLES = 18  # xfov, convergence distance, T[16]
 
 
@@ -29,16 +29,19 @@ class ClipParameters:
     ipd_m: float
     max_depth: float
     master_xfov: float
-    mode_flags: int                      # bit0 pointcloud, bit1 remove_edges, bit2 edge_points, bit3 infill key colour
+    mode_flags: int                      # bit0 pointcloud, bit1 remove_edges, bit2 edge_points, bit3 infill key colour,
+                                         # bit4 vr180, bit5 touchly0, bit6 touchly1 (sr:291-303, 406-407)
     xfov: np.ndarray                     # [N] degrees (sr:351-359, or the constant --xfov)
     convergence: np.ndarray              # [N] metres, already NaN-filled + smoothed (sr:343-349); 0 = none
     transformations: Optional[np.ndarray] = None   # [N,4,4], already re-based on the lock frame (sr:369-373)
+    touchly_max_depth: float = 5.0       # sr:302-303
+    touchly_min_depth: float = 0.0
 
     def pack(self) -> np.ndarray:
         N = self.n_frames
         blk = np.zeros(HEADER_DOUBLES + PER_FRAME_DOUBLES * N, np.float64)
         blk[:HEADER_DOUBLES] = [self.W, self.H, N, self.ipd_m, self.max_depth, self.master_xfov, self.mode_flags,
-                                0.0 if self.transformations is None else 1.0]
+                                0.0 if self.transformations is None else 1.0, self.touchly_max_depth, self.touchly_min_depth]
         body = blk[HEADER_DOUBLES:].reshape(N, PER_FRAME_DOUBLES)
         body[:, 0] = self.xfov
         body[:, 1] = self.convergence
@@ -53,7 +56,7 @@ class ClipParameters:
         body = blk[HEADER_DOUBLES:HEADER_DOUBLES + PER_FRAME_DOUBLES * N].reshape(N, PER_FRAME_DOUBLES)
         T = body[:, 2:].reshape(N, 4, 4).copy() if blk[7] != 0.0 else None
         return ClipParameters(W, H, N, float(blk[3]), float(blk[4]), float(blk[5]), int(blk[6]),
-                              body[:, 0].copy(), body[:, 1].copy(), T)
+                              body[:, 0].copy(), body[:, 1].copy(), T, float(blk[8]), float(blk[9]))
 
 
 def frame_range(rank: int, world: int, n_frames: int):

@@ -18,7 +18,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _lib
-from .depth_map_tools import compute_camera_matrix
+from .depth_map_tools import compute_camera_matrix, fov_from_camera_matrix
 
 
 # ------------------------------------------------------------------------------------------------
@@ -174,10 +174,25 @@ def finish_infill_mask(seed_rgb, key_rgb=(0, 255, 0)):
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
+VR180_SIZE = 1920      # sr:528: the VR180 render is always 1920 x 1920
+
+
+def vr180_render_fov(K):
+    """sr:527-535: the fov of the (square) VR180 render camera for input camera matrix K."""
+    fovx, fovy = fov_from_camera_matrix(K)
+    max_fov = max(fovx, fovy)
+    if max_fov >= 180:
+        raise ValueError("fov cant be 180 or over, the tool is not built to handle fisheye distorted input video")   # sr:531-532
+    return max(75, max_fov)
+
+
 def make_frame_params(W, H, xfov=None, yfov=None, *, master_xfov=45.0, pupillary_distance=63,
-                      convergence_distance=None, transformation=None):
+                      convergence_distance=None, transformation=None, vr180=False):
     """The per-frame scalars the reference computes before its render calls (sr:515-541, 563-566,
-    707-721) as one mdvt_frame_params record.  Pure host code (no GPU needed)."""
+    707-721) as one mdvt_frame_params record.  Pure host code (no GPU needed).
+    vr180: the render camera becomes the square `vr180_render_fov` camera and replaces the master fov
+    (sr:527-535); the render target is 1920 x 1920, which this build supports for 1920 x 1920 inputs only
+    (for any other input size the reference's own writer, sized 2W x H at sr:409-437, rejects the frames)."""
     if xfov is None and yfov is None:
         raise ValueError("Error: Either --xfov_file, --xfov or --yfov must be provided.")    # sr:319-320
     K = compute_camera_matrix(xfov, yfov, W, H)
@@ -189,6 +204,14 @@ def make_frame_params(W, H, xfov=None, yfov=None, *, master_xfov=45.0, pupillary
     xf = xfov
     if xf is None:      # sr:537 needs xf; with only --yfov the reference raises TypeError. Use K's xfov.
         xf = float(np.rad2deg(2 * np.arctan2(W, 2 * K[0, 0])))
+    if vr180:
+        if (W, H) != (VR180_SIZE, VR180_SIZE):
+            raise ValueError(f"--vr180 renders {VR180_SIZE}x{VR180_SIZE} (sr:528); only inputs of that size are supported, got {W}x{H}")
+        render_fov = vr180_render_fov(K)
+        master_xfov = render_fov                                                             # sr:533
+        Kr = compute_camera_matrix(render_fov, render_fov, VR180_SIZE, VR180_SIZE).reshape(9)  # sr:535
+        for k in range(9):
+            p.Krender[k] = Kr[k]
     scale = master_fov_scale_depth(xf, master_xfov)
     p.depth_scale = scale
     p.convergence_angle = 0.0
@@ -275,10 +298,10 @@ class StereoRerenderer:
         return _lib.load()
 
     # -- per-frame scalars (sr:515-541, 563-566, 707-721) -------------------------------------
-    def frame_params(self, xfov=None, yfov=None, convergence_distance=None, transformation=None):
+    def frame_params(self, xfov=None, yfov=None, convergence_distance=None, transformation=None, vr180=False):
         return make_frame_params(self.W, self.H, xfov, yfov, master_xfov=self.master_xfov,
                                  pupillary_distance=self.pupillary_distance,
-                                 convergence_distance=convergence_distance, transformation=transformation)
+                                 convergence_distance=convergence_distance, transformation=transformation, vr180=vr180)
 
     # -- the per-frame loop body, batched -----------------------------------------------------
     def prepare(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
@@ -409,8 +432,12 @@ def build_arg_parser():
     ap.add_argument("--create_sbs_depth_video", action="store_true")
     ap.add_argument("--batch", default=16, type=int, help="frames per GPU submission")
     ap.add_argument("--green_and_black_infill_mask", action="store_true")
-    for flag in ("--touchly0", "--touchly1", "--vr180", "--do_basic_infill", "--compressed", "--mask_video",
-                 "--save_background", "--load_background"):
+    ap.add_argument("--vr180", action="store_true", help="VR180 180-degree side-by-side (1920x1920 inputs)")
+    ap.add_argument("--touchly0", action="store_true", help="Touchly0 format: left | right | left depth, needs VR180")
+    ap.add_argument("--touchly1", action="store_true", help="Touchly1 format: colour over depth, no stereo rendering")
+    ap.add_argument("--touchly_max_depth", default=5, type=float)
+    ap.add_argument("--touchly_min_depth", default=0, type=float)
+    for flag in ("--do_basic_infill", "--compressed", "--mask_video", "--save_background", "--load_background"):
         ap.add_argument(flag, nargs="?", const=True, default=None, help="reference flag outside the built hot path")
     return ap
 
@@ -418,8 +445,7 @@ def build_arg_parser():
 def main(argv=None):
     from . import clip
     args = build_arg_parser().parse_args(argv)
-    for flag in ("touchly0", "touchly1", "vr180", "do_basic_infill", "compressed", "mask_video", "save_background",
-                 "load_background"):
+    for flag in ("do_basic_infill", "compressed", "mask_video", "save_background", "load_background"):
         if getattr(args, flag) is not None:
             raise NotImplementedError(f"--{flag} is outside the hot path this build covers (DESIGN.md section 1)")
     if args.xfov is None and args.yfov is None and args.xfov_file is None:
@@ -440,7 +466,9 @@ def main(argv=None):
                             master_xfov=args.master_xfov, render_as_pointcloud=args.render_as_pointcloud,
                             remove_edges=(args.remove_edges and not args.dont_remove_edges),
                             infill_mask=(args.infill_mask and not args.dont_remove_edges),
-                            dont_place_points_in_edges=args.dont_place_points_in_edges)
+                            dont_place_points_in_edges=args.dont_place_points_in_edges,
+                            vr180=args.vr180, touchly0=args.touchly0, touchly1=args.touchly1,
+                            touchly_max_depth=args.touchly_max_depth, touchly_min_depth=args.touchly_min_depth)
     if int(os.environ.get("RANK", "0")) == 0:
         frames, secs = float(stats[:, 0].sum()), float(stats[:, 1].max())
         print(f"Processing complete. Output saved to: {final}  ({frames:.0f} frames, {frames / secs:.1f} frames/s incl. host I/O)")

@@ -20,7 +20,7 @@ def mods():
 
 def _oracle_frame(orc, clipp, r, rec, d, c, T):
     K = np.array([rec.K[k] for k in range(9)]).reshape(3, 3)
-    op = orc.make_params(clipp.W, clipp.H, K, ipd_m=clipp.ipd_m, max_depth=clipp.max_depth, depth_scale=rec.depth_scale,
+    op = orc.make_params(clipp.W, clipp.H, K, ipd_m=r.pupillary_distance / 1000, max_depth=clipp.max_depth, depth_scale=rec.depth_scale,
                          mode=orc.MODE_POINTS if r.mode == 0 else orc.MODE_MESH, remove_edges=r.remove_edges,
                          edge_points=r.edge_points, conv_angle=rec.convergence_angle, T=T, key_rgb=r.key_rgb)
     return orc.render_stereo(op, d, c, want_depth=True)
@@ -140,3 +140,84 @@ def test_cli_end_to_end(mods, orc, tmp_path, capsys):
         assert np.array_equal(sbs[t][:, :W], want["left_rgb"]) and np.array_equal(sbs[t][:, W:], want["right_rgb"])
         assert np.array_equal(mask[t][:, :W], want["left_mask"]) and np.array_equal(mask[t][:, W:], want["right_mask"])
     r.close()
+
+
+def _touchly_np(depth, tmax, tmin, zero_is_far):
+    """sr:549-551 / 687-691 literally."""
+    d8 = np.rint(np.maximum(0, np.minimum(depth, tmax) - tmin) * (255 / (tmax - tmin))).astype(np.uint8)
+    if zero_is_far:
+        d8[d8 == 0] = 255
+    return np.repeat((255 - d8)[..., np.newaxis], 3, axis=-1)
+
+
+@pytest.mark.parametrize("posed", [False, True])
+def test_touchly1_clip(mods, orc, tmp_path, posed):
+    """--touchly1: colour over Touchly depth.  Without a pose file straight from the input (sr:548-552); with one,
+    a single unshifted render of the posed mesh (sr:673-691), holes showing the background colour."""
+    clip, sr, synthetic = mods
+    W, H, N = 160, 96, 5
+    d, c = synthetic.SyntheticScene(W, H, config_id=3, n_fg=5).clip(N)
+    dp, cp = str(tmp_path / "d.npy"), str(tmp_path / "c.npy")
+    np.save(dp, d); np.save(cp, c)
+    kw = dict(xfov=60.0, touchly1=True, touchly_max_depth=12.0, touchly_min_depth=1.0, infill_mask=posed)
+    if posed:
+        (tmp_path / "T.json").write_text(json.dumps(synthetic.synthetic_pose_track(N).tolist()))
+        kw["transformation_file"] = str(tmp_path / "T.json")
+    stats, final = clip.run(dp, cp, batch=2, **kw)
+    out = np.load(final)
+    assert out.shape == (N, 2 * H, W, 3)
+    cl = clip.load_clip_parameters(N, W, H, **kw)
+    r = clip.renderer_for(cl)
+    recs = clip.frame_param_records(r, cl, 0, N)
+    for t in range(N):
+        if not posed:
+            z = orc.decode_depth(d[t], cl.max_depth, recs[t].depth_scale)       # dfh:99-103 + sr:541 (scale 60 -> 45 deg)
+            assert np.array_equal(out[t, :H], c[t])
+            assert np.array_equal(out[t, H:], _touchly_np(z, 12.0, 1.0, False)), t
+        else:
+            assert r.pupillary_distance == 0 and recs[t].convergence_angle == 0.0
+            want = _oracle_frame(orc, cl, r, recs[t], d[t], c[t], cl.transformations[t])
+            img = want["left_rgb"].copy()
+            img[want["left_mask"] > 0] = (0, 255, 0)                                # raw render: background colour in holes
+            assert np.array_equal(out[t, :H], img), t
+            assert np.array_equal(out[t, H:], _touchly_np(want["left_depth"], 12.0, 1.0, True)), t
+    r.close()
+
+
+@pytest.mark.parametrize("touchly0", [False, True])
+def test_vr180_clip(mods, orc, tmp_path, touchly0):
+    """--vr180 / --touchly0 (sr:406-407, 527-535, 825-829, 914-918): 1920x1920 render with the square VR180 camera,
+    every image through convert_to_equirectangular; other input sizes are refused."""
+    clip, sr, synthetic = mods
+    W = H = 1920
+    N = 2
+    d, c = synthetic.SyntheticScene(W, H, config_id=3, n_fg=6).clip(N)
+    dp, cp = str(tmp_path / "d.npy"), str(tmp_path / "c.npy")
+    np.save(dp, d); np.save(cp, c)
+    kw = dict(xfov=90.0, pupillary_distance=65, vr180=not touchly0, touchly0=touchly0, render_as_pointcloud=touchly0)
+    (tmp_path / "xfov.json").write_text(json.dumps([90.0, 70.0]))                 # per-frame fov: 90 -> render fov 90, 70 -> 75
+    kw.pop("xfov"); kw["xfov_file"] = str(tmp_path / "xfov.json")
+    stats, final = clip.run(dp, cp, batch=2, **kw)
+    out = np.load(final)
+    assert out.shape == (N, H, (3 if touchly0 else 2) * W, 3)
+    cl = clip.load_clip_parameters(N, W, H, **kw)
+    assert cl.mode_flags & 16
+    r = clip.renderer_for(cl)
+    recs = clip.frame_param_records(r, cl, 0, N)
+    for t, fov in enumerate((90.0, 75.0)):
+        rec = recs[t]
+        K = np.array([rec.K[k] for k in range(9)]).reshape(3, 3)
+        Kr = np.array([rec.Krender[k] for k in range(9)]).reshape(3, 3)
+        assert abs(sr.vr180_render_fov(K) - fov) < 1e-9 and abs(Kr[0, 0] - 960 / np.tan(np.radians(fov / 2))) < 1e-9
+        fov = sr.vr180_render_fov(K)        # 89.99999999999999 for the 90-degree frame: fov_from_camera_matrix round trip (sr:529-533)
+        op = orc.make_params(W, H, K, Kr=Kr, ipd_m=cl.ipd_m, max_depth=cl.max_depth, depth_scale=rec.depth_scale,
+                             mode=orc.MODE_POINTS if r.mode == 0 else orc.MODE_MESH)
+        want = orc.render_stereo(op, d[t], c[t], want_depth=True)
+        assert np.array_equal(out[t, :, :W], orc.convert_to_equirectangular(want["left_rgb"], fov)), t
+        assert np.array_equal(out[t, :, W:2 * W], orc.convert_to_equirectangular(want["right_rgb"], fov)), t
+        if touchly0:
+            plane = _touchly_np(want["left_depth"], 5.0, 0.0, True)
+            assert np.array_equal(out[t, :, 2 * W:], orc.convert_to_equirectangular(plane, fov)), t
+    r.close()
+    with pytest.raises(ValueError):
+        sr.make_frame_params(1920, 1080, 60.0, vr180=True)

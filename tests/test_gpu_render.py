@@ -654,3 +654,25 @@ def test_equirect_remap_rejects_bad_arguments(mods):
     tx = torch.zeros(16, device="cuda")
     rc = _lib.load().mdvt_equirect_remap(ctx.handle, t.data_ptr(), 16, 0, t.data_ptr() + 1, 48, 0, 1, tx.data_ptr(), tx.data_ptr(), None)
     assert rc == -1 and b"pitch" in _lib.load().mdvt_last_error(ctx.handle)
+
+
+@pytest.mark.parametrize("mode", ["points", "mesh", "mesh_infill"])
+def test_mixed_batch_keeps_each_frames_own_arithmetic(mods, orc, mode):
+    """A batch mixing pure-shift frames with pose / convergence frames: every frame equals the oracle run on
+    that frame alone (the pure-shift / general selection is per frame, never per batch), with hole counts."""
+    _lib, sr, synthetic = mods
+    W, H, N = 128, 72, 7
+    d, c = synthetic.SyntheticScene(W, H, config_id=2, n_fg=5).clip(N)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=(mode == "points"), infill_mask=(mode == "mesh_infill"))
+    T = synthetic.synthetic_pose_track(N)
+    kinds = ["pure", "conv", "pure", "pure", "pose", "conv", "pure"]
+    recs = [r.frame_params(xfov=45.0, convergence_distance=3.0 if k == "conv" else None,
+                           transformation=T[t] if k == "pose" else None) for t, k in enumerate(kinds)]
+    got = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), recs, want_depth=True, want_hole_counts=True)
+    for t, k in enumerate(kinds):
+        want = _oracle(orc, r, recs[t], d[t], c[t], T=T[t] if k == "pose" else None)
+        one = {key: got[key][t] for key in ("sbs", "mask", "depth")}
+        _compare(one, want, W, tag=f"{mode} frame {t} ({k})")
+        hc = got["hole_counts"][t].cpu().numpy()
+        assert hc[0] == np.count_nonzero(want["left_mask"]) and hc[1] == np.count_nonzero(want["right_mask"])
+    r.close()

@@ -177,7 +177,7 @@ def test_cli_rejects_what_is_out_of_scope(tmp_path):
     d = str(tmp_path / "d.npy")
     np.save(d, np.zeros((1, 4, 4, 3), np.uint8))
     with pytest.raises(NotImplementedError):
-        sr.main(["--depth_video", d, "--xfov", "45", "--vr180"])
+        sr.main(["--depth_video", d, "--xfov", "45", "--do_basic_infill"])
     with pytest.raises(ValueError):
         sr.main(["--depth_video", d])
     with pytest.raises(FileNotFoundError):
