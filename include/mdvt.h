@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 4
+#define MDVT_VERSION_MINOR 5
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -51,7 +51,9 @@ typedef enum mdvt_mode {
 typedef struct mdvt_config {
     int32_t mode;                /* mdvt_mode                                                       */
     int32_t remove_edges;        /* sr:568-573 (implied by --infill_mask / --remove_edges / --do_basic_infill) */
-    int32_t edge_points;         /* !--dont_place_points_in_edges (sr:589-606); needs remove_edges   */
+    int32_t edge_points;         /* !--dont_place_points_in_edges (sr:589-606); needs remove_edges.  1: splat and
+                                    paint into the holes (sr:813-814); 2: splat for the seed image only, holes stay
+                                    black (--do_basic_infill fills them afterwards, sr:809-812)          */
     int32_t reserved0;
     double ipd_m;                /* --pupillary_distance / 1000 (sr:458-459)                         */
     double max_depth;            /* --max_depth (dfh:22)                                             */
@@ -161,6 +163,25 @@ int mdvt_equirect_tables(int width, int height, double input_fov_deg, float* h_m
 int mdvt_equirect_remap(mdvt_ctx* ctx, const uint8_t* d_src, size_t src_pitch, size_t src_stride, uint8_t* d_dst,
                         size_t dst_pitch, size_t dst_stride, int n_images, const float* d_map_x, const float* d_map_y,
                         void* stream);
+
+/* stereo_rerender.masked_blur(img, ksize=(6,6), sigma=0) (sr:114-153): a Gaussian that ignores pure black pixels
+ * (black stays black).  cv2.getGaussianKernel / cv2.filter2D(BORDER_ISOLATED) by their published definitions: f32
+ * correlation with the f64-built 6x6 kernel, anchor (3,3), zero border, 36 taps summed row-major without
+ * contraction, result truncated to u8.  u8 RGB rows of the ctx's W x H. */
+int mdvt_masked_blur(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, uint8_t* d_out, size_t out_pitch, void* stream);
+
+/* The completion of the infill-mask image, sr:803-808 + 816, for n_images seed images (the left_seed / right_seed
+ * outputs of mdvt_render_stereo): every key-coloured or black pixel is inpainted from the normal-coloured ones
+ * (cv2.inpaint(..., 3, INPAINT_TELEA)'s role), the key-coloured pixels keep the inpainted value, black ones return
+ * to black, then masked_blur.  The inpaint uses Telea's weights as OpenCV publishes them but fills LEVEL BY LEVEL
+ * (round r = every unknown pixel with a 4-neighbour known before round r), not in OpenCV's one-pixel-at-a-time
+ * heap order -- the parallel form of the fast-marching front; it is not bit-identical to cv2.inpaint.
+ * max_rounds (<= 0: 512) bounds the front's travel; the rounds stop early once no key-coloured pixel is left, and
+ * d_remaining (optional, n_images x uint32) receives the number of key-coloured pixels not reached.
+ * The key colour is the ctx's cfg.key_rgb.  d_out may not alias d_seed. */
+int mdvt_finish_infill_mask(mdvt_ctx* ctx, const uint8_t* d_seed, size_t seed_pitch, size_t seed_stride, uint8_t* d_out,
+                            size_t out_pitch, size_t out_stride, int n_images, int max_rounds, uint32_t* d_remaining,
+                            void* stream);
 
 #ifdef __cplusplus
 }

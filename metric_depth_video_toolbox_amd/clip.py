@@ -11,12 +11,12 @@ a device-side FFV1 codec is out of scope, so this driver works on raw frame dump
                         dfh:163-179)
   <depth>_stereo.npy_holemask.npy   uint8 [N, H, 2W]   255 = hole (sr:740 / 854)
   <depth>_stereo.npy_depth.npy      uint8 [N, H, 2W, 3] B,G,R 16-bit depth code of both eyes (sr:930-939)
-  <depth>_stereo.npy_infillmask.npy uint8 [N, H, 2W, 3] only with --infill_mask --green_and_black_infill_mask:
-                        the key colour (0,255,0) at holes, black elsewhere (sr:787-793, 921-928; RGB order).
-  <depth>_stereo.npy_infillmask_seed.npy  uint8 [N, H, 2W, 3] with --infill_mask (without the green/black flag):
-                        the normal-coloured mask as it stands just before cv2.inpaint (sr:803) -- key colour /
-                        border normals / removed-vertex normals.  stereo_rerender.finish_infill_mask() applies
-                        the remaining OpenCV steps (TELEA + masked blur) where cv2 is installed.
+  <depth>_stereo.npy_infillmask.npy uint8 [N, H, 2W, 3] with --infill_mask (sr:787-808, 921-928; RGB order): the
+                        normal-coloured mask -- black outside holes, inside them the screen-space normal pointing
+                        out of the hole as (n+1)/2*255, inpainted from the removed-vertex normals at the splatted
+                        edge points and blurred (device: StereoRerenderer.finish_infill_mask) -- or, with
+                        --green_and_black_infill_mask, just the key colour (0,255,0) at holes.
+  --do_basic_infill     the holes of the stereo output are filled by marching along those normals (sr:809-812).
 
 Output-format variants (sr:406-422, 548-552, 677-702, 825-829, 914-918); the VR180 ones need 1920x1920 inputs:
   --vr180      both eyes rendered with the square VR180 camera, each put through convert_to_equirectangular
@@ -47,7 +47,7 @@ def load_clip_parameters(n_frames: int, W: int, H: int, *, xfov=None, xfov_file=
                          transformation_file=None, transformation_lock_frame: int = 0, pupillary_distance=63,
                          max_depth=100, master_xfov: float = 45.0, render_as_pointcloud=False, remove_edges=False,
                          infill_mask=False, dont_place_points_in_edges=False, vr180=False, touchly0=False,
-                         touchly1=False, touchly_max_depth=5.0, touchly_min_depth=0.0) -> D.ClipParameters:
+                         touchly1=False, touchly_max_depth=5.0, touchly_min_depth=0.0, do_basic_infill=False) -> D.ClipParameters:
     """What sr:318-373 does before the loop, on rank 0."""
     if xfov is None and xfov_file is None:
         raise ValueError("Error: Either --xfov_file, --xfov or --yfov must be provided.")            # sr:319-320
@@ -81,14 +81,14 @@ def load_clip_parameters(n_frames: int, W: int, H: int, *, xfov=None, xfov_file=
         if len(T) < n_frames:
             raise ValueError("transformation file has fewer entries than frames")
         T = T[:n_frames]
-    rm = bool(infill_mask or remove_edges)
+    rm = bool(infill_mask or remove_edges or do_basic_infill)                                          # sr:568-570
     flags = (1 if render_as_pointcloud else 0) | (2 if rm else 0) | (4 if (rm and not dont_place_points_in_edges) else 0) \
         | (8 if infill_mask else 0)
     if touchly0:
         vr180 = True                                                                                   # sr:406-407
     if touchly0 and touchly1:
         raise ValueError("--touchly0 and --touchly1 are different output formats; pick one")
-    flags |= (16 if vr180 else 0) | (32 if touchly0 else 0) | (64 if touchly1 else 0)
+    flags |= (16 if vr180 else 0) | (32 if touchly0 else 0) | (64 if touchly1 else 0) | (128 if do_basic_infill else 0)
     if not float(touchly_max_depth) > float(touchly_min_depth):
         raise ValueError("touchly_max_depth must exceed touchly_min_depth")
     return D.ClipParameters(W, H, n_frames, pupillary_distance / 1000, float(max_depth), float(master_xfov), flags,
@@ -115,7 +115,8 @@ def renderer_for(clip: D.ClipParameters, device: Optional[int] = None) -> Stereo
     return StereoRerenderer(clip.W, clip.H, device=device, pupillary_distance=pd,
                             max_depth=clip.max_depth, master_xfov=clip.master_xfov,
                             render_as_pointcloud=bool(f & 1), remove_edges=bool(f & 2) and not bool(f & 8),
-                            infill_mask=bool(f & 8), dont_place_points_in_edges=not bool(f & 4))
+                            infill_mask=bool(f & 8), dont_place_points_in_edges=not bool(f & 4),
+                            do_basic_infill=bool(f & 128), dont_remove_edges=not bool(f & 2))
 
 
 def frame_param_records(r: StereoRerenderer, clip: D.ClipParameters, lo: int, hi: int):
@@ -176,7 +177,7 @@ def _post_touchly1(r, clip, scales, d_depth_in, d_color_in, d_sbs, d_mask, d_z, 
 
 
 def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParameters, *, lo: int = 0,
-                hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, out_seed=None, device: Optional[int] = None):
+                hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, out_infill=None, device: Optional[int] = None):
     """Render frames [lo, hi) of a clip.  depth_frames / color_frames / out_*: array-likes indexed
     [frame] (NumPy arrays or memmaps, uint8).  Returns (frames, seconds, hole_pixels)."""
     import time
@@ -194,7 +195,12 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     posed = clip.transformations is not None
     skip_render = touchly1 and not posed                      # sr:548-552: "fast path we can skip the full render pass"
     want_z = want_zrgb or touchly0 or (touchly1 and posed)
-    want_seed = out_seed is not None
+    basic_infill = bool(clip.mode_flags & 128) and not touchly1
+    want_infill = out_infill is not None
+    want_seed = (want_infill or basic_infill) and bool(clip.mode_flags & 2)
+    # without --infill_mask the key colour is black and every black pixel counts as "to fill" (sr:803-805): the front
+    # then has to cross the whole frame, as the reference's own cv2.inpaint call does
+    telea_rounds = 0 if (clip.mode_flags & 8) else W + H
     oH, oW = output_shape(clip)
     post = vr180 or touchly1                                   # the main output is a post-processed image
 
@@ -207,7 +213,8 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             "h_d": pinned((B, H, W, 3), torch.uint8), "h_c": pinned((B, H, W, 3), torch.uint8),
             "h_sbs": pinned((B, oH, oW, 3), torch.uint8), "h_mask": pinned((B, H, 2 * W), torch.uint8),
             "h_zrgb": pinned((B, H, 2 * W, 3), torch.uint8) if want_zrgb else None,
-            "h_seed": pinned((B, H, 2 * W, 3), torch.uint8) if want_seed else None,
+            "h_seed": pinned((B, H, 2 * W, 3), torch.uint8) if want_infill else None,
+            "d_infill": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if want_seed else None,
             "d_d": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
             "d_c": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
             "d_sbs": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev),
@@ -234,8 +241,8 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         holes += int(np.count_nonzero(m))
         if want_zrgb:
             out_depth_rgb[a:a + n] = st["h_zrgb"][:n].numpy()
-        if want_seed:
-            out_seed[a:a + n] = st["h_seed"][:n].numpy()
+        if want_infill:
+            out_infill[a:a + n] = st["h_seed"][:n].numpy()
         st["pending"] = None
 
     t0 = time.perf_counter()
@@ -265,6 +272,17 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         if want_zrgb:                               # sr:930-939: both eyes through the 16-bit code, B,G,R
             for f in range(n):
                 dfh.encode_depth_frame(st["d_z"][f], clip.max_depth, bgr=True, out=st["d_zrgb"][f])
+        if want_seed and res is not None:              # sr:803-808: finish the normal-coloured mask on the device, per eye
+            for eye in range(2):
+                r.finish_infill_mask(res["seed"][:, :, eye * W:(eye + 1) * W], out=st["d_infill"][:n, :, eye * W:(eye + 1) * W],
+                                     max_rounds=telea_rounds)
+            if basic_infill:                           # sr:809-812: march along the normals into the holes
+                from .stereo_rerender import infill_using_normals
+                for f in range(n):
+                    for eye in range(2):
+                        sl = slice(eye * W, (eye + 1) * W)
+                        normals = (st["d_infill"][f, :, sl].to(torch.float32) / 255.0) * 2 - 1
+                        st["d_sbs"][f, :, sl] = infill_using_normals(st["d_sbs"][f, :, sl], st["d_mask"][f, :, sl] > 0, normals)
         main = st["d_sbs"][:n]
         if touchly1:
             main = _post_touchly1(r, clip, [rec.depth_scale for rec in brecs], st["d_d"], st["d_c"], st["d_sbs"], st["d_mask"], st["d_z"], st["d_post"], n, posed)
@@ -277,9 +295,8 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             st["h_mask"][:n].copy_(st["d_mask"][:n], non_blocking=True)
             if want_zrgb:
                 st["h_zrgb"][:n].copy_(st["d_zrgb"][:n], non_blocking=True)
-            if want_seed and res is not None:
-                st["h_seed"][:n].copy_(res["seed"], non_blocking=True)
-                res["seed"].record_stream(s_out)
+            if want_infill and want_seed and res is not None:
+                st["h_seed"][:n].copy_(st["d_infill"][:n], non_blocking=True)
             st["out_done"].record(s_out)
         st["pending"] = (a, n)
     for st in sets:
@@ -323,10 +340,8 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
              "mask": (tmp + "_holemask.npy", final + "_holemask.npy", (N, H, 2 * W))}
     if create_sbs_depth_video:
         names["depth"] = (tmp + "_depth.npy", final + "_depth.npy", (N, H, 2 * W, 3))
-    if green_and_black_infill_mask and clip_kwargs.get("infill_mask"):
+    if clip_kwargs.get("infill_mask"):
         names["infill"] = (tmp + "_infillmask.npy", final + "_infillmask.npy", (N, H, 2 * W, 3))
-    elif clip_kwargs.get("infill_mask"):
-        names["seed"] = (tmp + "_infillmask_seed.npy", final + "_infillmask_seed.npy", (N, H, 2 * W, 3))
     if rank == 0:
         for t, _, shape in names.values():
             np.lib.format.open_memmap(t, mode="w+", dtype=np.uint8, shape=shape).flush()
@@ -336,8 +351,9 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     outs = {k: np.load(v[0], mmap_mode="r+") for k, v in names.items()}
     lo, hi = D.frame_range(rank, world, N)
     frames, secs, holes = render_clip(depth, color, outs["sbs"], outs["mask"], clip, lo=lo, hi=hi, batch=batch,
-                                      out_depth_rgb=outs.get("depth"), out_seed=outs.get("seed"))
-    if "infill" in outs:        # sr:787-793 with --green_and_black_infill_mask: bg_color at holes, black elsewhere
+                                      out_depth_rgb=outs.get("depth"),
+                                      out_infill=None if green_and_black_infill_mask else outs.get("infill"))
+    if "infill" in outs and green_and_black_infill_mask:    # sr:787-793: bg_color at holes, black elsewhere
         key = np.array([0, 255, 0], np.uint8)
         for a in range(lo, hi, 8):
             b = min(hi, a + 8)

@@ -56,6 +56,9 @@ struct mdvt_ctx {
     uint8_t* unused = nullptr;
     uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
     int row_counts_frames = 0;
+    // infill-mask completion: per image stamp u16 + T f32 + work image u8x3, and the per-image counters
+    int telea_images = 0, telea_rounds = 0;
+    mdvt::TeleaWorkspace telea{};
 };
 
 namespace {
@@ -258,6 +261,15 @@ int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flag
     return MDVT_OK;
 }
 
+static void free_telea(mdvt_ctx* c)
+{
+    mdvt::TeleaWorkspace& w = c->telea;
+    void* ptrs[] = {w.stamp, w.T, w.img, w.queued, w.list[0], w.list[1], w.counts, w.remaining, w.last_round};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    w = mdvt::TeleaWorkspace{};
+    c->telea_images = 0; c->telea_rounds = 0;
+}
+
 int mdvt_destroy(mdvt_ctx* c)
 {
     if (!c) return MDVT_OK;
@@ -272,6 +284,7 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->tri_invalid) (void)hipFree(c->tri_invalid);
     if (c->unused) (void)hipFree(c->unused);
     if (c->row_counts) (void)hipFree(c->row_counts);
+    free_telea(c);
     delete c;
     return MDVT_OK;
 }
@@ -283,6 +296,7 @@ int mdvt_set_config(mdvt_ctx* c, const mdvt_config* cfg)
     if (cfg->mode != MDVT_MODE_POINTS && cfg->mode != MDVT_MODE_MESH) return fail(c, MDVT_ERR_INVALID_ARG, "unknown mode %d", cfg->mode);
     if (!(cfg->max_depth > 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "max_depth must be > 0");
     if (!(cfg->ipd_m >= 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "ipd_m must be >= 0");
+    if (cfg->edge_points < 0 || cfg->edge_points > 2) return fail(c, MDVT_ERR_INVALID_ARG, "edge_points must be 0, 1 or 2");
     if (cfg->edge_points && !cfg->remove_edges) return fail(c, MDVT_ERR_INVALID_ARG, "edge_points needs remove_edges (sr:589)");
     c->cfg = *cfg;
     c->cfg_set = true;
@@ -394,6 +408,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         a.row_counts = c->row_counts;
     }
     a.fp = dfp;
+    a.edge_paint = c->cfg.edge_points != 2;
     a.W = W; a.H = H;
     a.key_rgb = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     a.keys[0] = c->keys[0]; a.keys[1] = c->keys[1];
@@ -570,6 +585,80 @@ int mdvt_equirect_remap(mdvt_ctx* c, const uint8_t* d_src, size_t src_pitch, siz
     DeviceGuard g(c->device);
     MDVT_HIP(c, launch_equirect_remap(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_images, c->W, c->H,
                                       d_map_x, d_map_y, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
+namespace {
+// cv2.getGaussianKernel(6, 0) as published: sigma = 0.3*((n-1)*0.5 - 1) + 0.8, exp in f64, scaled by 1/sum; the
+// 2-D kernel is the f64 outer product (sr:124-125) rounded to f32 (what filter2D does for an f32 image).
+mdvt::BlurKernel masked_blur_kernel()
+{
+    double g[6], sum = 0.0;
+    const double sigma = 0.3 * ((6 - 1) * 0.5 - 1.0) + 0.8, scale2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < 6; ++i) { const double x = (double)i - (6 - 1) * 0.5; g[i] = exp(scale2 * x * x); sum += g[i]; }
+    sum = 1.0 / sum;
+    for (int i = 0; i < 6; ++i) g[i] *= sum;
+    mdvt::BlurKernel K;
+    for (int y = 0; y < 6; ++y) for (int x = 0; x < 6; ++x) K.k[6 * y + x] = (float)(g[y] * g[x]);
+    return K;
+}
+constexpr int kTeleaChunk = 16;      // images per pass (12 B/px of workspace each)
+}  // namespace
+
+int mdvt_masked_blur(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, uint8_t* d_out, size_t out_pitch, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_img || !d_out) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (img_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (d_img == d_out) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias d_img");
+    DeviceGuard g(c->device);
+    MDVT_HIP(c, launch_masked_blur(d_img, img_pitch, 0, nullptr, 0, 0, d_out, out_pitch, 0, 1, c->W, c->H, masked_blur_kernel(), 0u,
+                                   (hipStream_t)stream));
+    return MDVT_OK;
+}
+
+int mdvt_finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, size_t seed_pitch, size_t seed_stride, uint8_t* d_out,
+                            size_t out_pitch, size_t out_stride, int n_images, int max_rounds, uint32_t* d_remaining, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_seed || !d_out) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (n_images < 1) return fail(c, MDVT_ERR_INVALID_ARG, "n_images must be >= 1");
+    if (seed_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (d_seed == d_out) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias d_seed");
+    if (max_rounds <= 0) max_rounds = 512;
+    if (max_rounds > 65000) return fail(c, MDVT_ERR_INVALID_ARG, "max_rounds must be <= 65000");
+    DeviceGuard g(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int W = c->W, H = c->H;
+    const size_t npx = (size_t)W * H;
+    const int chunk = n_images < kTeleaChunk ? n_images : kTeleaChunk;
+    if (c->telea_images < chunk || c->telea_rounds < max_rounds) {
+        MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
+        const int images = chunk > c->telea_images ? chunk : c->telea_images;
+        const int rounds = max_rounds > c->telea_rounds ? max_rounds : c->telea_rounds;
+        free_telea(c);
+        mdvt::TeleaWorkspace& w = c->telea;
+        MDVT_HIP(c, hipMalloc((void**)&w.stamp, (size_t)images * npx * sizeof(uint16_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.T, (size_t)images * npx * sizeof(float)));
+        MDVT_HIP(c, hipMalloc((void**)&w.img, (size_t)images * npx * 3));
+        MDVT_HIP(c, hipMalloc((void**)&w.queued, (size_t)images * npx * sizeof(uint32_t)));
+        for (int k = 0; k < 2; ++k) MDVT_HIP(c, hipMalloc((void**)&w.list[k], (size_t)images * npx * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.counts, ((size_t)rounds + 2) * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.remaining, (size_t)images * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.last_round, (size_t)images * sizeof(uint32_t)));
+        c->telea_images = images; c->telea_rounds = rounds;
+    }
+    const uint32_t key = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
+    const mdvt::BlurKernel K = masked_blur_kernel();
+    for (int i0 = 0; i0 < n_images; i0 += chunk) {
+        const int n = n_images - i0 < chunk ? n_images - i0 : chunk;
+        const uint8_t* seed = d_seed + (size_t)i0 * seed_stride;
+        MDVT_HIP(c, launch_telea(seed, seed_pitch, seed_stride, c->telea, n, W, H, 3, max_rounds, key, s));   // sr:806, inpaintRadius = 3
+        MDVT_HIP(c, launch_masked_blur(c->telea.img, (size_t)3 * W, 3 * npx, seed, seed_pitch, seed_stride,
+                                       d_out + (size_t)i0 * out_stride, out_pitch, out_stride, n, W, H, K, key, s));   // sr:807-808
+        if (d_remaining)
+            MDVT_HIP(c, hipMemcpyAsync(d_remaining + i0, c->telea.remaining, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
     return MDVT_OK;
 }
 

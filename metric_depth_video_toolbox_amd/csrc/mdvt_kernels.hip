@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
                 uint32_t out = hole ? 0u : rgb;                       // sr:793
                 if (EDGE && hole) {
                     const uint32_t ek = eb[(size_t)eye * W + x];
-                    if (ek != kEmpty32) {
+                    if (ek != kEmpty32 && a.edge_paint) {
                         // colour of source column (ek & 0xFFFF) of this row (sr:813-814)
                         out = load_px_bytes(crow, (int)(ek & 0xFFFFu));
                     }
@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
         uint32_t esrc = ~0u;
         if (EDGE && hole && ek[q] != kEmpty64) {
             esrc = (uint32_t)ek[q];
-            out = load_px_bytes(cbase + (size_t)(esrc >> 16) * a.color_pitch, (int)(esrc & 0xFFFFu));
+            if (a.edge_paint) out = load_px_bytes(cbase + (size_t)(esrc >> 16) * a.color_pitch, (int)(esrc & 0xFFFFu));
         }
         opx[q] = out;
         om[q] = hole ? 255u : 0u;
@@ -1179,7 +1179,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                 uint32_t esrc = ~0u;
                 if (EDGEPTS) {
                     const uint32_t ek = eb[x];
-                    if (hole && ek != kEmpty32) { out = load_px_bytes(crow_k, (int)(ek & 0xFFFFu)); esrc = ((uint32_t)k << 16) | (ek & 0xFFFFu); }
+                    if (hole && ek != kEmpty32) { if (a.edge_paint) out = load_px_bytes(crow_k, (int)(ek & 0xFFFFu)); esrc = ((uint32_t)k << 16) | (ek & 0xFFFFu); }
                     if (eye == 0) eb[x] = kEmpty32;
                 }
                 if (SEED && a.seed[eye]) spx[q] = seed_pixel(a, fp, f, eye, x, k, hole, esrc, 1);
@@ -1547,6 +1547,272 @@ hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t sr
         dim3 grid((W + 255) / 256, H, n);
         hipLaunchKernelGGL((k_equirect_remap<1>), grid, dim3(256), 0, s, src, src_pitch, src_stride, dst, dst_pitch, dst_stride, W, H, mx, my);
     }
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// infill-mask completion (sr:803-808, 114-153): level-synchronous Telea inpaint + masked Gaussian
+// =================================================================================================
+// State per image: stamp u16 (0 known from the start, 0xFFFF unknown, r = filled in round r), T f32, the work
+// image (seed copy, filled in place).  Round r reads only pixels with stamp < r, so the in-place writes of the
+// same round (stamp = r) are never observed: one launch = one Jacobi step, no double buffering.
+constexpr uint16_t kTeleaUnknown = 0xFFFFu;
+
+// The front is kept as work lists: list[r] holds the pixels to try in round r (global index im*H*W + y*W + x); a
+// pixel filled in round r appends its still-unknown 4-neighbours to list[r+1] (deduplicated through `queued`).
+// Entries that turn out to be filled already (they were part of the same round's front) are skipped when read.
+// last_round[im]: rounds > last_round are no-ops for the image; set to r by the thread that fills the image's last
+// key-coloured pixel in round r -- so every thread of round r still runs, whatever the order (deterministic).
+struct TeleaArgs {
+    uint16_t* stamp; float* T; uint8_t* img;      // [n][H*W] / [n][H*W*3]
+    uint32_t* queued;                             // [n][H*W] last round a pixel was appended for
+    uint32_t* list[2];                            // work lists, alternating by round parity, capacity n*H*W each
+    uint32_t* counts;                             // [max_rounds + 2] list sizes by round
+    uint32_t* remaining;                          // [n] key-coloured pixels still unfilled
+    uint32_t* last_round;                         // [n]
+    int W, H, n, radius;
+    uint32_t key_rgb;
+};
+
+// Appends `idx` to `list` for every lane with `want`, one atomicAdd per wave.
+__device__ __forceinline__ void telea_append(bool want, uint32_t idx, uint32_t* list, uint32_t* count)
+{
+    const u64 m = __ballot(want);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
+}
+
+__global__ void __launch_bounds__(256) k_telea_init(const uint8_t* __restrict__ seed, size_t seed_pitch, size_t seed_stride,
+                                                    TeleaArgs a)
+{
+    const uint32_t key_rgb = a.key_rgb;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
+    const int W = a.W, H = a.H;
+    const bool in = x < W;
+    bool green = false, front = false;
+    const size_t o = (size_t)im * W * H + (size_t)y * W + (in ? x : 0);
+    if (in) {
+        const uint8_t* sim = seed + (size_t)im * seed_stride;
+        auto masked = [&](int xx, int yy) {                   // sr:803-805: key-coloured or black = to inpaint
+            const uint32_t p = load_px_bytes(sim + (size_t)yy * seed_pitch, xx);
+            return p == key_rgb || p == 0u;
+        };
+        const uint32_t px = load_px_bytes(sim + (size_t)y * seed_pitch, x);
+        green = px == key_rgb;
+        const bool unk = green || px == 0u;
+        a.stamp[o] = unk ? kTeleaUnknown : (uint16_t)0;
+        a.T[o] = 0.0f;
+        a.queued[o] = 0u;
+        store_px_bytes(a.img + 3 * ((size_t)im * W * H + (size_t)y * W), x, px);
+        front = unk && ((x > 0 && !masked(x - 1, y)) || (x + 1 < W && !masked(x + 1, y)) ||
+                        (y > 0 && !masked(x, y - 1)) || (y + 1 < H && !masked(x, y + 1)));
+    }
+    telea_append(front, (uint32_t)o, a.list[1], &a.counts[1]);
+    const u64 m = __ballot(green);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.remaining[im], (uint32_t)__popcll(m));
+}
+
+__global__ void k_telea_begin(TeleaArgs a)
+{
+    const int im = blockIdx.x * blockDim.x + threadIdx.x;
+    if (im < a.n) a.last_round[im] = a.remaining[im] ? 0xFFFFFFFFu : 0u;     // nothing key-coloured: nothing to do
+}
+
+struct TeleaView {
+    const uint16_t* stamp; const float* T; const uint8_t* img; int W, H; uint32_t r;
+    __device__ __forceinline__ bool known(int x, int y) const
+    {
+        return x >= 0 && x < W && y >= 0 && y < H && (uint32_t)stamp[(size_t)y * W + x] < r;
+    }
+    __device__ __forceinline__ float t(int x, int y) const { return T[(size_t)y * W + x]; }
+    __device__ float solve(int x1, int y1, int x2, int y2) const
+    {
+        const bool k1 = known(x1, y1), k2 = known(x2, y2);
+        const double a11 = k1 ? (double)t(x1, y1) : 1.0e6, a22 = k2 ? (double)t(x2, y2) : 1.0e6;
+        const double m12 = a11 < a22 ? a11 : a22;
+        double sol;
+        if (k1) {
+            if (k2) sol = fabs(a11 - a22) >= 1.0 ? 1.0 + m12 : (a11 + a22 + sqrt(2.0 - (a11 - a22) * (a11 - a22))) * 0.5;
+            else sol = 1.0 + a11;
+        } else if (k2) sol = 1.0 + a22;
+        else sol = 1.0 + m12;
+        return (float)sol;
+    }
+};
+
+// One pixel of the front: Telea's estimate from the pixels known before round r inside the radius.
+__device__ uint32_t telea_pixel(const TeleaView& s, int x, int y, int R, float& tout)
+{
+    const int W = s.W;
+    float t = s.solve(x, y - 1, x - 1, y);
+    t = fminf(t, s.solve(x, y + 1, x - 1, y));
+    t = fminf(t, s.solve(x, y - 1, x + 1, y));
+    t = fminf(t, s.solve(x, y + 1, x + 1, y));
+    tout = t;
+    float gtx, gty;
+    if (s.known(x + 1, y)) gtx = s.known(x - 1, y) ? (s.t(x + 1, y) - s.t(x - 1, y)) * 0.5f : s.t(x + 1, y) - t;
+    else gtx = s.known(x - 1, y) ? t - s.t(x - 1, y) : 0.0f;
+    if (s.known(x, y + 1)) gty = s.known(x, y - 1) ? (s.t(x, y + 1) - s.t(x, y - 1)) * 0.5f : s.t(x, y + 1) - t;
+    else gty = s.known(x, y - 1) ? t - s.t(x, y - 1) : 0.0f;
+
+    float Ia[3] = {0.0f, 0.0f, 0.0f}, Jx[3] = {0.0f, 0.0f, 0.0f}, Jy[3] = {0.0f, 0.0f, 0.0f}, sw = 1.0e-20f;
+    for (int k = y - R; k <= y + R; ++k)
+        for (int l = x - R; l <= x + R; ++l) {
+            if (!s.known(l, k)) continue;
+            if ((l - x) * (l - x) + (k - y) * (k - y) > R * R) continue;
+            const float ry = (float)(y - k), rx = (float)(x - l);
+            const float vl = rx * rx + ry * ry;
+            const float dst = (float)(1.0 / ((double)vl * sqrt((double)vl)));
+            const float lev = (float)(1.0 / (1.0 + fabs((double)(s.t(l, k) - t))));
+            float dir = rx * gtx + ry * gty;
+            if (fabsf(dir) <= 0.01f) dir = 0.000001f;
+            const float w = fabsf((dst * lev) * dir);
+            const bool xp = s.known(l + 1, k), xm = s.known(l - 1, k), yp = s.known(l, k + 1), ym = s.known(l, k - 1);
+            const uint8_t* I0 = s.img + 3 * ((size_t)k * W + l);
+            const uint32_t c0 = load_px_bytes(I0, 0);
+            const uint32_t cxp = xp ? load_px_bytes(I0, 1) : 0u, cxm = xm ? load_px_bytes(I0, -1) : 0u;
+            const uint32_t cyp = yp ? load_px_bytes(I0, W) : 0u, cym = ym ? load_px_bytes(I0, -W) : 0u;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const int sh = 8 * ch;
+                const int v0 = (c0 >> sh) & 0xFF, vxp = (cxp >> sh) & 0xFF, vxm = (cxm >> sh) & 0xFF, vyp = (cyp >> sh) & 0xFF, vym = (cym >> sh) & 0xFF;
+                float gix, giy;
+                if (xp) gix = xm ? (float)(vxp - vxm) * 2.0f : (float)(vxp - v0);
+                else gix = xm ? (float)(v0 - vxm) : 0.0f;
+                if (yp) giy = ym ? (float)(vyp - vym) * 2.0f : (float)(vyp - v0);
+                else giy = ym ? (float)(v0 - vym) : 0.0f;
+                Ia[ch] = Ia[ch] + w * (float)v0;
+                Jx[ch] = Jx[ch] - w * (gix * rx);
+                Jy[ch] = Jy[ch] - w * (giy * ry);
+            }
+            sw = sw + w;
+        }
+    uint32_t out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float jj = Jx[ch] * Jx[ch] + Jy[ch] * Jy[ch];
+        const float sat = (float)(((double)(Ia[ch] / sw) + (double)(Jx[ch] + Jy[ch]) / (sqrt((double)jj) + (double)1.0e-20f)) + (double)0.5f);
+        float v = rintf(sat);
+        if (!(v >= 0.0f)) v = 0.0f;
+        if (v > 255.0f) v = 255.0f;
+        out |= (uint32_t)v << (8 * ch);
+    }
+    return out;
+}
+
+__global__ void __launch_bounds__(256) k_telea_round(TeleaArgs a, uint32_t r)
+{
+    const uint32_t count = a.counts[r];
+    const uint32_t* list = a.list[r & 1];
+    uint32_t* next = a.list[(r + 1) & 1];
+    const int W = a.W, H = a.H;
+    const uint32_t npx = (uint32_t)W * (uint32_t)H;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // whole waves iterate together (the appends below use wave-wide ballots)
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < count; base += stride) {
+        const uint32_t idx = base + (threadIdx.x & 63);
+        bool act = idx < count;
+        uint32_t e = 0, im = 0, o = 0;
+        int x = 0, y = 0;
+        if (act) {
+            e = list[idx]; im = e / npx; o = e - im * npx; y = (int)(o / (uint32_t)W); x = (int)(o - (uint32_t)y * (uint32_t)W);
+            act = r <= a.last_round[im] && a.stamp[e] == kTeleaUnknown;      // image finished earlier / pixel filled in the previous front
+        }
+        if (act) {
+            const size_t ib = (size_t)im * npx;
+            TeleaView s{a.stamp + ib, a.T + ib, a.img + 3 * ib, W, H, r};
+            float t;
+            const uint32_t out = telea_pixel(s, x, y, a.radius, t);
+            const bool green = load_px_bytes(s.img, (int)o) == a.key_rgb;     // still the seed value: key-coloured?
+            a.T[e] = t;
+            store_px_bytes(a.img + 3 * ib, (int)o, out);
+            a.stamp[e] = (uint16_t)r;
+            if (green && atomicSub(&a.remaining[im], 1u) == 1u) a.last_round[im] = r;
+        }
+        // the still-unknown 4-neighbours form the next front (a neighbour that belongs to this round's front may get
+        // appended too; it is skipped when read because its stamp is r by then)
+        const int nx[4] = {x - 1, x + 1, x, x}, ny[4] = {y, y, y - 1, y + 1};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            bool want = act && nx[d] >= 0 && nx[d] < W && ny[d] >= 0 && ny[d] < H;
+            uint32_t q = 0;
+            if (want) {
+                q = im * npx + (uint32_t)ny[d] * (uint32_t)W + (uint32_t)nx[d];
+                want = a.stamp[q] == kTeleaUnknown && atomicMax(&a.queued[q], r + 1u) < r + 1u;
+            }
+            telea_append(want, q, next, &a.counts[r + 1]);
+        }
+    }
+}
+
+// sr:807: only the key-coloured pixels take the inpainted value, black ones go back to black; then masked_blur.
+// Both in one pass: the 36 taps read the work image and zero it on the fly where the seed was black.
+__global__ void __launch_bounds__(256) k_masked_blur(const uint8_t* __restrict__ img, size_t img_pitch, size_t img_stride,
+                                                     const uint8_t* __restrict__ seed, size_t seed_pitch, size_t seed_stride,
+                                                     uint8_t* __restrict__ out, size_t out_pitch, size_t out_stride,
+                                                     int W, int H, BlurKernel K, uint32_t key_rgb)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
+    if (x >= W) return;
+    const uint8_t* ibase = img + (size_t)im * img_stride;
+    const uint8_t* sbase = seed ? seed + (size_t)im * seed_stride : nullptr;
+    float acc[3] = {0.0f, 0.0f, 0.0f}, wsum = 0.0f;
+    uint32_t centre = 0;
+#pragma unroll
+    for (int ky = 0; ky < 6; ++ky) {
+        const int sy = y + ky - 3;
+        if (sy < 0 || sy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 6; ++kx) {
+            const int sx = x + kx - 3;
+            if (sx < 0 || sx >= W) continue;
+            uint32_t px = load_px_bytes(ibase + (size_t)sy * img_pitch, sx);
+            if (sbase && key_rgb != 0u && load_px_bytes(sbase + (size_t)sy * seed_pitch, sx) == 0u) px = 0u;
+            const float k = K.k[6 * ky + kx];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + k * (float)((px >> (8 * c)) & 0xFF);
+            if (px) wsum = wsum + k;
+            if (ky == 3 && kx == 3) centre = px;
+        }
+    }
+    uint32_t o = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = (wsum == 0.0f || centre == 0u) ? 0.0f : acc[c] / wsum;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        o |= (uint32_t)v << (8 * c);
+    }
+    store_px_bytes(out + (size_t)im * out_stride + (size_t)y * out_pitch, x, o);
+}
+
+hipError_t launch_telea(const uint8_t* seed, size_t seed_pitch, size_t seed_stride, const TeleaWorkspace& ws, int n, int W, int H,
+                        int radius, int max_rounds, uint32_t key_rgb, hipStream_t s)
+{
+    TeleaArgs a{ws.stamp, ws.T, ws.img, ws.queued, {ws.list[0], ws.list[1]}, ws.counts, ws.remaining, ws.last_round, W, H, n, radius, key_rgb};
+    hipError_t e = hipMemsetAsync(ws.remaining, 0, (size_t)n * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws.counts, 0, ((size_t)max_rounds + 2) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_telea_init, dim3((W + 255) / 256, H, n), dim3(256), 0, s, seed, seed_pitch, seed_stride, a);
+    hipLaunchKernelGGL(k_telea_begin, dim3((n + 63) / 64), dim3(64), 0, s, a);
+    // a fixed, modest grid per round: the front is a few 10^4 pixels per image, and an exhausted front costs one
+    // near-empty launch
+    const dim3 grid(1024), block(256);
+    for (int r = 1; r <= max_rounds; ++r) hipLaunchKernelGGL(k_telea_round, grid, block, 0, s, a, (uint32_t)r);
+    return hipGetLastError();
+}
+
+hipError_t launch_masked_blur(const uint8_t* img, size_t img_pitch, size_t img_stride, const uint8_t* seed, size_t seed_pitch,
+                              size_t seed_stride, uint8_t* out, size_t out_pitch, size_t out_stride, int n, int W, int H,
+                              const BlurKernel& K, uint32_t key_rgb, hipStream_t s)
+{
+    const dim3 grid((W + 255) / 256, H, n), block(256);
+    hipLaunchKernelGGL(k_masked_blur, grid, block, 0, s, img, img_pitch, img_stride, seed, seed_pitch, seed_stride, out, out_pitch,
+                       out_stride, W, H, K, key_rgb);
     return hipGetLastError();
 }
 

@@ -146,32 +146,22 @@ def convert_to_equirectangular(image, input_fov=100, out=None):
     return out
 
 
-def finish_infill_mask(seed_rgb, key_rgb=(0, 255, 0)):
-    """Host-side completion of one eye's infill-mask image from the device-rendered SEED (the state of
-    left_img_mask at sr:803): cv2.inpaint(TELEA) over the still-green and black pixels, inpainted values
-    written back into the green ones, then the black-ignoring 6x6 Gaussian of masked_blur (sr:804-808,
-    114-153).  These two steps are OpenCV arithmetic (TELEA's fast-marching order is sequential) and stay
-    on the host; they need `cv2`, which is not part of this image -- without it this raises ImportError.
-    seed_rgb: uint8 [H,W,3] (NumPy).  Returns uint8 [H,W,3]."""
-    import cv2                                                          # noqa: F401  (ImportError if absent)
-    seed = np.ascontiguousarray(seed_rgb, np.uint8)
-    green = np.all(seed == np.array(key_rgb, np.uint8), axis=-1)
-    green_and_black = green | np.all(seed == 0, axis=-1)
-    inpainted = cv2.inpaint(seed, (green_and_black * 255).astype("uint8"), inpaintRadius=3, flags=cv2.INPAINT_TELEA)
-    img = seed.copy()
-    img[green] = inpainted[green]
-    # masked_blur (sr:114-153): Gaussian 6x6 that ignores pure black pixels
-    g1d = cv2.getGaussianKernel(6, 0)
-    kernel = g1d @ g1d.T
-    black = np.all(img == 0, axis=2)
-    valid = (~black).astype(np.float32)
-    bsum = cv2.filter2D(img.astype(np.float32), -1, kernel, borderType=cv2.BORDER_ISOLATED)
-    wsum = cv2.filter2D(valid, -1, kernel, borderType=cv2.BORDER_ISOLATED)
-    w = wsum[..., None]
-    out = bsum / np.where(w == 0, 1.0, w)
-    out[wsum == 0] = 0
-    out[black] = 0
-    return np.clip(out, 0, 255).astype(np.uint8)
+def masked_blur(img, out=None):
+    """Device version of the reference's masked_blur(img, ksize=(6,6), sigma=0) (sr:114-153): a 6x6 Gaussian that
+    ignores pure black pixels.  uint8 CUDA [H,W,3] (rows may be strided) -> uint8 [H,W,3]."""
+    import torch
+    from .depth_frames_helper import _ctx
+    assert img.is_cuda and img.dtype == torch.uint8 and img.dim() == 3 and img.shape[2] == 3
+    assert img.stride(2) == 1 and img.stride(1) == 3, "pixels must be packed RGB"
+    H, W = int(img.shape[0]), int(img.shape[1])
+    if out is None:
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device=img.device)
+    assert out.shape == img.shape and out.stride(2) == 1 and out.stride(1) == 3
+    ctx = _ctx(img.device.index or 0, W, H)
+    s = torch.cuda.current_stream(img.device)
+    ctx.check(_lib.load().mdvt_masked_blur(ctx.handle, img.data_ptr(), img.stride(0), out.data_ptr(), out.stride(0),
+                                           C.c_void_p(s.cuda_stream)))
+    return out
 
 
 VR180_SIZE = 1920      # sr:528: the VR180 render is always 1920 x 1920
@@ -281,12 +271,13 @@ class StereoRerenderer:
             rm = False                                                     # sr:572-573
         self.remove_edges = rm
         self.edge_points = rm and not dont_place_points_in_edges           # sr:589
+        self.do_basic_infill = bool(do_basic_infill)                       # edge points then only feed the mask (sr:809-812)
         self.key_rgb = (0, 255, 0) if infill_mask else (0, 0, 0)           # sr:555-558
         self.ctx = _lib.Context(self.device, self.W, self.H)
         cfg = _lib.MdvtConfig()
         cfg.mode = self.mode
         cfg.remove_edges = int(self.remove_edges)
-        cfg.edge_points = int(self.edge_points)
+        cfg.edge_points = (2 if self.do_basic_infill else 1) if self.edge_points else 0
         cfg.ipd_m = self.pupillary_distance / 1000                         # sr:458-459
         cfg.max_depth = float(self.max_depth)
         for k in range(3):
@@ -369,6 +360,29 @@ class StereoRerenderer:
                             want_depth=want_depth, out_depth=out_depth, want_maskbits=want_maskbits,
                             want_hole_counts=want_hole_counts, want_seed=want_seed).launch(stream)
 
+    def finish_infill_mask(self, seed, out=None, max_rounds: int = 0, want_remaining: bool = False):
+        """sr:803-808 + 816 on the device: seed image(s) from render(want_seed=True) -> the finished infill-mask
+        image(s): Telea-weighted inpaint of the key-coloured / black pixels (level by level, see include/mdvt.h),
+        key-coloured pixels keep the inpainted normal, then masked_blur.  seed: uint8 CUDA [H,W,3] or [N,H,W,3],
+        rows / images may be strided (e.g. one eye of the side-by-side seed buffer).  Returns the image(s)
+        (and, with want_remaining, an int32 tensor [N] of key-coloured pixels the front did not reach)."""
+        torch = self.torch
+        assert seed.is_cuda and seed.dtype == torch.uint8 and seed.dim() in (3, 4) and seed.shape[-1] == 3
+        assert seed.stride(-1) == 1 and seed.stride(-2) == 3, "pixels must be packed RGB"
+        assert tuple(seed.shape[-3:-1]) == (self.H, self.W)
+        batched = seed.dim() == 4
+        N = int(seed.shape[0]) if batched else 1
+        if out is None:
+            out = torch.empty(tuple(seed.shape), dtype=torch.uint8, device=seed.device)
+        assert out.shape == seed.shape and out.stride(-1) == 1 and out.stride(-2) == 3
+        rem = torch.zeros(N, dtype=torch.int32, device=seed.device) if want_remaining else None
+        s = torch.cuda.current_stream(seed.device)
+        self.ctx.check(self._L.mdvt_finish_infill_mask(
+            self.ctx.handle, seed.data_ptr(), seed.stride(-3), seed.stride(0) if batched else 0, out.data_ptr(),
+            out.stride(-3), out.stride(0) if batched else 0, N, int(max_rounds), rem.data_ptr() if rem is not None else None,
+            C.c_void_p(s.cuda_stream)))
+        return (out, rem) if want_remaining else out
+
     @staticmethod
     def pack_params(params, n_frames: int):
         """One record, a sequence of N records, or an already packed ctypes array -> ctypes array of N.
@@ -437,7 +451,8 @@ def build_arg_parser():
     ap.add_argument("--touchly1", action="store_true", help="Touchly1 format: colour over depth, no stereo rendering")
     ap.add_argument("--touchly_max_depth", default=5, type=float)
     ap.add_argument("--touchly_min_depth", default=0, type=float)
-    for flag in ("--do_basic_infill", "--compressed", "--mask_video", "--save_background", "--load_background"):
+    ap.add_argument("--do_basic_infill", action="store_true", help="fill the holes by marching along the infill-mask normals")
+    for flag in ("--compressed", "--mask_video", "--save_background", "--load_background"):
         ap.add_argument(flag, nargs="?", const=True, default=None, help="reference flag outside the built hot path")
     return ap
 
@@ -445,7 +460,7 @@ def build_arg_parser():
 def main(argv=None):
     from . import clip
     args = build_arg_parser().parse_args(argv)
-    for flag in ("do_basic_infill", "compressed", "mask_video", "save_background", "load_background"):
+    for flag in ("compressed", "mask_video", "save_background", "load_background"):
         if getattr(args, flag) is not None:
             raise NotImplementedError(f"--{flag} is outside the hot path this build covers (DESIGN.md section 1)")
     if args.xfov is None and args.yfov is None and args.xfov_file is None:
@@ -468,6 +483,7 @@ def main(argv=None):
                             infill_mask=(args.infill_mask and not args.dont_remove_edges),
                             dont_place_points_in_edges=args.dont_place_points_in_edges,
                             vr180=args.vr180, touchly0=args.touchly0, touchly1=args.touchly1,
+                            do_basic_infill=(args.do_basic_infill and not args.dont_remove_edges),
                             touchly_max_depth=args.touchly_max_depth, touchly_min_depth=args.touchly_min_depth)
     if int(os.environ.get("RANK", "0")) == 0:
         frames, secs = float(stats[:, 0].sum()), float(stats[:, 1].max())

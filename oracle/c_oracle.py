@@ -70,6 +70,14 @@ def lib():
         L.orc_equirect_tables.restype = None
         L.orc_remap_linear.argtypes = [u8p, C.c_int, C.c_int, f32p, f32p, u8p]
         L.orc_remap_linear.restype = None
+        L.orc_masked_blur_kernel.argtypes = [f32p]
+        L.orc_masked_blur_kernel.restype = None
+        L.orc_masked_blur.argtypes = [u8p, C.c_int, C.c_int, u8p]
+        L.orc_masked_blur.restype = None
+        L.orc_telea_levels.argtypes = [u8p, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_telea_levels.restype = C.c_int
+        L.orc_finish_infill_mask.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, u8p, u8p]
+        L.orc_finish_infill_mask.restype = C.c_int
         _lib = L
     return _lib
 
@@ -142,7 +150,7 @@ def make_params(W, H, K, *, Kr=None, ipd_m=0.065, max_depth=100.0, depth_scale=1
     p.W, p.H = int(W), int(H)
     p.mode = int(mode)
     p.remove_edges = int(bool(remove_edges))
-    p.edge_points = int(bool(edge_points))
+    p.edge_points = int(edge_points)
     kk = k4(K)
     kr = kk if Kr is None else k4(Kr)
     for i in range(4):
@@ -240,3 +248,40 @@ def convert_to_equirectangular(image: np.ndarray, input_fov: float = 100.0) -> n
     H, W = image.shape[:2]
     X, Y = equirect_maps(W, H, input_fov)
     return remap_linear(image, X, Y)
+
+
+def masked_blur_kernel() -> np.ndarray:
+    K = np.empty(36, np.float32)
+    lib().orc_masked_blur_kernel(_p(K, C.c_float))
+    return K.reshape(6, 6)
+
+
+def masked_blur(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape[:2]
+    out = np.empty_like(img)
+    lib().orc_masked_blur(_p(img, C.c_uint8), W, H, _p(out, C.c_uint8))
+    return out
+
+
+def telea_levels(img: np.ndarray, mask: np.ndarray, must_fill=None, radius: int = 3, max_rounds: int = 65000):
+    """-> (filled image, number of must_fill / mask pixels left unfilled)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    H, W = mask.shape
+    mf = None if must_fill is None else np.ascontiguousarray(must_fill, np.uint8)
+    out = np.empty_like(img)
+    rem = lib().orc_telea_levels(_p(img, C.c_uint8), _p(mask, C.c_uint8), None if mf is None else _p(mf, C.c_uint8),
+                                 W, H, int(radius), int(max_rounds), _p(out, C.c_uint8))
+    return out, rem
+
+
+def finish_infill_mask(seed: np.ndarray, key_rgb=(0, 255, 0), max_rounds: int = 65000, want_blur: bool = False):
+    seed = np.ascontiguousarray(seed, np.uint8)
+    H, W = seed.shape[:2]
+    key = np.array(list(key_rgb) + [0], np.uint8)
+    out = np.empty_like(seed)
+    blur = np.empty_like(seed) if want_blur else None
+    rem = lib().orc_finish_infill_mask(_p(seed, C.c_uint8), W, H, _p(key, C.c_uint8), int(max_rounds), _p(out, C.c_uint8),
+                                       _p(blur, C.c_uint8) if want_blur else None)
+    return (out, blur, rem) if want_blur else (out, rem)

@@ -514,7 +514,7 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
                 if (!out_mask[o]) continue;                  /* sr:776: only where still background */
                 if (!(z < ez[o])) continue;                  /* ties: lower source index wins (decree) */
                 ez[o] = z;
-                memcpy(out_rgb + 3 * o, color + 3 * k, 3);
+                if (p->edge_points != 2) memcpy(out_rgb + 3 * o, color + 3 * k, 3);      /* 2: seed only (sr:809-812) */
                 if (out_seed) orc_edge_normal_colour(&e, P + 3 * k, vnormals + 3 * k, out_seed + 3 * o);   /* sr:802 */
             }
         free(ez);
@@ -672,4 +672,196 @@ void orc_remap_linear(const uint8_t* src, int W, int H, const float* map_x, cons
             }
             for (int c = 0; c < 3; ++c) dst[3 * o + c] = (uint8_t)((acc[c] + (1 << 14)) >> 15);
         }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* infill-mask completion (sr:803-808, 114-153): TELEA-type inpaint + masked blur             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* cv2.getGaussianKernel(6, 0) as published (sigma = 0.3*((n-1)*0.5 - 1) + 0.8 = 1.25, exp in f64, scaled by
+ * the reciprocal of the sum), outer product in f64 (g1d @ g1d.T, sr:124-125), rounded to f32 (what
+ * cv2.filter2D does with a kernel for an f32 image). */
+void orc_masked_blur_kernel(float K[36])
+{
+    double g[6], sum = 0.0;
+    const double sigma = 0.3 * ((6 - 1) * 0.5 - 1.0) + 0.8, scale2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < 6; ++i) { const double x = (double)i - (6 - 1) * 0.5; g[i] = exp(scale2 * x * x); sum += g[i]; }
+    sum = 1.0 / sum;
+    for (int i = 0; i < 6; ++i) g[i] *= sum;
+    for (int y = 0; y < 6; ++y) for (int x = 0; x < 6; ++x) K[6 * y + x] = (float)(g[y] * g[x]);
+}
+
+void orc_masked_blur(const uint8_t* img, int W, int H, uint8_t* out)
+{
+    float K[36];
+    orc_masked_blur_kernel(K);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float acc[3] = { 0.0f, 0.0f, 0.0f }, wsum = 0.0f;
+            for (int ky = 0; ky < 6; ++ky)
+                for (int kx = 0; kx < 6; ++kx) {                  /* correlation, anchor (3,3), zero border */
+                    const int sx = x + kx - 3, sy = y + ky - 3;
+                    if (sx < 0 || sx >= W || sy < 0 || sy >= H) continue;
+                    const uint8_t* s = img + 3 * ((size_t)sy * W + sx);
+                    const float k = K[6 * ky + kx];
+                    for (int c = 0; c < 3; ++c) acc[c] = acc[c] + k * (float)s[c];
+                    if (s[0] | s[1] | s[2]) wsum = wsum + k;       /* valid_mask = 1 where not black (sr:129-132) */
+                }
+            const uint8_t* p = img + 3 * ((size_t)y * W + x);
+            uint8_t* o = out + 3 * ((size_t)y * W + x);
+            const int black = !(p[0] | p[1] | p[2]);
+            for (int c = 0; c < 3; ++c) {
+                float v = (wsum == 0.0f || black) ? 0.0f : acc[c] / wsum;      /* sr:146-150 */
+                if (v < 0.0f) v = 0.0f;
+                if (v > 255.0f) v = 255.0f;
+                o[c] = (uint8_t)v;                                             /* np.clip(...).astype(np.uint8) */
+            }
+        }
+}
+
+/* Telea's inpainting weights (A. Telea, "An image inpainting technique based on the fast marching method", 2004;
+ * the arithmetic follows OpenCV's published icvTeleaInpaintFMM / FastMarching_solve) applied LEVEL-SYNCHRONOUSLY:
+ * round r fills every unknown pixel that has a 4-neighbour known at the start of the round (known = original or
+ * filled in a round < r), reading only that state.  OpenCV pops one pixel at a time from a heap ordered by T, so
+ * its fill order -- and with it the low-order bits of the result -- differs: PARITY UNPINNED, by construction not
+ * bit-identical to cv2.inpaint.  Further decrees: T = 0 at every originally known pixel; out-of-image neighbours
+ * count as unknown.  stamp: 0 = known from the start, 0xFFFF = unknown, r = filled in round r. */
+#define ORC_T_UNKNOWN 0xFFFFu
+
+typedef struct { int W, H; const uint16_t* stamp; const float* T; const uint8_t* img; } orc_telea_state;
+
+static inline int orc_tk(const orc_telea_state* s, int x, int y, unsigned r)      /* known before round r? */
+{
+    return x >= 0 && x < s->W && y >= 0 && y < s->H && s->stamp[(size_t)y * s->W + x] < r;
+}
+
+static float orc_telea_solve(const orc_telea_state* s, int x1, int y1, int x2, int y2, unsigned r)
+{
+    const int k1 = orc_tk(s, x1, y1, r), k2 = orc_tk(s, x2, y2, r);
+    const double a11 = k1 ? (double)s->T[(size_t)y1 * s->W + x1] : 1.0e6, a22 = k2 ? (double)s->T[(size_t)y2 * s->W + x2] : 1.0e6;
+    const double m12 = a11 < a22 ? a11 : a22;
+    double sol;
+    if (k1) {
+        if (k2) sol = fabs(a11 - a22) >= 1.0 ? 1.0 + m12 : (a11 + a22 + sqrt(2.0 - (a11 - a22) * (a11 - a22))) * 0.5;
+        else sol = 1.0 + a11;
+    } else if (k2) sol = 1.0 + a22;
+    else sol = 1.0 + m12;
+    return (float)sol;
+}
+
+static void orc_telea_pixel(const orc_telea_state* s, int x, int y, unsigned r, int radius, float* Tout, uint8_t* rgb)
+{
+    const int W = s->W;
+    float t = orc_telea_solve(s, x, y - 1, x - 1, y, r);
+    float c = orc_telea_solve(s, x, y + 1, x - 1, y, r); if (c < t) t = c;
+    c = orc_telea_solve(s, x, y - 1, x + 1, y, r); if (c < t) t = c;
+    c = orc_telea_solve(s, x, y + 1, x + 1, y, r); if (c < t) t = c;
+    *Tout = t;
+#define ORC_TT(xx, yy) (s->T[(size_t)(yy) * W + (xx)])
+    float gtx, gty;
+    if (orc_tk(s, x + 1, y, r)) gtx = orc_tk(s, x - 1, y, r) ? (ORC_TT(x + 1, y) - ORC_TT(x - 1, y)) * 0.5f : ORC_TT(x + 1, y) - t;
+    else gtx = orc_tk(s, x - 1, y, r) ? t - ORC_TT(x - 1, y) : 0.0f;
+    if (orc_tk(s, x, y + 1, r)) gty = orc_tk(s, x, y - 1, r) ? (ORC_TT(x, y + 1) - ORC_TT(x, y - 1)) * 0.5f : ORC_TT(x, y + 1) - t;
+    else gty = orc_tk(s, x, y - 1, r) ? t - ORC_TT(x, y - 1) : 0.0f;
+    float Ia[3] = { 0, 0, 0 }, Jx[3] = { 0, 0, 0 }, Jy[3] = { 0, 0, 0 }, sw = 1.0e-20f;
+    for (int k = y - radius; k <= y + radius; ++k)
+        for (int l = x - radius; l <= x + radius; ++l) {
+            if (!orc_tk(s, l, k, r)) continue;
+            if ((l - x) * (l - x) + (k - y) * (k - y) > radius * radius) continue;
+            const float ry = (float)(y - k), rx = (float)(x - l);
+            const float vl = rx * rx + ry * ry;
+            const float dst = (float)(1.0 / ((double)vl * sqrt((double)vl)));
+            const float lev = (float)(1.0 / (1.0 + fabs((double)(ORC_TT(l, k) - t))));
+            float dir = rx * gtx + ry * gty;
+            if (fabsf(dir) <= 0.01f) dir = 0.000001f;
+            const float w = fabsf((dst * lev) * dir);
+            const int xp = orc_tk(s, l + 1, k, r), xm = orc_tk(s, l - 1, k, r), yp = orc_tk(s, l, k + 1, r), ym = orc_tk(s, l, k - 1, r);
+            const uint8_t* I0 = s->img + 3 * ((size_t)k * W + l);
+            for (int ch = 0; ch < 3; ++ch) {
+                float gix, giy;
+                if (xp) gix = xm ? (float)((int)I0[3 + ch] - (int)I0[-3 + ch]) * 2.0f : (float)((int)I0[3 + ch] - (int)I0[ch]);
+                else gix = xm ? (float)((int)I0[ch] - (int)I0[-3 + ch]) : 0.0f;
+                if (yp) giy = ym ? (float)((int)I0[3 * W + ch] - (int)I0[-3 * W + ch]) * 2.0f : (float)((int)I0[3 * W + ch] - (int)I0[ch]);
+                else giy = ym ? (float)((int)I0[ch] - (int)I0[-3 * W + ch]) : 0.0f;
+                Ia[ch] = Ia[ch] + w * (float)I0[ch];
+                Jx[ch] = Jx[ch] - w * (gix * rx);
+                Jy[ch] = Jy[ch] - w * (giy * ry);
+            }
+            sw = sw + w;
+        }
+#undef ORC_TT
+    for (int ch = 0; ch < 3; ++ch) {
+        const float jj = Jx[ch] * Jx[ch] + Jy[ch] * Jy[ch];
+        const float sat = (float)(((double)(Ia[ch] / sw) + (double)(Jx[ch] + Jy[ch]) / (sqrt((double)jj) + (double)1.0e-20f)) + (double)0.5f);
+        float v = rintf(sat);                                   /* saturate_cast<uchar>: cvRound, then clamp */
+        if (!(v >= 0.0f)) v = 0.0f;
+        if (v > 255.0f) v = 255.0f;
+        rgb[ch] = (uint8_t)v;
+    }
+}
+
+int orc_telea_levels(const uint8_t* img, const uint8_t* mask, const uint8_t* must_fill, int W, int H, int radius,
+                     int max_rounds, uint8_t* out)
+{
+    const size_t n = (size_t)W * H;
+    uint16_t* stamp = (uint16_t*)malloc(n * sizeof(uint16_t));
+    float* T = (float*)calloc(n, sizeof(float));
+    uint32_t* front = (uint32_t*)malloc(n * sizeof(uint32_t));
+    float* ft = (float*)malloc(n * sizeof(float));
+    uint8_t* frgb = (uint8_t*)malloc(n * 3);
+    memcpy(out, img, n * 3);
+    long remaining = 0;
+    for (size_t k = 0; k < n; ++k) {
+        stamp[k] = mask[k] ? ORC_T_UNKNOWN : 0;
+        if (mask[k] && (!must_fill || must_fill[k])) ++remaining;
+    }
+    if (max_rounds > 65000) max_rounds = 65000;
+    orc_telea_state s = { W, H, stamp, T, out };
+    for (unsigned r = 1; r <= (unsigned)max_rounds && remaining > 0; ++r) {
+        size_t nf = 0;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const size_t k = (size_t)y * W + x;
+                if (stamp[k] != ORC_T_UNKNOWN) continue;
+                if (!(orc_tk(&s, x - 1, y, r) || orc_tk(&s, x + 1, y, r) || orc_tk(&s, x, y - 1, r) || orc_tk(&s, x, y + 1, r))) continue;
+                orc_telea_pixel(&s, x, y, r, radius, &ft[nf], frgb + 3 * nf);
+                front[nf++] = (uint32_t)k;
+            }
+        if (nf == 0) break;
+        for (size_t q = 0; q < nf; ++q) {                        /* commit after the scan: the round read old state only */
+            const size_t k = front[q];
+            stamp[k] = (uint16_t)r; T[k] = ft[q]; memcpy(out + 3 * k, frgb + 3 * q, 3);
+            if (!must_fill || must_fill[k]) --remaining;
+        }
+    }
+    free(stamp); free(T); free(front); free(ft); free(frgb);
+    return (int)remaining;
+}
+
+/* sr:803-808 for one eye, from the seed image of orc_render_stereo_seed to the bytes written to the infill-mask
+ * video (sr:815-816 / 921-928), including NumPy's float round trips:
+ *   lut1[v] = uint8(float64(float32(v)/float32(255)) * 255)      sr:807 into the float64 image, then sr:808's *255
+ *   lut2[v] = uint8((float32(v)/float32(255)) * float32(255))    sr:808 .astype('float32')/255.0, then sr:816
+ * blur_u8 (optional) receives masked_blur's own uint8 output (the normals --do_basic_infill marches along). */
+int orc_finish_infill_mask(const uint8_t* seed, int W, int H, const uint8_t* key_rgb, int max_rounds, uint8_t* out, uint8_t* blur_u8)
+{
+    const size_t n = (size_t)W * H;
+    uint8_t* mask = (uint8_t*)calloc(n + 1, 1); uint8_t* green = (uint8_t*)calloc(n + 1, 1);
+    uint8_t* filled = (uint8_t*)malloc(n * 3); uint8_t* merged = (uint8_t*)malloc(n * 3); uint8_t* blur = (uint8_t*)malloc(n * 3);
+    for (size_t k = 0; k < n; ++k) {
+        const uint8_t* p = seed + 3 * k;
+        green[k] = p[0] == key_rgb[0] && p[1] == key_rgb[1] && p[2] == key_rgb[2];      /* sr:803 */
+        mask[k] = green[k] || !(p[0] | p[1] | p[2]);                                     /* sr:804-805 */
+    }
+    const int remaining = orc_telea_levels(seed, mask, green, W, H, 3, max_rounds, filled);   /* sr:806 */
+    for (size_t k = 0; k < n; ++k)
+        for (int c = 0; c < 3; ++c) {
+            const uint8_t v = filled[3 * k + c];
+            merged[3 * k + c] = green[k] ? (uint8_t)((double)((float)v / 255.0f) * 255.0) : seed[3 * k + c];   /* sr:807-808 */
+        }
+    orc_masked_blur(merged, W, H, blur);
+    if (blur_u8) memcpy(blur_u8, blur, n * 3);
+    for (size_t k = 0; k < 3 * n; ++k) out[k] = (uint8_t)(((float)blur[k] / 255.0f) * 255.0f);               /* sr:808, 816 */
+    free(mask); free(green); free(filled); free(merged); free(blur);
+    return remaining;
 }

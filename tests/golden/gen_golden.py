@@ -224,7 +224,35 @@ def main():
             eq[f"{name}_corner"] = np.array([captured["x"][0, 0], captured["y"][0, 0], captured["x"][-1, -1]], np.float32)
     np.savez_compressed(os.path.join(HERE, "equirect.npz"), meta=json.dumps(meta), **eq)
 
-    for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz", "equirect.npz"):
+    # ------------------------------------------------------------------ masked_blur (sr:114-153)
+    # cv2 is absent: getGaussianKernel is stubbed with OpenCV's published formula and filter2D with
+    # scipy.ndimage.correlate (f32, zero border, anchor 3 for the 6-tap kernel).  What this pins is the reference's
+    # own NumPy around those two calls (black handling, normalisation, clip, truncation); the f32 summation order
+    # of the stub differs from any real filter2D, so consumers compare within 1 LSB.
+    from scipy import ndimage
+
+    def _gauss(n, sigma):
+        sigma = 0.3 * ((n - 1) * 0.5 - 1) + 0.8 if sigma <= 0 else sigma
+        x = np.arange(n, dtype=np.float64) - (n - 1) * 0.5
+        g = np.exp(-0.5 / (sigma * sigma) * x * x)
+        return (g * (1.0 / g.sum())).reshape(n, 1)
+
+    def _filter2d(src, ddepth, kernel, borderType=None):
+        k = kernel.astype(np.float32)
+        if src.ndim == 3:
+            return np.stack([ndimage.correlate(src[..., c], k, mode="constant", cval=0.0) for c in range(src.shape[2])], -1)
+        return ndimage.correlate(src, k, mode="constant", cval=0.0)
+    cv2_stub.getGaussianKernel, cv2_stub.filter2D, cv2_stub.BORDER_ISOLATED = _gauss, _filter2d, 16
+    mb = {}
+    r3 = np.random.default_rng(4242)
+    img = r3.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    img[5:20, 8:30] = 0; img[30:, :6] = 0; img[0, :] = 0; img[22:26, 40:44] = (0, 0, 7)
+    mb["a_img"], mb["a_out"] = img, sr.masked_blur(img.copy())
+    img2 = np.zeros((24, 24, 3), np.uint8); img2[10:14, 10:14] = (255, 128, 1); img2[3, 3] = (9, 9, 9)
+    mb["b_img"], mb["b_out"] = img2, sr.masked_blur(img2.copy())
+    np.savez_compressed(os.path.join(HERE, "masked_blur.npz"), meta=json.dumps(meta), **mb)
+
+    for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz", "equirect.npz", "masked_blur.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

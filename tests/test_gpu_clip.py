@@ -122,7 +122,7 @@ def test_cli_end_to_end(mods, orc, tmp_path, capsys):
     np.save(dp, d); np.save(cp, c)
     rc = sr.main(["--depth_video", dp, "--color_video", cp, "--xfov", "50", "--pupillary_distance", "65",
                   "--infill_mask", "--max_frames", "5", "--batch", "3"])
-    seed = np.load(dp + "_stereo.npy_infillmask_seed.npy")
+    finished = np.load(dp + "_stereo.npy_infillmask.npy")                 # the normal-coloured mask (sr:787-808)
     os.remove(dp + "_stereo.npy")
     rc = sr.main(["--depth_video", dp, "--color_video", cp, "--xfov", "50", "--pupillary_distance", "65",
                   "--infill_mask", "--green_and_black_infill_mask", "--max_frames", "5", "--batch", "3"])
@@ -136,7 +136,8 @@ def test_cli_end_to_end(mods, orc, tmp_path, capsys):
         op = orc.make_params(W, H, K, ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_MESH,
                              remove_edges=True, edge_points=True, key_rgb=(0, 255, 0))
         want = orc.render_stereo(op, d[t], c[t], want_seed=True)
-        assert np.array_equal(seed[t][:, :W], want["left_seed"]) and np.array_equal(seed[t][:, W:], want["right_seed"])
+        assert np.array_equal(finished[t][:, :W], orc.finish_infill_mask(want["left_seed"])[0])
+        assert np.array_equal(finished[t][:, W:], orc.finish_infill_mask(want["right_seed"])[0])
         assert np.array_equal(sbs[t][:, :W], want["left_rgb"]) and np.array_equal(sbs[t][:, W:], want["right_rgb"])
         assert np.array_equal(mask[t][:, :W], want["left_mask"]) and np.array_equal(mask[t][:, W:], want["right_mask"])
     r.close()
@@ -221,3 +222,39 @@ def test_vr180_clip(mods, orc, tmp_path, touchly0):
     r.close()
     with pytest.raises(ValueError):
         sr.make_frame_params(1920, 1080, 60.0, vr180=True)
+
+
+@pytest.mark.parametrize("basic", [False, True])
+def test_infill_mask_clip(mods, orc, tmp_path, basic):
+    """--infill_mask through files: <out>_infillmask.npy holds the finished normal-coloured mask of both eyes
+    (sr:787-808, 921-928); with --do_basic_infill the stereo frames have their holes filled along it (sr:809-812)."""
+    clip, sr, synthetic = mods
+    W, H, N = 192, 108, 5
+    d, c = synthetic.SyntheticScene(W, H, config_id=3, n_fg=6).clip(N)
+    dp, cp = str(tmp_path / "d.npy"), str(tmp_path / "c.npy")
+    np.save(dp, d); np.save(cp, c)
+    conv = [2.0, float("nan"), 2.2, 2.3, 0.0]
+    (tmp_path / "conv.json").write_text(json.dumps(conv))
+    kw = dict(xfov=45.0, pupillary_distance=65, infill_mask=True, do_basic_infill=basic, convergence_file=str(tmp_path / "conv.json"))
+    stats, final = clip.run(dp, cp, batch=2, **kw)
+    sbs, mask, im = np.load(final), np.load(final + "_holemask.npy"), np.load(final + "_infillmask.npy")
+    assert im.shape == (N, H, 2 * W, 3) and not os.path.exists(final + "_infillmask_seed.npy")
+    cl = clip.load_clip_parameters(N, W, H, **kw)
+    r = clip.renderer_for(cl)
+    assert r.do_basic_infill == basic and r.remove_edges and r.edge_points
+    recs = clip.frame_param_records(r, cl, 0, N)
+    for t in range(N):
+        K = np.array([recs[t].K[k] for k in range(9)]).reshape(3, 3)
+        op = orc.make_params(W, H, K, ipd_m=0.065, depth_scale=recs[t].depth_scale, mode=orc.MODE_MESH, remove_edges=True,
+                             edge_points=2 if basic else 1, conv_angle=recs[t].convergence_angle, key_rgb=(0, 255, 0))
+        want = orc.render_stereo(op, d[t], c[t], want_seed=True)
+        for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+            wfin, wrem = orc.finish_infill_mask(want[eye + "_seed"])
+            assert wrem == 0 and np.array_equal(im[t][:, sl], wfin), (t, eye)
+            assert np.array_equal(mask[t][:, sl], want[eye + "_mask"])
+            wimg = want[eye + "_rgb"]
+            if basic:
+                wn = ((wfin.astype(np.float32) / np.float32(255.0)) * 2 - 1).astype(np.float32)
+                wimg = orc.infill_using_normals(wimg, want[eye + "_mask"] > 0, wn)
+            assert np.array_equal(sbs[t][:, sl], wimg), (t, eye)
+    r.close()

@@ -676,3 +676,95 @@ def test_mixed_batch_keeps_each_frames_own_arithmetic(mods, orc, mode):
         hc = got["hole_counts"][t].cpu().numpy()
         assert hc[0] == np.count_nonzero(want["left_mask"]) and hc[1] == np.count_nonzero(want["right_mask"])
     r.close()
+
+
+def test_masked_blur_matches_the_oracle(mods, orc, golden):
+    _lib, sr, synthetic = mods
+    rng = np.random.default_rng(3)
+    for W, H in ((56, 40), (250, 61), (641, 33)):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        img[H // 4:H // 2, W // 5:W // 2] = 0; img[:, :3] = 0; img[H - 1] = 0; img[2, 2] = (0, 0, 1)
+        assert np.array_equal(sr.masked_blur(torch.from_numpy(img).cuda()).cpu().numpy(), orc.masked_blur(img))
+    g = golden("masked_blur")                              # the reference's own glue (stubbed cv2 calls): <= 1 LSB
+    got = sr.masked_blur(torch.from_numpy(g["a_img"]).cuda()).cpu().numpy()
+    assert np.abs(got.astype(int) - g["a_out"].astype(int)).max() <= 1
+
+
+def _synthetic_seed(rng, W, H, key=(0, 255, 0)):
+    seed = np.zeros((H, W, 3), np.uint8)
+    for _ in range(5):                                      # holes: key colour, normal-coloured points along their edges
+        x0, y0 = int(rng.integers(1, W - 12)), int(rng.integers(1, H - 12))
+        w, h = int(rng.integers(4, max(5, W // 4))), int(rng.integers(4, max(5, H // 3)))
+        seed[y0:y0 + h, x0:x0 + w] = key
+        for _ in range(w + h):
+            seed[y0 + int(rng.integers(0, h)) if y0 + h <= H else y0, min(W - 1, x0 + int(rng.integers(0, 2)))] = rng.integers(1, 255, 3)
+    seed[:, 0] = np.where(np.all(seed[:, 0] == key, -1)[:, None], np.array([255, 127, 127], np.uint8), seed[:, 0])
+    return np.clip(seed[:H, :W], 0, 255)
+
+
+@pytest.mark.parametrize("W,H", [(96, 64), (250, 61)])
+def test_finish_infill_mask_matches_the_oracle(mods, orc, W, H):
+    """sr:803-808 on the device (level-synchronous Telea inpaint + masked blur) vs the oracle, bit for bit: batched,
+    through strided side-by-side views, with a round limit (same pixels left unfilled) and with a black key."""
+    _lib, sr, synthetic = mods
+    rng = np.random.default_rng(W + H)
+    seeds = np.stack([_synthetic_seed(rng, W, H) for _ in range(3)])
+    r = sr.StereoRerenderer(W, H, infill_mask=True)
+    t = torch.from_numpy(seeds).cuda()
+    got, rem = r.finish_infill_mask(t, want_remaining=True)
+    for k in range(3):
+        want, wrem = orc.finish_infill_mask(seeds[k])
+        assert np.array_equal(got[k].cpu().numpy(), want), k
+        assert int(rem[k]) == wrem == 0
+        assert not np.any(np.all(want == (0, 255, 0), -1))                              # no key colour survives
+        assert not want[np.all(seeds[k] == 0, -1)].any()                                # black (no hole) stays black
+    # side-by-side layout: the two eyes are column halves of one buffer
+    sbs = torch.cat([t[0], t[1]], dim=1).contiguous()
+    out = torch.zeros_like(sbs)
+    r.finish_infill_mask(sbs[:, :W], out=out[:, :W]); r.finish_infill_mask(sbs[:, W:], out=out[:, W:])
+    assert np.array_equal(out.cpu().numpy(), np.concatenate([orc.finish_infill_mask(seeds[0])[0], orc.finish_infill_mask(seeds[1])[0]], 1))
+    # round limit: the front stops after 2 levels, the same key-coloured pixels stay unfilled on both sides
+    got2, rem2 = r.finish_infill_mask(t[2], max_rounds=2, want_remaining=True)
+    want2, wrem2 = orc.finish_infill_mask(seeds[2], max_rounds=2)
+    assert np.array_equal(got2.cpu().numpy(), want2) and int(rem2[0]) == wrem2 and wrem2 > 0
+    r.close()
+    # black key (no --infill_mask): every black pixel is to be filled and keeps its value (sr:803-807 with bg (0,0,0))
+    rb = sr.StereoRerenderer(W, H, remove_edges=True)
+    sb = seeds[0].copy(); sb[np.all(sb == (0, 255, 0), -1)] = 0
+    gb = rb.finish_infill_mask(torch.from_numpy(sb).cuda(), max_rounds=W + H).cpu().numpy()
+    wb, wr = orc.finish_infill_mask(sb, key_rgb=(0, 0, 0), max_rounds=W + H)
+    assert np.array_equal(gb, wb) and wr == 0
+    rb.close()
+
+
+@pytest.mark.parametrize("mode,conv", [("mesh", None), ("mesh", 2.5), ("points", None)])
+def test_infill_mask_and_basic_infill_from_a_render(mods, orc, mode, conv):
+    """The product-default chain on real seeds: render(--infill_mask) -> seed -> finished mask, and the
+    --do_basic_infill variant (edge points feed the mask only, holes filled by marching along its normals)."""
+    _lib, sr, synthetic = mods
+    W, H = 250, 141
+    d, c = _scene(synthetic, W, H, seed=21, n_fg=5)
+    for basic in (False, True):
+        r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=(mode == "points"), infill_mask=True,
+                                do_basic_infill=basic)
+        p = r.frame_params(xfov=45.0, convergence_distance=conv)
+        res = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), p, want_seed=True)
+        op = orc.make_params(W, H, _K(p), ipd_m=0.065, depth_scale=p.depth_scale, mode=orc.MODE_POINTS if mode == "points" else orc.MODE_MESH,
+                             remove_edges=True, edge_points=2 if basic else 1, conv_angle=p.convergence_angle, key_rgb=(0, 255, 0))
+        want = orc.render_stereo(op, d, c, want_seed=True)
+        _compare({"sbs": res["sbs"], "mask": res["mask"]}, want, W, tag=f"{mode} basic={basic}")
+        for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+            assert np.array_equal(res["seed"][:, sl].cpu().numpy(), want[eye + "_seed"])
+            fin = r.finish_infill_mask(res["seed"][:, sl])
+            wfin, wrem = orc.finish_infill_mask(want[eye + "_seed"])
+            assert wrem == 0 and np.array_equal(fin.cpu().numpy(), wfin), (mode, basic, eye)
+            hole = want[eye + "_mask"] > 0
+            assert np.array_equal(np.any(wfin != 0, -1), hole)                 # consumers' test: mask != black <=> hole
+            if basic:
+                normals = (fin.to(torch.float32) / 255.0) * 2 - 1              # sr:810
+                img = sr.infill_using_normals(res["sbs"][:, sl], res["mask"][:, sl] > 0, normals).cpu().numpy()
+                wn = ((wfin.astype(np.float32) / np.float32(255.0)) * 2 - 1).astype(np.float32)
+                wimg = orc.infill_using_normals(want[eye + "_rgb"], hole, wn)
+                assert np.array_equal(img, wimg)
+                assert (np.all(img == 0, -1) & hole).sum() < 0.5 * hole.sum()  # most of the hole area got colour
+        r.close()

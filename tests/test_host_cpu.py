@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(lib):
     declared = sorted(set(re.findall(r"\b(mdvt_[a-z_]+)\s*\(", hdr)))
     assert declared == sorted(lib.SYMBOLS), "keep _lib.SYMBOLS in step with include/mdvt.h"
     assert lib.exported_symbols() == list(lib.SYMBOLS)
-    assert lib.load().mdvt_version() == (0 << 16) | 4
+    assert lib.load().mdvt_version() == (0 << 16) | 5
 
 
 def test_struct_layouts_match_the_header(lib):
@@ -177,7 +177,7 @@ def test_cli_rejects_what_is_out_of_scope(tmp_path):
     d = str(tmp_path / "d.npy")
     np.save(d, np.zeros((1, 4, 4, 3), np.uint8))
     with pytest.raises(NotImplementedError):
-        sr.main(["--depth_video", d, "--xfov", "45", "--do_basic_infill"])
+        sr.main(["--depth_video", d, "--xfov", "45", "--mask_video", "m.mkv"])
     with pytest.raises(ValueError):
         sr.main(["--depth_video", d])
     with pytest.raises(FileNotFoundError):
@@ -197,18 +197,3 @@ def test_equirect_tables_of_the_library_match_the_reference_maps(lib, golden):
     _check_equirect_tables(golden("equirect"), sr.equirect_tables, maps)
     with pytest.raises(ValueError):
         sr.equirect_tables(64, 64, 180.0)
-
-
-def test_finish_infill_mask_needs_cv2():
-    from metric_depth_video_toolbox_amd import stereo_rerender as sr
-    try:
-        import cv2  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            sr.finish_infill_mask(np.zeros((8, 8, 3), np.uint8))
-    else:
-        seed = np.zeros((16, 16, 3), np.uint8)
-        seed[4:12, 4:12] = (0, 255, 0)
-        seed[4:12, 4] = (255, 127, 127)
-        out = sr.finish_infill_mask(seed)
-        assert out.shape == seed.shape and not out[0, 0].any() and out[8, 8].any()

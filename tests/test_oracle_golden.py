@@ -233,3 +233,57 @@ def test_remap_linear_known_answers(orc):
     # negative fractional coordinate: floor semantics of >> 5 (x = -0.25 -> ix -1, fx 24)
     out = orc.remap_linear(src, np.full_like(gx, -0.25), gy)
     assert np.array_equal(out, np.broadcast_to(((src[:, :1].astype(np.int32) * 24 * 32 * 32 + (1 << 14)) >> 15), out.shape))
+
+
+# ------------------------------------------------------------------------------- infill-mask completion
+def test_masked_blur_glue_golden(orc, golden):
+    """orc_masked_blur against the reference's masked_blur run with cv2.getGaussianKernel / cv2.filter2D stubbed
+    (published formula / scipy correlate): pins the NumPy around the two OpenCV calls; the stub's f32 summation
+    order is not OpenCV's nor the oracle's, hence <= 1 LSB."""
+    g = golden("masked_blur")
+    for n in "ab":
+        got, want = orc.masked_blur(g[f"{n}_img"]), g[f"{n}_out"]
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+        assert np.array_equal(np.all(got == 0, -1), np.all(want == 0, -1))           # black stays black, exactly
+    K = orc.masked_blur_kernel()
+    assert K.shape == (6, 6) and np.array_equal(K, K.T) and abs(float(K.sum()) - 1.0) < 1e-6 and K[2, 2] == K[3, 3] == K.max()
+
+
+def test_infill_mask_float_round_trips_are_the_identity():
+    """sr:807-808 and 816 push u8 values through float32 / float64 and back with truncation; evaluated literally
+    with NumPy every one of the 256 values survives, so the device path may carry u8 throughout."""
+    v = np.arange(256, dtype=np.uint8)
+    img64 = np.zeros(256, np.float64)
+    img64[:] = v.astype("float32") / 255.0                                             # sr:807 into the float64 image
+    assert np.array_equal((img64 * 255).astype("uint8"), v)                            # sr:808 (left_img_mask*255).astype('uint8')
+    assert np.array_equal(((v.astype("float32") / 255.0) * 255).astype(np.uint8), v)   # sr:808 + sr:816
+
+
+def test_telea_levels_properties(orc):
+    rng = np.random.default_rng(11)
+    H, W = 48, 64
+    img = rng.integers(1, 256, (H, W, 3), dtype=np.uint8)
+    mask = np.zeros((H, W), np.uint8)
+    mask[10:30, 12:40] = 1; mask[0:6, 50:] = 1; mask[40:, 0:9] = 1
+    out, rem = orc.telea_levels(img, mask)
+    assert rem == 0 and np.array_equal(out[mask == 0], img[mask == 0])                 # known pixels untouched, all filled
+    # level-synchronous: a pixel at 4-neighbour (L1) distance d from the known set is filled in round d
+    out3, rem3 = orc.telea_levels(img, mask, max_rounds=3)
+    from scipy import ndimage
+    dist = ndimage.distance_transform_cdt(mask, metric="taxicab")
+    assert rem3 == int((dist > 3).sum())
+    assert np.array_equal(out3[(dist <= 3)], out[(dist <= 3)])                         # earlier levels never change later
+    # must_fill: the rounds stop once these are done, pixels farther out stay as they were
+    mf = np.zeros_like(mask); mf[10:30, 12:15] = 1
+    out_mf, rem_mf = orc.telea_levels(img, mask, must_fill=mf)
+    assert rem_mf == 0 and np.array_equal(out_mf[dist <= 2], out[dist <= 2])
+    stopped = int(dist[mf > 0].max())
+    assert np.array_equal(out_mf[dist > stopped], img[dist > stopped])
+    # a flat neighbourhood: value + 0.5 rounded half to even (OpenCV's "+0.5 then cvRound")
+    flat = np.full((9, 9, 3), 10, np.uint8); m1 = np.zeros((9, 9), np.uint8); m1[4, 4] = 1
+    assert orc.telea_levels(flat, m1)[0][4, 4, 0] == 10
+    flat[...] = 77
+    assert orc.telea_levels(flat, m1)[0][4, 4, 0] == 78
+    # nothing known: nothing happens
+    out0, rem0 = orc.telea_levels(img, np.ones((H, W), np.uint8))
+    assert rem0 == H * W and np.array_equal(out0, img)
