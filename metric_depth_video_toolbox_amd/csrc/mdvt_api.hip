@@ -264,7 +264,7 @@ int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flag
 static void free_telea(mdvt_ctx* c)
 {
     mdvt::TeleaWorkspace& w = c->telea;
-    void* ptrs[] = {w.stamp, w.T, w.img, w.queued, w.list[0], w.list[1], w.counts, w.remaining, w.last_round};
+    void* ptrs[] = {w.stamp, w.T, w.img, w.queued, w.need, w.list, w.counts, w.remaining, w.last_round};      // offs lives inside counts
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = mdvt::TeleaWorkspace{};
     c->telea_images = 0; c->telea_rounds = 0;
@@ -602,7 +602,8 @@ mdvt::BlurKernel masked_blur_kernel()
     for (int y = 0; y < 6; ++y) for (int x = 0; x < 6; ++x) K.k[6 * y + x] = (float)(g[y] * g[x]);
     return K;
 }
-constexpr int kTeleaChunk = 16;      // images per pass (12 B/px of workspace each)
+constexpr int kTeleaChunk = mdvt::kTeleaMaxImages;      // images per pass (18 B/px of workspace each)
+
 }  // namespace
 
 int mdvt_masked_blur(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, uint8_t* d_out, size_t out_pitch, void* stream)
@@ -625,7 +626,7 @@ int mdvt_finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, size_t seed_pitc
     if (n_images < 1) return fail(c, MDVT_ERR_INVALID_ARG, "n_images must be >= 1");
     if (seed_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
     if (d_seed == d_out) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias d_seed");
-    if (max_rounds <= 0) max_rounds = 512;
+    if (max_rounds <= 0) max_rounds = 256;
     if (max_rounds > 65000) return fail(c, MDVT_ERR_INVALID_ARG, "max_rounds must be <= 65000");
     DeviceGuard g(c->device);
     hipStream_t s = (hipStream_t)stream;
@@ -634,26 +635,29 @@ int mdvt_finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, size_t seed_pitc
     const int chunk = n_images < kTeleaChunk ? n_images : kTeleaChunk;
     if (c->telea_images < chunk || c->telea_rounds < max_rounds) {
         MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
-        const int images = chunk > c->telea_images ? chunk : c->telea_images;
+        const int images = kTeleaChunk;                      // a full pass: the level kernels scan kTeleaMaxImages counters
         const int rounds = max_rounds > c->telea_rounds ? max_rounds : c->telea_rounds;
         free_telea(c);
         mdvt::TeleaWorkspace& w = c->telea;
         MDVT_HIP(c, hipMalloc((void**)&w.stamp, (size_t)images * npx * sizeof(uint16_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.T, (size_t)images * npx * sizeof(float)));
-        MDVT_HIP(c, hipMalloc((void**)&w.img, (size_t)images * npx * 3));
+        MDVT_HIP(c, hipMalloc((void**)&w.img, (size_t)images * npx * 3 + 4));      // + 4: pixels are fetched as unaligned dwords
         MDVT_HIP(c, hipMalloc((void**)&w.queued, (size_t)images * npx * sizeof(uint32_t)));
-        for (int k = 0; k < 2; ++k) MDVT_HIP(c, hipMalloc((void**)&w.list[k], (size_t)images * npx * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.counts, ((size_t)rounds + 2) * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.need, (size_t)images * npx));
+        MDVT_HIP(c, hipMalloc((void**)&w.list, (size_t)images * npx * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.counts, 2 * ((size_t)rounds + 2) * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.remaining, (size_t)images * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.last_round, (size_t)images * sizeof(uint32_t)));
         c->telea_images = images; c->telea_rounds = rounds;
     }
+    c->telea.offs = c->telea.counts + (max_rounds + 2);
     const uint32_t key = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     const mdvt::BlurKernel K = masked_blur_kernel();
     for (int i0 = 0; i0 < n_images; i0 += chunk) {
         const int n = n_images - i0 < chunk ? n_images - i0 : chunk;
         const uint8_t* seed = d_seed + (size_t)i0 * seed_stride;
-        MDVT_HIP(c, launch_telea(seed, seed_pitch, seed_stride, c->telea, n, W, H, 3, max_rounds, key, s));   // sr:806, inpaintRadius = 3
+        MDVT_HIP(c, launch_telea_init(seed, seed_pitch, seed_stride, c->telea, n, W, H, max_rounds, key, s));
+        MDVT_HIP(c, launch_telea_rounds(c->telea, W, H, max_rounds, key, s));                               // sr:806, inpaintRadius = 3
         MDVT_HIP(c, launch_masked_blur(c->telea.img, (size_t)3 * W, 3 * npx, seed, seed_pitch, seed_stride,
                                        d_out + (size_t)i0 * out_stride, out_pitch, out_stride, n, W, H, K, key, s));   // sr:807-808
         if (d_remaining)

@@ -85,14 +85,17 @@ hipError_t launch_touchly_depth(const float* depth, size_t depth_pitch, uint8_t*
                                 float tmax, float tmin, float k, int zero_is_far, hipStream_t s);
 hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst, size_t dst_pitch,
                                  size_t dst_stride, int n, int W, int H, const float* mx, const float* my, hipStream_t s);
-struct TeleaWorkspace {              // per image: stamp u16, T f32, work image u8x3, queued u32, two u32 work lists
-    uint16_t* stamp; float* T; uint8_t* img; uint32_t* queued; uint32_t* list[2];
-    uint32_t* counts;                // [max_rounds + 2]
+struct TeleaWorkspace {              // per image pixel: stamp u16, T f32, work image u8x3, queued u32, need u8, list u32
+    uint16_t* stamp; float* T; uint8_t* img; uint32_t* queued; uint8_t* need; uint32_t* list;
+    uint32_t* counts;                // [max_rounds + 2], followed by
+    uint32_t* offs;                  // [max_rounds + 2] (one allocation: offs = counts + max_rounds + 2)
     uint32_t* remaining;             // [images]
     uint32_t* last_round;            // [images]
 };
-hipError_t launch_telea(const uint8_t* seed, size_t seed_pitch, size_t seed_stride, const TeleaWorkspace& ws, int n, int W, int H,
-                        int radius, int max_rounds, uint32_t key_rgb, hipStream_t s);
+constexpr int kTeleaMaxImages = 16;  // images per pass
+hipError_t launch_telea_init(const uint8_t* seed, size_t seed_pitch, size_t seed_stride, const TeleaWorkspace& ws, int n, int W, int H,
+                             int max_rounds, uint32_t key_rgb, hipStream_t s);
+hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int max_rounds, uint32_t key_rgb, hipStream_t s);
 struct BlurKernel { float k[36]; };      // masked_blur's 6x6 Gaussian, f32, row major (built on the host in f64)
 hipError_t launch_masked_blur(const uint8_t* img, size_t img_pitch, size_t img_stride, const uint8_t* seed, size_t seed_pitch,
                               size_t seed_stride, uint8_t* out, size_t out_pitch, size_t out_stride, int n, int W, int H,

@@ -1558,19 +1558,28 @@ hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t sr
 // same round (stamp = r) are never observed: one launch = one Jacobi step, no double buffering.
 constexpr uint16_t kTeleaUnknown = 0xFFFFu;
 
-// The front is kept as work lists: list[r] holds the pixels to try in round r (global index im*H*W + y*W + x); a
-// pixel filled in round r appends its still-unknown 4-neighbours to list[r+1] (deduplicated through `queued`).
-// Entries that turn out to be filled already (they were part of the same round's front) are skipped when read.
-// last_round[im]: rounds > last_round are no-ops for the image; set to r by the thread that fills the image's last
-// key-coloured pixel in round r -- so every thread of round r still runs, whatever the order (deterministic).
+// Three passes over the same levels, so that the expensive estimate only runs where the result can reach a hole:
+//   A  k_telea_levels  r = 1 .. R   breadth-first levels: stamp = r for every unknown pixel with a 4-neighbour known
+//                                   before round r; the pixels of level r are list[off[r] .. off[r]+counts[r]) of one
+//                                   append-only list (a pixel filled in round r appends its unknown neighbours for
+//                                   r+1, once: `queued`).  Per image the levels stop after the round in which its last
+//                                   key-coloured pixel was reached (last_round, written by the thread whose atomicSub
+//                                   takes `remaining` to zero, so every thread of that round still runs: deterministic).
+//   B  k_telea_need    r = R .. 1   which estimates are needed: key-coloured pixels, and every pixel of a lower
+//                                   level that a needed pixel reads (its radius-3 disc and their 4-neighbours).
+//   C  k_telea_fill    r = 1 .. R   Telea's estimate for the needed pixels of level r, reading levels < r.
+// A black (non-hole) pixel that no key-coloured pixel depends on is never estimated -- it returns to black at
+// sr:807 anyway -- which removes ~90 % of the estimates of a front that also grows outwards from the holes.
 struct TeleaArgs {
     uint16_t* stamp; float* T; uint8_t* img;      // [n][H*W] / [n][H*W*3]
-    uint32_t* queued;                             // [n][H*W] last round a pixel was appended for
-    uint32_t* list[2];                            // work lists, alternating by round parity, capacity n*H*W each
-    uint32_t* counts;                             // [max_rounds + 2] list sizes by round
-    uint32_t* remaining;                          // [n] key-coloured pixels still unfilled
+    uint32_t* queued;                             // [n][H*W] nonzero once a pixel has been appended to a level
+    uint8_t* need;                                // [n][H*W]
+    uint32_t* list;                               // all levels back to back, capacity n*H*W
+    uint32_t* counts;                             // [max_rounds + 2] level sizes
+    uint32_t* offs;                               // [max_rounds + 2] level offsets into `list`
+    uint32_t* remaining;                          // [n] key-coloured pixels not reached yet
     uint32_t* last_round;                         // [n]
-    int W, H, n, radius;
+    int W, H, n;
     uint32_t key_rgb;
 };
 
@@ -1606,12 +1615,13 @@ __global__ void __launch_bounds__(256) k_telea_init(const uint8_t* __restrict__ 
         const bool unk = green || px == 0u;
         a.stamp[o] = unk ? kTeleaUnknown : (uint16_t)0;
         a.T[o] = 0.0f;
-        a.queued[o] = 0u;
+        a.need[o] = green ? 1 : 0;
         store_px_bytes(a.img + 3 * ((size_t)im * W * H + (size_t)y * W), x, px);
         front = unk && ((x > 0 && !masked(x - 1, y)) || (x + 1 < W && !masked(x + 1, y)) ||
                         (y > 0 && !masked(x, y - 1)) || (y + 1 < H && !masked(x, y + 1)));
+        a.queued[o] = front ? 1u : 0u;
     }
-    telea_append(front, (uint32_t)o, a.list[1], &a.counts[1]);
+    telea_append(front, (uint32_t)o, a.list, &a.counts[1]);            // level 1 starts at offset 0
     const u64 m = __ballot(green);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.remaining[im], (uint32_t)__popcll(m));
 }
@@ -1644,108 +1654,222 @@ struct TeleaView {
     }
 };
 
-// One pixel of the front: Telea's estimate from the pixels known before round r inside the radius.
-__device__ uint32_t telea_pixel(const TeleaView& s, int x, int y, int R, float& tout)
+// Decodes list entry idx of level r.
+struct TeleaEntry { uint32_t e, im, o; int x, y; };
+__device__ __forceinline__ TeleaEntry telea_entry(const TeleaArgs& a, uint32_t off, uint32_t idx)
 {
-    const int W = s.W;
-    float t = s.solve(x, y - 1, x - 1, y);
-    t = fminf(t, s.solve(x, y + 1, x - 1, y));
-    t = fminf(t, s.solve(x, y - 1, x + 1, y));
-    t = fminf(t, s.solve(x, y + 1, x + 1, y));
-    tout = t;
-    float gtx, gty;
-    if (s.known(x + 1, y)) gtx = s.known(x - 1, y) ? (s.t(x + 1, y) - s.t(x - 1, y)) * 0.5f : s.t(x + 1, y) - t;
-    else gtx = s.known(x - 1, y) ? t - s.t(x - 1, y) : 0.0f;
-    if (s.known(x, y + 1)) gty = s.known(x, y - 1) ? (s.t(x, y + 1) - s.t(x, y - 1)) * 0.5f : s.t(x, y + 1) - t;
-    else gty = s.known(x, y - 1) ? t - s.t(x, y - 1) : 0.0f;
-
-    float Ia[3] = {0.0f, 0.0f, 0.0f}, Jx[3] = {0.0f, 0.0f, 0.0f}, Jy[3] = {0.0f, 0.0f, 0.0f}, sw = 1.0e-20f;
-    for (int k = y - R; k <= y + R; ++k)
-        for (int l = x - R; l <= x + R; ++l) {
-            if (!s.known(l, k)) continue;
-            if ((l - x) * (l - x) + (k - y) * (k - y) > R * R) continue;
-            const float ry = (float)(y - k), rx = (float)(x - l);
-            const float vl = rx * rx + ry * ry;
-            const float dst = (float)(1.0 / ((double)vl * sqrt((double)vl)));
-            const float lev = (float)(1.0 / (1.0 + fabs((double)(s.t(l, k) - t))));
-            float dir = rx * gtx + ry * gty;
-            if (fabsf(dir) <= 0.01f) dir = 0.000001f;
-            const float w = fabsf((dst * lev) * dir);
-            const bool xp = s.known(l + 1, k), xm = s.known(l - 1, k), yp = s.known(l, k + 1), ym = s.known(l, k - 1);
-            const uint8_t* I0 = s.img + 3 * ((size_t)k * W + l);
-            const uint32_t c0 = load_px_bytes(I0, 0);
-            const uint32_t cxp = xp ? load_px_bytes(I0, 1) : 0u, cxm = xm ? load_px_bytes(I0, -1) : 0u;
-            const uint32_t cyp = yp ? load_px_bytes(I0, W) : 0u, cym = ym ? load_px_bytes(I0, -W) : 0u;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const int sh = 8 * ch;
-                const int v0 = (c0 >> sh) & 0xFF, vxp = (cxp >> sh) & 0xFF, vxm = (cxm >> sh) & 0xFF, vyp = (cyp >> sh) & 0xFF, vym = (cym >> sh) & 0xFF;
-                float gix, giy;
-                if (xp) gix = xm ? (float)(vxp - vxm) * 2.0f : (float)(vxp - v0);
-                else gix = xm ? (float)(v0 - vxm) : 0.0f;
-                if (yp) giy = ym ? (float)(vyp - vym) * 2.0f : (float)(vyp - v0);
-                else giy = ym ? (float)(v0 - vym) : 0.0f;
-                Ia[ch] = Ia[ch] + w * (float)v0;
-                Jx[ch] = Jx[ch] - w * (gix * rx);
-                Jy[ch] = Jy[ch] - w * (giy * ry);
-            }
-            sw = sw + w;
-        }
-    uint32_t out = 0;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float jj = Jx[ch] * Jx[ch] + Jy[ch] * Jy[ch];
-        const float sat = (float)(((double)(Ia[ch] / sw) + (double)(Jx[ch] + Jy[ch]) / (sqrt((double)jj) + (double)1.0e-20f)) + (double)0.5f);
-        float v = rintf(sat);
-        if (!(v >= 0.0f)) v = 0.0f;
-        if (v > 255.0f) v = 255.0f;
-        out |= (uint32_t)v << (8 * ch);
-    }
-    return out;
+    TeleaEntry t;
+    const uint32_t npx = (uint32_t)a.W * (uint32_t)a.H;
+    t.e = a.list[off + idx]; t.im = t.e / npx; t.o = t.e - t.im * npx;
+    t.y = (int)(t.o / (uint32_t)a.W); t.x = (int)(t.o - (uint32_t)t.y * (uint32_t)a.W);
+    return t;
 }
 
-__global__ void __launch_bounds__(256) k_telea_round(TeleaArgs a, uint32_t r)
+__global__ void __launch_bounds__(256) k_telea_levels(TeleaArgs a, uint32_t r)
 {
-    const uint32_t count = a.counts[r];
-    const uint32_t* list = a.list[r & 1];
-    uint32_t* next = a.list[(r + 1) & 1];
+    const uint32_t count = a.counts[r], off = a.offs[r], off_next = off + count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.offs[r + 1] = off_next;
     const int W = a.W, H = a.H;
     const uint32_t npx = (uint32_t)W * (uint32_t)H;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    // whole waves iterate together (the appends below use wave-wide ballots)
-    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < count; base += stride) {
-        const uint32_t idx = base + (threadIdx.x & 63);
+    // candidates of one block iteration are compacted in LDS and appended with ONE atomicAdd on the level counter
+    // (thousands of same-address atomics per round serialise in L2: that alone cost 300 us per round)
+    __shared__ uint32_t cand[4 * 256];
+    __shared__ uint32_t wave_cnt[4], wave_off[4], block_base;
+    __shared__ uint32_t reached[kTeleaMaxImages];          // key-coloured pixels this block reached, per image
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < kTeleaMaxImages; k += blockDim.x) reached[k] = 0u;
+    __syncthreads();
+    for (uint32_t bbase = blockIdx.x * blockDim.x; bbase < count; bbase += gridDim.x * blockDim.x) {   // block-uniform trip count
+        const uint32_t idx = bbase + threadIdx.x;
         bool act = idx < count;
-        uint32_t e = 0, im = 0, o = 0;
-        int x = 0, y = 0;
+        TeleaEntry t{};
         if (act) {
-            e = list[idx]; im = e / npx; o = e - im * npx; y = (int)(o / (uint32_t)W); x = (int)(o - (uint32_t)y * (uint32_t)W);
-            act = r <= a.last_round[im] && a.stamp[e] == kTeleaUnknown;      // image finished earlier / pixel filled in the previous front
+            t = telea_entry(a, off, idx);
+            act = r <= a.last_round[t.im];                                  // the image's holes were all reached earlier
         }
         if (act) {
-            const size_t ib = (size_t)im * npx;
-            TeleaView s{a.stamp + ib, a.T + ib, a.img + 3 * ib, W, H, r};
-            float t;
-            const uint32_t out = telea_pixel(s, x, y, a.radius, t);
-            const bool green = load_px_bytes(s.img, (int)o) == a.key_rgb;     // still the seed value: key-coloured?
-            a.T[e] = t;
-            store_px_bytes(a.img + 3 * ib, (int)o, out);
-            a.stamp[e] = (uint16_t)r;
-            if (green && atomicSub(&a.remaining[im], 1u) == 1u) a.last_round[im] = r;
+            a.stamp[t.e] = (uint16_t)r;
+            const bool green = load_px_bytes(a.img + 3 * (size_t)t.im * npx, (int)t.o) == a.key_rgb;
+            if (green) atomicAdd(&reached[t.im], 1u);                       // LDS; one global atomic per (block, image) at the end
         }
-        // the still-unknown 4-neighbours form the next front (a neighbour that belongs to this round's front may get
-        // appended too; it is skipped when read because its stamp is r by then)
-        const int nx[4] = {x - 1, x + 1, x, x}, ny[4] = {y, y, y - 1, y + 1};
+        const int nx[4] = {t.x - 1, t.x + 1, t.x, t.x}, ny[4] = {t.y, t.y, t.y - 1, t.y + 1};
+        uint32_t q[4];
+        bool want[4];
+        uint32_t mine = 0;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            bool want = act && nx[d] >= 0 && nx[d] < W && ny[d] >= 0 && ny[d] < H;
-            uint32_t q = 0;
-            if (want) {
-                q = im * npx + (uint32_t)ny[d] * (uint32_t)W + (uint32_t)nx[d];
-                want = a.stamp[q] == kTeleaUnknown && atomicMax(&a.queued[q], r + 1u) < r + 1u;
+            want[d] = act && nx[d] >= 0 && nx[d] < W && ny[d] >= 0 && ny[d] < H;
+            q[d] = 0;
+            if (want[d]) {
+                q[d] = t.im * npx + (uint32_t)ny[d] * (uint32_t)W + (uint32_t)nx[d];
+                want[d] = a.stamp[q[d]] == kTeleaUnknown && atomicMax(&a.queued[q[d]], r + 1u) == 0u;     // never appended before
             }
-            telea_append(want, q, next, &a.counts[r + 1]);
+            mine += want[d] ? 1u : 0u;
         }
+        // exclusive prefix of `mine` inside the wave, wave totals through LDS
+        uint32_t pre = mine;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) { const uint32_t v = __shfl_up(pre, sh); if (lane >= sh) pre += v; }
+        if (lane == 63) wave_cnt[wave] = pre;
+        pre -= mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < 4; ++w) { wave_off[w] = tot; tot += wave_cnt[w]; }
+            block_base = tot ? atomicAdd(&a.counts[r + 1], tot) : 0u;
+            wave_cnt[0] = tot;
+        }
+        __syncthreads();
+        uint32_t pos = wave_off[wave] + pre;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) if (want[d]) cand[pos++] = q[d];
+        const uint32_t tot = wave_cnt[0], gbase = block_base;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < tot; k += blockDim.x) a.list[off_next + gbase + k] = cand[k];
+        __syncthreads();
+    }
+    // the thread whose subtraction takes an image's counter to zero closes the image after this round
+    if ((int)threadIdx.x < a.n) {
+        const uint32_t got = reached[threadIdx.x];
+        if (got && atomicSub(&a.remaining[threadIdx.x], got) == got) a.last_round[threadIdx.x] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
+{
+    const uint32_t count = a.counts[r], off = a.offs[r];
+    const int W = a.W, H = a.H;
+    const uint32_t npx = (uint32_t)W * (uint32_t)H;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
+        const TeleaEntry t = telea_entry(a, off, idx);
+        if (!a.need[t.e] || a.stamp[t.e] != (uint16_t)r) continue;
+        const size_t ib = (size_t)t.im * npx;
+#pragma unroll
+        for (int dy = -4; dy <= 4; ++dy)
+#pragma unroll
+            for (int dx = -4; dx <= 4; ++dx) {
+                if (abs(dx) + abs(dy) > 5 || (abs(dx) == 4 && abs(dy) > 1) || (abs(dy) == 4 && abs(dx) > 1)) continue;   // what telea_pixel reads
+                const int xx = t.x + dx, yy = t.y + dy;
+                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                const size_t u = ib + (size_t)yy * W + xx;
+                const uint32_t su = a.stamp[u];
+                if (su != 0u && su < r) a.need[u] = 1;
+            }
+    }
+}
+
+constexpr uint32_t kFillEntries = 64;
+
+// The radius-3 disc without its centre, in the oracle's row-major order (28 pixels).
+__device__ __constant__ const int8_t kDiscDx[32] = {0, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2, -3, -2, -1, 1, 2, 3, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2, 0, 0, 0, 0, 0};
+__device__ __constant__ const int8_t kDiscDy[32] = {-3, -2, -2, -2, -2, -2, -1, -1, -1, -1, -1, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 0, 0, 0, 0};
+
+// Pass C, lane-parallel: one half-wave (32 lanes) per needed pixel, lane j < 28 = disc pixel j.  Every lane fetches
+// and weighs its own disc pixel (a dozen loads, ~300 instructions instead of one lane walking all 28: the level's
+// latency is what bounds this pass, not its throughput); the 10 running sums (Ia, Jx, Jy per channel and the
+// weight) are then added up in the oracle's order j = 0..27 by 10 lanes reading the terms from LDS -- the same
+// left-to-right f32 chain as telea_pixel(), so the result is bit-identical to it (and to the oracle).
+__global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
+{
+    const uint32_t count = a.counts[r], off = a.offs[r];
+    const int W = a.W, H = a.H;
+    const uint32_t npx = (uint32_t)W * (uint32_t)H;
+    __shared__ uint32_t todo[256];
+    __shared__ uint32_t n_todo;
+    __shared__ float red[8][10][32];
+    const int lane32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    // a block takes kFillEntries list entries at a time (about an eighth of them are needed): few enough that its 8
+    // half-waves each get one or two pixels, so a level's time is a couple of pixel latencies whatever its size
+    for (uint32_t bbase = blockIdx.x * kFillEntries; bbase < count; bbase += gridDim.x * kFillEntries) {   // block-uniform
+        if (threadIdx.x == 0) n_todo = 0;
+        __syncthreads();
+        const uint32_t idx = bbase + threadIdx.x;
+        if (threadIdx.x < kFillEntries && idx < count) {
+            const uint32_t e = a.list[off + idx];
+            if (a.need[e] && a.stamp[e] == (uint16_t)r) todo[atomicAdd(&n_todo, 1u)] = e;          // order is irrelevant: pixels of a level are independent
+        }
+        __syncthreads();
+        const uint32_t n = n_todo;
+        for (uint32_t k = hw; k < n; k += 8) {                 // half-wave uniform
+            const uint32_t e = todo[k], im = e / npx, o = e - im * npx;
+            const int y = (int)(o / (uint32_t)W), x = (int)(o - (uint32_t)y * (uint32_t)W);
+            const size_t ib = (size_t)im * npx;
+            TeleaView s{a.stamp + ib, a.T + ib, a.img + 3 * ib, W, H, r};
+            // T of the pixel and its gradient: every lane computes them (same addresses: one broadcast fetch)
+            float t = s.solve(x, y - 1, x - 1, y);
+            t = fminf(t, s.solve(x, y + 1, x - 1, y));
+            t = fminf(t, s.solve(x, y - 1, x + 1, y));
+            t = fminf(t, s.solve(x, y + 1, x + 1, y));
+            float gtx, gty;
+            if (s.known(x + 1, y)) gtx = s.known(x - 1, y) ? (s.t(x + 1, y) - s.t(x - 1, y)) * 0.5f : s.t(x + 1, y) - t;
+            else gtx = s.known(x - 1, y) ? t - s.t(x - 1, y) : 0.0f;
+            if (s.known(x, y + 1)) gty = s.known(x, y - 1) ? (s.t(x, y + 1) - s.t(x, y - 1)) * 0.5f : s.t(x, y + 1) - t;
+            else gty = s.known(x, y - 1) ? t - s.t(x, y - 1) : 0.0f;
+
+            float term[10];
+#pragma unroll
+            for (int c = 0; c < 10; ++c) term[c] = 0.0f;
+            if (lane32 < 28) {
+                const int dl = kDiscDx[lane32], dk = kDiscDy[lane32];
+                const int l = x + dl, kk = y + dk;
+                if (s.known(l, kk)) {
+                    const float ry = (float)(-dk), rx = (float)(-dl);
+                    const float vl = rx * rx + ry * ry;
+                    const float dst = (float)(1.0 / ((double)vl * sqrt((double)vl)));
+                    const float lev = (float)(1.0 / (1.0 + fabs((double)(s.t(l, kk) - t))));
+                    float dir = rx * gtx + ry * gty;
+                    if (fabsf(dir) <= 0.01f) dir = 0.000001f;
+                    const float w = fabsf((dst * lev) * dir);
+                    const bool xp = s.known(l + 1, kk), xm = s.known(l - 1, kk), yp = s.known(l, kk + 1), ym = s.known(l, kk - 1);
+                    const uint8_t* I0 = s.img + 3 * ((size_t)kk * W + l);
+                    const uint32_t c0 = load_px_bytes(I0, 0);
+                    const uint32_t cxp = xp ? load_px_bytes(I0, 1) : 0u, cxm = xm ? load_px_bytes(I0, -1) : 0u;
+                    const uint32_t cyp = yp ? load_px_bytes(I0, W) : 0u, cym = ym ? load_px_bytes(I0, -W) : 0u;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const int sh = 8 * ch;
+                        const int v0 = (c0 >> sh) & 0xFF, vxp = (cxp >> sh) & 0xFF, vxm = (cxm >> sh) & 0xFF, vyp = (cyp >> sh) & 0xFF, vym = (cym >> sh) & 0xFF;
+                        float gix, giy;
+                        if (xp) gix = xm ? (float)(vxp - vxm) * 2.0f : (float)(vxp - v0);
+                        else gix = xm ? (float)(v0 - vxm) : 0.0f;
+                        if (yp) giy = ym ? (float)(vyp - vym) * 2.0f : (float)(vyp - v0);
+                        else giy = ym ? (float)(v0 - vym) : 0.0f;
+                        term[ch] = w * (float)v0;              // Ia += .
+                        term[3 + ch] = w * (gix * rx);         // Jx -= .
+                        term[6 + ch] = w * (giy * ry);         // Jy -= .
+                    }
+                    term[9] = w;                               // s  += .
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 10; ++c) red[hw][c][lane32] = term[c];
+            __builtin_amdgcn_wave_barrier();                   // the half-wave's LDS writes precede its reads (same wave: program order + lgkmcnt)
+            float acc = 0.0f;
+            if (lane32 < 10) {
+                acc = lane32 == 9 ? 1.0e-20f : 0.0f;
+                const bool sub = lane32 >= 3 && lane32 < 9;
+                for (int j = 0; j < 28; ++j) {
+                    const float v = red[hw][lane32][j];
+                    acc = sub ? acc - v : acc + v;             // a term of 0 (pixel not known) leaves acc unchanged, exactly
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int hbase = (threadIdx.x & 63) & 32;         // first lane of this half-wave inside the wave
+            const int ch = lane32 < 3 ? lane32 : 0;
+            const float Ia = __shfl(acc, hbase + ch), Jx = __shfl(acc, hbase + 3 + ch), Jy = __shfl(acc, hbase + 6 + ch), sw = __shfl(acc, hbase + 9);
+            const float jj = Jx * Jx + Jy * Jy;
+            const float sat = (float)(((double)(Ia / sw) + (double)(Jx + Jy) / (sqrt((double)jj) + (double)1.0e-20f)) + (double)0.5f);
+            float v = rintf(sat);
+            if (!(v >= 0.0f)) v = 0.0f;
+            if (v > 255.0f) v = 255.0f;
+            const uint32_t byte = (uint32_t)v;
+            const uint32_t out = __shfl(byte, hbase) | (__shfl(byte, hbase + 1) << 8) | (__shfl(byte, hbase + 2) << 16);
+            if (lane32 == 0) {
+                a.T[e] = t;
+                store_px_bytes(a.img + 3 * ib, (int)o, out);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1760,6 +1884,11 @@ __global__ void __launch_bounds__(256) k_masked_blur(const uint8_t* __restrict__
     if (x >= W) return;
     const uint8_t* ibase = img + (size_t)im * img_stride;
     const uint8_t* sbase = seed ? seed + (size_t)im * seed_stride : nullptr;
+    {   // a black pixel stays black whatever surrounds it (sr:151) -- and outside the holes the mask is black
+        uint32_t c = load_px_bytes(ibase + (size_t)y * img_pitch, x);
+        if (sbase && key_rgb != 0u && load_px_bytes(sbase + (size_t)y * seed_pitch, x) == 0u) c = 0u;
+        if (c == 0u) { store_px_bytes(out + (size_t)im * out_stride + (size_t)y * out_pitch, x, 0u); return; }
+    }
     float acc[3] = {0.0f, 0.0f, 0.0f}, wsum = 0.0f;
     uint32_t centre = 0;
 #pragma unroll
@@ -1789,20 +1918,37 @@ __global__ void __launch_bounds__(256) k_masked_blur(const uint8_t* __restrict__
     store_px_bytes(out + (size_t)im * out_stride + (size_t)y * out_pitch, x, o);
 }
 
-hipError_t launch_telea(const uint8_t* seed, size_t seed_pitch, size_t seed_stride, const TeleaWorkspace& ws, int n, int W, int H,
-                        int radius, int max_rounds, uint32_t key_rgb, hipStream_t s)
+static TeleaArgs telea_args(const TeleaWorkspace& ws, int n, int W, int H, uint32_t key_rgb)
 {
-    TeleaArgs a{ws.stamp, ws.T, ws.img, ws.queued, {ws.list[0], ws.list[1]}, ws.counts, ws.remaining, ws.last_round, W, H, n, radius, key_rgb};
-    hipError_t e = hipMemsetAsync(ws.remaining, 0, (size_t)n * sizeof(uint32_t), s);
+    return TeleaArgs{ws.stamp, ws.T, ws.img, ws.queued, ws.need, ws.list, ws.counts, ws.offs, ws.remaining, ws.last_round, W, H, n, key_rgb};
+}
+
+// Per-call part: reset the counters, copy the seeds into the work image, build level 1.
+hipError_t launch_telea_init(const uint8_t* seed, size_t seed_pitch, size_t seed_stride, const TeleaWorkspace& ws, int n, int W, int H,
+                             int max_rounds, uint32_t key_rgb, hipStream_t s)
+{
+    const TeleaArgs a = telea_args(ws, n, W, H, key_rgb);
+    hipError_t e = hipMemsetAsync(ws.remaining, 0, (size_t)kTeleaMaxImages * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws.counts, 0, ((size_t)max_rounds + 2) * sizeof(uint32_t), s);
+    e = hipMemsetAsync(ws.counts, 0, 2 * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts and offs (adjacent)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_telea_init, dim3((W + 255) / 256, H, n), dim3(256), 0, s, seed, seed_pitch, seed_stride, a);
     hipLaunchKernelGGL(k_telea_begin, dim3((n + 63) / 64), dim3(64), 0, s, a);
-    // a fixed, modest grid per round: the front is a few 10^4 pixels per image, and an exhausted front costs one
-    // near-empty launch
-    const dim3 grid(1024), block(256);
-    for (int r = 1; r <= max_rounds; ++r) hipLaunchKernelGGL(k_telea_round, grid, block, 0, s, a, (uint32_t)r);
+    return hipGetLastError();
+}
+
+// The 3 x max_rounds level launches (replaying them from a captured HIP graph was measured: no gain, the ~4 us
+// between dependent kernels is the device's, not the host's).
+hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int max_rounds, uint32_t key_rgb, hipStream_t s)
+{
+    const TeleaArgs a = telea_args(ws, kTeleaMaxImages, W, H, key_rgb);
+    // fixed, modest grids: a level is a few 10^4 pixels per image, and an exhausted level costs one near-empty launch
+    int nb = 512;
+    if (const char* e = getenv("MDVT_TELEA_BLOCKS")) { const int v = atoi(e); if (v > 0) nb = v; }      // tuning hook
+    const dim3 grid(nb), block(256);
+    for (int r = 1; r <= max_rounds; ++r) hipLaunchKernelGGL(k_telea_levels, grid, block, 0, s, a, (uint32_t)r);
+    for (int r = max_rounds; r >= 1; --r) hipLaunchKernelGGL(k_telea_need, grid, block, 0, s, a, (uint32_t)r);
+    for (int r = 1; r <= max_rounds; ++r) hipLaunchKernelGGL(k_telea_fill, dim3(4 * nb), block, 0, s, a, (uint32_t)r);
     return hipGetLastError();
 }
 
