@@ -177,7 +177,8 @@ def _post_touchly1(r, clip, scales, d_depth_in, d_color_in, d_sbs, d_mask, d_z, 
 
 
 def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParameters, *, lo: int = 0,
-                hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, out_infill=None, device: Optional[int] = None):
+                hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, out_infill=None, green_and_black: bool = False,
+                device: Optional[int] = None):
     """Render frames [lo, hi) of a clip.  depth_frames / color_frames / out_*: array-likes indexed
     [frame] (NumPy arrays or memmaps, uint8).  Returns (frames, seconds, hole_pixels)."""
     import time
@@ -197,7 +198,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     want_z = want_zrgb or touchly0 or (touchly1 and posed)
     basic_infill = bool(clip.mode_flags & 128) and not touchly1
     want_infill = out_infill is not None
-    want_seed = (want_infill or basic_infill) and bool(clip.mode_flags & 2)
+    want_seed = ((want_infill and not green_and_black) or basic_infill) and bool(clip.mode_flags & 2)
     # without --infill_mask the key colour is black and every black pixel counts as "to fill" (sr:803-805): the front
     # then has to cross the whole frame, as the reference's own cv2.inpaint call does
     telea_rounds = 0 if (clip.mode_flags & 8) else W + H
@@ -214,7 +215,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             "h_sbs": pinned((B, oH, oW, 3), torch.uint8), "h_mask": pinned((B, H, 2 * W), torch.uint8),
             "h_zrgb": pinned((B, H, 2 * W, 3), torch.uint8) if want_zrgb else None,
             "h_seed": pinned((B, H, 2 * W, 3), torch.uint8) if want_infill else None,
-            "d_infill": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if want_seed else None,
+            "d_infill": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if (want_seed or want_infill) else None,
             "d_d": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
             "d_c": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
             "d_sbs": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev),
@@ -283,6 +284,9 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
                         sl = slice(eye * W, (eye + 1) * W)
                         normals = (st["d_infill"][f, :, sl].to(torch.float32) / 255.0) * 2 - 1
                         st["d_sbs"][f, :, sl] = infill_using_normals(st["d_sbs"][f, :, sl], st["d_mask"][f, :, sl] > 0, normals)
+        if want_infill and green_and_black and res is not None:      # sr:787-793: the key colour at holes, black elsewhere
+            key = torch.tensor(r.key_rgb, dtype=torch.uint8, device=dev)
+            torch.mul((st["d_mask"][:n] > 0)[..., None], key, out=st["d_infill"][:n])
         main = st["d_sbs"][:n]
         if touchly1:
             main = _post_touchly1(r, clip, [rec.depth_scale for rec in brecs], st["d_d"], st["d_c"], st["d_sbs"], st["d_mask"], st["d_z"], st["d_post"], n, posed)
@@ -295,7 +299,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             st["h_mask"][:n].copy_(st["d_mask"][:n], non_blocking=True)
             if want_zrgb:
                 st["h_zrgb"][:n].copy_(st["d_zrgb"][:n], non_blocking=True)
-            if want_infill and want_seed and res is not None:
+            if want_infill and res is not None:
                 st["h_seed"][:n].copy_(st["d_infill"][:n], non_blocking=True)
             st["out_done"].record(s_out)
         st["pending"] = (a, n)
@@ -352,12 +356,7 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     lo, hi = D.frame_range(rank, world, N)
     frames, secs, holes = render_clip(depth, color, outs["sbs"], outs["mask"], clip, lo=lo, hi=hi, batch=batch,
                                       out_depth_rgb=outs.get("depth"),
-                                      out_infill=None if green_and_black_infill_mask else outs.get("infill"))
-    if "infill" in outs and green_and_black_infill_mask:    # sr:787-793: bg_color at holes, black elsewhere
-        key = np.array([0, 255, 0], np.uint8)
-        for a in range(lo, hi, 8):
-            b = min(hi, a + 8)
-            outs["infill"][a:b] = (outs["mask"][a:b] > 0)[..., None] * key
+                                      out_infill=outs.get("infill"), green_and_black=green_and_black_infill_mask)
     for o in outs.values():
         o.flush()
     stats = D.gather_rank_stats(frames, secs, holes)
