@@ -28,7 +28,8 @@ Side-cars are the reference's own JSON formats: xfov list (sr:351-359), converge
 (sr:343-349), transformations list of 4x4 (sr:362-373).
 
 Pipelining: per batch, H2D on a copy stream from pinned staging -> render on the compute stream ->
-D2H on a second copy stream into pinned staging; two staging sets alternate, HIP events order them.
+D2H on a second copy stream into pinned staging, HIP events order them; the host copies into and out of the pinned
+staging run on helper threads one batch ahead of / behind the submitting thread; three staging sets rotate.
 """
 from __future__ import annotations
 
@@ -208,8 +209,9 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     def pinned(shape, dtype):
         return torch.empty(shape, dtype=dtype, pin_memory=True)
 
+    NSETS = 3
     sets = []
-    for _ in range(2):
+    for _ in range(NSETS):
         sets.append({
             "h_d": pinned((B, H, W, 3), torch.uint8), "h_c": pinned((B, H, W, 3), torch.uint8),
             "h_sbs": pinned((B, oH, oW, 3), torch.uint8), "h_mask": pinned((B, H, 2 * W), torch.uint8),
@@ -224,37 +226,52 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             "d_zrgb": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if want_zrgb else None,
             "d_post": torch.zeros((B, oH, oW, 3), dtype=torch.uint8, device=dev) if post else None,
             "in_done": torch.cuda.Event(), "render_done": torch.cuda.Event(), "out_done": torch.cuda.Event(),
-            "pending": None,
+            "loaded": None, "stored": None,
         })
     s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     s_cmp = torch.cuda.current_stream(dev)
-    holes = 0
 
-    def drain(st):
-        nonlocal holes
-        if st["pending"] is None:
-            return
-        a, n = st["pending"]
-        st["out_done"].synchronize()
+    # Host side of the pipeline: the two big memcpys per batch (frame dump -> pinned inputs, pinned outputs -> output
+    # dumps; 29 MB per 1080p frame, NumPy drops the GIL inside them) run on helper threads, one batch ahead / behind
+    # the thread that feeds the GPU.  Three staging sets keep the three stages out of each other's buffers.
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=4)
+
+    def load(st, a, n):
+        st["in_done"].synchronize()                 # the H2D copies that last read these pinned buffers are done
+        st["h_d"][:n].numpy()[...] = depth_frames[a:a + n]
+        st["h_c"][:n].numpy()[...] = color_frames[a:a + n]
+
+    def store_main(st, a, n):
         out_sbs[a:a + n] = st["h_sbs"][:n].numpy()
+
+    def store(st, a, n):
+        st["out_done"].synchronize()
+        side = pool.submit(store_main, st, a, n)    # the largest output on its own thread
         m = st["h_mask"][:n].numpy()
         out_mask[a:a + n] = m
-        holes += int(np.count_nonzero(m))
+        h = int(np.count_nonzero(m))
         if want_zrgb:
             out_depth_rgb[a:a + n] = st["h_zrgb"][:n].numpy()
         if want_infill:
             out_infill[a:a + n] = st["h_seed"][:n].numpy()
-        st["pending"] = None
+        side.result()
+        return h
 
+    starts = list(range(lo, hi, B))
     t0 = time.perf_counter()
-    k = 0
-    for a in range(lo, hi, B):
+    if starts:
+        sets[0]["loaded"] = pool.submit(load, sets[0], starts[0], min(B, hi - starts[0]))
+    stores = []
+    for k, a in enumerate(starts):
         n = min(B, hi - a)
-        st = sets[k % 2]
-        k += 1
-        drain(st)                                   # this staging set's previous batch must have left
-        st["h_d"][:n].numpy()[...] = depth_frames[a:a + n]
-        st["h_c"][:n].numpy()[...] = color_frames[a:a + n]
+        st = sets[k % NSETS]
+        st["loaded"].result()                       # this batch's inputs are in pinned memory
+        if k + 1 < len(starts):                     # next batch's inputs: start copying now
+            nx = sets[(k + 1) % NSETS]
+            nx["loaded"] = pool.submit(load, nx, starts[k + 1], min(B, hi - starts[k + 1]))
+        if st["stored"] is not None:
+            st["stored"].result()                   # this set's pinned outputs have been written out
         with torch.cuda.stream(s_in):
             s_in.wait_event(st["render_done"])      # device inputs free again
             st["d_d"][:n].copy_(st["h_d"][:n], non_blocking=True)
@@ -302,11 +319,12 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             if want_infill and res is not None:
                 st["h_seed"][:n].copy_(st["d_infill"][:n], non_blocking=True)
             st["out_done"].record(s_out)
-        st["pending"] = (a, n)
-    for st in sets:
-        drain(st)
+        st["stored"] = pool.submit(store, st, a, n)
+        stores.append(st["stored"])
+    holes = sum(f.result() for f in stores)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    pool.shutdown()
     r.close()
     return hi - lo, dt, holes
 
