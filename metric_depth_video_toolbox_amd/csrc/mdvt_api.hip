@@ -632,6 +632,8 @@ int mdvt_finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, size_t seed_pitc
     hipStream_t s = (hipStream_t)stream;
     const int W = c->W, H = c->H;
     const size_t npx = (size_t)W * H;
+    if ((unsigned long long)kTeleaChunk * npx > 0xFFFFFFFFull)      // work-list entries are 32-bit pixel indices over a full pass
+        return fail(c, MDVT_ERR_UNSUPPORTED, "frame too large for the infill-mask completion (%d x %d)", W, H);
     const int chunk = n_images < kTeleaChunk ? n_images : kTeleaChunk;
     if (c->telea_images < chunk || c->telea_rounds < max_rounds) {
         MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
