@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 5
+#define MDVT_VERSION_MINOR 6
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -182,6 +182,13 @@ int mdvt_masked_blur(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, uint
 int mdvt_finish_infill_mask(mdvt_ctx* ctx, const uint8_t* d_seed, size_t seed_pitch, size_t seed_stride, uint8_t* d_out,
                             size_t out_pitch, size_t out_stride, int n_images, int max_rounds, uint32_t* d_remaining,
                             void* stream);
+
+/* The same for both eyes of n_frames frames in one pass (the seed outputs of one mdvt_render_stereo_batch call): the
+ * level launches are shared by all 2 * n_frames images, which halves their count per frame.  d_remaining (optional):
+ * 2 * n_frames x uint32, the left eyes of all frames first, then the right eyes. */
+int mdvt_finish_infill_mask_stereo(mdvt_ctx* ctx, const uint8_t* d_left_seed, const uint8_t* d_right_seed, size_t seed_pitch,
+                                   size_t seed_stride, uint8_t* d_left_out, uint8_t* d_right_out, size_t out_pitch,
+                                   size_t out_stride, int n_frames, int max_rounds, uint32_t* d_remaining, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,8 @@ STATUS_NAMES = {0: "MDVT_OK", -1: "MDVT_ERR_INVALID_ARG", -2: "MDVT_ERR_HIP", -3
 SYMBOLS = ("mdvt_version", "mdvt_create", "mdvt_destroy", "mdvt_last_error", "mdvt_set_config",
            "mdvt_render_stereo", "mdvt_render_stereo_batch", "mdvt_decode_depth", "mdvt_encode_depth",
            "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side", "mdvt_touchly_depth",
-           "mdvt_equirect_tables", "mdvt_equirect_remap", "mdvt_masked_blur", "mdvt_finish_infill_mask")
+           "mdvt_equirect_tables", "mdvt_equirect_remap", "mdvt_masked_blur", "mdvt_finish_infill_mask",
+           "mdvt_finish_infill_mask_stereo")
 
 
 class MdvtError(RuntimeError):
@@ -102,6 +103,8 @@ def load():
     L.mdvt_masked_blur.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
     L.mdvt_finish_infill_mask.restype = C.c_int
     L.mdvt_finish_infill_mask.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, vp, vp]
+    L.mdvt_finish_infill_mask_stereo.restype = C.c_int
+    L.mdvt_finish_infill_mask_stereo.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, vp, vp]
     _lib = L
     return L
 

@@ -291,9 +291,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             for f in range(n):
                 dfh.encode_depth_frame(st["d_z"][f], clip.max_depth, bgr=True, out=st["d_zrgb"][f])
         if want_seed and res is not None:              # sr:803-808: finish the normal-coloured mask on the device, per eye
-            for eye in range(2):
-                r.finish_infill_mask(res["seed"][:, :, eye * W:(eye + 1) * W], out=st["d_infill"][:n, :, eye * W:(eye + 1) * W],
-                                     max_rounds=telea_rounds)
+            r.finish_infill_mask_sbs(res["seed"], out=st["d_infill"][:n], max_rounds=telea_rounds)
             if basic_infill:                           # sr:809-812: march along the normals into the holes
                 from .stereo_rerender import infill_using_normals
                 for f in range(n):

@@ -613,19 +613,21 @@ int mdvt_masked_blur(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, uint8_
     if (img_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
     if (d_img == d_out) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias d_img");
     DeviceGuard g(c->device);
-    MDVT_HIP(c, launch_masked_blur(d_img, img_pitch, 0, nullptr, 0, 0, d_out, out_pitch, 0, 1, c->W, c->H, masked_blur_kernel(), 0u,
-                                   (hipStream_t)stream));
+    const mdvt::ImageSet in{const_cast<uint8_t*>(d_img), img_pitch, 0, 0, 1}, out{d_out, out_pitch, 0, 0, 1};
+    MDVT_HIP(c, launch_masked_blur(in, nullptr, out, 1, c->W, c->H, masked_blur_kernel(), 0u, (hipStream_t)stream));
     return MDVT_OK;
 }
 
-int mdvt_finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, size_t seed_pitch, size_t seed_stride, uint8_t* d_out,
-                            size_t out_pitch, size_t out_stride, int n_images, int max_rounds, uint32_t* d_remaining, void* stream)
+static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t* d_seed_right, size_t seed_pitch, size_t seed_stride,
+                              uint8_t* d_out, uint8_t* d_out_right, size_t out_pitch, size_t out_stride, int n_frames, int max_rounds,
+                              uint32_t* d_remaining, void* stream)
 {
     if (!c) return MDVT_ERR_INVALID_ARG;
     if (!d_seed || !d_out) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
-    if (n_images < 1) return fail(c, MDVT_ERR_INVALID_ARG, "n_images must be >= 1");
+    if ((d_seed_right == nullptr) != (d_out_right == nullptr)) return fail(c, MDVT_ERR_INVALID_ARG, "right-eye seed and output go together");
+    if (n_frames < 1) return fail(c, MDVT_ERR_INVALID_ARG, "n_images must be >= 1");
     if (seed_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
-    if (d_seed == d_out) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias d_seed");
+    if (d_seed == d_out || (d_seed_right && d_seed_right == d_out_right)) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias d_seed");
     if (max_rounds <= 0) max_rounds = 256;
     if (max_rounds > 65000) return fail(c, MDVT_ERR_INVALID_ARG, "max_rounds must be <= 65000");
     DeviceGuard g(c->device);
@@ -634,8 +636,7 @@ int mdvt_finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, size_t seed_pitc
     const size_t npx = (size_t)W * H;
     if ((unsigned long long)kTeleaChunk * npx > 0xFFFFFFFFull)      // work-list entries are 32-bit pixel indices over a full pass
         return fail(c, MDVT_ERR_UNSUPPORTED, "frame too large for the infill-mask completion (%d x %d)", W, H);
-    const int chunk = n_images < kTeleaChunk ? n_images : kTeleaChunk;
-    if (c->telea_images < chunk || c->telea_rounds < max_rounds) {
+    if (c->telea_images < kTeleaChunk || c->telea_rounds < max_rounds) {
         MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
         const int images = kTeleaChunk;                      // a full pass: the level kernels scan kTeleaMaxImages counters
         const int rounds = max_rounds > c->telea_rounds ? max_rounds : c->telea_rounds;
@@ -655,17 +656,40 @@ int mdvt_finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, size_t seed_pitc
     c->telea.offs = c->telea.counts + (max_rounds + 2);
     const uint32_t key = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     const mdvt::BlurKernel K = masked_blur_kernel();
-    for (int i0 = 0; i0 < n_images; i0 += chunk) {
-        const int n = n_images - i0 < chunk ? n_images - i0 : chunk;
-        const uint8_t* seed = d_seed + (size_t)i0 * seed_stride;
-        MDVT_HIP(c, launch_telea_init(seed, seed_pitch, seed_stride, c->telea, n, W, H, max_rounds, key, s));
+    const int eyes = d_seed_right ? 2 : 1;
+    const int fchunk = kTeleaChunk / eyes;                   // frames per pass: both eyes of a frame travel together
+    for (int f0 = 0; f0 < n_frames; f0 += fchunk) {
+        const int nf = n_frames - f0 < fchunk ? n_frames - f0 : fchunk, n = nf * eyes;
+        const mdvt::ImageSet seed{const_cast<uint8_t*>(d_seed) + (size_t)f0 * seed_stride, seed_pitch, seed_stride,
+                                  d_seed_right ? d_seed_right - d_seed : 0, nf};
+        const mdvt::ImageSet out{d_out + (size_t)f0 * out_stride, out_pitch, out_stride, d_out_right ? d_out_right - d_out : 0, nf};
+        const mdvt::ImageSet work{c->telea.img, (size_t)3 * W, 3 * npx, 0, n};
+        MDVT_HIP(c, launch_telea_init(seed, c->telea, n, W, H, max_rounds, key, s));
         MDVT_HIP(c, launch_telea_rounds(c->telea, W, H, max_rounds, key, s));                               // sr:806, inpaintRadius = 3
-        MDVT_HIP(c, launch_masked_blur(c->telea.img, (size_t)3 * W, 3 * npx, seed, seed_pitch, seed_stride,
-                                       d_out + (size_t)i0 * out_stride, out_pitch, out_stride, n, W, H, K, key, s));   // sr:807-808
-        if (d_remaining)
-            MDVT_HIP(c, hipMemcpyAsync(d_remaining + i0, c->telea.remaining, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        MDVT_HIP(c, launch_masked_blur(work, &seed, out, n, W, H, K, key, s));                              // sr:807-808
+        if (d_remaining) {      // image order of the result: left eyes of all frames, then right eyes
+            for (int e = 0; e < eyes; ++e)
+                MDVT_HIP(c, hipMemcpyAsync(d_remaining + (size_t)e * n_frames + f0, c->telea.remaining + (size_t)e * nf,
+                                           (size_t)nf * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        }
     }
     return MDVT_OK;
+}
+
+int mdvt_finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, size_t seed_pitch, size_t seed_stride, uint8_t* d_out,
+                            size_t out_pitch, size_t out_stride, int n_images, int max_rounds, uint32_t* d_remaining, void* stream)
+{
+    return finish_infill_mask(c, d_seed, nullptr, seed_pitch, seed_stride, d_out, nullptr, out_pitch, out_stride, n_images, max_rounds,
+                              d_remaining, stream);
+}
+
+int mdvt_finish_infill_mask_stereo(mdvt_ctx* c, const uint8_t* d_left_seed, const uint8_t* d_right_seed, size_t seed_pitch,
+                                   size_t seed_stride, uint8_t* d_left_out, uint8_t* d_right_out, size_t out_pitch, size_t out_stride,
+                                   int n_frames, int max_rounds, uint32_t* d_remaining, void* stream)
+{
+    if (c && (!d_right_seed || !d_right_out)) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    return finish_infill_mask(c, d_left_seed, d_right_seed, seed_pitch, seed_stride, d_left_out, d_right_out, out_pitch, out_stride,
+                              n_frames, max_rounds, d_remaining, stream);
 }
 
 }  // extern "C"

@@ -85,6 +85,12 @@ hipError_t launch_touchly_depth(const float* depth, size_t depth_pitch, uint8_t*
                                 float tmax, float tmin, float k, int zero_is_far, hipStream_t s);
 hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst, size_t dst_pitch,
                                  size_t dst_stride, int n, int W, int H, const float* mx, const float* my, hipStream_t s);
+// n images addressed as `per_eye` frames x (1 or 2) eyes: image im = frame (im % per_eye) of eye (im / per_eye).
+struct ImageSet {
+    uint8_t* base; size_t pitch, stride; ptrdiff_t eye_offset; int per_eye;
+    __host__ __device__ uint8_t* image(int im) const { return base + (size_t)(im % per_eye) * stride + (ptrdiff_t)(im / per_eye) * eye_offset; }
+};
+
 struct TeleaWorkspace {              // per image pixel: stamp u16, T f32, work image u8x3, queued u32, need u8, list u32
     uint16_t* stamp; float* T; uint8_t* img; uint32_t* queued; uint8_t* need; uint32_t* list;
     uint32_t* counts;                // [max_rounds + 2], followed by
@@ -93,12 +99,11 @@ struct TeleaWorkspace {              // per image pixel: stamp u16, T f32, work 
     uint32_t* last_round;            // [images]
 };
 constexpr int kTeleaMaxImages = 16;  // images per pass
-hipError_t launch_telea_init(const uint8_t* seed, size_t seed_pitch, size_t seed_stride, const TeleaWorkspace& ws, int n, int W, int H,
-                             int max_rounds, uint32_t key_rgb, hipStream_t s);
+hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int n, int W, int H, int max_rounds, uint32_t key_rgb,
+                             hipStream_t s);
 hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int max_rounds, uint32_t key_rgb, hipStream_t s);
 struct BlurKernel { float k[36]; };      // masked_blur's 6x6 Gaussian, f32, row major (built on the host in f64)
-hipError_t launch_masked_blur(const uint8_t* img, size_t img_pitch, size_t img_stride, const uint8_t* seed, size_t seed_pitch,
-                              size_t seed_stride, uint8_t* out, size_t out_pitch, size_t out_stride, int n, int W, int H,
+hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const ImageSet& out, int n, int W, int H,
                               const BlurKernel& K, uint32_t key_rgb, hipStream_t s);
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);

@@ -1595,9 +1595,9 @@ __device__ __forceinline__ void telea_append(bool want, uint32_t idx, uint32_t* 
     if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
 }
 
-__global__ void __launch_bounds__(256) k_telea_init(const uint8_t* __restrict__ seed, size_t seed_pitch, size_t seed_stride,
-                                                    TeleaArgs a)
+__global__ void __launch_bounds__(256) k_telea_init(ImageSet seed, TeleaArgs a)
 {
+    const size_t seed_pitch = seed.pitch;
     const uint32_t key_rgb = a.key_rgb;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
     const int W = a.W, H = a.H;
@@ -1605,7 +1605,7 @@ __global__ void __launch_bounds__(256) k_telea_init(const uint8_t* __restrict__ 
     bool green = false, front = false;
     const size_t o = (size_t)im * W * H + (size_t)y * W + (in ? x : 0);
     if (in) {
-        const uint8_t* sim = seed + (size_t)im * seed_stride;
+        const uint8_t* sim = seed.image(im);
         auto masked = [&](int xx, int yy) {                   // sr:803-805: key-coloured or black = to inpaint
             const uint32_t p = load_px_bytes(sim + (size_t)yy * seed_pitch, xx);
             return p == key_rgb || p == 0u;
@@ -1875,19 +1875,19 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
 
 // sr:807: only the key-coloured pixels take the inpainted value, black ones go back to black; then masked_blur.
 // Both in one pass: the 36 taps read the work image and zero it on the fly where the seed was black.
-__global__ void __launch_bounds__(256) k_masked_blur(const uint8_t* __restrict__ img, size_t img_pitch, size_t img_stride,
-                                                     const uint8_t* __restrict__ seed, size_t seed_pitch, size_t seed_stride,
-                                                     uint8_t* __restrict__ out, size_t out_pitch, size_t out_stride,
-                                                     int W, int H, BlurKernel K, uint32_t key_rgb)
+__global__ void __launch_bounds__(256) k_masked_blur(ImageSet imgs, ImageSet seeds, ImageSet outs, int W, int H, BlurKernel K,
+                                                     uint32_t key_rgb)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
     if (x >= W) return;
-    const uint8_t* ibase = img + (size_t)im * img_stride;
-    const uint8_t* sbase = seed ? seed + (size_t)im * seed_stride : nullptr;
+    const size_t img_pitch = imgs.pitch, seed_pitch = seeds.pitch, out_pitch = outs.pitch;
+    const uint8_t* ibase = imgs.image(im);
+    const uint8_t* sbase = seeds.base ? seeds.image(im) : nullptr;
+    uint8_t* out = outs.image(im);
     {   // a black pixel stays black whatever surrounds it (sr:151) -- and outside the holes the mask is black
         uint32_t c = load_px_bytes(ibase + (size_t)y * img_pitch, x);
         if (sbase && key_rgb != 0u && load_px_bytes(sbase + (size_t)y * seed_pitch, x) == 0u) c = 0u;
-        if (c == 0u) { store_px_bytes(out + (size_t)im * out_stride + (size_t)y * out_pitch, x, 0u); return; }
+        if (c == 0u) { store_px_bytes(out + (size_t)y * out_pitch, x, 0u); return; }
     }
     float acc[3] = {0.0f, 0.0f, 0.0f}, wsum = 0.0f;
     uint32_t centre = 0;
@@ -1915,7 +1915,7 @@ __global__ void __launch_bounds__(256) k_masked_blur(const uint8_t* __restrict__
         v = fminf(fmaxf(v, 0.0f), 255.0f);
         o |= (uint32_t)v << (8 * c);
     }
-    store_px_bytes(out + (size_t)im * out_stride + (size_t)y * out_pitch, x, o);
+    store_px_bytes(out + (size_t)y * out_pitch, x, o);
 }
 
 static TeleaArgs telea_args(const TeleaWorkspace& ws, int n, int W, int H, uint32_t key_rgb)
@@ -1924,15 +1924,15 @@ static TeleaArgs telea_args(const TeleaWorkspace& ws, int n, int W, int H, uint3
 }
 
 // Per-call part: reset the counters, copy the seeds into the work image, build level 1.
-hipError_t launch_telea_init(const uint8_t* seed, size_t seed_pitch, size_t seed_stride, const TeleaWorkspace& ws, int n, int W, int H,
-                             int max_rounds, uint32_t key_rgb, hipStream_t s)
+hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int n, int W, int H, int max_rounds, uint32_t key_rgb,
+                             hipStream_t s)
 {
     const TeleaArgs a = telea_args(ws, n, W, H, key_rgb);
     hipError_t e = hipMemsetAsync(ws.remaining, 0, (size_t)kTeleaMaxImages * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws.counts, 0, 2 * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts and offs (adjacent)
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_telea_init, dim3((W + 255) / 256, H, n), dim3(256), 0, s, seed, seed_pitch, seed_stride, a);
+    hipLaunchKernelGGL(k_telea_init, dim3((W + 255) / 256, H, n), dim3(256), 0, s, seed, a);
     hipLaunchKernelGGL(k_telea_begin, dim3((n + 63) / 64), dim3(64), 0, s, a);
     return hipGetLastError();
 }
@@ -1952,13 +1952,12 @@ hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int max_r
     return hipGetLastError();
 }
 
-hipError_t launch_masked_blur(const uint8_t* img, size_t img_pitch, size_t img_stride, const uint8_t* seed, size_t seed_pitch,
-                              size_t seed_stride, uint8_t* out, size_t out_pitch, size_t out_stride, int n, int W, int H,
+hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const ImageSet& out, int n, int W, int H,
                               const BlurKernel& K, uint32_t key_rgb, hipStream_t s)
 {
     const dim3 grid((W + 255) / 256, H, n), block(256);
-    hipLaunchKernelGGL(k_masked_blur, grid, block, 0, s, img, img_pitch, img_stride, seed, seed_pitch, seed_stride, out, out_pitch,
-                       out_stride, W, H, K, key_rgb);
+    const ImageSet none{nullptr, 0, 0, 0, 1};
+    hipLaunchKernelGGL(k_masked_blur, grid, block, 0, s, img, seed ? *seed : none, out, W, H, K, key_rgb);
     return hipGetLastError();
 }
 

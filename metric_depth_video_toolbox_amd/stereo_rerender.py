@@ -360,6 +360,32 @@ class StereoRerenderer:
                             want_depth=want_depth, out_depth=out_depth, want_maskbits=want_maskbits,
                             want_hole_counts=want_hole_counts, want_seed=want_seed).launch(stream)
 
+    def finish_infill_mask_sbs(self, seed_sbs, out=None, max_rounds: int = 0, want_remaining: bool = False):
+        """finish_infill_mask for side-by-side seed buffers [N,H,2W,3] (render(want_seed=True)["seed"]): both eyes of
+        all frames in one pass (mdvt_finish_infill_mask_stereo).  Returns [N,H,2W,3] (and, with want_remaining, an
+        int32 tensor [2,N]: left eyes, right eyes)."""
+        torch = self.torch
+        W, H = self.W, self.H
+        single = seed_sbs.dim() == 3
+        if single:
+            seed_sbs = seed_sbs[None]
+        assert seed_sbs.is_cuda and seed_sbs.dtype == torch.uint8 and tuple(seed_sbs.shape[1:]) == (H, 2 * W, 3)
+        assert seed_sbs.stride(-1) == 1 and seed_sbs.stride(-2) == 3, "pixels must be packed RGB"
+        N = int(seed_sbs.shape[0])
+        if out is None:
+            out = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=seed_sbs.device)
+        elif out.dim() == 3:
+            out = out[None]
+        assert tuple(out.shape) == (N, H, 2 * W, 3) and out.stride(-1) == 1 and out.stride(-2) == 3
+        rem = torch.zeros((2, N), dtype=torch.int32, device=seed_sbs.device) if want_remaining else None
+        s = torch.cuda.current_stream(seed_sbs.device)
+        self.ctx.check(self._L.mdvt_finish_infill_mask_stereo(
+            self.ctx.handle, seed_sbs.data_ptr(), seed_sbs.data_ptr() + 3 * W, seed_sbs.stride(1), seed_sbs.stride(0),
+            out.data_ptr(), out.data_ptr() + 3 * W, out.stride(1), out.stride(0), N, int(max_rounds),
+            rem.data_ptr() if rem is not None else None, C.c_void_p(s.cuda_stream)))
+        res = out[0] if single else out
+        return (res, rem) if want_remaining else res
+
     def finish_infill_mask(self, seed, out=None, max_rounds: int = 0, want_remaining: bool = False):
         """sr:803-808 + 816 on the device: seed image(s) from render(want_seed=True) -> the finished infill-mask
         image(s): Telea-weighted inpaint of the key-coloured / black pixels (level by level, see include/mdvt.h),

@@ -723,6 +723,14 @@ def test_finish_infill_mask_matches_the_oracle(mods, orc, W, H):
     out = torch.zeros_like(sbs)
     r.finish_infill_mask(sbs[:, :W], out=out[:, :W]); r.finish_infill_mask(sbs[:, W:], out=out[:, W:])
     assert np.array_equal(out.cpu().numpy(), np.concatenate([orc.finish_infill_mask(seeds[0])[0], orc.finish_infill_mask(seeds[1])[0]], 1))
+    # both eyes of several frames in one pass (mdvt_finish_infill_mask_stereo): 10 frames = 20 images > one 16-image pass
+    many = torch.stack([sbs] * 10)
+    many[3, :, :W] = t[2]
+    got_sbs, rem_sbs = r.finish_infill_mask_sbs(many, want_remaining=True)
+    assert tuple(rem_sbs.shape) == (2, 10) and int(rem_sbs.sum()) == 0
+    assert np.array_equal(got_sbs[0].cpu().numpy(), out.cpu().numpy()) and np.array_equal(got_sbs[9].cpu().numpy(), out.cpu().numpy())
+    assert np.array_equal(got_sbs[3, :, :W].cpu().numpy(), orc.finish_infill_mask(seeds[2])[0])
+    assert np.array_equal(got_sbs[3, :, W:].cpu().numpy(), orc.finish_infill_mask(seeds[1])[0])
     # round limit: the front stops after 2 levels, the same key-coloured pixels stay unfilled on both sides
     got2, rem2 = r.finish_infill_mask(t[2], max_rounds=2, want_remaining=True)
     want2, wrem2 = orc.finish_infill_mask(seeds[2], max_rounds=2)

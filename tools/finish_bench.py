@@ -17,6 +17,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--rounds", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--per-eye", action="store_true", help="one call per eye instead of the stereo entry point")
 a = ap.parse_args()
 W, H, N = a.width, a.height, a.frames
 d, c = synthetic.SyntheticScene(W, H, config_id=3).clip(N)
@@ -29,9 +30,12 @@ ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 for rep in range(a.reps):
     torch.cuda.synchronize()
     ev[0].record()
-    for eye in range(2):
-        _, rem = r.finish_infill_mask(seed[:, :, eye * W:(eye + 1) * W], out=out[:, :, eye * W:(eye + 1) * W], max_rounds=a.rounds,
-                                      want_remaining=True)
+    if a.per_eye:
+        for eye in range(2):
+            _, rem = r.finish_infill_mask(seed[:, :, eye * W:(eye + 1) * W], out=out[:, :, eye * W:(eye + 1) * W], max_rounds=a.rounds,
+                                          want_remaining=True)
+    else:
+        _, rem = r.finish_infill_mask_sbs(seed, out=out, max_rounds=a.rounds, want_remaining=True)
     ev[1].record()
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1])
