@@ -636,9 +636,11 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
     const size_t npx = (size_t)W * H;
     if ((unsigned long long)kTeleaChunk * npx > 0xFFFFFFFFull)      // work-list entries are 32-bit pixel indices over a full pass
         return fail(c, MDVT_ERR_UNSUPPORTED, "frame too large for the infill-mask completion (%d x %d)", W, H);
-    if (c->telea_images < kTeleaChunk || c->telea_rounds < max_rounds) {
+    const int eyes_ = d_seed_right ? 2 : 1;
+    const int want_images = n_frames * eyes_ < kTeleaChunk ? n_frames * eyes_ : kTeleaChunk;
+    if (c->telea_images < want_images || c->telea_rounds < max_rounds) {
         MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
-        const int images = kTeleaChunk;                      // a full pass: the level kernels scan kTeleaMaxImages counters
+        const int images = want_images > c->telea_images ? want_images : c->telea_images;   // per-pixel arrays; the counters hold a full pass
         const int rounds = max_rounds > c->telea_rounds ? max_rounds : c->telea_rounds;
         free_telea(c);
         mdvt::TeleaWorkspace& w = c->telea;
@@ -649,8 +651,8 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
         MDVT_HIP(c, hipMalloc((void**)&w.need, (size_t)images * npx));
         MDVT_HIP(c, hipMalloc((void**)&w.list, (size_t)images * npx * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.counts, 2 * ((size_t)rounds + 2) * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.remaining, (size_t)images * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.last_round, (size_t)images * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.remaining, (size_t)kTeleaChunk * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.last_round, (size_t)kTeleaChunk * sizeof(uint32_t)));
         c->telea_images = images; c->telea_rounds = rounds;
     }
     c->telea.offs = c->telea.counts + (max_rounds + 2);

@@ -98,7 +98,7 @@ struct TeleaWorkspace {              // per image pixel: stamp u16, T f32, work 
     uint32_t* remaining;             // [images]
     uint32_t* last_round;            // [images]
 };
-constexpr int kTeleaMaxImages = 16;  // images per pass
+constexpr int kTeleaMaxImages = 32;  // images per pass
 hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int n, int W, int H, int max_rounds, uint32_t key_rgb,
                              hipStream_t s);
 hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int max_rounds, uint32_t key_rgb, hipStream_t s);
