@@ -128,10 +128,12 @@ __device__ __forceinline__ void vertex_f64(const FrameDev& f, int i, int j, int 
 // Division-free screening of the same test.  cos < c0  <=>  dot < c0 * (|n||v| + 1e-15); with the
 // unnormalised view vector vs = a+b+c (v = -vs/3) this is  -n.vs < c0 * |n| |vs|  up to the 1e-15 term.
 // Squaring removes the square roots.  The screening value carries ~1e-15 relative rounding error and
-// ignores the 1e-15 term (<= 1e-8 relative for any triangle bigger than a few square microns), so a
-// triangle whose margin is below kScreenMargin is NOT decided here and goes through the exact formula;
-// everything else provably gets the decision the exact formula would give.
+// ignores the 1e-15 term, which moves the threshold by the relative amount 1e-15 / (|n||v|): a triangle with
+// |n||v| < 1e-8 (content nearer than ~0.3 m at 1080p: tiny triangles, tiny view vectors) is therefore NOT
+// decided here, nor is one whose margin is below kScreenMargin (5e-7 in linear terms, against <= 1e-7 from the
+// dropped term); both go through the exact formula.  Everything else provably gets the exact formula's decision.
 constexpr double kScreenMargin = 1e-6;
+constexpr double kScreenMinNNSS = 9e-16;          // (3 |n||v|)^2 for |n||v| = 1e-8
 
 // returns 0 = valid, 1 = oblique (removed), 2 = undecided
 __device__ __forceinline__ int tri_oblique_screen(const double (&a)[3], const double (&b)[3], const double (&c)[3])
@@ -147,7 +149,7 @@ __device__ __forceinline__ int tri_oblique_screen(const double (&a)[3], const do
     const double ss = (sx * sx + sy * sy) + sz * sz;                   // 9 * |v|^2
     const double c0 = 0x1.1df0b2b89dd37p-6;
     const double rhs = (c0 * c0) * (nn * ss);                          // (c0 |n| |vs|)^2
-    if (!(rhs > 1e-60)) return 2;                                      // degenerate / zero depth: exact path
+    if (!(nn * ss > kScreenMinNNSS)) return 2;                         // degenerate / zero depth / tiny: exact path
     const double lhs = d * fabs(d);                                    // signed square
     const double tol = kScreenMargin * rhs;
     if (lhs < rhs - tol) return 1;

@@ -481,9 +481,13 @@ def test_randomised_parity_sweep(mods, orc):
     """Seeded random sweep over sizes (incl. tiny / odd), camera scalars, modes, flags, poses and
     degenerate depth content; every output plane must equal the oracle bit for bit."""
     _lib, sr, synthetic = mods
-    rng = np.random.default_rng(20260927)
+    import os
+    # soak runs: MDVT_SWEEP_SEED / MDVT_SWEEP_CASES widen the sweep (e.g. 400 cases per seed) without touching the default
+    rng = np.random.default_rng(int(os.environ.get("MDVT_SWEEP_SEED", "20260927")))
     sizes = [(2, 2), (3, 2), (4, 4), (5, 3), (8, 8), (17, 9), (36, 20), (61, 33), (64, 32), (100, 31), (128, 16), (200, 12)]
-    n_cases = 60
+    n_cases = int(os.environ.get("MDVT_SWEEP_CASES", "60"))
+    if n_cases > 60:
+        sizes += [(320, 200), (257, 129), (96, 96)]
     for case in range(n_cases):
         W, H = sizes[int(rng.integers(len(sizes)))]
         mesh = bool(rng.integers(2))
@@ -518,9 +522,19 @@ def test_randomised_parity_sweep(mods, orc):
             T[:3, 3] *= float(rng.choice([1.0, 20.0]))
         p = r.frame_params(xfov=xfov, convergence_distance=float(rng.uniform(0.3, 8.0)) if kind in (1, 3) else None,
                            transformation=T)
-        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+        want_seed = infill and H >= 3 and W >= 3
+        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True, want_seed=want_seed)
         tag = f"sweep#{case} {W}x{H} mesh={mesh} infill={infill} no_pts={no_pts} ipd={ipd} xfov={xfov} md={max_depth} kind={kind} style={style}"
-        _compare(got, _oracle(orc, r, p, depth_rgb, color, T=T), W, tag)
+        op = orc.make_params(W, H, _K(p), ipd_m=ipd / 1000, max_depth=max_depth, depth_scale=p.depth_scale,
+                             mode=orc.MODE_MESH if mesh else orc.MODE_POINTS, remove_edges=r.remove_edges, edge_points=int(r.edge_points),
+                             conv_angle=p.convergence_angle, T=T, key_rgb=r.key_rgb)
+        want = orc.render_stereo(op, depth_rgb, color, want_depth=True, want_seed=want_seed)
+        _compare({k: got[k] for k in ("sbs", "mask", "depth")}, want, W, tag)
+        if want_seed:            # the infill-mask chain on whatever seeds this case produced
+            fin = r.finish_infill_mask_sbs(got["seed"]).cpu().numpy()
+            for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+                assert np.array_equal(got["seed"][:, sl].cpu().numpy(), want[eye + "_seed"]), tag + " seed " + eye
+                assert np.array_equal(fin[:, sl], orc.finish_infill_mask(want[eye + "_seed"], max_rounds=256)[0]), tag + " finish " + eye
         r.close()
 
 
@@ -776,3 +790,28 @@ def test_infill_mask_and_basic_infill_from_a_render(mods, orc, mode, conv):
                 assert np.array_equal(img, wimg)
                 assert (np.all(img == 0, -1) & hole).sum() < 0.5 * hole.sum()  # most of the hole area got colour
         r.close()
+
+
+def test_edge_filter_on_sub_millimetre_depths(mods, orc):
+    """Regression (found by the widened sweep): content a fraction of a millimetre from the camera makes |n||v| of the
+    89-degree test comparable with the reference's +1e-15 guard term, which the division-free screening ignores --
+    such triangles must take the exact formula.  Depth codes 0..3 at max_depth 5 with a 25-degree master fov."""
+    _lib, sr, synthetic = mods
+    rng = np.random.default_rng(109)
+    W, H = 64, 32
+    for trial in range(6):
+        depth_rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        depth_rgb[..., 0] = 0
+        depth_rgb[..., 2] = rng.integers(0, 4 + 3 * trial, (H, W))
+        color = rng.integers(1, 256, (H, W, 3), dtype=np.uint8)
+        for mesh in (True, False):
+            r = sr.StereoRerenderer(W, H, pupillary_distance=0 if trial % 2 == 0 else 65, max_depth=5, master_xfov=25.0,
+                                    render_as_pointcloud=not mesh, infill_mask=True, dont_place_points_in_edges=(trial < 3))
+            p = r.frame_params(xfov=45.0)
+            zs = orc.decode_depth(depth_rgb, 5, p.depth_scale)
+            tri, unused, _ = orc.edge_filter(zs, _K(p), mesh)
+            gt, gu = r.edge_filter(torch.from_numpy(depth_rgb).cuda(), p)
+            assert np.array_equal(gt.cpu().numpy(), tri) and np.array_equal(gu.cpu().numpy(), unused), (trial, mesh)
+            got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+            _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"tiny depths trial {trial} mesh={mesh}")
+            r.close()
