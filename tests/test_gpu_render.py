@@ -486,8 +486,9 @@ def test_randomised_parity_sweep(mods, orc):
     rng = np.random.default_rng(int(os.environ.get("MDVT_SWEEP_SEED", "20260927")))
     sizes = [(2, 2), (3, 2), (4, 4), (5, 3), (8, 8), (17, 9), (36, 20), (61, 33), (64, 32), (100, 31), (128, 16), (200, 12)]
     n_cases = int(os.environ.get("MDVT_SWEEP_CASES", "60"))
-    if n_cases > 60:
-        sizes += [(320, 200), (257, 129), (96, 96)]
+    soak = n_cases > 60
+    if soak:
+        sizes += [(320, 200), (257, 129), (96, 96), (512, 9), (40, 300)]
     for case in range(n_cases):
         W, H = sizes[int(rng.integers(len(sizes)))]
         mesh = bool(rng.integers(2))
@@ -499,7 +500,26 @@ def test_randomised_parity_sweep(mods, orc):
         max_depth = int(rng.choice([5, 20, 100, 655]))
         kind = int(rng.integers(4))                      # 0 pure, 1 convergence, 2 pose, 3 both
         depth_rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
-        style = int(rng.integers(4))
+        style = int(rng.integers(8 if soak else 4))
+        if soak and rng.integers(4) == 0:                # soak only: extreme camera scalars
+            ipd = int(rng.choice([2000, 7, 250]))
+            xfov = float(rng.choice([5.0, 150.0, 170.0, 33.3]))
+        if style == 4:                                   # foreground rectangles over a far plane (typical scene structure)
+            code = np.full((H, W), int(rng.integers(3000, 60000)), np.uint32)
+            for _ in range(int(rng.integers(1, 6))):
+                x0, y0 = int(rng.integers(W)), int(rng.integers(H))
+                code[y0:y0 + int(rng.integers(1, H + 1)), x0:x0 + int(rng.integers(1, W + 1))] = int(rng.integers(50, 3000))
+            depth_rgb[..., 0] = (code >> 8) & 0xFF; depth_rgb[..., 2] = code & 0xFF
+        elif style == 5:                                 # one-code noise on a slope: z ties and 1-LSB steps everywhere
+            code = (int(rng.integers(300, 40000)) + np.arange(W)[None, :] // 3 + rng.integers(0, 2, (H, W))).astype(np.uint32)
+            depth_rgb[..., 0] = (code >> 8) & 0xFF; depth_rgb[..., 2] = code & 0xFF
+        elif style == 6:                                 # alternating near / far columns or rows: maximal folding
+            near, far = int(rng.integers(20, 400)), int(rng.integers(5000, 65000))
+            stripes = (np.arange(W)[None, :] if rng.integers(2) else np.arange(H)[:, None]) // int(rng.integers(1, 4)) % 2
+            code = np.where(np.broadcast_to(stripes, (H, W)) == 0, near, far).astype(np.uint32)
+            depth_rgb[..., 0] = (code >> 8) & 0xFF; depth_rgb[..., 2] = code & 0xFF
+        elif style == 7:                                 # the far end of the code range
+            depth_rgb[..., 0] = 255; depth_rgb[..., 2] = rng.integers(200, 256, (H, W))
         if style == 0:                                   # smooth plane + a step
             code = (2000 + 40 * np.arange(W)[None, :] + 7 * np.arange(H)[:, None]).astype(np.uint32)
             code[:, W // 2:] //= 3
@@ -520,8 +540,15 @@ def test_randomised_parity_sweep(mods, orc):
         if kind >= 2:
             T = synthetic.synthetic_pose_track(64)[int(rng.integers(1, 64))]
             T[:3, 3] *= float(rng.choice([1.0, 20.0]))
-        p = r.frame_params(xfov=xfov, convergence_distance=float(rng.uniform(0.3, 8.0)) if kind in (1, 3) else None,
-                           transformation=T)
+            if soak and rng.integers(3) == 0:            # a big rotation about a random axis, possibly looking backwards
+                ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+                ang = float(rng.choice([0.3, 1.0, 1.5708, 3.1])); Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * (Kx @ Kx)
+                T = T.copy(); T[:3, :3] = R @ T[:3, :3]
+        conv_d = float(rng.uniform(0.3, 8.0)) if kind in (1, 3) else None
+        if soak and conv_d is not None and rng.integers(5) == 0:
+            conv_d = float(rng.choice([0.02, 0.05, 500.0]))
+        p = r.frame_params(xfov=xfov, convergence_distance=conv_d, transformation=T)
         want_seed = infill and H >= 3 and W >= 3
         got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True, want_seed=want_seed)
         tag = f"sweep#{case} {W}x{H} mesh={mesh} infill={infill} no_pts={no_pts} ipd={ipd} xfov={xfov} md={max_depth} kind={kind} style={style}"
