@@ -486,9 +486,11 @@ def test_randomised_parity_sweep(mods, orc):
     rng = np.random.default_rng(int(os.environ.get("MDVT_SWEEP_SEED", "20260927")))
     sizes = [(2, 2), (3, 2), (4, 4), (5, 3), (8, 8), (17, 9), (36, 20), (61, 33), (64, 32), (100, 31), (128, 16), (200, 12)]
     n_cases = int(os.environ.get("MDVT_SWEEP_CASES", "60"))
-    soak = n_cases > 60
+    soak = n_cases > 60 or "MDVT_SWEEP_SIZES" in os.environ
     if soak:
         sizes += [(320, 200), (257, 129), (96, 96), (512, 9), (40, 300)]
+    if "MDVT_SWEEP_SIZES" in os.environ:                 # e.g. "1920x1080,1280x720": full-size soak (the oracle takes seconds per case)
+        sizes = [tuple(int(v) for v in t.split("x")) for t in os.environ["MDVT_SWEEP_SIZES"].split(",")]
     for case in range(n_cases):
         W, H = sizes[int(rng.integers(len(sizes)))]
         mesh = bool(rng.integers(2))
@@ -842,3 +844,53 @@ def test_edge_filter_on_sub_millimetre_depths(mods, orc):
             got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
             _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"tiny depths trial {trial} mesh={mesh}")
             r.close()
+
+
+def test_randomised_aux_sweep(mods, orc):
+    """Seeded random sweep over the stand-alone entry points (codec, Touchly plane, equirect remap, masked blur,
+    normal-marching infill, mark_lower_side) against the oracle; MDVT_SWEEP_SEED / MDVT_SWEEP_CASES widen it."""
+    import os
+    _lib, sr, synthetic = mods
+    from metric_depth_video_toolbox_amd import depth_frames_helper as dfh, infill_common
+    rng = np.random.default_rng(int(os.environ.get("MDVT_SWEEP_SEED", "20260928")))
+    n_cases = int(os.environ.get("MDVT_SWEEP_CASES", "12"))
+    sizes = [(2, 2), (5, 3), (17, 9), (33, 17), (64, 48), (100, 31), (130, 70), (257, 129)]
+    for case in range(n_cases):
+        W, H = sizes[int(rng.integers(len(sizes)))]
+        tag = f"aux#{case} {W}x{H}"
+        # codec both ways
+        md = int(rng.choice([5, 20, 100, 655])); scale = float(rng.choice([1.0, 0.37, 1.3938468501173518]))
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        z = dfh.decode_rgb_depth_frame(torch.from_numpy(rgb).cuda(), md, True, depth_scale=scale)
+        assert np.array_equal(z.cpu().numpy().view(np.uint32), orc.decode_depth(rgb, md, scale).view(np.uint32)), tag
+        d = (rng.uniform(-2, md * 1.2, (H, W)) * rng.choice([1.0, 1e-3])).astype(np.float32)
+        enc = dfh.encode_depth_frame(torch.from_numpy(d).cuda(), md, bgr=False).cpu().numpy()
+        assert np.array_equal(enc, orc.encode_depth(d, md)), tag
+        # Touchly plane
+        tmax, tmin = float(rng.uniform(1, 20)), float(rng.uniform(0, 0.9))
+        for zf in (False, True):
+            d8 = np.rint(np.maximum(0, np.minimum(np.abs(d), tmax) - tmin) * (255 / (tmax - tmin))).astype(np.uint8)
+            if zf:
+                d8[d8 == 0] = 255
+            got = sr.touchly_depth(torch.from_numpy(np.abs(d)).cuda(), tmax, tmin, zero_is_far=zf).cpu().numpy()
+            assert np.array_equal(got, np.repeat((255 - d8)[..., None], 3, axis=-1)), tag
+        # equirect remap
+        fov = float(rng.uniform(1.0, 179.0))
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        assert np.array_equal(sr.convert_to_equirectangular(torch.from_numpy(img).cuda(), fov).cpu().numpy(),
+                              orc.convert_to_equirectangular(img, fov)), tag + f" fov {fov}"
+        # masked blur
+        bl = img.copy(); bl[rng.uniform(size=(H, W)) < rng.uniform(0, 0.9)] = 0
+        assert np.array_equal(sr.masked_blur(torch.from_numpy(bl).cuda()).cpu().numpy(), orc.masked_blur(bl)), tag
+        # normal-marching infill and mark_lower_side
+        hole = rng.uniform(size=(H, W)) < rng.uniform(0, 0.6)
+        ang = rng.uniform(0, 2 * np.pi, (H, W)); mag = rng.uniform(0, 1, (H, W))
+        nrm = np.stack([np.cos(ang) * mag, np.sin(ang) * mag, rng.uniform(-1, 1, (H, W))], -1).astype(np.float32)
+        nrm[rng.uniform(size=(H, W)) < 0.05] = (0.0, 1.0, 0.0)
+        steps = int(rng.choice([3, 40, 400]))
+        got = sr.infill_using_normals(torch.from_numpy(img).cuda(), torch.from_numpy(hole).cuda(), torch.from_numpy(nrm).cuda(), steps)
+        assert np.array_equal(got.cpu().numpy(), orc.infill_using_normals(img, hole, nrm, steps)), tag
+        msk = img.copy(); msk[~hole] = 0
+        steps = int(rng.choice([2, 8, 30]))
+        got = infill_common.mark_lower_side(torch.from_numpy(msk).cuda(), steps)
+        assert np.array_equal(got.cpu().numpy(), orc.mark_lower_side(msk, steps)), tag
