@@ -76,6 +76,8 @@ def lib():
         L.orc_masked_blur.restype = None
         L.orc_telea_levels.argtypes = [u8p, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_telea_levels.restype = C.c_int
+        L.orc_telea_fmm.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_telea_fmm.restype = None
         L.orc_finish_infill_mask.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, u8p, u8p]
         L.orc_finish_infill_mask.restype = C.c_int
         _lib = L
@@ -285,3 +287,13 @@ def finish_infill_mask(seed: np.ndarray, key_rgb=(0, 255, 0), max_rounds: int = 
     rem = lib().orc_finish_infill_mask(_p(seed, C.c_uint8), W, H, _p(key, C.c_uint8), int(max_rounds), _p(out, C.c_uint8),
                                        _p(blur, C.c_uint8) if want_blur else None)
     return (out, blur, rem) if want_blur else (out, rem)
+
+
+def telea_fmm(img: np.ndarray, mask: np.ndarray, radius: int = 3) -> np.ndarray:
+    """Sequential fast-marching order (cv2.inpaint's), same estimator: for measuring the effect of the order only."""
+    img = np.ascontiguousarray(img, np.uint8)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    H, W = mask.shape
+    out = np.empty_like(img)
+    lib().orc_telea_fmm(_p(img, C.c_uint8), _p(mask, C.c_uint8), W, H, int(radius), _p(out, C.c_uint8))
+    return out

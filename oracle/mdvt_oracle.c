@@ -865,3 +865,78 @@ int orc_finish_infill_mask(const uint8_t* seed, int W, int H, const uint8_t* key
     free(mask); free(green); free(filled); free(merged); free(blur);
     return remaining;
 }
+
+/* The SEQUENTIAL fast-marching order of cv2.inpaint(INPAINT_TELEA), with the same per-pixel estimator and the same
+ * decrees as orc_telea_levels (T = 0 at known pixels, out-of-image = unknown): a heap ordered by T (ties: first in,
+ * first out), one pixel popped at a time, its unknown 4-neighbours estimated from everything not INSIDE at that
+ * moment.  Not used for parity -- it exists to MEASURE how far the level-synchronous order of orc_telea_levels /
+ * the device moves the result away from the sequential one (tests/test_oracle_golden.py reports the statistics). */
+typedef struct { float t; uint32_t seq; uint32_t idx; } orc_heap_item;
+
+static void orc_heap_push(orc_heap_item* h, size_t* n, orc_heap_item it)
+{
+    size_t k = (*n)++;
+    h[k] = it;
+    while (k > 0) {
+        const size_t p = (k - 1) / 2;
+        if (h[p].t < h[k].t || (h[p].t == h[k].t && h[p].seq < h[k].seq)) break;
+        const orc_heap_item tmp = h[p]; h[p] = h[k]; h[k] = tmp; k = p;
+    }
+}
+
+static orc_heap_item orc_heap_pop(orc_heap_item* h, size_t* n)
+{
+    const orc_heap_item top = h[0];
+    h[0] = h[--(*n)];
+    size_t k = 0;
+    for (;;) {
+        size_t l = 2 * k + 1, r = l + 1, m = k;
+        if (l < *n && (h[l].t < h[m].t || (h[l].t == h[m].t && h[l].seq < h[m].seq))) m = l;
+        if (r < *n && (h[r].t < h[m].t || (h[r].t == h[m].t && h[r].seq < h[m].seq))) m = r;
+        if (m == k) break;
+        const orc_heap_item tmp = h[m]; h[m] = h[k]; h[k] = tmp; k = m;
+    }
+    return top;
+}
+
+void orc_telea_fmm(const uint8_t* img, const uint8_t* mask, int W, int H, int radius, uint8_t* out)
+{
+    const size_t n = (size_t)W * H;
+    /* stamp doubles as the flag: 0 = not INSIDE (known or band), 0xFFFF = INSIDE; orc_telea_pixel() with r = 1 then
+     * reads exactly "everything not INSIDE right now" */
+    uint16_t* stamp = (uint16_t*)malloc(n * sizeof(uint16_t));
+    float* T = (float*)calloc(n, sizeof(float));
+    orc_heap_item* heap = (orc_heap_item*)malloc((4 * n + 4) * sizeof(orc_heap_item));
+    size_t hn = 0;
+    uint32_t seq = 0;
+    memcpy(out, img, n * 3);
+    for (size_t k = 0; k < n; ++k) stamp[k] = mask[k] ? ORC_T_UNKNOWN : 0;
+    orc_telea_state s = { W, H, stamp, T, out };
+    const int dx[4] = { 0, -1, 0, 1 }, dy[4] = { -1, 0, 1, 0 };        /* OpenCV's neighbour order: (i-1,j), (i,j-1), (i+1,j), (i,j+1) */
+    for (int y = 0; y < H; ++y)                                          /* the initial band: known pixels next to the mask, T = 0 */
+        for (int x = 0; x < W; ++x) {
+            if (stamp[(size_t)y * W + x]) continue;
+            int band = 0;
+            for (int d = 0; d < 4; ++d) {
+                const int xx = x + dx[d], yy = y + dy[d];
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H && stamp[(size_t)yy * W + xx]) band = 1;
+            }
+            if (band) { const orc_heap_item it = { 0.0f, seq++, (uint32_t)((size_t)y * W + x) }; orc_heap_push(heap, &hn, it); }
+        }
+    while (hn) {
+        const orc_heap_item it = orc_heap_pop(heap, &hn);
+        const int y = (int)(it.idx / (uint32_t)W), x = (int)(it.idx % (uint32_t)W);
+        for (int d = 0; d < 4; ++d) {
+            const int xx = x + dx[d], yy = y + dy[d];
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const size_t q = (size_t)yy * W + xx;
+            if (stamp[q] != ORC_T_UNKNOWN) continue;
+            float t; uint8_t rgb[3];
+            orc_telea_pixel(&s, xx, yy, 1, radius, &t, rgb);
+            T[q] = t; memcpy(out + 3 * q, rgb, 3); stamp[q] = 0;          /* BAND: from now on a source for others */
+            const orc_heap_item nq = { t, seq++, (uint32_t)q };
+            orc_heap_push(heap, &hn, nq);
+        }
+    }
+    free(stamp); free(T); free(heap);
+}
