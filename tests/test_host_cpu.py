@@ -199,3 +199,29 @@ def test_equirect_tables_of_the_library_match_the_reference_maps(lib, golden):
     _check_equirect_tables(golden("equirect"), sr.equirect_tables, maps)
     with pytest.raises(ValueError):
         sr.equirect_tables(64, 64, 180.0)
+
+
+def test_output_variants_are_carried_by_the_clip_parameters():
+    """--vr180 / --touchly0 / --touchly1 / --do_basic_infill (sr:291-303, 406-422, 568-573): flags, output shapes and
+    the VR180 render camera, all host logic."""
+    from metric_depth_video_toolbox_amd import clip, distributed as D, stereo_rerender as sr
+    c = clip.load_clip_parameters(3, 1920, 1920, xfov=60.0, touchly0=True, touchly_max_depth=7.0, touchly_min_depth=0.5)
+    assert c.mode_flags & 16 and c.mode_flags & 32 and clip.output_shape(c) == (1920, 3 * 1920)          # touchly0 implies vr180
+    d = D.ClipParameters.unpack(c.pack())
+    assert (d.touchly_max_depth, d.touchly_min_depth, d.mode_flags) == (7.0, 0.5, c.mode_flags)
+    assert clip.output_shape(clip.load_clip_parameters(3, 64, 48, xfov=60.0, touchly1=True)) == (96, 64)
+    assert clip.output_shape(clip.load_clip_parameters(3, 64, 48, xfov=60.0)) == (48, 128)
+    b = clip.load_clip_parameters(3, 64, 48, xfov=60.0, do_basic_infill=True)
+    assert b.mode_flags & 128 and b.mode_flags & 2 and b.mode_flags & 4 and not b.mode_flags & 8             # edge filter on, key stays black
+    with pytest.raises(ValueError):
+        clip.load_clip_parameters(3, 64, 48, xfov=60.0, touchly0=True, touchly1=True)
+    with pytest.raises(ValueError):
+        clip.load_clip_parameters(3, 64, 48, xfov=60.0, touchly1=True, touchly_max_depth=1.0, touchly_min_depth=1.0)
+    # VR180 camera: square, fov = max(75, max input fov), and it replaces the master fov in the depth scale (sr:527-541)
+    p = sr.make_frame_params(1920, 1920, 60.0, vr180=True)
+    assert abs(p.Krender[0] - 960 / math.tan(math.radians(37.5))) < 1e-9 and p.Krender[0] == p.Krender[4] and p.Krender[2] == 960.0
+    assert p.depth_scale == 1.0 / (math.tan(math.radians(75.0 / 2)) / math.tan(math.radians(60.0 / 2)))
+    p = sr.make_frame_params(1920, 1920, 120.0, vr180=True)
+    assert abs(sr.vr180_render_fov(np.array([p.K[k] for k in range(9)]).reshape(3, 3)) - 120.0) < 1e-9
+    with pytest.raises(ValueError):
+        sr.make_frame_params(1280, 720, 60.0, vr180=True)
