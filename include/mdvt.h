@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 6
+#define MDVT_VERSION_MINOR 7
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -163,6 +163,12 @@ int mdvt_equirect_tables(int width, int height, double input_fov_deg, float* h_m
 int mdvt_equirect_remap(mdvt_ctx* ctx, const uint8_t* d_src, size_t src_pitch, size_t src_stride, uint8_t* d_dst,
                         size_t dst_pitch, size_t dst_stride, int n_images, const float* d_map_x, const float* d_map_y,
                         void* stream);
+
+/* cv2.cvtColor(frame, COLOR_BGR2RGB) on the way in (sr:493, 505) and COLOR_RGB2BGR on the way out (sr:928, 941):
+ * bytes 0 and 2 of every pixel of n_images interleaved u8 images of the ctx's W x H swap.  In place (d_dst == d_src with
+ * equal pitch / stride) is allowed. */
+int mdvt_swap_rb(mdvt_ctx* ctx, const uint8_t* d_src, size_t src_pitch, size_t src_stride, uint8_t* d_dst, size_t dst_pitch,
+                 size_t dst_stride, int n_images, void* stream);
 
 /* stereo_rerender.masked_blur(img, ksize=(6,6), sigma=0) (sr:114-153): a Gaussian that ignores pure black pixels
  * (black stays black).  cv2.getGaussianKernel / cv2.filter2D(BORDER_ISOLATED) by their published definitions: f32

@@ -606,6 +606,19 @@ constexpr int kTeleaChunk = mdvt::kTeleaMaxImages;      // images per pass (18 B
 
 }  // namespace
 
+int mdvt_swap_rb(mdvt_ctx* c, const uint8_t* d_src, size_t src_pitch, size_t src_stride, uint8_t* d_dst, size_t dst_pitch,
+                 size_t dst_stride, int n_images, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_src || !d_dst) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (n_images < 1) return fail(c, MDVT_ERR_INVALID_ARG, "n_images must be >= 1");
+    if (src_pitch < (size_t)3 * c->W || dst_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    DeviceGuard g(c->device);
+    const mdvt::ImageSet in{const_cast<uint8_t*>(d_src), src_pitch, src_stride, 0, n_images}, out{d_dst, dst_pitch, dst_stride, 0, n_images};
+    MDVT_HIP(c, launch_swap_rb(in, out, n_images, c->W, c->H, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
 int mdvt_masked_blur(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, uint8_t* d_out, size_t out_pitch, void* stream)
 {
     if (!c) return MDVT_ERR_INVALID_ARG;

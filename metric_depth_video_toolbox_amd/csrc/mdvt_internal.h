@@ -102,6 +102,7 @@ constexpr int kTeleaMaxImages = 32;  // images per pass
 hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int n, int W, int H, int max_rounds, uint32_t key_rgb,
                              hipStream_t s);
 hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int max_rounds, uint32_t key_rgb, hipStream_t s);
+hipError_t launch_swap_rb(const ImageSet& src, const ImageSet& dst, int n, int W, int H, hipStream_t s);
 struct BlurKernel { float k[36]; };      // masked_blur's 6x6 Gaussian, f32, row major (built on the host in f64)
 hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const ImageSet& out, int n, int W, int H,
                               const BlurKernel& K, uint32_t key_rgb, hipStream_t s);

@@ -1963,6 +1963,28 @@ hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const I
     return hipGetLastError();
 }
 
+// cv2.cvtColor(BGR2RGB / RGB2BGR) of interleaved u8 frames (sr:493, 505, 928, 941): bytes 0 and 2 of every pixel swap.
+template <int PX>
+__global__ void __launch_bounds__(256) k_swap_rb(ImageSet src, ImageSet dst, int W, int H)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
+    if (g >= W / PX) return;
+    uint32_t px[PX];
+    RowIO<PX>::load(src.image(im) + (size_t)y * src.pitch, g, px);
+#pragma unroll
+    for (int q = 0; q < PX; ++q) px[q] = (px[q] & 0x00FF00u) | ((px[q] >> 16) & 0xFFu) | ((px[q] & 0xFFu) << 16);
+    RowIO<PX>::store_rgb(dst.image(im) + (size_t)y * dst.pitch, g, px);
+}
+
+hipError_t launch_swap_rb(const ImageSet& src, const ImageSet& dst, int n, int W, int H, hipStream_t s)
+{
+    const bool vec4 = W % 4 == 0 && ((uintptr_t)src.base % 4 == 0) && ((uintptr_t)dst.base % 4 == 0) && src.pitch % 4 == 0 &&
+                      dst.pitch % 4 == 0 && src.stride % 4 == 0 && dst.stride % 4 == 0;
+    if (vec4) hipLaunchKernelGGL((k_swap_rb<4>), dim3((W / 4 + 255) / 256, H, n), dim3(256), 0, s, src, dst, W, H);
+    else hipLaunchKernelGGL((k_swap_rb<1>), dim3((W + 255) / 256, H, n), dim3(256), 0, s, src, dst, W, H);
+    return hipGetLastError();
+}
+
 // =================================================================================================
 // launch plumbing
 // =================================================================================================

@@ -50,3 +50,23 @@ def encode_depth_frame(depth, max_depth, bgr: bool = True, out=None):
     ctx.check(_lib.load().mdvt_encode_depth(ctx.handle, depth.data_ptr(), 4 * W, out.data_ptr(), 3 * W,
                                             float(max_depth), int(bool(bgr)), C.c_void_p(s.cuda_stream)))
     return out
+
+
+def swap_rb(frames, out=None):
+    """cv2.cvtColor(frame, COLOR_BGR2RGB) / COLOR_RGB2BGR (sr:493, 505, 928, 941) on the device: uint8 CUDA [H,W,3] or
+    [N,H,W,3] (rows / images may be strided) -> the same with bytes 0 and 2 of every pixel swapped.  out may be
+    `frames` itself (in place)."""
+    import torch
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() in (3, 4) and frames.shape[-1] == 3
+    assert frames.stride(-1) == 1 and frames.stride(-2) == 3, "pixels must be packed"
+    batched = frames.dim() == 4
+    N = int(frames.shape[0]) if batched else 1
+    H, W = int(frames.shape[-3]), int(frames.shape[-2])
+    if out is None:
+        out = torch.empty(tuple(frames.shape), dtype=torch.uint8, device=frames.device)
+    assert out.shape == frames.shape and out.stride(-1) == 1 and out.stride(-2) == 3
+    ctx = _ctx(frames.device.index or 0, W, H)
+    s = torch.cuda.current_stream(frames.device)
+    ctx.check(_lib.load().mdvt_swap_rb(ctx.handle, frames.data_ptr(), frames.stride(-3), frames.stride(0) if batched else 0,
+                                       out.data_ptr(), out.stride(-3), out.stride(0) if batched else 0, N, C.c_void_p(s.cuda_stream)))
+    return out

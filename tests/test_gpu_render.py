@@ -894,3 +894,19 @@ def test_randomised_aux_sweep(mods, orc):
         steps = int(rng.choice([2, 8, 30]))
         got = infill_common.mark_lower_side(torch.from_numpy(msk).cuda(), steps)
         assert np.array_equal(got.cpu().numpy(), orc.mark_lower_side(msk, steps)), tag
+
+
+def test_swap_rb_is_cvtcolor_bgr_rgb(mods):
+    """cv2.cvtColor(BGR2RGB / RGB2BGR) (sr:493, 505, 928, 941) = the channel flip img[..., ::-1], batched, strided, in place."""
+    _lib, sr, synthetic = mods
+    from metric_depth_video_toolbox_amd import depth_frames_helper as dfh
+    rng = np.random.default_rng(2)
+    for W, H in ((250, 37), (64, 48), (1920, 8)):
+        img = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+        t = torch.from_numpy(img).cuda()
+        assert np.array_equal(dfh.swap_rb(t).cpu().numpy(), img[..., ::-1])
+        assert np.array_equal(dfh.swap_rb(t[1]).cpu().numpy(), img[1][..., ::-1])
+        half = t[:, :, : W // 2]                                   # strided rows
+        assert np.array_equal(dfh.swap_rb(half).cpu().numpy(), img[:, :, : W // 2, ::-1])
+        dfh.swap_rb(t, out=t)                                       # in place
+        assert np.array_equal(t.cpu().numpy(), img[..., ::-1])
