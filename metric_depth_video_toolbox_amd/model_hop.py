@@ -62,10 +62,13 @@ def depth_to_rgb_code(depth, max_depth: float, out=None):
     if out is None:
         out = torch.empty((N, H, W, 3), dtype=torch.uint8, device=depth.device)
     from .depth_frames_helper import _ctx
-    ctx = _ctx(depth.device.index or 0, W, N * H)
     s = torch.cuda.current_stream(depth.device)
-    ctx.check(_lib.load().mdvt_encode_depth(ctx.handle, depth.data_ptr(), 4 * W, out.data_ptr(), 3 * W,
-                                            float(max_depth), 0, C.c_void_p(s.cuda_stream)))
+    group = max(1, 32767 // H)                      # a context takes at most 32767 rows
+    for a in range(0, N, group):
+        n = min(group, N - a)
+        ctx = _ctx(depth.device.index or 0, W, n * H)
+        ctx.check(_lib.load().mdvt_encode_depth(ctx.handle, depth[a].data_ptr(), 4 * W, out[a].data_ptr(), 3 * W,
+                                                float(max_depth), 0, C.c_void_p(s.cuda_stream)))
     return out
 
 

@@ -38,3 +38,16 @@ def test_depth_model_feeds_the_render_kernels_on_one_stream(orc):
         assert np.array_equal(mask[:, :W], want["left_mask"]) and np.array_equal(mask[:, W:], want["right_mask"])
         assert np.array_equal(sbs[:, :W], want["left_rgb"]) and np.array_equal(sbs[:, W:], want["right_rgb"])
     r.close()
+
+
+def test_depth_to_rgb_code_on_batches_taller_than_one_context(orc):
+    """40 frames of 1080 rows exceed the 32767-row limit of one context: the batch is encoded in groups, every frame
+    still equals the reference encoder (dfh:5-11, 48-61)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from metric_depth_video_toolbox_amd import model_hop
+    rng = np.random.default_rng(9)
+    d = rng.uniform(0, 25, (40, 1080, 64)).astype(np.float32)
+    got = model_hop.depth_to_rgb_code(torch.from_numpy(d).cuda(), 20).cpu().numpy()
+    for k in (0, 29, 30, 39):
+        assert np.array_equal(got[k], orc.encode_depth(d[k], 20))
