@@ -33,6 +33,30 @@ __global__ void __launch_bounds__(TPB) k_pattern_rows(const uint8_t* d, const ui
     }
 }
 
+// the same with non-temporal loads and stores (NT bit 0 loads, bit 1 stores)
+template <int TPB, int NT>
+__global__ void __launch_bounds__(TPB) k_pattern_rows_nt(const uint8_t* d, const uint8_t* c, uint8_t* sbs, uint8_t* mask, int W, int H)
+{
+    const int fr = blockIdx.x / H, i = blockIdx.x - fr * H;
+    const uint32_t* dr = (const uint32_t*)(d + ((size_t)fr * H + i) * 3 * W);
+    const uint32_t* cr = (const uint32_t*)(c + ((size_t)fr * H + i) * 3 * W);
+    uint32_t* l = (uint32_t*)(sbs + ((size_t)fr * H + i) * 6 * W);
+    uint32_t* r = l + 3 * W / 4;
+    uint32_t* ml = (uint32_t*)(mask + ((size_t)fr * H + i) * 2 * W);
+    uint32_t* mr = ml + W / 4;
+#define LD(p) ((NT & 1) ? __builtin_nontemporal_load(p) : *(p))
+#define ST(v, p) do { if (NT & 2) __builtin_nontemporal_store((uint32_t)(v), p); else *(p) = (v); } while (0)
+    for (int g = threadIdx.x; g < W / 4; g += TPB) {
+        uint32_t a0 = LD(dr + 3 * g), a1 = LD(dr + 3 * g + 1), a2 = LD(dr + 3 * g + 2);
+        uint32_t b0 = LD(cr + 3 * g), b1 = LD(cr + 3 * g + 1), b2 = LD(cr + 3 * g + 2);
+        ST(a0 ^ b0, l + 3 * g); ST(a1 ^ b1, l + 3 * g + 1); ST(a2 ^ b2, l + 3 * g + 2);
+        ST(a0 + b0, r + 3 * g); ST(a1 + b1, r + 3 * g + 1); ST(a2 + b2, r + 3 * g + 2);
+        ST(a0 & b1, ml + g); ST(a2 | b0, mr + g);
+    }
+#undef LD
+#undef ST
+}
+
 // flat grid-stride version of the same traffic
 __global__ void k_pattern_flat(const uint32_t* d, const uint32_t* c, uint32_t* l, uint32_t* r, uint32_t* ml, uint32_t* mr, size_t ngroups)
 {
@@ -90,6 +114,16 @@ int main()
         printf("pattern rows TPB=512                      : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL(k_pattern_rows<128>, dim3(N * H), dim3(128), 0, 0, d, c, sbs, mask, W, H); }, 20);
         printf("pattern rows TPB=128                      : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
+    }
+    {
+        float ms = time_ms([&] { hipLaunchKernelGGL((k_pattern_rows_nt<512, 1>), dim3(N * H), dim3(512), 0, 0, d, c, sbs, mask, W, H); }, 20);
+        printf("pattern rows TPB=512, nt loads            : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_pattern_rows_nt<512, 2>), dim3(N * H), dim3(512), 0, 0, d, c, sbs, mask, W, H); }, 20);
+        printf("pattern rows TPB=512, nt stores           : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_pattern_rows_nt<512, 3>), dim3(N * H), dim3(512), 0, 0, d, c, sbs, mask, W, H); }, 20);
+        printf("pattern rows TPB=512, nt loads + stores   : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_pattern_rows_nt<256, 3>), dim3(N * H), dim3(256), 0, 0, d, c, sbs, mask, W, H); }, 20);
+        printf("pattern rows TPB=256, nt loads + stores   : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
     }
     for (int blocks : {1024, 2048, 4096, 8192}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(k_pattern_flat, dim3(blocks), dim3(256), 0, 0, (const uint32_t*)d, (const uint32_t*)c,
