@@ -1716,8 +1716,17 @@ __global__ void __launch_bounds__(256) k_telea_levels(TeleaArgs a, uint32_t r)
             act = r <= a.last_round[t.im];                                  // the image's holes were all reached earlier
         }
         if (act) {
+            // T of the pixel (FastMarching_solve over the four quadrants) depends on levels and earlier T only, not on
+            // colours: computed here, once, by one lane -- the fill pass just reads it
+            const size_t ib = (size_t)t.im * npx;
+            const TeleaView s{a.stamp + ib, a.T + ib, a.img + 3 * ib, W, H, r};
+            float tv = s.solve(t.x, t.y - 1, t.x - 1, t.y);
+            tv = fminf(tv, s.solve(t.x, t.y + 1, t.x - 1, t.y));
+            tv = fminf(tv, s.solve(t.x, t.y - 1, t.x + 1, t.y));
+            tv = fminf(tv, s.solve(t.x, t.y + 1, t.x + 1, t.y));
+            a.T[t.e] = tv;
             a.stamp[t.e] = (uint16_t)r;
-            const bool green = load_px_bytes(a.img + 3 * (size_t)t.im * npx, (int)t.o) == a.key_rgb;
+            const bool green = load_px_bytes(a.img + 3 * ib, (int)t.o) == a.key_rgb;
             if (green) atomicAdd(&reached[t.im], 1u);                       // LDS; one global atomic per (block, image) at the end
         }
         const int nx[4] = {t.x - 1, t.x + 1, t.x, t.x}, ny[4] = {t.y, t.y, t.y - 1, t.y + 1};
@@ -1823,11 +1832,8 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
             const int y = (int)(o / (uint32_t)W), x = (int)(o - (uint32_t)y * (uint32_t)W);
             const size_t ib = (size_t)im * npx;
             TeleaView s{a.stamp + ib, a.T + ib, a.img + 3 * ib, W, H, r};
-            // T of the pixel and its gradient: every lane computes them (same addresses: one broadcast fetch)
-            float t = s.solve(x, y - 1, x - 1, y);
-            t = fminf(t, s.solve(x, y + 1, x - 1, y));
-            t = fminf(t, s.solve(x, y - 1, x + 1, y));
-            t = fminf(t, s.solve(x, y + 1, x + 1, y));
+            // T of the pixel (from the levels pass) and its gradient: every lane reads them (same addresses: one broadcast fetch)
+            const float t = a.T[e];
             float gtx, gty;
             if (s.known(x + 1, y)) gtx = s.known(x - 1, y) ? (s.t(x + 1, y) - s.t(x - 1, y)) * 0.5f : s.t(x + 1, y) - t;
             else gtx = s.known(x - 1, y) ? t - s.t(x - 1, y) : 0.0f;
@@ -1892,10 +1898,7 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
             if (v > 255.0f) v = 255.0f;
             const uint32_t byte = (uint32_t)v;
             const uint32_t out = __shfl(byte, hbase) | (__shfl(byte, hbase + 1) << 8) | (__shfl(byte, hbase + 2) << 16);
-            if (lane32 == 0) {
-                a.T[e] = t;
-                store_px_bytes(a.img + 3 * ib, (int)o, out);
-            }
+            if (lane32 == 0) store_px_bytes(a.img + 3 * ib, (int)o, out);
         }
         __syncthreads();
     }
