@@ -1623,6 +1623,8 @@ __device__ __forceinline__ void telea_append(bool want, uint32_t idx, uint32_t* 
     if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
 }
 
+// T and `queued` are zeroed with memsets beforehand; this pass writes the level stamps, the need flags, the work image
+// and level 1 (one list append per block, not per wave: same-address atomics serialise).
 __global__ void __launch_bounds__(256) k_telea_init(ImageSet seed, TeleaArgs a)
 {
     const size_t seed_pitch = seed.pitch;
@@ -1642,16 +1644,29 @@ __global__ void __launch_bounds__(256) k_telea_init(ImageSet seed, TeleaArgs a)
         green = px == key_rgb;
         const bool unk = green || px == 0u;
         a.stamp[o] = unk ? kTeleaUnknown : (uint16_t)0;
-        a.T[o] = 0.0f;
         a.need[o] = green ? 1 : 0;
         store_px_bytes(a.img + 3 * ((size_t)im * W * H + (size_t)y * W), x, px);
         front = unk && ((x > 0 && !masked(x - 1, y)) || (x + 1 < W && !masked(x + 1, y)) ||
                         (y > 0 && !masked(x, y - 1)) || (y + 1 < H && !masked(x, y + 1)));
-        a.queued[o] = front ? 1u : 0u;
+        if (front) a.queued[o] = 1u;
     }
-    telea_append(front, (uint32_t)o, a.list, &a.counts[1]);            // level 1 starts at offset 0
-    const u64 m = __ballot(green);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.remaining[im], (uint32_t)__popcll(m));
+    __shared__ uint32_t wave_front[4], wave_green[4], block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 mf = __ballot(front), mg = __ballot(green);
+    if (lane == 0) { wave_front[wave] = (uint32_t)__popcll(mf); wave_green[wave] = (uint32_t)__popcll(mg); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nf = wave_front[0] + wave_front[1] + wave_front[2] + wave_front[3];
+        const uint32_t ng = wave_green[0] + wave_green[1] + wave_green[2] + wave_green[3];
+        block_base = nf ? atomicAdd(&a.counts[1], nf) : 0u;                 // level 1 starts at offset 0
+        if (ng) atomicAdd(&a.remaining[im], ng);
+    }
+    __syncthreads();
+    if (front) {
+        uint32_t pos = block_base + (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) pos += wave_front[w];
+        a.list[pos] = (uint32_t)o;
+    }
 }
 
 __global__ void k_telea_begin(TeleaArgs a)
@@ -1963,6 +1978,9 @@ hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(ws.counts, 0, 2 * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts and offs (adjacent)
     if (e != hipSuccess) return e;
+    const size_t npx = (size_t)n * W * H;
+    if ((e = hipMemsetAsync(ws.T, 0, npx * sizeof(float), s)) != hipSuccess) return e;           // T = 0 at every known pixel
+    if ((e = hipMemsetAsync(ws.queued, 0, npx * sizeof(uint32_t), s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_telea_init, dim3((W + 255) / 256, H, n), dim3(256), 0, s, seed, a);
     hipLaunchKernelGGL(k_telea_begin, dim3((n + 63) / 64), dim3(64), 0, s, a);
     return hipGetLastError();
