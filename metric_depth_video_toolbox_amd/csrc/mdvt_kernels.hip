@@ -1871,9 +1871,14 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
                     const float w = fabsf((dst * lev) * dir);
                     const bool xp = s.known(l + 1, kk), xm = s.known(l - 1, kk), yp = s.known(l, kk + 1), ym = s.known(l, kk - 1);
                     const uint8_t* I0 = s.img + 3 * ((size_t)kk * W + l);
-                    const uint32_t c0 = load_px_bytes(I0, 0);
-                    const uint32_t cxp = xp ? load_px_bytes(I0, 1) : 0u, cxm = xm ? load_px_bytes(I0, -1) : 0u;
-                    const uint32_t cyp = yp ? load_px_bytes(I0, W) : 0u, cym = ym ? load_px_bytes(I0, -W) : 0u;
+                    auto px_at = [&](int d) {               // one unaligned dword instead of three byte loads (the work image is padded by 4 bytes)
+                        uint32_t v;
+                        __builtin_memcpy(&v, I0 + 3 * (ptrdiff_t)d, 4);
+                        return v & 0xFFFFFFu;
+                    };
+                    const uint32_t c0 = px_at(0);
+                    const uint32_t cxp = xp ? px_at(1) : 0u, cxm = xm ? px_at(-1) : 0u;
+                    const uint32_t cyp = yp ? px_at(W) : 0u, cym = ym ? px_at(-W) : 0u;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         const int sh = 8 * ch;
