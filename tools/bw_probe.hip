@@ -57,6 +57,29 @@ __global__ void __launch_bounds__(TPB) k_pattern_rows_nt(const uint8_t* d, const
 #undef ST
 }
 
+// R consecutive rows per workgroup (longer contiguous bursts per stream), non-temporal
+template <int TPB, int R>
+__global__ void __launch_bounds__(TPB) k_pattern_multirow_nt(const uint8_t* d, const uint8_t* c, uint8_t* sbs, uint8_t* mask, int W, int H)
+{
+    const size_t row0 = (size_t)blockIdx.x * R;
+    for (int rr = 0; rr < R; ++rr) {
+        const size_t row = row0 + rr;
+        const uint32_t* dr = (const uint32_t*)(d + row * 3 * W);
+        const uint32_t* cr = (const uint32_t*)(c + row * 3 * W);
+        uint32_t* l = (uint32_t*)(sbs + row * 6 * W);
+        uint32_t* r = l + 3 * W / 4;
+        uint32_t* ml = (uint32_t*)(mask + row * 2 * W);
+        uint32_t* mr = ml + W / 4;
+        for (int g = threadIdx.x; g < W / 4; g += TPB) {
+            uint32_t a0 = __builtin_nontemporal_load(dr + 3 * g), a1 = __builtin_nontemporal_load(dr + 3 * g + 1), a2 = __builtin_nontemporal_load(dr + 3 * g + 2);
+            uint32_t b0 = __builtin_nontemporal_load(cr + 3 * g), b1 = __builtin_nontemporal_load(cr + 3 * g + 1), b2 = __builtin_nontemporal_load(cr + 3 * g + 2);
+            __builtin_nontemporal_store(a0 ^ b0, l + 3 * g); __builtin_nontemporal_store(a1 ^ b1, l + 3 * g + 1); __builtin_nontemporal_store(a2 ^ b2, l + 3 * g + 2);
+            __builtin_nontemporal_store(a0 + b0, r + 3 * g); __builtin_nontemporal_store(a1 + b1, r + 3 * g + 1); __builtin_nontemporal_store(a2 + b2, r + 3 * g + 2);
+            __builtin_nontemporal_store(a0 & b1, ml + g); __builtin_nontemporal_store(a2 | b0, mr + g);
+        }
+    }
+}
+
 // flat grid-stride version of the same traffic
 __global__ void k_pattern_flat(const uint32_t* d, const uint32_t* c, uint32_t* l, uint32_t* r, uint32_t* ml, uint32_t* mr, size_t ngroups)
 {
@@ -124,6 +147,14 @@ int main()
         printf("pattern rows TPB=512, nt loads + stores   : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((k_pattern_rows_nt<256, 3>), dim3(N * H), dim3(256), 0, 0, d, c, sbs, mask, W, H); }, 20);
         printf("pattern rows TPB=256, nt loads + stores   : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
+    }
+    {
+        float ms = time_ms([&] { hipLaunchKernelGGL((k_pattern_multirow_nt<512, 2>), dim3(N * H / 2), dim3(512), 0, 0, d, c, sbs, mask, W, H); }, 20);
+        printf("2 rows per WG, TPB=512, nt                : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_pattern_multirow_nt<512, 4>), dim3(N * H / 4), dim3(512), 0, 0, d, c, sbs, mask, W, H); }, 20);
+        printf("4 rows per WG, TPB=512, nt                : %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_pattern_multirow_nt<1024, 2>), dim3(N * H / 2), dim3(1024), 0, 0, d, c, sbs, mask, W, H); }, 20);
+        printf("2 rows per WG, TPB=1024 (2 rows in flight): %.1f us  %.2f TB/s\n", ms * 1e3, bytes / ms / 1e9);
     }
     for (int blocks : {1024, 2048, 4096, 8192}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(k_pattern_flat, dim3(blocks), dim3(256), 0, 0, (const uint32_t*)d, (const uint32_t*)c,
