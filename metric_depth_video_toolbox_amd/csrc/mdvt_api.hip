@@ -340,12 +340,8 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     }
     // The arithmetic of a frame (pure shift or general) is its own property, never its batch
     // neighbours': consecutive frames of one kind form a run, every run gets its own launches.
-    struct Run { int f0, f1, general; };
+    struct Run { int f0, f1, general; };        // general here = "takes the global-key kernels"
     std::vector<Run> runs;
-    for (int k = 0; k < n_frames; ++k) {
-        if (runs.empty() || runs.back().general != fd[(size_t)k].general) runs.push_back({k, k + 1, fd[(size_t)k].general});
-        else runs.back().f1 = k + 1;
-    }
 
     const FrameDev* dfp = nullptr;
     ParamSlot* slot = nullptr;
@@ -365,6 +361,16 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                 (!zout || ((!io->left_depth || aligned(io->left_depth, 16)) && (!io->right_depth || aligned(io->right_depth, 16)) &&
                            io->zout_pitch % 16 == 0 && io->zout_stride % 16 == 0));
 
+    // A pure-shift frame wider than the LDS row kernels can hold (10 240 px for points, ~4 300 for the mesh with edge
+    // points) is rendered by the global-key kernels instead -- with its own pure-shift arithmetic (FrameDev.general
+    // stays 0), so the pixels do not depend on which kernels ran.  MDVT_FORCE_GLOBAL=1 sends every frame that way (tests).
+    const bool wide = !mdvt::render_fits_lds(plan, W) || getenv("MDVT_FORCE_GLOBAL") != nullptr;
+    if (wide) general = 1;
+    for (int k = 0; k < n_frames; ++k) {
+        const int g = (wide || fd[(size_t)k].general) ? 1 : 0;
+        if (runs.empty() || runs.back().general != g) runs.push_back({k, k + 1, g});
+        else runs.back().f1 = k + 1;
+    }
     const bool need_keys = general != 0;
     const bool need_ekeys = general && plan.edge_points;
     const bool need_gverts = general && plan.mode == MDVT_MODE_MESH;

@@ -78,6 +78,35 @@ __device__ __forceinline__ Vert vertex_general(const FrameDev& f, const float* M
     return o;
 }
 
+// The frame's own arithmetic for kernels that serve both kinds of frame: the general 3x4 map, or
+// for a pure-shift frame u = gx +- dl/Z, v = gy exactly as the LDS row kernels evaluate it (frames too wide for
+// their LDS z-buffers are rendered by the global-key kernels and must not change a bit because of it).
+__device__ __forceinline__ Vert vertex_for_eye(const FrameDev& f, int eye, float gx, float gy, float z, float xc, float yc)
+{
+    if (f.general) return vertex_general(f, f.M[eye], xc, yc, z);
+    Vert o;
+    const float d = f.dl / z;
+    o.u = eye == 0 ? gx + d : gx - d;
+    o.v = gy;
+    o.z = z;
+    o.ok = z > kNear;
+    return o;
+}
+
+// Edge point (sr:599-600, 746) of vertex (i, j): screen position before rounding.
+__device__ __forceinline__ Vert edge_point_for_eye(const FrameDev& f, int eye, int i, float gx, float z, float xc, float yc)
+{
+    if (f.general) return vertex_general(f, f.M[eye], xc * f.sW, yc * f.sH, z);
+    Vert o;
+    const float ex = ((gx - f.cx) * f.sW) + f.cx;
+    const float d = f.dl / z;
+    o.u = eye == 0 ? ex + d : ex - d;
+    o.v = (float)i;                      // the exact-arithmetic row i*(1-1/H^2)+1/2 rounds to i (decree)
+    o.z = z;
+    o.ok = z > kNear;
+    return o;
+}
+
 // ---- rasteriser pieces --------------------------------------------------------------------
 // Snapped coordinates are int32 (|x| <= 2^21 px * 256 = 2^29), so every coordinate difference fits
 // int32 and every product below is one 32x32->64 multiply (v_mad_i64_i32).

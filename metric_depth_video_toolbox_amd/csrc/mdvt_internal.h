@@ -109,5 +109,6 @@ hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const I
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 size_t render_lds_bytes(const RenderPlan& plan, int W);
+bool render_fits_lds(const RenderPlan& plan, int W);      // can the pure-shift row kernels hold a row of this width in LDS?
 
 }  // namespace mdvt

@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
         if (EDGE_ONLY) return;
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
-            const Vert v = vertex_general(fp, fp.M[eye], xc, yc, z);
+            const Vert v = vertex_for_eye(fp, eye, gx, gy, z, xc, yc);
             if (!v.ok) continue;
             if (!(v.u >= 0.0f && v.u < (float)W && v.v >= 0.0f && v.v < (float)H)) continue;
             const int px = (int)floorf(v.u), py = (int)floorf(v.v);
@@ -759,10 +759,9 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
             atomicMin(&a.keys[eye][(size_t)fr * a.ws_stride_px + (size_t)py * W + px], key);
         }
     } else if (EDGE) {
-        const float xe = xc * fp.sW, ye = yc * fp.sH;        // sr:599-600
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
-            const Vert v = vertex_general(fp, fp.M[eye], xe, ye, z);
+            const Vert v = edge_point_for_eye(fp, eye, i, gx, z, xc, yc);        // sr:599-600
             if (!v.ok) continue;
             if (!(v.u > -1.0f && v.u < (float)W + 1.0f && v.v > -1.0f && v.v < (float)H + 1.0f)) continue;
             const int px = (int)rintf(v.u), py = (int)rintf(v.v);   // np.round (sr:746)
@@ -1247,10 +1246,11 @@ __global__ void __launch_bounds__(256) k_mesh_vertices_general(RenderArgs a)
     const float z = decode_z(code16_of(load_px_bytes(drow, j)), fp.mult, fp.scale);
     const uint32_t rgb = load_px_bytes(crow, j);
     float xc, yc;
-    camera_point(fp, (float)j * fp.sx, (float)i * fp.sy, z, xc, yc);
+    const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
+    camera_point(fp, gx, gy, z, xc, yc);
 #pragma unroll
     for (int eye = 0; eye < 2; ++eye) {
-        const Vert v = vertex_general(fp, fp.M[eye], xc, yc, z);
+        const Vert v = vertex_for_eye(fp, eye, gx, gy, z, xc, yc);
         const float iz = v.ok ? 1.0f / v.z : 0.0f;          // 0 flags a vertex behind the near plane
         a.gverts[eye][(size_t)fr * a.ws_stride_px + (size_t)i * W + j] =
             make_uint4((uint32_t)snap(v.u), (uint32_t)snap(v.v), __float_as_uint(iz), rgb);
@@ -2042,6 +2042,13 @@ hipError_t launch_swap_rb(const ImageSet& src, const ImageSet& dst, int n, int W
 // =================================================================================================
 
 constexpr size_t kMaxLds = 160 * 1024;
+
+bool render_fits_lds(const RenderPlan& plan, int W)
+{
+    RenderPlan p = plan;
+    p.general = 0;
+    return render_lds_bytes(p, W) <= kMaxLds;
+}
 
 size_t render_lds_bytes(const RenderPlan& plan, int W)
 {

@@ -295,19 +295,60 @@ def test_errors_are_reported_not_swallowed(mods):
 
 @pytest.mark.parametrize("W,H,infill", [(3840, 40, True), (3840, 40, False), (4600, 24, True), (5000, 24, False)])
 def test_mesh_wide_frames_use_compact_lds_vertices(mods, orc, W, H, infill):
-    """Row widths whose 16-byte LDS vertex rows would exceed 160 KB take the 12-byte variant."""
+    """Row widths whose 16-byte LDS vertex rows would exceed 160 KB take the 12-byte variant; beyond that (4600 px with
+    edge points) the frame goes to the global-key kernels -- with the same pure-shift arithmetic, so nothing changes."""
     _lib, sr, synthetic = mods
     depth_rgb, color = _scene(synthetic, W, H, seed=W + H, n_fg=10)
     r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=infill)
     p = r.frame_params(xfov=45.0)
-    if W * 36 > 160 * 1024 and infill:
-        with pytest.raises(_lib.MdvtError) as e:
-            r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p)
-        assert e.value.code == -3
-    else:
-        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
-        _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"wide mesh {W}")
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"wide mesh {W}")
     r.close()
+
+
+@pytest.mark.parametrize("W,H", [(20000, 4), (65535, 2), (12, 3000), (2, 32767)])
+def test_extreme_frame_shapes(mods, orc, W, H):
+    """The largest width / height a context takes, every mode: rows too wide for the LDS z-buffers (10 240 px for
+    points) are rendered by the global-key kernels with the frame's own pure-shift arithmetic -- bit-exact as ever."""
+    _lib, sr, synthetic = mods
+    rng = np.random.default_rng(W + H)
+    for mesh in (False, True):
+        for infill in (False, True):
+            d = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            d[..., 0] = rng.integers(2, 40, (H, W))
+            c = rng.integers(1, 256, (H, W, 3), dtype=np.uint8)
+            r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not mesh, infill_mask=infill)
+            p = r.frame_params(xfov=60.0)
+            got = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), p, want_depth=True)
+            _compare(got, _oracle(orc, r, p, d, c), W, f"{W}x{H} mesh={mesh} infill={infill}")
+            r.close()
+    with pytest.raises(_lib.MdvtError):
+        _lib.Context(0, 65536, 2)
+    with pytest.raises(_lib.MdvtError):
+        _lib.Context(0, 2, 32768)
+
+
+def test_global_key_kernels_keep_the_pure_shift_arithmetic(mods, orc, monkeypatch):
+    """MDVT_FORCE_GLOBAL=1 routes pure-shift frames through the kernels of the general path (as too-wide frames are);
+    the frame's arithmetic is its own, so every plane still equals the oracle's pure-shift evaluation."""
+    _lib, sr, synthetic = mods
+    monkeypatch.setenv("MDVT_FORCE_GLOBAL", "1")
+    for W, H in ((250, 37), (64, 48)):
+        depth_rgb, color = _scene(synthetic, W, H, seed=5)
+        for mesh in (False, True):
+            for infill in (False, True):
+                r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not mesh, infill_mask=infill)
+                p = r.frame_params(xfov=45.0)
+                got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True, want_seed=infill)
+                op = orc.make_params(W, H, _K(p), ipd_m=0.065, depth_scale=p.depth_scale, mode=orc.MODE_MESH if mesh else orc.MODE_POINTS,
+                                     remove_edges=r.remove_edges, edge_points=int(r.edge_points), key_rgb=r.key_rgb)
+                assert op.general == 0
+                want = orc.render_stereo(op, depth_rgb, color, want_depth=True, want_seed=infill)
+                _compare({k: got[k] for k in ("sbs", "mask", "depth")}, want, W, f"forced global mesh={mesh} infill={infill}")
+                if infill:
+                    assert np.array_equal(got["seed"][:, :W].cpu().numpy(), want["left_seed"])
+                    assert np.array_equal(got["seed"][:, W:].cpu().numpy(), want["right_seed"])
+                r.close()
 
 
 @pytest.mark.parametrize("kind", ["points_fast", "points_edges", "mesh", "points_general", "odd_width"])
