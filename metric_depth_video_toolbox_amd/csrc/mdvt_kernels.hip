@@ -2054,7 +2054,7 @@ size_t render_lds_bytes(const RenderPlan& plan, int W)
 {
     if (plan.general) return 0;
     if (plan.mode == MDVT_MODE_POINTS) {
-        size_t b = 2 * (size_t)W * sizeof(u64);
+        size_t b = (2 * (size_t)W + 2) * sizeof(u64) + 64;       // + the trash word and the per-wave counters of the fast kernel
         if (plan.edge_points) b += 2 * (size_t)W * sizeof(uint32_t);
         return b;
     }

@@ -953,3 +953,22 @@ def test_swap_rb_is_cvtcolor_bgr_rgb(mods):
         assert np.array_equal(dfh.swap_rb(half).cpu().numpy(), img[:, :, : W // 2, ::-1])
         dfh.swap_rb(t, out=t)                                       # in place
         assert np.array_equal(t.cpu().numpy(), img[..., ::-1])
+
+
+@pytest.mark.parametrize("W", [10236, 10240, 6824, 6828, 4296, 4300, 5120])
+def test_widths_around_the_lds_limits(mods, orc, W):
+    """The last widths whose rows fit the LDS z-buffers and the first that do not (points 10 240 / 6 826 with edge points,
+    mesh 5 120 / ~4 300): both sides of every switch-over render, and render the same thing."""
+    _lib, sr, synthetic = mods
+    rng = np.random.default_rng(W)
+    H = 3
+    for mesh in (False, True):
+        for infill in (False, True):
+            d = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            d[..., 0] = rng.integers(2, 40, (H, W))
+            c = rng.integers(1, 256, (H, W, 3), dtype=np.uint8)
+            r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not mesh, infill_mask=infill)
+            p = r.frame_params(xfov=60.0)
+            got = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), p, want_depth=True)
+            _compare(got, _oracle(orc, r, p, d, c), W, f"W={W} mesh={mesh} infill={infill}")
+            r.close()
