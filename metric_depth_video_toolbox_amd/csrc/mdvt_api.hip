@@ -264,7 +264,7 @@ int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flag
 static void free_telea(mdvt_ctx* c)
 {
     mdvt::TeleaWorkspace& w = c->telea;
-    void* ptrs[] = {w.stamp, w.T, w.img, w.queued, w.need, w.list, w.counts, w.remaining, w.last_round};      // offs lives inside counts
+    void* ptrs[] = {w.stamp, w.T, w.img, w.queued, w.need, w.list, w.nlist, w.counts, w.remaining, w.last_round};   // offs / ncounts live inside counts
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = mdvt::TeleaWorkspace{};
     c->telea_images = 0; c->telea_rounds = 0;
@@ -669,12 +669,14 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
         MDVT_HIP(c, hipMalloc((void**)&w.queued, (size_t)images * npx * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.need, (size_t)images * npx));
         MDVT_HIP(c, hipMalloc((void**)&w.list, (size_t)images * npx * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.counts, 2 * ((size_t)rounds + 2) * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.nlist, (size_t)images * npx * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.counts, 3 * ((size_t)rounds + 2) * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.remaining, (size_t)kTeleaChunk * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.last_round, (size_t)kTeleaChunk * sizeof(uint32_t)));
         c->telea_images = images; c->telea_rounds = rounds;
     }
     c->telea.offs = c->telea.counts + (max_rounds + 2);
+    c->telea.ncounts = c->telea.offs + (max_rounds + 2);
     const uint32_t key = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     const mdvt::BlurKernel K = masked_blur_kernel();
     const int eyes = d_seed_right ? 2 : 1;

@@ -1603,8 +1603,10 @@ struct TeleaArgs {
     uint32_t* queued;                             // [n][H*W] nonzero once a pixel has been appended to a level
     uint8_t* need;                                // [n][H*W]
     uint32_t* list;                               // all levels back to back, capacity n*H*W
+    uint32_t* nlist;                              // the needed pixels of each level, compacted (same offsets as `list`)
     uint32_t* counts;                             // [max_rounds + 2] level sizes
     uint32_t* offs;                               // [max_rounds + 2] level offsets into `list`
+    uint32_t* ncounts;                            // [max_rounds + 2] needed pixels per level
     uint32_t* remaining;                          // [n] key-coloured pixels not reached yet
     uint32_t* last_round;                         // [n]
     int W, H, n;
@@ -1792,25 +1794,48 @@ __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
     const uint32_t count = a.counts[r], off = a.offs[r];
     const int W = a.W, H = a.H;
     const uint32_t npx = (uint32_t)W * (uint32_t)H;
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
-        const TeleaEntry t = telea_entry(a, off, idx);
-        if (!a.need[t.e] || a.stamp[t.e] != (uint16_t)r) continue;
-        const size_t ib = (size_t)t.im * npx;
+    // The need flags of level r are final here (only higher levels set them), so this pass also compacts the needed
+    // pixels of the level into nlist: the fill pass then spreads exactly those over its half-waves.
+    __shared__ uint32_t wave_cnt[4], block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t bbase = blockIdx.x * blockDim.x; bbase < count; bbase += gridDim.x * blockDim.x) {       // block-uniform
+        const uint32_t idx = bbase + threadIdx.x;
+        TeleaEntry t{};
+        bool needed = false;
+        if (idx < count) {
+            t = telea_entry(a, off, idx);
+            needed = a.need[t.e] && a.stamp[t.e] == (uint16_t)r;
+        }
+        if (needed) {
+            const size_t ib = (size_t)t.im * npx;
 #pragma unroll
-        for (int dy = -4; dy <= 4; ++dy)
+            for (int dy = -4; dy <= 4; ++dy)
 #pragma unroll
-            for (int dx = -4; dx <= 4; ++dx) {
-                if (abs(dx) + abs(dy) > 5 || (abs(dx) == 4 && abs(dy) > 1) || (abs(dy) == 4 && abs(dx) > 1)) continue;   // what telea_pixel reads
-                const int xx = t.x + dx, yy = t.y + dy;
-                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-                const size_t u = ib + (size_t)yy * W + xx;
-                const uint32_t su = a.stamp[u];
-                if (su != 0u && su < r) a.need[u] = 1;
-            }
+                for (int dx = -4; dx <= 4; ++dx) {
+                    if (abs(dx) + abs(dy) > 5 || (abs(dx) == 4 && abs(dy) > 1) || (abs(dy) == 4 && abs(dx) > 1)) continue;   // what the estimate reads
+                    const int xx = t.x + dx, yy = t.y + dy;
+                    if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                    const size_t u = ib + (size_t)yy * W + xx;
+                    const uint32_t su = a.stamp[u];
+                    if (su != 0u && su < r) a.need[u] = 1;
+                }
+        }
+        const u64 m = __ballot(needed);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            block_base = tot ? atomicAdd(&a.ncounts[r], tot) : 0u;
+        }
+        __syncthreads();
+        if (needed) {
+            uint32_t pos = block_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+            a.nlist[off + pos] = t.e;
+        }
+        __syncthreads();
     }
 }
-
-constexpr uint32_t kFillEntries = 64;
 
 // The radius-3 disc without its centre, in the oracle's row-major order (28 pixels).
 __device__ __constant__ const int8_t kDiscDx[32] = {0, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2, -3, -2, -1, 1, 2, 3, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2, 0, 0, 0, 0, 0};
@@ -1823,62 +1848,67 @@ __device__ __constant__ const int8_t kDiscDy[32] = {-3, -2, -2, -2, -2, -2, -1, 
 // left-to-right f32 chain as telea_pixel(), so the result is bit-identical to it (and to the oracle).
 __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
 {
-    const uint32_t count = a.counts[r], off = a.offs[r];
+    const uint32_t off = a.offs[r];
     const int W = a.W, H = a.H;
     const uint32_t npx = (uint32_t)W * (uint32_t)H;
-    __shared__ uint32_t todo[256];
-    __shared__ uint32_t n_todo;
     __shared__ float red[8][10][32];
+    // the 9x9 neighbourhood of the pixel a half-wave works on, fetched once and coalesced along its rows (a lane fetching
+    // its own disc pixel and that pixel's neighbours cost ~340 cache-line requests per pixel; this is ~40)
+    __shared__ uint32_t wcol[8][81];
+    __shared__ float wt[8][81];
+    __shared__ uint8_t wkn[8][84];
     const int lane32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
-    // a block takes kFillEntries list entries at a time (about an eighth of them are needed): few enough that its 8
-    // half-waves each get one or two pixels, so a level's time is a couple of pixel latencies whatever its size
-    for (uint32_t bbase = blockIdx.x * kFillEntries; bbase < count; bbase += gridDim.x * kFillEntries) {   // block-uniform
-        if (threadIdx.x == 0) n_todo = 0;
-        __syncthreads();
-        const uint32_t idx = bbase + threadIdx.x;
-        if (threadIdx.x < kFillEntries && idx < count) {
-            const uint32_t e = a.list[off + idx];
-            if (a.need[e] && a.stamp[e] == (uint16_t)r) todo[atomicAdd(&n_todo, 1u)] = e;          // order is irrelevant: pixels of a level are independent
-        }
-        __syncthreads();
-        const uint32_t n = n_todo;
-        for (uint32_t k = hw; k < n; k += 8) {                 // half-wave uniform
-            const uint32_t e = todo[k], im = e / npx, o = e - im * npx;
+    const uint32_t nneed = a.ncounts[r];
+    {
+        // every entry of nlist is a pixel to estimate: they are dealt round-robin to all half-waves of the grid
+        for (uint32_t k = blockIdx.x * 8 + hw; k < nneed; k += gridDim.x * 8) {                 // half-wave uniform
+            const uint32_t e = a.nlist[off + k], im = e / npx, o = e - im * npx;
             const int y = (int)(o / (uint32_t)W), x = (int)(o - (uint32_t)y * (uint32_t)W);
             const size_t ib = (size_t)im * npx;
-            TeleaView s{a.stamp + ib, a.T + ib, a.img + 3 * ib, W, H, r};
-            // T of the pixel (from the levels pass) and its gradient: every lane reads them (same addresses: one broadcast fetch)
-            const float t = a.T[e];
+            const uint16_t* stamp = a.stamp + ib;
+            const float* Tm = a.T + ib;
+            const uint8_t* img = a.img + 3 * ib;
+#pragma unroll
+            for (int q = lane32; q < 81; q += 32) {
+                const int wy = q / 9, wx = q - 9 * wy;
+                const int xx = x - 4 + wx, yy = y - 4 + wy;
+                const bool inb = xx >= 0 && xx < W && yy >= 0 && yy < H;
+                const size_t oo = (size_t)(inb ? yy : y) * W + (inb ? xx : x);
+                uint32_t c;
+                __builtin_memcpy(&c, img + 3 * oo, 4);          // unaligned dword: the work image is padded by 4 bytes
+                wcol[hw][q] = c & 0xFFFFFFu;
+                wt[hw][q] = Tm[oo];
+                wkn[hw][q] = (inb && (uint32_t)stamp[oo] < r) ? 1 : 0;
+            }
+            __builtin_amdgcn_wave_barrier();                   // LDS is in order within a wave: the reads below see these writes
+#define WK(dx, dy) (wkn[hw][((dy) + 4) * 9 + (dx) + 4] != 0)
+#define WT(dx, dy) (wt[hw][((dy) + 4) * 9 + (dx) + 4])
+#define WC(dx, dy) (wcol[hw][((dy) + 4) * 9 + (dx) + 4])
+            // T of the pixel (from the levels pass) and its gradient
+            const float t = WT(0, 0);
             float gtx, gty;
-            if (s.known(x + 1, y)) gtx = s.known(x - 1, y) ? (s.t(x + 1, y) - s.t(x - 1, y)) * 0.5f : s.t(x + 1, y) - t;
-            else gtx = s.known(x - 1, y) ? t - s.t(x - 1, y) : 0.0f;
-            if (s.known(x, y + 1)) gty = s.known(x, y - 1) ? (s.t(x, y + 1) - s.t(x, y - 1)) * 0.5f : s.t(x, y + 1) - t;
-            else gty = s.known(x, y - 1) ? t - s.t(x, y - 1) : 0.0f;
+            if (WK(1, 0)) gtx = WK(-1, 0) ? (WT(1, 0) - WT(-1, 0)) * 0.5f : WT(1, 0) - t;
+            else gtx = WK(-1, 0) ? t - WT(-1, 0) : 0.0f;
+            if (WK(0, 1)) gty = WK(0, -1) ? (WT(0, 1) - WT(0, -1)) * 0.5f : WT(0, 1) - t;
+            else gty = WK(0, -1) ? t - WT(0, -1) : 0.0f;
 
             float term[10];
 #pragma unroll
             for (int c = 0; c < 10; ++c) term[c] = 0.0f;
             if (lane32 < 28) {
                 const int dl = kDiscDx[lane32], dk = kDiscDy[lane32];
-                const int l = x + dl, kk = y + dk;
-                if (s.known(l, kk)) {
+                if (WK(dl, dk)) {
                     const float ry = (float)(-dk), rx = (float)(-dl);
                     const float vl = rx * rx + ry * ry;
                     const float dst = (float)(1.0 / ((double)vl * sqrt((double)vl)));
-                    const float lev = (float)(1.0 / (1.0 + fabs((double)(s.t(l, kk) - t))));
+                    const float lev = (float)(1.0 / (1.0 + fabs((double)(WT(dl, dk) - t))));
                     float dir = rx * gtx + ry * gty;
                     if (fabsf(dir) <= 0.01f) dir = 0.000001f;
                     const float w = fabsf((dst * lev) * dir);
-                    const bool xp = s.known(l + 1, kk), xm = s.known(l - 1, kk), yp = s.known(l, kk + 1), ym = s.known(l, kk - 1);
-                    const uint8_t* I0 = s.img + 3 * ((size_t)kk * W + l);
-                    auto px_at = [&](int d) {               // one unaligned dword instead of three byte loads (the work image is padded by 4 bytes)
-                        uint32_t v;
-                        __builtin_memcpy(&v, I0 + 3 * (ptrdiff_t)d, 4);
-                        return v & 0xFFFFFFu;
-                    };
-                    const uint32_t c0 = px_at(0);
-                    const uint32_t cxp = xp ? px_at(1) : 0u, cxm = xm ? px_at(-1) : 0u;
-                    const uint32_t cyp = yp ? px_at(W) : 0u, cym = ym ? px_at(-W) : 0u;
+                    const bool xp = WK(dl + 1, dk), xm = WK(dl - 1, dk), yp = WK(dl, dk + 1), ym = WK(dl, dk - 1);
+                    const uint32_t c0 = WC(dl, dk);
+                    const uint32_t cxp = xp ? WC(dl + 1, dk) : 0u, cxm = xm ? WC(dl - 1, dk) : 0u;
+                    const uint32_t cyp = yp ? WC(dl, dk + 1) : 0u, cym = ym ? WC(dl, dk - 1) : 0u;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         const int sh = 8 * ch;
@@ -1895,6 +1925,9 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
                     term[9] = w;                               // s  += .
                 }
             }
+#undef WK
+#undef WT
+#undef WC
 #pragma unroll
             for (int c = 0; c < 10; ++c) red[hw][c][lane32] = term[c];
             __builtin_amdgcn_wave_barrier();                   // the half-wave's LDS writes precede its reads (same wave: program order + lgkmcnt)
@@ -1920,7 +1953,6 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
             const uint32_t out = __shfl(byte, hbase) | (__shfl(byte, hbase + 1) << 8) | (__shfl(byte, hbase + 2) << 16);
             if (lane32 == 0) store_px_bytes(a.img + 3 * ib, (int)o, out);
         }
-        __syncthreads();
     }
 }
 
@@ -1971,7 +2003,8 @@ __global__ void __launch_bounds__(256) k_masked_blur(ImageSet imgs, ImageSet see
 
 static TeleaArgs telea_args(const TeleaWorkspace& ws, int n, int W, int H, uint32_t key_rgb)
 {
-    return TeleaArgs{ws.stamp, ws.T, ws.img, ws.queued, ws.need, ws.list, ws.counts, ws.offs, ws.remaining, ws.last_round, W, H, n, key_rgb};
+    return TeleaArgs{ws.stamp, ws.T, ws.img, ws.queued, ws.need, ws.list, ws.nlist, ws.counts, ws.offs, ws.ncounts, ws.remaining, ws.last_round,
+                     W, H, n, key_rgb};
 }
 
 // Per-call part: reset the counters, copy the seeds into the work image, build level 1.
@@ -1981,7 +2014,7 @@ hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int
     const TeleaArgs a = telea_args(ws, n, W, H, key_rgb);
     hipError_t e = hipMemsetAsync(ws.remaining, 0, (size_t)kTeleaMaxImages * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws.counts, 0, 2 * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts and offs (adjacent)
+    e = hipMemsetAsync(ws.counts, 0, 3 * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts, offs and ncounts (adjacent)
     if (e != hipSuccess) return e;
     const size_t npx = (size_t)n * W * H;
     if ((e = hipMemsetAsync(ws.T, 0, npx * sizeof(float), s)) != hipSuccess) return e;           // T = 0 at every known pixel
