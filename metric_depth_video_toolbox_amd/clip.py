@@ -215,6 +215,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         sets.append({
             "h_d": pinned((B, H, W, 3), torch.uint8), "h_c": pinned((B, H, W, 3), torch.uint8),
             "h_sbs": pinned((B, oH, oW, 3), torch.uint8), "h_mask": pinned((B, H, 2 * W), torch.uint8),
+            "h_counts": pinned((B, 2), torch.int32),
             "h_zrgb": pinned((B, H, 2 * W, 3), torch.uint8) if want_zrgb else None,
             "h_seed": pinned((B, H, 2 * W, 3), torch.uint8) if want_infill else None,
             "d_infill": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if (want_seed or want_infill) else None,
@@ -248,9 +249,8 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     def store(st, a, n):
         st["out_done"].synchronize()
         side = pool.submit(store_main, st, a, n)    # the largest output on its own thread
-        m = st["h_mask"][:n].numpy()
-        out_mask[a:a + n] = m
-        h = int(np.count_nonzero(m))
+        out_mask[a:a + n] = st["h_mask"][:n].numpy()
+        h = int(st["h_counts"][:n].sum())           # hole pixels, counted on the device (mdvt_io.hole_counts)
         if want_zrgb:
             out_depth_rgb[a:a + n] = st["h_zrgb"][:n].numpy()
         if want_infill:
@@ -286,7 +286,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         else:
             res = r.render(st["d_d"][:n], st["d_c"][:n], brecs, out_sbs=st["d_sbs"][:n],
                            out_mask=st["d_mask"][:n], want_depth=want_z, out_depth=st["d_z"][:n] if want_z else None,
-                           want_seed=want_seed)
+                           want_seed=want_seed, want_hole_counts=True)
         if want_zrgb:                               # sr:930-939: both eyes through the 16-bit code, B,G,R
             for f in range(n):
                 dfh.encode_depth_frame(st["d_z"][f], clip.max_depth, bgr=True, out=st["d_zrgb"][f])
@@ -312,6 +312,11 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             s_out.wait_event(st["render_done"])
             st["h_sbs"][:n].copy_(main, non_blocking=True)
             st["h_mask"][:n].copy_(st["d_mask"][:n], non_blocking=True)
+            if res is not None:
+                st["h_counts"][:n].copy_(res["hole_counts"], non_blocking=True)
+                res["hole_counts"].record_stream(s_out)
+            else:
+                st["h_counts"][:n].zero_()
             if want_zrgb:
                 st["h_zrgb"][:n].copy_(st["d_zrgb"][:n], non_blocking=True)
             if want_infill and res is not None:
