@@ -194,6 +194,30 @@ __device__ __forceinline__ bool tri_sample(const TriSetup& t, int px, int py, fl
     return true;
 }
 
+// The same for a walk over a small pixel box: the three edge values at one pixel centre, advanced by exact integer
+// steps (one pixel right: w_k -= 256 dy_k; one pixel down: w_k += 256 dx_k) instead of six products per pixel.
+struct TriWalk { i64 w0, w1, w2; };
+__device__ __forceinline__ TriWalk tri_walk_start(const TriSetup& t, int px, int py)
+{
+    const int Xc = px * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
+    return TriWalk{mul64(t.dx0, Yc - t.by0) - mul64(t.dy0, Xc - t.bx0), mul64(t.dx1, Yc - t.by1) - mul64(t.dy1, Xc - t.bx1),
+                   mul64(t.dx2, Yc - t.by2) - mul64(t.dy2, Xc - t.bx2)};
+}
+__device__ __forceinline__ void tri_walk_right(const TriSetup& t, TriWalk& w)
+{
+    w.w0 -= (i64)t.dy0 * kSubpix; w.w1 -= (i64)t.dy1 * kSubpix; w.w2 -= (i64)t.dy2 * kSubpix;
+}
+__device__ __forceinline__ void tri_walk_down(const TriSetup& t, TriWalk& w)
+{
+    w.w0 += (i64)t.dx0 * kSubpix; w.w1 += (i64)t.dx1 * kSubpix; w.w2 += (i64)t.dx2 * kSubpix;
+}
+__device__ __forceinline__ bool tri_walk_sample(const TriSetup& t, const TriWalk& w, float& q0, float& q1, float& q2)
+{
+    if (!(edge_in(w.w0, t.dx0, t.dy0) && edge_in(w.w1, t.dx1, t.dy1) && edge_in(w.w2, t.dx2, t.dy2))) return false;
+    tri_weights(t.area2, t.iz0, t.iz1, t.iz2, w.w0, w.w1, w.w2, q0, q1, q2);
+    return true;
+}
+
 // Perspective-correct colour, rounded half-even to u8 (decree): rint(((q0 c0 + q1 c1) + q2 c2) * (1/iz)).
 __device__ __forceinline__ uint32_t shade_channel(float q0, float q1, float q2, float riz,
                                                   uint32_t c0, uint32_t c1, uint32_t c2)

@@ -1344,13 +1344,19 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                                     atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, A.w, v1.w, v2.w));
                                 }
                             }
-                    } else if (!(a.debug_skip & 16))
-                        for (int py = py0; py <= py1; ++py)
+                    } else if (!(a.debug_skip & 16)) {
+                        TriWalk row = tri_walk_start(t, px0, py0);
+                        for (int py = py0; py <= py1; ++py) {
+                            TriWalk w = row;
                             for (int px = px0; px <= px1; ++px) {
                                 float q0, q1, q2;
-                                if (!tri_sample(t, px, py, q0, q1, q2)) continue;
-                                atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, A.w, v1.w, v2.w));
+                                if (tri_walk_sample(t, w, q0, q1, q2))
+                                    atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, A.w, v1.w, v2.w));
+                                tri_walk_right(t, w);
                             }
+                            tri_walk_down(t, row);
+                        }
+                    }
                 }
             }
             u64 m = (a.debug_skip & 8) ? 0ull : __ballot(big);
