@@ -177,8 +177,16 @@ __device__ __forceinline__ void tri_weights(i64 area2, float iz0, float iz1, flo
                                             float& q0, float& q1, float& q2)
 {
     const bool small = area2 < 0x7FFFFFFFll;                              // 0 <= w_k <= area2 inside
-    const float ra = 1.0f / i64_to_f32(area2, small);
-    const float l0 = i64_to_f32(w0, small) * ra, l1 = i64_to_f32(w1, small) * ra, l2 = i64_to_f32(w2, small) * ra;
+    float fa, f0, f1, f2;
+    if (__ballot(!small) == 0ull) {
+        // every active lane's triangle is small (the rule, except rubber-sheet triangles): one v_cvt_f32_i32 each.  A
+        // per-lane select would make the compiler evaluate the ~10-instruction 64-bit conversion as well, four times.
+        fa = (float)(int)area2; f0 = (float)(int)w0; f1 = (float)(int)w1; f2 = (float)(int)w2;
+    } else {
+        fa = i64_to_f32(area2, small); f0 = i64_to_f32(w0, small); f1 = i64_to_f32(w1, small); f2 = i64_to_f32(w2, small);
+    }
+    const float ra = 1.0f / fa;
+    const float l0 = f0 * ra, l1 = f1 * ra, l2 = f2 * ra;
     q0 = l0 * iz0; q1 = l1 * iz1; q2 = l2 * iz2;
 }
 
