@@ -953,9 +953,11 @@ __device__ __forceinline__ void regular_cell_pixel(const RegularCell& r, int px,
     const bool in1 = e0 >= 0 && ed < 0 && !(r.flags & 1);
     const bool in2 = ed >= 0 && e1 < 0 && !(r.flags & 2);
     if (!(in1 || in2)) return;
-    const i64 area2 = in1 ? mul64(hh, r.XC - r.XB) : mul64(hh, r.XD - r.XA);
-    const i64 w0 = in1 ? mul64(r.XC - r.XB, bb) : -e1;
-    const i64 w1 = in1 ? -ed : mul64(r.XD - r.XA, tt);
+    const int wd = in1 ? r.XC - r.XB : r.XD - r.XA;          // the triangle's horizontal edge (operands selected, not products)
+    const i64 area2 = mul64(hh, wd);
+    const i64 wh = mul64(wd, in1 ? bb : tt);
+    const i64 w0 = in1 ? wh : -e1;
+    const i64 w1 = in1 ? -ed : wh;
     const i64 w2 = in1 ? e0 : ed;
     float q0, q1, q2;
     tri_weights(area2, r.izA, in1 ? r.izB : r.izC, in1 ? r.izC : r.izD, w0, w1, w2, q0, q1, q2);
@@ -991,6 +993,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
     const int Yt = c >= 0 ? snap((float)c * fp.sy) : 0;
     const int Yb = c >= 0 ? snap((float)(c + 1) * fp.sy) : 0;
     const int tt = Yc - Yt, bb = Yb - Yc, hh = Yb - Yt;     // scanline position inside the cell row (sub-pixels)
+    const float tf = c >= 0 ? (float)tt / (float)hh : 0.0f; // scanline height inside the cell row, for the candidate estimate only
 
     // ---- stage the two vertex rows, clear the z-buffer ----
     if (c >= 0 && !(a.debug_skip & 4)) {
@@ -1075,9 +1078,10 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                             // disparity jump.  Candidate pixels from a float estimate of the two crossings,
                             // widened by one pixel (the estimate is good to ~0.1 px inside the snap range); the
                             // exact integer tests in regular_cell_pixel decide.
-                            const float rh = 1.0f / (float)hh;
-                            int q0 = (int)floorf(((float)kcol0 * rh - 128.0f) * (1.0f / 256.0f));
-                            int q1 = (int)floorf(((float)kcol1 * rh - 128.0f) * (1.0f / 256.0f)) + 1;
+                            // crossings XA + (XB-XA) t/h and XD + (XC-XD) t/h from 32-bit conversions (the 64-bit kcol values
+                            // would cost ~10 instructions each to convert); only the estimate, the integer tests decide
+                            int q0 = (int)floorf((((float)XA + (float)(XB - XA) * tf) - 128.0f) * (1.0f / 256.0f));
+                            int q1 = (int)floorf((((float)XD + (float)(XC - XD) * tf) - 128.0f) * (1.0f / 256.0f)) + 1;
                             if (q0 < p0) q0 = p0;
                             if (q1 > p1) q1 = p1;
                             rp0 = q0; rp1 = q1;
