@@ -54,6 +54,8 @@ struct mdvt_ctx {
     bool keys_dirty = false;          // a general-path submission was interrupted between splat and resolve
     uint8_t* tri_invalid = nullptr;
     uint8_t* unused = nullptr;
+    uint32_t* bigq = nullptr;         // general mesh path: queue of large triangles + its counter (last dword)
+    uint32_t bigq_cap = 0;
     uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
     int row_counts_frames = 0;
     // infill-mask completion: per image stamp u16 + T f32 + work image u8x3, and the per-image counters
@@ -215,6 +217,13 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     }
     if (need_gverts && !c->ws_gverts) {
         for (int e = 0; e < 2; ++e) MDVT_HIP(c, hipMalloc((void**)&c->gverts[e], nf * npx * sizeof(uint4)));
+        if (c->bigq) (void)hipFree(c->bigq);
+        c->bigq = nullptr;
+        // room for one large triangle per 8 pixels of a launch set (more than any scene short of white noise produces;
+        // beyond that the owning workgroup rasterises them itself)
+        const size_t cap = nf * npx / 8 + 1024;
+        c->bigq_cap = cap > 0x3FFFFFFFu ? 0x3FFFFFFFu : (uint32_t)cap;
+        MDVT_HIP(c, hipMalloc((void**)&c->bigq, ((size_t)c->bigq_cap * mdvt::kBigRecDwords + 1) * sizeof(uint32_t)));
         c->ws_gverts = true;
     }
     if (need_edges && !c->ws_edges) {
@@ -281,6 +290,7 @@ int mdvt_destroy(mdvt_ctx* c)
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); if (c->gverts[e]) (void)hipFree(c->gverts[e]); }
+    if (c->bigq) (void)hipFree(c->bigq);
     if (c->tri_invalid) (void)hipFree(c->tri_invalid);
     if (c->unused) (void)hipFree(c->unused);
     if (c->row_counts) (void)hipFree(c->row_counts);
@@ -421,6 +431,9 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.ekeys[0] = c->ekeys[0]; a.ekeys[1] = c->ekeys[1];
     a.gverts[0] = c->gverts[0]; a.gverts[1] = c->gverts[1];
     a.tri_invalid = c->tri_invalid; a.unused = c->unused;
+    if (c->bigq && getenv("MDVT_NO_BIGQ") == nullptr) {
+        a.bigq = c->bigq; a.bigq_cap = c->bigq_cap; a.bigq_count = c->bigq + (size_t)c->bigq_cap * mdvt::kBigRecDwords;
+    }
     a.ws_stride_px = (size_t)W * H;
     a.ws_stride_tri = 2 * (size_t)(W - 1) * (H - 1);
 

@@ -51,6 +51,8 @@ struct RenderArgs {
     uint4* gverts[2];            // general mesh path: per-eye projected vertices {X, Y (snapped), 1/Z', rgb}, [slot][H*W]
     uint8_t* tri_invalid;        // [slot][2*(H-1)*(W-1)]
     uint8_t* unused;             // [slot][H*W]
+    // general mesh path: queue of large triangles (records of kBigRecDwords dwords), rasterised by k_mesh_raster_big
+    uint32_t* bigq; uint32_t* bigq_count; uint32_t bigq_cap;
     size_t ws_stride_px;         // H*W (elements) between slots
     size_t ws_stride_tri;        // 2*(H-1)*(W-1)
     int32_t edge_paint;          // 1: edge points are painted into the holes (sr:813-814); 0: seed image only (--do_basic_infill, sr:809-812)
@@ -65,6 +67,8 @@ hipError_t launch_encode_depth(const float* depth, size_t depth_pitch, uint8_t* 
 hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t stride, const FrameDev* fp, int frame0,
                               int n, int W, int H, int of_by_one, uint8_t* tri_invalid, size_t tri_stride,
                               uint8_t* unused, size_t unused_stride, hipStream_t s);
+
+constexpr int kBigRecDwords = 32;    // 25 used: normalised edges, base points, area, 1/Z, pixel box, colours, frame/eye
 
 struct RenderPlan {
     int mode;            // mdvt_mode

@@ -1285,6 +1285,7 @@ __device__ __forceinline__ bool tri_row_range(const TriSetup& t, int py, int px0
 }
 
 constexpr int kSmallBox = 12;      // bounding boxes up to this many pixel centres are walked by the owning lane
+constexpr int kBigQueueMinPix = 256;  // boxes from this many pixel centres on go to the queue of k_mesh_raster_big
 
 // Stage 2: one thread per cell, both triangles, both eyes.  Triangles with a large bounding box (rubber
 // sheet across depth edges, sheared cells) are broadcast lane by lane and rasterised by the whole wave.
@@ -1363,6 +1364,33 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                     }
                 }
             }
+            // Large triangles cluster (a horizontal depth edge under vertical parallax turns a whole row of cells into
+            // them), so the workgroups that own them used to run far longer than the rest.  They go to a queue instead,
+            // which k_mesh_raster_big spreads over the whole chip; only if the queue is full are they rasterised here.
+            if (a.bigq && !(a.debug_skip & 8)) {
+                // (a box of a few hundred pixel centres is cheaper to finish here than to write out and read back)
+                const bool toq = big && (i64)(px1 - px0 + 1) * (py1 - py0 + 1) >= kBigQueueMinPix;
+                const u64 mq = __ballot(toq);
+                if (mq) {
+                    uint32_t base = 0;
+                    const int first = __ffsll((long long)mq) - 1;
+                    if (lane == first) base = atomicAdd(a.bigq_count, (uint32_t)__popcll(mq));
+                    base = __shfl(base, first);
+                    const uint32_t slot = base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+                    if (toq && slot < a.bigq_cap) {
+                        uint32_t* rec = a.bigq + (size_t)slot * kBigRecDwords;
+                        rec[0] = (uint32_t)t.dx0; rec[1] = (uint32_t)t.dy0; rec[2] = (uint32_t)t.dx1; rec[3] = (uint32_t)t.dy1;
+                        rec[4] = (uint32_t)t.dx2; rec[5] = (uint32_t)t.dy2; rec[6] = (uint32_t)t.bx0; rec[7] = (uint32_t)t.by0;
+                        rec[8] = (uint32_t)t.bx1; rec[9] = (uint32_t)t.by1; rec[10] = (uint32_t)t.bx2; rec[11] = (uint32_t)t.by2;
+                        rec[12] = (uint32_t)t.area2; rec[13] = (uint32_t)((u64)t.area2 >> 32);
+                        rec[14] = __float_as_uint(t.iz0); rec[15] = __float_as_uint(t.iz1); rec[16] = __float_as_uint(t.iz2);
+                        rec[17] = (uint32_t)px0; rec[18] = (uint32_t)px1; rec[19] = (uint32_t)py0; rec[20] = (uint32_t)py1;
+                        rec[21] = A.w; rec[22] = v1.w; rec[23] = v2.w;
+                        rec[24] = (uint32_t)fr * 2u + (uint32_t)eye;
+                        big = false;
+                    }
+                }
+            }
             u64 m = (a.debug_skip & 8) ? 0ull : __ballot(big);
             while (m) {
                 const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
@@ -1399,6 +1427,38 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
     }
 }
 
+
+
+// The queued large triangles of one launch, one wave per triangle at a time, dealt round-robin to every wave of the grid.
+__global__ void __launch_bounds__(256) k_mesh_raster_big(RenderArgs a)
+{
+    const int W = a.W;
+    const uint32_t total = min(*a.bigq_count, a.bigq_cap);
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t k = wave; k < total; k += nwaves) {
+        const uint32_t* rec = a.bigq + (size_t)k * kBigRecDwords;
+        TriSetup b;
+        b.dx0 = (int)rec[0]; b.dy0 = (int)rec[1]; b.dx1 = (int)rec[2]; b.dy1 = (int)rec[3]; b.dx2 = (int)rec[4]; b.dy2 = (int)rec[5];
+        b.bx0 = (int)rec[6]; b.by0 = (int)rec[7]; b.bx1 = (int)rec[8]; b.by1 = (int)rec[9]; b.bx2 = (int)rec[10]; b.by2 = (int)rec[11];
+        b.area2 = (i64)(((u64)rec[13] << 32) | rec[12]);
+        b.iz0 = __uint_as_float(rec[14]); b.iz1 = __uint_as_float(rec[15]); b.iz2 = __uint_as_float(rec[16]);
+        const int bx0 = (int)rec[17], bx1 = (int)rec[18], by0 = (int)rec[19], by1 = (int)rec[20];
+        const uint32_t c0 = rec[21], c1 = rec[22], c2 = rec[23];
+        u64* keys = a.keys[rec[24] & 1u] + (size_t)(rec[24] >> 1) * a.ws_stride_px;
+        const int bw = bx1 - bx0 + 1;
+        const i64 npix = (i64)bw * (by1 - by0 + 1);
+        int px = bx0 + lane % bw, py = by0 + lane / bw;        // lanes walk the box in row-major order, 64 pixel centres per step
+        const int sx = 64 % bw, sy = 64 / bw;
+        for (i64 idx = lane; idx < npix; idx += 64) {
+            float q0, q1, q2;
+            if (tri_sample(b, px, py, q0, q1, q2))
+                atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, c0, c1, c2));
+            px += sx; py += sy;
+            if (px > bx1) { px -= bw; ++py; }
+        }
+    }
+}
 // =================================================================================================
 // infill_using_normals (sr:155-240): one thread per pixel, lock-step free ray march
 // =================================================================================================
@@ -2270,9 +2330,14 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
     hipLaunchKernelGGL(k_mesh_vertices_general, grid_v, dim3(256), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
+    if (a.bigq && (e = hipMemsetAsync(a.bigq_count, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
     if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_general<2>), grid_c, dim3(128), 0, s, a);
     else hipLaunchKernelGGL((k_mesh_raster_general<0>), grid_c, dim3(128), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (a.bigq) {
+        hipLaunchKernelGGL(k_mesh_raster_big, dim3(2048), dim3(256), 0, s, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (edge) {
         const dim3 grid_s((a.W + 255) / 256, a.H, plan.n);
         hipLaunchKernelGGL((k_points_splat_general<14>), grid_s, dim3(256), 0, s, a);
