@@ -393,6 +393,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         const int n = r.f1 - r.f0;
         if (!(r.general || plan.remove_edges)) return n;                  // no workspace: the whole run in one launch
         int ws_chunk = (r.general && plan.mode == MDVT_MODE_POINTS) ? 2 : kWorkspaceChunk;
+        if (r.general && plan.mode == MDVT_MODE_MESH) ws_chunk = 2 * kWorkspaceChunk;      // 16: measured -4 % (convergence) / -11 % (pose) vs 8
         if (tuned_chunk) ws_chunk = tuned_chunk;
         return n < ws_chunk ? n : ws_chunk;
     };
