@@ -182,8 +182,9 @@ int mdvt_masked_blur(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, uint
  * to black, then masked_blur.  The inpaint uses Telea's weights as OpenCV publishes them but fills LEVEL BY LEVEL
  * (round r = every unknown pixel with a 4-neighbour known before round r), not in OpenCV's one-pixel-at-a-time
  * heap order -- the parallel form of the fast-marching front; it is not bit-identical to cv2.inpaint.
- * max_rounds (<= 0: 256) bounds the front's travel (in pixels of 4-neighbour distance from the nearest seed); the rounds stop early once no key-coloured pixel is left, and
- * d_remaining (optional, n_images x uint32) receives the number of key-coloured pixels not reached.
+ * max_rounds (<= 0: 256, at most 65000) bounds the front's travel, in pixels of 4-neighbour distance from the nearest
+ * seed; the rounds stop early once no key-coloured pixel is left, and d_remaining (optional, n_images x uint32)
+ * receives the number of key-coloured pixels not reached.  Up to 32 images share one pass (22 B/px of workspace each).
  * The key colour is the ctx's cfg.key_rgb.  d_out may not alias d_seed. */
 int mdvt_finish_infill_mask(mdvt_ctx* ctx, const uint8_t* d_seed, size_t seed_pitch, size_t seed_stride, uint8_t* d_out,
                             size_t out_pitch, size_t out_stride, int n_images, int max_rounds, uint32_t* d_remaining,
