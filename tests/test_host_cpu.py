@@ -225,3 +225,15 @@ def test_output_variants_are_carried_by_the_clip_parameters():
     assert abs(sr.vr180_render_fov(np.array([p.K[k] for k in range(9)]).reshape(3, 3)) - 120.0) < 1e-9
     with pytest.raises(ValueError):
         sr.make_frame_params(1280, 720, 60.0, vr180=True)
+
+
+def test_every_abi_symbol_is_documented():
+    """INTEGRATION.md's symbol map and DESIGN.md's boundary paragraph name every entry point include/mdvt.h declares."""
+    hdr = open(os.path.join(REPO, "include", "mdvt.h")).read()
+    declared = sorted(set(re.findall(r"\b(mdvt_[a-z_]+)\s*\(", hdr)))
+    integ = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    design = open(os.path.join(REPO, "DESIGN.md")).read()
+    for sym in declared:
+        base = sym.replace("_stereo", "").replace("_batch", "")
+        assert sym in integ or base in integ, f"{sym} missing from INTEGRATION.md"
+        assert sym in design or base in design or sym.split("mdvt_")[1].split("_")[0] in design, f"{sym} missing from DESIGN.md"
