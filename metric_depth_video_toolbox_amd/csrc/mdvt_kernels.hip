@@ -1243,28 +1243,54 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 // Stage 1: every vertex is projected ONCE per eye (decode, unproject, 3x4 transform, pinhole, snap, 1/Z')
 // into a 16-byte record; the rasteriser then reads four records per cell instead of recomputing each
 // vertex for all six triangles that share it.
+template <bool STAGED>   // source rows staged through LDS as aligned dwords (else byte loads: any W / alignment)
 __global__ void __launch_bounds__(256) k_mesh_vertices_general(RenderArgs a)
 {
     const int W = a.W;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     const int fr = blockIdx.z;
-    if (j >= W) return;
     const int f = a.frame0 + fr;
     const FrameDev& fp = a.fp[f];
     const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
     const uint8_t* crow = a.color + (size_t)f * a.color_stride + (size_t)i * a.color_pitch;
-    const float z = decode_z(code16_of(load_px_bytes(drow, j)), fp.mult, fp.scale);
-    const uint32_t rgb = load_px_bytes(crow, j);
+    uint32_t dpx, rgb;
+    if (STAGED) {
+        // 256 pixels = 192 dwords per plane; the launcher guarantees 4-byte aligned rows and W % 4 == 0
+        __shared__ uint32_t sd[2][193];
+        const int t = threadIdx.x;
+        const size_t b0 = (size_t)blockIdx.x * 768;
+        const size_t row_bytes = (size_t)W * 3;
+        if (t < 192) {
+            const size_t off = b0 + (size_t)t * 4;
+            if (off < row_bytes) {
+                sd[0][t] = *(const uint32_t*)(drow + off);
+                sd[1][t] = *(const uint32_t*)(crow + off);
+            }
+        }
+        __syncthreads();
+        if (j >= W) return;
+        const int bo = t * 3, w = bo >> 2, sh = (bo & 3) * 8;
+        dpx = (uint32_t)((((u64)sd[0][w + 1] << 32) | sd[0][w]) >> sh) & 0xFFFFFFu;
+        rgb = (uint32_t)((((u64)sd[1][w + 1] << 32) | sd[1][w]) >> sh) & 0xFFFFFFu;
+    } else {
+        if (j >= W) return;
+        dpx = load_px_bytes(drow, j);
+        rgb = load_px_bytes(crow, j);
+    }
+    const float z = decode_z(code16_of(dpx), fp.mult, fp.scale);
     float xc, yc;
     const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
     camera_point(fp, gx, gy, z, xc, yc);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int eye = 0; eye < 2; ++eye) {
         const Vert v = vertex_for_eye(fp, eye, gx, gy, z, xc, yc);
         const float iz = v.ok ? 1.0f / v.z : 0.0f;          // 0 flags a vertex behind the near plane
-        a.gverts[eye][(size_t)fr * a.ws_stride_px + (size_t)i * W + j] =
-            make_uint4((uint32_t)snap(v.u), (uint32_t)snap(v.v), __float_as_uint(iz), rgb);
+        uint4* dst = &a.gverts[eye][(size_t)fr * a.ws_stride_px + (size_t)i * W + j];
+        // streamed: a launch set writes ~1 GB of records before the rasteriser reads the first one back
+        const u32x4 rec = {(uint32_t)snap(v.u), (uint32_t)snap(v.v), __float_as_uint(iz), rgb};
+        __builtin_nontemporal_store(rec, (u32x4*)dst);
     }
 }
 
@@ -2334,7 +2360,13 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
     const bool edge = plan.remove_edges && plan.edge_points;
     hipError_t e;
     const dim3 grid_v((a.W + 255) / 256, a.H, plan.n);
-    hipLaunchKernelGGL(k_mesh_vertices_general, grid_v, dim3(256), 0, s, a);
+    {
+        // rows that are dword-addressable are staged through LDS as aligned dwords; the rest take byte loads
+        const bool aligned = (a.W % 4 == 0) && (a.depth_pitch % 4 == 0) && (a.color_pitch % 4 == 0) && (a.depth_stride % 4 == 0) &&
+                             (a.color_stride % 4 == 0) && ((uintptr_t)a.depth % 4 == 0) && ((uintptr_t)a.color % 4 == 0);
+        if (aligned) hipLaunchKernelGGL(k_mesh_vertices_general<true>, grid_v, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_mesh_vertices_general<false>, grid_v, dim3(256), 0, s, a);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
     if (a.bigq && (e = hipMemsetAsync(a.bigq_count, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
