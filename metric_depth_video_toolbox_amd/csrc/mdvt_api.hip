@@ -115,6 +115,7 @@ int fill_frame_dev(mdvt_ctx* c, const mdvt_frame_params& p, FrameDev& f)
     f.sW = (float)(((double)W - 1.0) / (double)W);
     f.sH = (float)(((double)H - 1.0) / (double)H);
     f.Kd[0] = fx; f.Kd[1] = fy; f.Kd[2] = cx; f.Kd[3] = cy;
+    f.rKd[0] = 1.0 / fx; f.rKd[1] = 1.0 / fy;
     const double conv = (p.convergence_angle == p.convergence_angle) ? p.convergence_angle : 0.0;   // NaN -> none
     const bool same_k = fx == fxr && fy == fyr && cx == cxr && cy == cyr;
     f.general = (p.has_T || conv != 0.0 || !same_k) ? 1 : 0;
@@ -517,6 +518,7 @@ int mdvt_edge_filter(mdvt_ctx* c, const uint8_t* d_depth_rgb, size_t depth_pitch
     f.mult = (float)(c->cfg.max_depth / 4228250625.0);
     f.scale = (float)depth_scale;
     f.Kd[0] = K[0]; f.Kd[1] = K[4]; f.Kd[2] = K[2]; f.Kd[3] = K[5];
+    f.rKd[0] = 1.0 / K[0]; f.rKd[1] = 1.0 / K[4];
     const FrameDev* dfp = nullptr;
     ParamSlot* slot = nullptr;
     int rc = stage_params(c, fd, s, &dfp, &slot);

@@ -29,6 +29,7 @@ struct FrameDev {
     float M[2][12];      // per eye 3x4 = Translate(+-ipd/2) * Ry(-+a) * T, f32       sr:615-619, 724-725, 832-836
     double Kd[4];        // fx, fy, cx, cy in f64 for the 89-degree edge filter       dmt:1127-1128, 1283-1294
     double Md[2][12];    // the per-eye 3x4 maps in f64 (infill-mask seed normals)       sr:727-733
+    double rKd[2];       // 1/fx, 1/fy in f64: the edge filter's screening pass only (never the exact path)
 };
 
 struct RenderArgs {

@@ -140,13 +140,15 @@ __device__ __forceinline__ int tri_oblique_screen(const double (&a)[3], const do
 {
     const double e1x = b[0] - a[0], e1y = b[1] - a[1], e1z = b[2] - a[2];
     const double e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
-    const double nx = e1y * e2z - e1z * e2y;
-    const double ny = e1z * e2x - e1x * e2z;
-    const double nz = e1x * e2y - e1y * e2x;
+    // (explicit fused multiply-adds: the screen only has to be accurate, not bit-identical to anything, and the
+    //  filter is bound by the f64 VALU rate -- the exact path below keeps the decree's one-rounding-per-node form)
+    const double nx = fma(e1y, e2z, -(e1z * e2y));
+    const double ny = fma(e1z, e2x, -(e1x * e2z));
+    const double nz = fma(e1x, e2y, -(e1y * e2x));
     const double sx = (a[0] + b[0]) + c[0], sy = (a[1] + b[1]) + c[1], sz = (a[2] + b[2]) + c[2];
-    const double d = -((nx * sx + ny * sy) + nz * sz);                 // 3 * dot
-    const double nn = (nx * nx + ny * ny) + nz * nz;
-    const double ss = (sx * sx + sy * sy) + sz * sz;                   // 9 * |v|^2
+    const double d = -fma(nz, sz, fma(ny, sy, nx * sx));               // 3 * dot
+    const double nn = fma(nz, nz, fma(ny, ny, nx * nx));
+    const double ss = fma(sz, sz, fma(sy, sy, sx * sx));               // 9 * |v|^2
     const double c0 = 0x1.1df0b2b89dd37p-6;
     const double rhs = (c0 * c0) * (nn * ss);                          // (c0 |n| |vs|)^2
     if (!(nn * ss > kScreenMinNNSS)) return 2;                         // degenerate / zero depth / tiny: exact path
@@ -160,7 +162,8 @@ __device__ __forceinline__ int tri_oblique_screen(const double (&a)[3], const do
 // One thread per grid cell: both triangles of the cell.  `unused` must be zeroed beforehand.
 // NOTE f.sx / f.sy hold the mesh grid scale only when the frame was prepared for mesh mode; the host
 // passes scale factors explicitly so the filter can be run standalone for either grid.
-__global__ void k_edge_filter(const uint8_t* __restrict__ depth_rgb, size_t pitch, size_t stride,
+template <bool STAGED>   // the two source rows staged through LDS as aligned dwords (else byte loads: any W / alignment)
+__global__ void __launch_bounds__(128) k_edge_filter(const uint8_t* __restrict__ depth_rgb, size_t pitch, size_t stride,
                               const FrameDev* __restrict__ fp, int frame0, int W, int H, int of_by_one,
                               float sx, float sy,
                               uint8_t* __restrict__ tri_invalid, size_t tri_stride,
@@ -169,25 +172,54 @@ __global__ void k_edge_filter(const uint8_t* __restrict__ depth_rgb, size_t pitc
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     const int fr = blockIdx.z;
-    if (j >= W - 1 || i >= H - 1) return;
-    FrameDev f = fp[frame0 + fr];
-    f.sx = sx; f.sy = sy;
     const uint8_t* r0 = depth_rgb + (size_t)(frame0 + fr) * stride + (size_t)i * pitch;
     const uint8_t* r1 = r0 + pitch;
-    const float zA = decode_z(code16_of(load_px_bytes(r0, j)), f.mult, f.scale);
-    const float zD = decode_z(code16_of(load_px_bytes(r0, j + 1)), f.mult, f.scale);
-    const float zB = decode_z(code16_of(load_px_bytes(r1, j)), f.mult, f.scale);
-    const float zC = decode_z(code16_of(load_px_bytes(r1, j + 1)), f.mult, f.scale);
+    uint32_t pA, pD, pB, pC;
+    if (STAGED) {
+        // 129 pixels of two rows = 97 dwords each; the launcher guarantees 4-byte aligned rows and W % 4 == 0
+        __shared__ uint32_t sd[2][100];
+        const int t = threadIdx.x;
+        if (t < 98) {
+            const size_t off = (size_t)blockIdx.x * 384 + (size_t)t * 4;
+            if (off < (size_t)W * 3) {
+                sd[0][t] = *(const uint32_t*)(r0 + off);
+                sd[1][t] = *(const uint32_t*)(r1 + off);
+            }
+        }
+        __syncthreads();
+        if (j >= W - 1) return;
+        // pixels t and t + 1 are the six bytes from 3t on: dwords w .. w + 2
+        const int bo = t * 3, w = bo >> 2, sh = (bo & 3) * 8;
+        const u64 lo0 = ((u64)sd[0][w + 1] << 32) | sd[0][w], hi0 = ((u64)sd[0][w + 2] << 32) | sd[0][w + 1];
+        const u64 lo1 = ((u64)sd[1][w + 1] << 32) | sd[1][w], hi1 = ((u64)sd[1][w + 2] << 32) | sd[1][w + 1];
+        pA = (uint32_t)(lo0 >> sh) & 0xFFFFFFu;
+        pB = (uint32_t)(lo1 >> sh) & 0xFFFFFFu;
+        // pixel t + 1 starts 24 bits further: within (w, w+1) while sh <= 8, else within (w+1, w+2) at sh - 8
+        pD = sh <= 8 ? (uint32_t)(lo0 >> (sh + 24)) & 0xFFFFFFu : (uint32_t)(hi0 >> (sh - 8)) & 0xFFFFFFu;
+        pC = sh <= 8 ? (uint32_t)(lo1 >> (sh + 24)) & 0xFFFFFFu : (uint32_t)(hi1 >> (sh - 8)) & 0xFFFFFFu;
+    } else {
+        if (j >= W - 1) return;
+        pA = load_px_bytes(r0, j); pD = load_px_bytes(r0, j + 1);
+        pB = load_px_bytes(r1, j); pC = load_px_bytes(r1, j + 1);
+    }
+    FrameDev f = fp[frame0 + fr];
+    f.sx = sx; f.sy = sy;
+    const float zA = decode_z(code16_of(pA), f.mult, f.scale);
+    const float zD = decode_z(code16_of(pD), f.mult, f.scale);
+    const float zB = decode_z(code16_of(pB), f.mult, f.scale);
+    const float zC = decode_z(code16_of(pC), f.mult, f.scale);
     // screening vertices: the same unprojection with a reciprocal instead of the two divisions
-    const double rfx = 1.0 / f.Kd[0], rfy = 1.0 / f.Kd[1];
+    const double rfx = f.rKd[0], rfy = f.rKd[1];
     const double x0 = (of_by_one ? (double)((float)j * f.sx) : (double)j) - f.Kd[2];
     const double x1 = (of_by_one ? (double)((float)(j + 1) * f.sx) : (double)(j + 1)) - f.Kd[2];
     const double y0 = (of_by_one ? (double)((float)i * f.sy) : (double)i) - f.Kd[3];
     const double y1 = (of_by_one ? (double)((float)(i + 1) * f.sy) : (double)(i + 1)) - f.Kd[3];
-    const double A[3] = {x0 * (double)zA * rfx, y0 * (double)zA * rfy, (double)zA};
-    const double B[3] = {x0 * (double)zB * rfx, y1 * (double)zB * rfy, (double)zB};
-    const double Cc[3] = {x1 * (double)zC * rfx, y1 * (double)zC * rfy, (double)zC};
-    const double D[3] = {x1 * (double)zD * rfx, y0 * (double)zD * rfy, (double)zD};
+    const double x0r = x0 * rfx, x1r = x1 * rfx, y0r = y0 * rfy, y1r = y1 * rfy;
+    const double dA = (double)zA, dB = (double)zB, dC = (double)zC, dD = (double)zD;
+    const double A[3] = {x0r * dA, y0r * dA, dA};
+    const double B[3] = {x0r * dB, y1r * dB, dB};
+    const double Cc[3] = {x1r * dC, y1r * dC, dC};
+    const double D[3] = {x1r * dD, y0r * dD, dD};
     int s1 = tri_oblique_screen(A, B, Cc);      // tri1 = (v[i,j], v[i+1,j], v[i+1,j+1])
     int s2 = tri_oblique_screen(A, Cc, D);      // tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
     if (s1 == 2 || s2 == 2) {
@@ -225,8 +257,13 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
     const float sx = of_by_one ? (float)(((double)W + 1.0) / (double)W) : 1.0f;
     const float sy = of_by_one ? (float)(((double)H + 1.0) / (double)H) : 1.0f;
     dim3 grid((W - 1 + 127) / 128, H - 1, n);
-    hipLaunchKernelGGL(k_edge_filter, grid, dim3(128), 0, s, depth_rgb, pitch, stride, fp, frame0, W, H, of_by_one,
-                       sx, sy, tri_invalid, tri_stride, unused, unused_stride);
+    const bool aligned = (W % 4 == 0) && (pitch % 4 == 0) && (stride % 4 == 0) && ((uintptr_t)depth_rgb % 4 == 0);
+    if (aligned && getenv("MDVT_EF_STAGED"))
+        hipLaunchKernelGGL(k_edge_filter<true>, grid, dim3(128), 0, s, depth_rgb, pitch, stride, fp, frame0, W, H, of_by_one,
+                           sx, sy, tri_invalid, tri_stride, unused, unused_stride);
+    else
+        hipLaunchKernelGGL(k_edge_filter<false>, grid, dim3(128), 0, s, depth_rgb, pitch, stride, fp, frame0, W, H, of_by_one,
+                           sx, sy, tri_invalid, tri_stride, unused, unused_stride);
     return hipGetLastError();
 }
 
@@ -738,6 +775,8 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
     if (j >= W) return;
     const int f = a.frame0 + fr;
     const FrameDev& fp = a.fp[f];
+    const bool un = UNUSED && a.unused[(size_t)fr * a.ws_stride_px + (size_t)i * W + j];
+    if (EDGE_ONLY && !un) return;         // mesh mode: only the ~3 % removed vertices are splatted
     const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
     const uint32_t code = code16_of(load_px_bytes(drow, j));
     const float z = decode_z(code, fp.mult, fp.scale);
@@ -745,7 +784,6 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
     const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
     float xc, yc;
     camera_point(fp, gx, gy, z, xc, yc);
-    const bool un = UNUSED && a.unused[(size_t)fr * a.ws_stride_px + (size_t)i * W + j];
     const uint32_t src = ((uint32_t)i << 16) | (uint32_t)j;
     if (!un) {
         if (EDGE_ONLY) return;
