@@ -162,7 +162,6 @@ __device__ __forceinline__ int tri_oblique_screen(const double (&a)[3], const do
 // One thread per grid cell: both triangles of the cell.  `unused` must be zeroed beforehand.
 // NOTE f.sx / f.sy hold the mesh grid scale only when the frame was prepared for mesh mode; the host
 // passes scale factors explicitly so the filter can be run standalone for either grid.
-template <bool STAGED>   // the two source rows staged through LDS as aligned dwords (else byte loads: any W / alignment)
 __global__ void __launch_bounds__(128) k_edge_filter(const uint8_t* __restrict__ depth_rgb, size_t pitch, size_t stride,
                               const FrameDev* __restrict__ fp, int frame0, int W, int H, int of_by_one,
                               float sx, float sy,
@@ -172,36 +171,12 @@ __global__ void __launch_bounds__(128) k_edge_filter(const uint8_t* __restrict__
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     const int fr = blockIdx.z;
+    if (j >= W - 1 || i >= H - 1) return;
     const uint8_t* r0 = depth_rgb + (size_t)(frame0 + fr) * stride + (size_t)i * pitch;
     const uint8_t* r1 = r0 + pitch;
-    uint32_t pA, pD, pB, pC;
-    if (STAGED) {
-        // 129 pixels of two rows = 97 dwords each; the launcher guarantees 4-byte aligned rows and W % 4 == 0
-        __shared__ uint32_t sd[2][100];
-        const int t = threadIdx.x;
-        if (t < 98) {
-            const size_t off = (size_t)blockIdx.x * 384 + (size_t)t * 4;
-            if (off < (size_t)W * 3) {
-                sd[0][t] = *(const uint32_t*)(r0 + off);
-                sd[1][t] = *(const uint32_t*)(r1 + off);
-            }
-        }
-        __syncthreads();
-        if (j >= W - 1) return;
-        // pixels t and t + 1 are the six bytes from 3t on: dwords w .. w + 2
-        const int bo = t * 3, w = bo >> 2, sh = (bo & 3) * 8;
-        const u64 lo0 = ((u64)sd[0][w + 1] << 32) | sd[0][w], hi0 = ((u64)sd[0][w + 2] << 32) | sd[0][w + 1];
-        const u64 lo1 = ((u64)sd[1][w + 1] << 32) | sd[1][w], hi1 = ((u64)sd[1][w + 2] << 32) | sd[1][w + 1];
-        pA = (uint32_t)(lo0 >> sh) & 0xFFFFFFu;
-        pB = (uint32_t)(lo1 >> sh) & 0xFFFFFFu;
-        // pixel t + 1 starts 24 bits further: within (w, w+1) while sh <= 8, else within (w+1, w+2) at sh - 8
-        pD = sh <= 8 ? (uint32_t)(lo0 >> (sh + 24)) & 0xFFFFFFu : (uint32_t)(hi0 >> (sh - 8)) & 0xFFFFFFu;
-        pC = sh <= 8 ? (uint32_t)(lo1 >> (sh + 24)) & 0xFFFFFFu : (uint32_t)(hi1 >> (sh - 8)) & 0xFFFFFFu;
-    } else {
-        if (j >= W - 1) return;
-        pA = load_px_bytes(r0, j); pD = load_px_bytes(r0, j + 1);
-        pB = load_px_bytes(r1, j); pC = load_px_bytes(r1, j + 1);
-    }
+    // (byte loads: the kernel is bound by f64 arithmetic; staging the rows through LDS made it 10 % slower)
+    const uint32_t pA = load_px_bytes(r0, j), pD = load_px_bytes(r0, j + 1);
+    const uint32_t pB = load_px_bytes(r1, j), pC = load_px_bytes(r1, j + 1);
     FrameDev f = fp[frame0 + fr];
     f.sx = sx; f.sy = sy;
     const float zA = decode_z(code16_of(pA), f.mult, f.scale);
@@ -257,13 +232,8 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
     const float sx = of_by_one ? (float)(((double)W + 1.0) / (double)W) : 1.0f;
     const float sy = of_by_one ? (float)(((double)H + 1.0) / (double)H) : 1.0f;
     dim3 grid((W - 1 + 127) / 128, H - 1, n);
-    const bool aligned = (W % 4 == 0) && (pitch % 4 == 0) && (stride % 4 == 0) && ((uintptr_t)depth_rgb % 4 == 0);
-    if (aligned && getenv("MDVT_EF_STAGED"))
-        hipLaunchKernelGGL(k_edge_filter<true>, grid, dim3(128), 0, s, depth_rgb, pitch, stride, fp, frame0, W, H, of_by_one,
-                           sx, sy, tri_invalid, tri_stride, unused, unused_stride);
-    else
-        hipLaunchKernelGGL(k_edge_filter<false>, grid, dim3(128), 0, s, depth_rgb, pitch, stride, fp, frame0, W, H, of_by_one,
-                           sx, sy, tri_invalid, tri_stride, unused, unused_stride);
+    hipLaunchKernelGGL(k_edge_filter, grid, dim3(128), 0, s, depth_rgb, pitch, stride, fp, frame0, W, H, of_by_one,
+                       sx, sy, tri_invalid, tri_stride, unused, unused_stride);
     return hipGetLastError();
 }
 
@@ -797,6 +767,42 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
             atomicMin(&a.keys[eye][(size_t)fr * a.ws_stride_px + (size_t)py * W + px], key);
         }
     } else if (EDGE) {
+#pragma unroll
+        for (int eye = 0; eye < 2; ++eye) {
+            const Vert v = edge_point_for_eye(fp, eye, i, gx, z, xc, yc);        // sr:599-600
+            if (!v.ok) continue;
+            if (!(v.u > -1.0f && v.u < (float)W + 1.0f && v.v > -1.0f && v.v < (float)H + 1.0f)) continue;
+            const int px = (int)rintf(v.u), py = (int)rintf(v.v);   // np.round (sr:746)
+            if (px < 0 || px >= W || py < 0 || py >= H) continue;
+            const u64 key = ((u64)__float_as_uint(v.z) << 32) | src;
+            atomicMin(&a.ekeys[eye][(size_t)fr * a.ws_stride_px + (size_t)py * W + px], key);
+        }
+    }
+}
+
+// Mesh mode only splats the removed vertices (~3 % of the grid): four `unused` flags per thread as one dword, so the
+// pass is a 1 B/px scan with the vertex programme run for the few flagged vertices.  W % 4 == 0 (launcher).
+__global__ void __launch_bounds__(256) k_edge_points_splat4(RenderArgs a)
+{
+    const int W = a.W, H = a.H;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    const int fr = blockIdx.z;
+    if (g >= W / 4) return;
+    const uint32_t flags = *(const uint32_t*)(a.unused + (size_t)fr * a.ws_stride_px + (size_t)i * W + (size_t)g * 4);
+    if (!flags) return;
+    const int f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
+    for (int q = 0; q < 4; ++q) {
+        if (!((flags >> (8 * q)) & 0xFFu)) continue;
+        const int j = g * 4 + q;
+        const float z = decode_z(code16_of(load_px_bytes(drow, j)), fp.mult, fp.scale);
+        if (!(z > kNear)) continue;
+        const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
+        float xc, yc;
+        camera_point(fp, gx, gy, z, xc, yc);
+        const uint32_t src = ((uint32_t)i << 16) | (uint32_t)j;
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
             const Vert v = edge_point_for_eye(fp, eye, i, gx, z, xc, yc);        // sr:599-600
@@ -2416,8 +2422,13 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (edge) {
-        const dim3 grid_s((a.W + 255) / 256, a.H, plan.n);
-        hipLaunchKernelGGL((k_points_splat_general<14>), grid_s, dim3(256), 0, s, a);
+        if (a.W % 4 == 0) {
+            const dim3 grid_s((a.W / 4 + 255) / 256, a.H, plan.n);
+            hipLaunchKernelGGL(k_edge_points_splat4, grid_s, dim3(256), 0, s, a);
+        } else {
+            const dim3 grid_s((a.W + 255) / 256, a.H, plan.n);
+            hipLaunchKernelGGL((k_points_splat_general<14>), grid_s, dim3(256), 0, s, a);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return launch_resolve_general<true>(plan, a, s);
