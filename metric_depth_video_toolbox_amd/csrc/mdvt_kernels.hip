@@ -1382,13 +1382,28 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
         const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
         inv[0] = tinv[0]; inv[1] = tinv[ncell];
     }
+    // The 2 x 129 vertex records of both eyes are fetched once per workgroup, all loads in flight together: at
+    // 4 waves per SIMD the kernel is latency-limited in this prologue, and per-thread loads (four per eye, each
+    // record fetched by four threads, the eyes one after the other) cost two round trips instead of one.
+    __shared__ uint4 sv[2][2][129];
+    {
+        const int t = threadIdx.x;
+        const int j0 = blockIdx.x * blockDim.x;
+        const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
+        const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);      // (clamped: columns past the row end are never used)
+        const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
+        const uint4 r2 = a.gverts[1][base + jc], r3 = a.gverts[1][base + W + jc];
+        if (t < 4) sv[t >> 1][t & 1][128] = a.gverts[t >> 1][base + (size_t)(t & 1) * W + jx];
+        sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int eye = 0; eye < 2; ++eye) {
         u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
         uint4 A = make_uint4(0, 0, 0, 0), B = A, Cv = A, D = A;
         if (act) {
-            const uint4* v = a.gverts[eye] + (size_t)fr * a.ws_stride_px + (size_t)i * W + j;
-            A = v[0]; D = v[1]; B = v[W]; Cv = v[W + 1];
+            const int t = threadIdx.x;
+            A = sv[eye][0][t]; D = sv[eye][0][t + 1]; B = sv[eye][1][t]; Cv = sv[eye][1][t + 1];
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
