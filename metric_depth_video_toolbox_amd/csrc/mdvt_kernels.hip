@@ -1377,26 +1377,29 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
-    bool inv[2] = {false, false};
-    if (EDGES && act) {
-        const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
-        inv[0] = tinv[0]; inv[1] = tinv[ncell];
-    }
     // The 2 x 129 vertex records of both eyes are fetched once per workgroup, all loads in flight together: at
     // 4 waves per SIMD the kernel is latency-limited in this prologue, and per-thread loads (four per eye, each
     // record fetched by four threads, the eyes one after the other) cost two round trips instead of one.
     __shared__ uint4 sv[2][2][129];
+    uint32_t inv0 = 0, inv1 = 0;
     {
         const int t = threadIdx.x;
         const int j0 = blockIdx.x * blockDim.x;
         const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
         const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);      // (clamped: columns past the row end are never used)
+        uint4 rx = make_uint4(0, 0, 0, 0);                                  // the 129th column, issued first so that
+        if (t < 4) rx = (t & 2 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t & 1) * W + jx];   // wave 0 does not pay a second round trip
         const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
         const uint4 r2 = a.gverts[1][base + jc], r3 = a.gverts[1][base + W + jc];
-        if (t < 4) sv[t >> 1][t & 1][128] = a.gverts[t >> 1][base + (size_t)(t & 1) * W + jx];
+        if (EDGES && act) {                                                 // (issued behind the record loads, not before)
+            const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
+            inv0 = tinv[0]; inv1 = tinv[ncell];
+        }
+        if (t < 4) sv[t >> 1][t & 1][128] = rx;
         sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
     }
     __syncthreads();
+    const bool inv[2] = {inv0 != 0, inv1 != 0};
 #pragma unroll 1
     for (int eye = 0; eye < 2; ++eye) {
         u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
