@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 7
+#define MDVT_VERSION_MINOR 8
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -54,7 +54,10 @@ typedef struct mdvt_config {
     int32_t edge_points;         /* !--dont_place_points_in_edges (sr:589-606); needs remove_edges.  1: splat and
                                     paint into the holes (sr:813-814); 2: splat for the seed image only, holes stay
                                     black (--do_basic_infill fills them afterwards, sr:809-812)          */
-    int32_t reserved0;
+    int32_t cull;                /* mesh mode: 0 = draw both faces (default), 1 = cull back faces, 2 = cull front faces.
+                                    The grid's own winding (dmt:1243-1254: counter-clockwise on screen) is the front face.
+                                    dmt:1507-1556 never sets Open3D's mesh_show_back_face, whose legacy default (off) most
+                                    likely means GL_CULL_FACE: either behaviour can be matched once it has been observed */
     double ipd_m;                /* --pupillary_distance / 1000 (sr:458-459)                         */
     double max_depth;            /* --max_depth (dfh:22)                                             */
     uint8_t key_rgb[4];          /* bg_color*255: (0,0,0), or (0,255,0) with --infill_mask (sr:555-558) */
@@ -104,6 +107,14 @@ int mdvt_destroy(mdvt_ctx* ctx);
 const char* mdvt_last_error(const mdvt_ctx* ctx);
 
 int mdvt_set_config(mdvt_ctx* ctx, const mdvt_config* cfg);
+
+/* Device self-test of the arithmetic building blocks the kernels substitute for generic expansions (they must give
+ * the bits of the correctly rounded IEEE operation the decree of DESIGN.md names; dmt:1127-1128's divisions):
+ *   which = 0: rcp_exact(x) against 1/x for every f32 in [2^-32, 2^32)
+ *   which = 1: rcp_div_exact(a, x) against a/x for every f32 x in [2^-32, 2^32) and 16 numerators derived from `seed`
+ *   which = 2: v_cvt_pk_u8_f32 (the colour conversion of the shader) against rint / clamp [0,255] / NaN -> 0 for every f32
+ * h_mismatches (host, uint64) receives the number of differing results.  Synchronous. */
+int mdvt_selftest(mdvt_ctx* ctx, int which, uint64_t seed, uint64_t* h_mismatches);
 
 /* One iteration of the frame loop sr:512-907 for both eyes: decode -> (edge filter) -> unproject ->
  * pose / eye transform -> z-buffered render -> colour-key hole mask -> (edge-point splat). */

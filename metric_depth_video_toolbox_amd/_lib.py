@@ -24,7 +24,7 @@ SYMBOLS = ("mdvt_version", "mdvt_create", "mdvt_destroy", "mdvt_last_error", "md
            "mdvt_render_stereo", "mdvt_render_stereo_batch", "mdvt_decode_depth", "mdvt_encode_depth",
            "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side", "mdvt_touchly_depth",
            "mdvt_equirect_tables", "mdvt_equirect_remap", "mdvt_masked_blur", "mdvt_finish_infill_mask",
-           "mdvt_finish_infill_mask_stereo", "mdvt_swap_rb")
+           "mdvt_finish_infill_mask_stereo", "mdvt_swap_rb", "mdvt_selftest")
 
 
 class MdvtError(RuntimeError):
@@ -34,7 +34,7 @@ class MdvtError(RuntimeError):
 
 
 class MdvtConfig(C.Structure):
-    _fields_ = [("mode", C.c_int32), ("remove_edges", C.c_int32), ("edge_points", C.c_int32), ("reserved0", C.c_int32),
+    _fields_ = [("mode", C.c_int32), ("remove_edges", C.c_int32), ("edge_points", C.c_int32), ("cull", C.c_int32),
                 ("ipd_m", C.c_double), ("max_depth", C.c_double), ("key_rgb", C.c_uint8 * 4), ("reserved1", C.c_uint32)]
 
 
@@ -79,6 +79,8 @@ def load():
     L.mdvt_last_error.argtypes = [vp]
     L.mdvt_set_config.restype = C.c_int
     L.mdvt_set_config.argtypes = [vp, C.POINTER(MdvtConfig)]
+    L.mdvt_selftest.restype = C.c_int
+    L.mdvt_selftest.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]
     L.mdvt_render_stereo.restype = C.c_int
     L.mdvt_render_stereo.argtypes = [vp, C.POINTER(MdvtFrameParams), C.POINTER(MdvtIO), vp]
     L.mdvt_render_stereo_batch.restype = C.c_int

@@ -56,6 +56,7 @@ struct mdvt_ctx {
     uint8_t* unused = nullptr;
     uint32_t* bigq = nullptr;         // general mesh path: queue of large triangles + its counter (last dword)
     uint32_t bigq_cap = 0;
+    mdvt::RowCell* rowcell = nullptr; // [H] scanline -> cell row table of the mesh grid (pure-shift band kernel)
     uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
     int row_counts_frames = 0;
     // infill-mask completion: per image stamp u16 + T f32 + work image u8x3, and the per-image counters
@@ -237,6 +238,39 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
 
 bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
+// The decree's snap (mdvt_device.h) on the host: same IEEE operations (this file is compiled with -ffp-contract=off).
+int host_snap(float x)
+{
+    x = fminf(fmaxf(x, -kSnapLimit), kSnapLimit);
+    return (int)rintf(x * (float)kSubpix);
+}
+
+// Scanline k (centre 256 k + 128) is covered by the cell row c = largest i with snap(f32(i) * sy) <= centre, if that is
+// not the last vertex row (k_mesh_rows derives the same per workgroup).
+int ensure_rowcell(mdvt_ctx* c, hipStream_t s)
+{
+    if (c->rowcell) return MDVT_OK;
+    const int H = c->H;
+    const float sy = (float)(((double)H + 1.0) / (double)H);
+    std::vector<mdvt::RowCell> t((size_t)H);
+    for (int k = 0; k < H; ++k) {
+        const int Yc = k * kSubpix + kSubpix / 2;
+        int ilo = (int)(((float)k + 0.5f) / sy);
+        ilo = ilo < 0 ? 0 : (ilo > H - 1 ? H - 1 : ilo);
+        while (ilo > 0 && host_snap((float)ilo * sy) > Yc) --ilo;
+        while (ilo + 1 <= H - 1 && host_snap((float)(ilo + 1) * sy) <= Yc) ++ilo;
+        mdvt::RowCell r{};
+        r.c = (ilo <= H - 2) ? ilo : -1;
+        r.Yt = r.c >= 0 ? host_snap((float)r.c * sy) : 0;
+        r.Yb = r.c >= 0 ? host_snap((float)(r.c + 1) * sy) : 1;
+        t[(size_t)k] = r;
+    }
+    MDVT_HIP(c, hipMalloc((void**)&c->rowcell, (size_t)H * sizeof(mdvt::RowCell)));
+    MDVT_HIP(c, hipMemcpyAsync(c->rowcell, t.data(), (size_t)H * sizeof(mdvt::RowCell), hipMemcpyHostToDevice, s));
+    MDVT_HIP(c, hipStreamSynchronize(s));      // `t` is pageable host memory
+    return MDVT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -295,6 +329,7 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->tri_invalid) (void)hipFree(c->tri_invalid);
     if (c->unused) (void)hipFree(c->unused);
     if (c->row_counts) (void)hipFree(c->row_counts);
+    if (c->rowcell) (void)hipFree(c->rowcell);
     free_telea(c);
     delete c;
     return MDVT_OK;
@@ -309,8 +344,25 @@ int mdvt_set_config(mdvt_ctx* c, const mdvt_config* cfg)
     if (!(cfg->ipd_m >= 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "ipd_m must be >= 0");
     if (cfg->edge_points < 0 || cfg->edge_points > 2) return fail(c, MDVT_ERR_INVALID_ARG, "edge_points must be 0, 1 or 2");
     if (cfg->edge_points && !cfg->remove_edges) return fail(c, MDVT_ERR_INVALID_ARG, "edge_points needs remove_edges (sr:589)");
+    if (cfg->cull < 0 || cfg->cull > 2) return fail(c, MDVT_ERR_INVALID_ARG, "cull must be 0 (none), 1 (back) or 2 (front)");
     c->cfg = *cfg;
     c->cfg_set = true;
+    return MDVT_OK;
+}
+
+int mdvt_selftest(mdvt_ctx* c, int which, uint64_t seed, uint64_t* h_mismatches)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!h_mismatches || which < 0 || which > 2) return fail(c, MDVT_ERR_INVALID_ARG, "mdvt_selftest: which must be 0..2, h_mismatches not NULL");
+    DeviceGuard g(c->device);
+    unsigned long long* d = nullptr;
+    MDVT_HIP(c, hipMalloc((void**)&d, sizeof(unsigned long long)));
+    hipError_t e = launch_selftest(which, (unsigned long long)seed, d, nullptr);
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, MDVT_ERR_HIP, "mdvt_selftest: %s", hipGetErrorString(e));
+    *h_mismatches = (uint64_t)h;
     return MDVT_OK;
 }
 
@@ -427,6 +479,8 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     }
     a.fp = dfp;
     a.edge_paint = c->cfg.edge_points != 2;
+    a.cull = c->cfg.cull;
+    if (c->cfg.mode == MDVT_MODE_MESH) { if ((rc = ensure_rowcell(c, s)) != MDVT_OK) return rc; a.rowcell = c->rowcell; }
     a.W = W; a.H = H;
     a.key_rgb = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     a.keys[0] = c->keys[0]; a.keys[1] = c->keys[1];

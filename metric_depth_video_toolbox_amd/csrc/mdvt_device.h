@@ -1,8 +1,9 @@
 // mdvt_device.h -- device-side helpers shared by the kernels in mdvt_kernels.hip.
 //
 // Arithmetic decree: every f32 expression below is one IEEE operation per node, the
-// translation unit is compiled with -ffp-contract=off, divisions are the correctly rounded ones
-// (hipcc default), and nothing here may be rewritten into an FMA or a reciprocal-multiply.
+// translation unit is compiled with -ffp-contract=off and divisions are the correctly rounded ones --
+// either hipcc's IEEE expansion or rcp_exact / rcp_div_exact below, which produce the same bits (checked
+// exhaustively by mdvt_selftest).  Nothing may be rewritten into a contraction that changes a result.
 #pragma once
 
 #include "mdvt_internal.h"
@@ -54,6 +55,53 @@ __device__ __forceinline__ void store_px_bytes(uint8_t* row, int j, uint32_t px)
 {
     uint8_t* p = row + 3 * (size_t)j;
     p[0] = (uint8_t)px; p[1] = (uint8_t)(px >> 8); p[2] = (uint8_t)(px >> 16);
+}
+
+// ---- correctly rounded 1/x and a/b without the generic IEEE expansion ---------------------------
+// The decree asks for correctly rounded divisions.  hipcc's expansion (v_div_scale x2, v_rcp, 5 fma,
+// v_div_fmas, v_div_fixup) also covers denormals, infinities and over/underflowing quotients; the
+// rasteriser's operands are ordinary normal numbers, where Markstein's theorems give the same bits
+// in fewer operations (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, ch. 5):
+//   * y0 = v_rcp_f32(b) is within 1 ulp of 1/b; e = fma(-b, y0, 1); y = fma(e, y0, y0) is then RN(1/b)
+//     unless b's significand is all ones (the one exceptional case of the theorem);
+//   * with y = RN(1/b): q0 = RN(a y); q1 = fma(fma(-b, q0, a), y, q0) is a faithful rounding of a/b and
+//     q2 = fma(fma(-b, q1, a), y, q1) is RN(a/b).
+// Operands outside [2^-30, 2^30] or with an all-ones significand take the compiler's IEEE division, so
+// the result is the correctly rounded one for every input.  (A lone a/b gains nothing: the IEEE expansion is
+// the same iteration plus scaling, 10 instructions against 9; the gain is in 1/b -- 6 against 10 -- and in
+// sharing the reciprocal between 1/Z and dl/Z.)  Checked exhaustively against the IEEE
+// expansion on the device by mdvt_selftest (tests/test_gpu_arith.py).
+constexpr uint32_t kFastLoBits = 0x30800000u;       // 2^-30
+constexpr uint32_t kFastSpanBits = 0x1E000000u;     // 60 binades: [2^-30, 2^30)
+
+__device__ __forceinline__ bool fast_operand(float x)
+{
+    const uint32_t b = __float_as_uint(x);
+    return (b - kFastLoBits) < kFastSpanBits && (b & 0x7FFFFFu) != 0x7FFFFFu;
+}
+
+// (the empty asm keeps the compiler from speculating the slow path into a select: it must stay a branch that a wave
+//  skips unless one of its lanes needs it)
+__device__ __forceinline__ float rcp_exact(float b)
+{
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    float y = __builtin_fmaf(e, y0, y0);
+    if (__builtin_expect(!fast_operand(b), 0)) { asm volatile("; ieee 1/x" ::: "memory"); y = 1.0f / b; }
+    return y;
+}
+
+// RN(1/b) and RN(a/b) together (a vertex needs both 1/Z and dl/Z).  `a_ok`: a is in [2^-30, 2^30).
+__device__ __forceinline__ void rcp_div_exact(float a, bool a_ok, float b, float& inv, float& quot)
+{
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    float y = __builtin_fmaf(e, y0, y0);
+    const float q0 = a * y;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
+    float q = __builtin_fmaf(__builtin_fmaf(-b, q1, a), y, q1);
+    if (__builtin_expect(!(a_ok && fast_operand(b)), 0)) { asm volatile("; ieee a/x" ::: "memory"); y = 1.0f / b; q = a / b; }
+    inv = y; quot = q;
 }
 
 // ---- vertex programme (mirrors the decree, not the oracle's source) --------------------------
@@ -164,8 +212,8 @@ __device__ __forceinline__ bool tri_setup_snapped(TriSetup& t, int X0, int Y0, f
 
 __device__ __forceinline__ bool tri_setup(TriSetup& t, const Vert& a, const Vert& b, const Vert& c)
 {
-    return tri_setup_snapped(t, snap(a.u), snap(a.v), a.ok ? 1.0f / a.z : 0.0f, snap(b.u), snap(b.v),
-                             b.ok ? 1.0f / b.z : 0.0f, snap(c.u), snap(c.v), c.ok ? 1.0f / c.z : 0.0f);
+    return tri_setup_snapped(t, snap(a.u), snap(a.v), a.ok ? rcp_exact(a.z) : 0.0f, snap(b.u), snap(b.v),
+                             b.ok ? rcp_exact(b.z) : 0.0f, snap(c.u), snap(c.v), c.ok ? rcp_exact(c.z) : 0.0f);
 }
 
 // i64 -> f32, round to nearest even.  When the value fits int32 the single-instruction conversion
@@ -185,7 +233,7 @@ __device__ __forceinline__ void tri_weights(i64 area2, float iz0, float iz1, flo
     } else {
         fa = i64_to_f32(area2, small); f0 = i64_to_f32(w0, small); f1 = i64_to_f32(w1, small); f2 = i64_to_f32(w2, small);
     }
-    const float ra = 1.0f / fa;
+    const float ra = rcp_exact(fa);
     const float l0 = f0 * ra, l1 = f1 * ra, l2 = f2 * ra;
     q0 = l0 * iz0; q1 = l1 * iz1; q2 = l2 * iz2;
 }
@@ -226,24 +274,34 @@ __device__ __forceinline__ bool tri_walk_sample(const TriSetup& t, const TriWalk
     return true;
 }
 
-// Perspective-correct colour, rounded half-even to u8 (decree): rint(((q0 c0 + q1 c1) + q2 c2) * (1/iz)).
-__device__ __forceinline__ uint32_t shade_channel(float q0, float q1, float q2, float riz,
-                                                  uint32_t c0, uint32_t c1, uint32_t c2)
-{
-    const float num = (q0 * (float)c0 + q1 * (float)c1) + q2 * (float)c2;
-    float val = rintf(num * riz);
-    if (!(val >= 0.0f)) val = 0.0f;
-    if (val > 255.0f) val = 255.0f;
-    return (uint32_t)val;
-}
+// Perspective-correct colour, rounded half-even to u8 (decree): rint(((q0 c0 + q1 c1) + q2 c2) * (1/iz)) clamped to
+// [0, 255], NaN -> 0.  v_cvt_pk_u8_f32 IS that conversion (round to nearest even, saturating, NaN -> 0 -- checked for
+// every f32 by mdvt_selftest) and packs the byte in place; R and G travel as one v_pk_mul/add_f32 pair (two IEEE f32
+// operations per instruction).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t shade_px(float q0, float q1, float q2, float riz,
                                              uint32_t p0, uint32_t p1, uint32_t p2)
 {
-    const uint32_t r = shade_channel(q0, q1, q2, riz, p0 & 0xFF, p1 & 0xFF, p2 & 0xFF);
-    const uint32_t g = shade_channel(q0, q1, q2, riz, (p0 >> 8) & 0xFF, (p1 >> 8) & 0xFF, (p2 >> 8) & 0xFF);
-    const uint32_t b = shade_channel(q0, q1, q2, riz, p0 >> 16, p1 >> 16, p2 >> 16);
-    return r | (g << 8) | (b << 16);
+    const f32x2 a = {(float)(p0 & 0xFFu), (float)((p0 >> 8) & 0xFFu)};
+    const f32x2 b = {(float)(p1 & 0xFFu), (float)((p1 >> 8) & 0xFFu)};
+    const f32x2 c = {(float)(p2 & 0xFFu), (float)((p2 >> 8) & 0xFFu)};
+    const f32x2 num = (q0 * a + q1 * b) + q2 * c;
+    const f32x2 val = num * riz;
+    const float nb = (q0 * (float)((p0 >> 16) & 0xFFu) + q1 * (float)((p1 >> 16) & 0xFFu)) + q2 * (float)((p2 >> 16) & 0xFFu);
+    const float vb = nb * riz;
+    uint32_t out = __builtin_amdgcn_cvt_pk_u8_f32(val.x, 0u, 0u);
+    out = __builtin_amdgcn_cvt_pk_u8_f32(val.y, 1u, out);
+    return __builtin_amdgcn_cvt_pk_u8_f32(vb, 2u, out);
+}
+
+// The decree's own form of one channel (what shade_px must reproduce): used by the self-test only.
+__device__ __forceinline__ uint32_t shade_channel_reference(float v)
+{
+    float val = rintf(v);
+    if (!(val >= 0.0f)) val = 0.0f;
+    if (val > 255.0f) val = 255.0f;
+    return (uint32_t)val;
 }
 
 }  // namespace mdvt

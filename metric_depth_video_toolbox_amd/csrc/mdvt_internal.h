@@ -32,6 +32,10 @@ struct FrameDev {
     double rKd[2];       // 1/fx, 1/fy in f64: the edge filter's screening pass only (never the exact path)
 };
 
+// Which row of grid cells covers output scanline k of a pure-shift mesh frame, and that row's snapped extent (depends on
+// H and the grid scale only: one table per context, built on the host with the decree's own f32 operations).
+struct RowCell { int32_t c, Yt, Yb, pad; };     // c = -1: the scanline lies below the last vertex row
+
 struct RenderArgs {
     const uint8_t* depth; size_t depth_pitch, depth_stride;
     const uint8_t* color; size_t color_pitch, color_stride;
@@ -57,6 +61,8 @@ struct RenderArgs {
     size_t ws_stride_px;         // H*W (elements) between slots
     size_t ws_stride_tri;        // 2*(H-1)*(W-1)
     int32_t edge_paint;          // 1: edge points are painted into the holes (sr:813-814); 0: seed image only (--do_basic_infill, sr:809-812)
+    const RowCell* rowcell;      // [H], mesh mode
+    int32_t cull;                // 0 none, 1 back faces, 2 front faces (mdvt_config.cull)
     int32_t debug_skip;          // ablation hook for tools/kbench.py (env MDVT_DEBUG_SKIP): 1 raster, 2 resolve, 4 staging
 };
 
@@ -81,6 +87,9 @@ struct RenderPlan {
     int n;               // frames in this launch
 };
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+// mdvt_mesh_band.hip: the pure-shift mesh rows as bands (no edge removal)
+bool mesh_band_supported(const RenderPlan& plan, const RenderArgs& a);
+hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const uint8_t* hole, size_t hole_pitch,
                                  const float* normal, size_t normal_pitch, uint8_t* out, size_t out_pitch, int W, int H,
                                  int max_steps, hipStream_t s);
@@ -114,6 +123,7 @@ hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const I
                               const BlurKernel& K, uint32_t key_rgb, hipStream_t s);
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
+hipError_t launch_selftest(int which, unsigned long long seed, unsigned long long* d_mism, hipStream_t s);
 size_t render_lds_bytes(const RenderPlan& plan, int W);
 bool render_fits_lds(const RenderPlan& plan, int W);      // can the pure-shift row kernels hold a row of this width in LDS?
 

@@ -928,7 +928,7 @@ static hipError_t launch_resolve_general(const RenderPlan& plan, const RenderArg
 __device__ __forceinline__ u64 mesh_fragment_key(float q0, float q1, float q2, uint32_t c0, uint32_t c1, uint32_t c2)
 {
     const float iz = (q0 + q1) + q2;
-    const float riz = 1.0f / iz;
+    const float riz = rcp_exact(iz);
     return ((u64)(~__float_as_uint(iz)) << 32) | shade_px(q0, q1, q2, riz, c0, c1, c2);
 }
 
@@ -941,11 +941,12 @@ __device__ __forceinline__ MeshVert mesh_vertex(uint32_t dpx, uint32_t cpx, int 
     MeshVert v;
     const float z = decode_z(code16_of(dpx), fp.mult, fp.scale);
     const bool ok = z > kNear;
-    const float d = fp.dl / z;
+    float iz, d;
+    rcp_div_exact(fp.dl, fast_operand(fp.dl), z, iz, d);
     const float gx = (float)j * fp.sx;
     v.XL = snap(gx + d);
     v.XR = snap(gx - d);
-    v.iz = ok ? 1.0f / z : 0.0f;            // iz == 0 flags a vertex behind the near plane
+    v.iz = ok ? iz : 0.0f;                  // iz == 0 flags a vertex behind the near plane
     v.rgb = cpx;
     return v;
 }
@@ -1330,7 +1331,7 @@ __global__ void __launch_bounds__(256) k_mesh_vertices_general(RenderArgs a)
 #pragma unroll
     for (int eye = 0; eye < 2; ++eye) {
         const Vert v = vertex_for_eye(fp, eye, gx, gy, z, xc, yc);
-        const float iz = v.ok ? 1.0f / v.z : 0.0f;          // 0 flags a vertex behind the near plane
+        const float iz = v.ok ? rcp_exact(v.z) : 0.0f;      // 0 flags a vertex behind the near plane
         uint4* dst = &a.gverts[eye][(size_t)fr * a.ws_stride_px + (size_t)i * W + j];
         // streamed: a launch set writes ~1 GB of records before the rasteriser reads the first one back
         const u32x4 rec = {(uint32_t)snap(v.u), (uint32_t)snap(v.v), __float_as_uint(iz), rgb};
@@ -2460,6 +2461,7 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
         return plan.vec4 ? launch_points_rows_vec4(plan, a, s) : launch_points_rows_cfg<1, 256, 0>(plan, a, s);
     }
     if (plan.general) return launch_mesh_general(plan, a, s);
+    if (mesh_band_supported(plan, a) && getenv("MDVT_MESH_OLD") == nullptr) return launch_mesh_band(plan, a, s);
     return plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);
 }
 

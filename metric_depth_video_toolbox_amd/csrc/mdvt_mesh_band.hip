@@ -1,0 +1,418 @@
+// mdvt_mesh_band.hip -- MESH MODE, pure stereo shift: the reference's default draw mode (dmt:1243-1254 rendered by
+// dmt:1422-1572 after sr:724-725 / 832-836), one workgroup per (frame, band of output rows), z-buffer in LDS.
+//
+// Same results as k_mesh_rows (mdvt_kernels.hip) and the oracle -- the arithmetic decree of DESIGN.md section 3 is
+// untouched -- but organised around what the pure shift makes cheap:
+//
+//   * every vertex row is a horizontal line on screen (v = grid y), so output scanline k is covered by exactly one row
+//     c(k) of grid cells, and a cell meets the scanline in the interval between its two column edges, split by the
+//     diagonal A-C.  With tt = Yc - Yt, hh = Yb - Yt (uniform for the row) and
+//         kcol0 = (XB-XA) tt + hh XA,   kdiag = (XC-XA) tt + hh XA,   kcol1 = (XC-XD) tt + hh XD
+//     pixel centre Xc lies in tri1 = (A,B,C) iff kcol0 <= hh Xc < kdiag and in tri2 = (A,C,D) iff kdiag <= hh Xc < kcol1
+//     (a cell mirrored by a fold: the same with the bounds swapped) -- the top-left rule of the generic edge functions
+//     written out for edges that start and end on the two vertex rows.  The covered pixel columns of a cell are
+//     therefore [P(klo), P(khi)) with P(k) = ceil((k - 128 hh) / (256 hh)): an exact integer division by a
+//     row-uniform constant instead of candidate pixels tested one by one, and the integer barycentric weights are
+//     |differences| of the same three values.
+//   * all of this fits 32-bit integers with 24-bit multiplies (full rate; 32x32 and 64-bit multiplies are quarter
+//     rate) when the snapped coordinates are within +-2^20 sub-pixels (4096 px) -- cells outside that range, cells
+//     with a vertex behind the near plane and twisted / zero-width cells take the generic 64-bit triangle path, one
+//     cell at a time on the whole wave (rare).
+//   * a thread owns a cell and shades its FIRST covered pixel itself; further pixels of a cell (stretched cells, the
+//     rubber sheet across depth edges) go to a small per-wave stack in LDS as (cell, pixel) items that the wave
+//     shades 64 at a time -- no lane waits while a neighbour walks a long span.
+//   * a workgroup renders a band of output rows and keeps the two vertex rows it needs in an LDS ring, so each
+//     vertex row is decoded once per band instead of once per output row (HBM reads 6 B/px * (R+1)/R), with the
+//     next row's loads in flight while the current one is rasterised.
+//   * divisions: correctly rounded through rcp + fma corrections (mdvt_device.h) instead of the generic expansion.
+#include "mdvt_device.h"
+
+#include <stdlib.h>
+
+namespace mdvt {
+
+namespace {
+
+constexpr int kQueueWave = 128;        // (cell, pixel) items per wave: pushes of <= 64 followed by a drain keep it < 128
+constexpr int kCoordBound = 1 << 20;   // |X| of the fast path (sub-pixels)
+
+struct BandVert { int XL, XR; float iz; uint32_t rgb; };
+
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
+// One vertex of the grid: decode, 1/Z and dl/Z (correctly rounded), snapped x of both eyes.
+__device__ __forceinline__ int4 band_vertex(uint32_t dpx, uint32_t cpx, int j, const FrameDev& fp, bool dl_ok)
+{
+    const float z = decode_z(code16_of(dpx), fp.mult, fp.scale);
+    const bool ok = z > kNear;
+    float iz, d;
+    rcp_div_exact(fp.dl, dl_ok, z, iz, d);
+    const float gx = (float)j * fp.sx;
+    return make_int4(snap(gx + d), snap(gx - d), __float_as_int(ok ? iz : 0.0f), (int)cpx);
+}
+
+// P(k) = ceil((k - 128 hh) / D), D = 256 hh, clamped to [0, W].  c128 = 128 hh - 1, rD ~ 1/D (any f32 close to it: the
+// estimate is corrected by one exact step; |estimate - quotient| < 1 because quotient < 2^15 and the three roundings
+// are 2^-24 relative each).
+__device__ __forceinline__ int first_pixel(int k, int c128, int D, float rD, int W)
+{
+    int n = k + c128;
+    n = n < 0 ? 0 : n;
+    int q = (int)((float)n * rD);
+    const int rem = n - mul24(q, D);
+    q += rem < 0 ? -1 : (rem >= D ? 1 : 0);
+    return q > W ? W : q;
+}
+
+struct RowGeom {                 // uniform per output row
+    int c;                       // cell row covering the scanline, -1: none
+    int Yt, Yb, tt, bb, hh;
+    int D, c128;
+    float rD;
+};
+
+__device__ __forceinline__ RowGeom row_geometry(int k, const RowCell* __restrict__ table)
+{
+    RowGeom g;
+    const RowCell r = table[k];                // uniform: scalar loads
+    const int Yc = k * kSubpix + kSubpix / 2;
+    g.c = r.c; g.Yt = r.Yt; g.Yb = r.Yb;
+    g.tt = Yc - g.Yt; g.bb = g.Yb - Yc; g.hh = g.Yb - g.Yt;
+    g.D = g.hh * kSubpix; g.c128 = g.hh * (kSubpix / 2) - 1;
+    g.rD = __builtin_amdgcn_rcpf((float)g.D);  // an estimate is all first_pixel needs
+    return g;
+}
+
+// One pixel of a fast-path cell (both triangles in one orientation, all coordinates bounded, no near-plane vertex).
+// kcol0 / kcol1: the scanline crossings of the cell's two column edges (see the header).
+__device__ __forceinline__ void cell_pixel(int XA, int XB, int XC, int XD, float izA, float izB, float izC, float izD,
+                                           uint32_t cA, uint32_t cB, uint32_t cC, uint32_t cD, int kcol0, int kcol1, int px,
+                                           const RowGeom& g, u64* zb)
+{
+    const int kdiag = mad24(XC - XA, g.tt, mul24(g.hh, XA));
+    const int hX = mul24(g.hh, px * kSubpix + kSubpix / 2);
+    const bool regular = XD > XA;
+    const bool in1 = (hX < kdiag) == regular;
+    int wd = in1 ? XC - XB : XD - XA;
+    wd = wd < 0 ? -wd : wd;
+    const int area2 = mul24(g.hh, wd);
+    const int wconst = mul24(wd, in1 ? g.bb : g.tt);          // the vertex alone on its row: weight constant along the scanline
+    int ea = (in1 ? kdiag : kcol1) - hX;
+    int eb = hX - (in1 ? kcol0 : kdiag);
+    ea = ea < 0 ? -ea : ea;
+    eb = eb < 0 ? -eb : eb;
+    // tri1 = (A, B, C): w0 = wconst, w1 = |kdiag - hX|, w2 = |hX - kcol0|;  tri2 = (A, C, D): w0 = |kcol1 - hX|, w1 = wconst, w2 = |hX - kdiag|
+    const float f0 = (float)(in1 ? wconst : ea), f1 = (float)(in1 ? ea : wconst), f2 = (float)eb;
+    const float ra = rcp_exact((float)area2);
+    const float l0 = f0 * ra, l1 = f1 * ra, l2 = f2 * ra;
+    const float iz1 = in1 ? izB : izC, iz2 = in1 ? izC : izD;
+    const float q0 = l0 * izA, q1 = l1 * iz1, q2 = l2 * iz2;
+    const float iz = (q0 + q1) + q2;
+    const float riz = rcp_exact(iz);
+    const uint32_t rgb = shade_px(q0, q1, q2, riz, cA, in1 ? cB : cC, in1 ? cC : cD);
+    atomicMin(&zb[px], ((u64)(~__float_as_uint(iz)) << 32) | rgb);
+}
+
+// lane i <- lane i + 1 of the wave (lane 63 gets 0)
+__device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ float from_next_lane(float v) { return __int_as_float(from_next_lane(__float_as_int(v))); }
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_t)from_next_lane((int)v); }
+
+// Generic 64-bit path for one exotic cell, rasterised by the whole wave (uniform arguments).
+__device__ __forceinline__ void exotic_cell_wave(int XA, int XB, int XC, int XD, float izA, float izB, float izC, float izD,
+                                              uint32_t cA, uint32_t cB, uint32_t cC, uint32_t cD, uint32_t skip, int Yt, int Yb,
+                                              int k, int W, int lane, u64* zb)
+{
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (skip & (1u << pass)) continue;
+        TriSetup t;
+        // vertex order of the reference: tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]); tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
+        const bool ok = pass == 0 ? tri_setup_snapped(t, XA, Yt, izA, XB, Yb, izB, XC, Yb, izC)
+                                  : tri_setup_snapped(t, XA, Yt, izA, XC, Yb, izC, XD, Yt, izD);
+        if (!ok) continue;
+        int q0p = floordiv_subpix(t.minX - kSubpix / 2 + kSubpix - 1), q1p = floordiv_subpix(t.maxX - kSubpix / 2);
+        if (q0p < 0) q0p = 0;
+        if (q1p > W - 1) q1p = W - 1;
+        const uint32_t c1 = pass == 0 ? cB : cC, c2 = pass == 0 ? cC : cD;
+        for (int px = q0p + lane; px <= q1p; px += 64) {
+            float q0, q1, q2;
+            if (!tri_sample(t, px, k, q0, q1, q2)) continue;
+            const float iz = (q0 + q1) + q2;
+            const float riz = rcp_exact(iz);
+            atomicMin(&zb[px], ((u64)(~__float_as_uint(iz)) << 32) | shade_px(q0, q1, q2, riz, cA, c1, c2));
+        }
+    }
+}
+
+}  // namespace
+
+// FLAGS bit 0: depth planes.  (remove_edges variants are rendered by k_mesh_rows.)
+template <int FLAGS, int TPB>
+__global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per_band, int nbands)
+{
+    constexpr bool ZOUT = FLAGS & 1;
+    const uint32_t cull = (uint32_t)a.cull;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = a.W, H = a.H, W4 = W >> 2;
+    u64* zb = (u64*)smem;                                   // [W] z keys of the eye being rendered
+    int4* verts = (int4*)(zb + W);                          // [2][W]: vertex row i lives in slot i & 1
+    uint32_t* queue = (uint32_t*)(verts + 2 * (size_t)W);   // [NW][kQueueWave]
+
+    const int fr = blockIdx.x / nbands;
+    const int band = blockIdx.x - fr * nbands;
+    const int k0 = band * rows_per_band;
+    const int k1 = min(k0 + rows_per_band, H);
+    const int f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool dl_ok = fast_operand(fp.dl);
+    uint32_t* wq = queue + wave * kQueueWave;
+    const bool act4 = tid < W4;
+
+    const uint8_t* dbase = a.depth + (size_t)f * a.depth_stride;
+    const uint8_t* cbase = a.color + (size_t)f * a.color_stride;
+
+    int have0 = -1, have1 = -1;                 // vertex row held by slot 0 / 1 (uniform)
+    int pf_row = -1;                            // vertex row sitting in the prefetch registers (uniform)
+    uint32_t pd0 = 0, pd1 = 0, pd2 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
+
+    auto fetch_row = [&](int r) {
+        if (act4) {
+            const uint32_t* dp = (const uint32_t*)(dbase + (size_t)r * a.depth_pitch) + 3 * tid;
+            const uint32_t* cp = (const uint32_t*)(cbase + (size_t)r * a.color_pitch) + 3 * tid;
+            pd0 = dp[0]; pd1 = dp[1]; pd2 = dp[2];
+            pc0 = cp[0]; pc1 = cp[1]; pc2 = cp[2];
+        }
+        pf_row = r;
+    };
+    auto stage_row = [&](int r) {               // prefetch registers -> LDS vertex records
+        if (pf_row != r) fetch_row(r);
+        if (act4) {
+            uint32_t dpx[4], cpx[4];
+            unpack4(pd0, pd1, pd2, dpx);
+            unpack4(pc0, pc1, pc2, cpx);
+            int4* dst = verts + (size_t)(r & 1) * W + 4 * tid;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = band_vertex(dpx[q], cpx[q], 4 * tid + q, fp, dl_ok);
+        }
+        if (r & 1) have1 = r; else have0 = r;
+        pf_row = -1;
+    };
+
+    for (int x = tid; x < W; x += TPB) zb[x] = kEmpty64;
+
+    // The loop starts one row early: that prologue pass only stages the two vertex rows of scanline k0 (so that the
+    // staging code exists once).
+    RowGeom g = row_geometry(k0, a.rowcell);
+    g.c = -1;
+#pragma unroll 1
+    for (int k = k0 - 1; k < k1; ++k) {
+        // the vertex row the next scanline may need, in flight while this one is rasterised
+        RowGeom gn = g;
+        if (k + 1 < k1) {
+            gn = row_geometry(k + 1, a.rowcell);
+            if (gn.c >= 0) {
+                const int need = ((gn.c & 1) ? have1 : have0) != gn.c ? gn.c : gn.c + 1;
+                const int held = (need & 1) ? have1 : have0;
+                if (held != need && pf_row != need) fetch_row(need);
+            }
+        }
+        const int4* vt = verts + (size_t)(g.c & 1) * W;             // vertex row c
+        const int4* vb = verts + (size_t)((g.c + 1) & 1) * W;       // vertex row c + 1
+
+#pragma unroll 1
+        for (int eye = 0; eye < 2; ++eye) {
+            if (g.c >= 0 && !(a.debug_skip & 1)) {
+                int qn = 0;                                          // items on this wave's stack (uniform)
+                // A wave takes 63 consecutive cells per pass: lane l works out column c0 + l (its crossing of the scanline and
+                // the first pixel at or after it) and owns the cell between its column and the next lane's, whose values
+                // arrive through one DPP move each; lane 63 only provides that neighbour.  One more pass than there are
+                // cells: the last one only empties the stack.
+                constexpr int kCellsPerPass = 63 * (TPB / 64);
+#pragma unroll 1
+                for (int c0 = 0; ; c0 += kCellsPerPass) {
+                    const bool final_pass = c0 >= W - 1;
+                    const int j = c0 + wave * 63 + lane;
+                    // (columns past the row end read the last column: never used, `cell` below masks them)
+                    const int jc = j < W ? j : W - 1;
+                    const int4 A = vt[jc], B = vb[jc];
+                    const int XA = eye == 0 ? A.x : A.y, XB = eye == 0 ? B.x : B.y;
+                    const float izA = __int_as_float(A.z), izB = __int_as_float(B.z);
+                    const uint32_t cA = (uint32_t)A.w, cB = (uint32_t)B.w;
+                    const int colok = (izA > 0.0f && izB > 0.0f && (((uint32_t)(XA + kCoordBound) | (uint32_t)(XB + kCoordBound)) >> 21) == 0u) ? 1 : 0;
+                    const int kcol0 = mad24(XB - XA, g.tt, mul24(g.hh, XA));
+                    const int pA = first_pixel(kcol0, g.c128, g.D, g.rD, W);
+                    const int XD = from_next_lane(XA), XC = from_next_lane(XB), kcol1 = from_next_lane(kcol0), pD = from_next_lane(pA);
+                    const float izD = from_next_lane(izA), izC = from_next_lane(izB);
+                    const uint32_t cD = from_next_lane(cA), cC = from_next_lane(cB);
+                    const int okD = from_next_lane(colok);
+                    const bool cell = lane < 63 && j < W - 1 && !final_pass;
+                    const int s1 = XC - XB, s2 = XD - XA;
+                    const bool regular = s2 > 0;
+                    const bool fast = cell && colok && okD && ((s1 > 0 && s2 > 0) || (s1 < 0 && s2 < 0));
+                    const bool exotic = cell && !fast;
+                    // culling (mdvt_config.cull): the grid's own orientation is the front face
+                    const bool drawn = fast && !(cull && (cull == 1u) != regular);
+                    const int plo = regular ? pA : pD;
+                    int n = drawn ? (regular ? pD - pA : pA - pD) : 0;
+                    if (n > 0 && !(a.debug_skip & 16))
+                        cell_pixel(XA, XB, XC, XD, izA, izB, izC, izD, cA, cB, cC, cD, kcol0, kcol1, plo, g, zb);
+                    // Further pixels of the cell become (cell, pixel) items on the wave's stack, shaded 64 at a time: first
+                    // one item per lane and round (spans of up to 4 px), then the long spans (rubber sheet across a depth
+                    // edge), one cell at a time written by the whole wave.  One loop, so that the shading code exists once.
+                    if (a.debug_skip & 8) n = 0;
+                    u64 lm = __ballot(n > 4);
+                    if (__ballot(n > 1) != 0ull || final_pass) {
+                        int round = 1, lcell = 0, lpix = 0, lrem = 0;
+                        for (;;) {
+                            if (qn >= 64 || (final_pass && qn > 0)) {
+                                const int cnt = qn >= 64 ? 64 : qn;
+                                qn -= cnt;
+                                if (lane < cnt) {
+                                    const uint32_t it = wq[qn + lane];
+                                    const int ij = (int)(it >> 16), px = (int)(it & 0xFFFFu);
+                                    const int4 A = vt[ij], D = vt[ij + 1], B = vb[ij], Cv = vb[ij + 1];
+                                    const int iXA = eye == 0 ? A.x : A.y, iXB = eye == 0 ? B.x : B.y, iXC = eye == 0 ? Cv.x : Cv.y, iXD = eye == 0 ? D.x : D.y;
+                                    cell_pixel(iXA, iXB, iXC, iXD, __int_as_float(A.z), __int_as_float(B.z), __int_as_float(Cv.z), __int_as_float(D.z),
+                                               (uint32_t)A.w, (uint32_t)B.w, (uint32_t)Cv.w, (uint32_t)D.w,
+                                               mad24(iXB - iXA, g.tt, mul24(g.hh, iXA)), mad24(iXC - iXD, g.tt, mul24(g.hh, iXD)), px, g, zb);
+                                }
+                                continue;
+                            }
+                            if (round < 4) {
+                                const bool want = n > round;
+                                const u64 m = __ballot(want);
+                                if (want) wq[qn + (int)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)j << 16) | (uint32_t)(plo + round);
+                                qn += (int)__popcll(m);
+                                round = m ? round + 1 : 4;
+                                continue;
+                            }
+                            if (lrem == 0 && lm) {
+                                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
+                                lm &= lm - 1;
+                                lcell = __builtin_amdgcn_readlane(j, l);
+                                lpix = __builtin_amdgcn_readlane(plo, l) + 4;
+                                lrem = __builtin_amdgcn_readlane(n, l) - 4;
+                            }
+                            if (lrem > 0) {
+                                const int cnt = lrem < 64 ? lrem : 64;
+                                if (lane < cnt) wq[qn + lane] = ((uint32_t)lcell << 16) | (uint32_t)(lpix + lane);
+                                qn += cnt; lpix += cnt; lrem -= cnt;
+                                continue;
+                            }
+                            break;
+                        }
+                    }
+                    if (final_pass) break;
+                    // exotic cells (near plane, out of the 24-bit range, twisted, zero width): generic path, whole wave
+                    u64 em = (a.debug_skip & 8) ? 0ull : __ballot(exotic);
+                    while (em) {
+                        const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)em) - 1);
+                        em &= em - 1;
+#define MDVT_BI(v) __builtin_amdgcn_readlane(v, l)
+#define MDVT_BF(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l))
+#define MDVT_BU(v) (uint32_t)__builtin_amdgcn_readlane((int)(v), l)
+                        uint32_t sk = 0;
+                        const int bXA = MDVT_BI(XA), bXB = MDVT_BI(XB), bXC = MDVT_BI(XC), bXD = MDVT_BI(XD);
+                        if (cull) {        // per triangle: area2 of tri1 = hh (XB - XC), of tri2 = -hh (XD - XA); front = negative
+                            const bool back1 = bXB > bXC, back2 = bXA > bXD;
+                            if ((cull == 1u) == back1 && bXB != bXC) sk |= 1u;
+                            if ((cull == 1u) == back2 && bXA != bXD) sk |= 2u;
+                        }
+                        exotic_cell_wave(bXA, bXB, bXC, bXD, MDVT_BF(izA), MDVT_BF(izB), MDVT_BF(izC), MDVT_BF(izD),
+                                         MDVT_BU(cA), MDVT_BU(cB), MDVT_BU(cC), MDVT_BU(cD), sk, g.Yt, g.Yb, k, W, lane, zb);
+#undef MDVT_BI
+#undef MDVT_BF
+#undef MDVT_BU
+                    }
+                }
+            }
+            __syncthreads();
+
+            // the next scanline's vertex row replaces the one no longer needed (its last reader was the raster above)
+            if (eye == 1 && k + 1 < k1 && gn.c >= 0) {
+#pragma unroll 1
+                for (int r = gn.c; r <= gn.c + 1; ++r)
+                    if (((r & 1) ? have1 : have0) != r) stage_row(r);
+            }
+
+            // ---- resolve this eye: LDS keys -> colour-key hole test -> coalesced stores; the keys are reset on the way ----
+            if (act4 && k >= k0 && !(a.debug_skip & 2)) {
+                uint4* zq = (uint4*)zb + 2 * tid;
+                const uint4 k01 = zq[0], k23 = zq[1];
+                zq[0] = make_uint4(~0u, ~0u, ~0u, ~0u); zq[1] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                const uint32_t hi[4] = {k01.y, k01.w, k23.y, k23.w};
+                const uint32_t lo[4] = {k01.x, k01.z, k23.x, k23.z};
+                uint32_t o[4], mw = 0;
+                float oz[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool covered = !(hi[q] == ~0u && lo[q] == ~0u);
+                    const uint32_t rgb = lo[q] & 0xFFFFFFu;
+                    const bool hole = !covered || rgb == a.key_rgb;          // sr:740
+                    o[q] = hole ? 0u : rgb;                                  // sr:793
+                    mw |= hole ? (0xFFu << (8 * q)) : 0u;
+                    if (ZOUT) oz[q] = covered ? 1.0f / __uint_as_float(~hi[q]) : 0.0f;
+                }
+                uint32_t* op = (uint32_t*)(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)k * a.rgb_pitch) + 3 * tid;
+                __builtin_nontemporal_store(__builtin_amdgcn_perm(o[1], o[0], 0x04020100u), op);
+                __builtin_nontemporal_store(__builtin_amdgcn_perm(o[2], o[1], 0x05040201u), op + 1);
+                __builtin_nontemporal_store(__builtin_amdgcn_perm(o[3], o[2], 0x06050402u), op + 2);
+                __builtin_nontemporal_store(mw, (uint32_t*)(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)k * a.mask_pitch) + tid);
+                if (ZOUT && a.zout[eye]) {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    const f32x4 v = {oz[0], oz[1], oz[2], oz[3]};
+                    __builtin_nontemporal_store(v, (f32x4*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)k * a.zout_pitch) + tid);
+                }
+            }
+            __syncthreads();
+        }
+        g = gn;
+    }
+}
+
+size_t mesh_band_lds_bytes(int W, int tpb)
+{
+    return (size_t)W * sizeof(u64) + 2 * (size_t)W * 16 + (size_t)(tpb / 64) * kQueueWave * sizeof(uint32_t);
+}
+
+// Can the band kernel render this launch?  (4-byte aligned rows, no edge removal, LDS for one row.)
+bool mesh_band_supported(const RenderPlan& plan, const RenderArgs& a)
+{
+    if (!plan.vec4 || plan.general || plan.remove_edges || a.seed[0]) return false;
+    if (a.W < 8 || a.W > 4096 || a.W > 4 * 1024) return false;       // 1024 threads x 4 px; the 24-bit fast path assumes W*256 <= 2^20
+    return mesh_band_lds_bytes(a.W, a.W / 4 <= 512 ? 512 : 1024) <= 160 * 1024;
+}
+
+template <int TPB>
+static hipError_t launch_mesh_band_tpb(const RenderPlan& plan, const RenderArgs& a, int rows, hipStream_t s)
+{
+    size_t lds = mesh_band_lds_bytes(a.W, TPB);
+    if (const char* e = getenv("MDVT_LDS_PAD")) lds += (size_t)atoi(e);      // occupancy probe (tools/kbench.py)
+    const int nbands = (a.H + rows - 1) / rows;
+    const dim3 grid((unsigned)(plan.n * nbands)), block(TPB);
+    const bool zout = a.zout[0] || a.zout[1];
+    if (zout) {
+        (void)hipFuncSetAttribute((const void*)k_mesh_band<1, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_mesh_band<1, TPB>), grid, block, lds, s, a, rows, nbands);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_mesh_band<0, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_mesh_band<0, TPB>), grid, block, lds, s, a, rows, nbands);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
+{
+    RenderArgs a = a_in;
+    if (const char* e = getenv("MDVT_DEBUG_SKIP")) a.debug_skip = atoi(e);
+    int rows = 8;
+    if (const char* e = getenv("MDVT_MESH_BAND")) { const int v = atoi(e); if (v > 0) rows = v; }     // tuning hook
+    if (rows > a.H) rows = a.H;
+    if (a.W / 4 <= 512) return launch_mesh_band_tpb<512>(plan, a, rows, s);
+    return launch_mesh_band_tpb<1024>(plan, a, rows, s);
+}
+
+}  // namespace mdvt
