@@ -6,9 +6,16 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of --frames synthetic 1920x1080 frames
-(BASELINE.json configs[1]'s shape, batched so the working set exceeds the 256 MiB Infinity Cache),
-already resident in HBM when the timed region starts.  Weak scaling: every rank renders its own
-batch; `value` = frames all ranks rendered / max-over-ranks wall time.  Rank 0 prints ONE JSON line.
+(BASELINE.json configs[1]'s shape; 128 frames = 3.7 GB of inputs + outputs, far past the 256 MiB
+Infinity Cache), already resident in HBM when the timed region starts.  Weak scaling: every rank
+renders its own batch; `value` = frames all ranks rendered / max-over-ranks wall time.  Rank 0 prints
+ONE JSON line; its "extra" object carries the other draw modes (mesh = the reference's default,
+mesh + --infill_mask + convergence = movie_2_3D.py's default), the batch-size sweep and the
+300-frame clip of BASELINE configs[2] (strong scaling: the clip's frames are split over the ranks).
+
+`--gpus N` with N > 1 and no torchrun environment re-executes itself under torch.distributed.run with
+N ranks (one per GPU); it exits non-zero if the node has fewer than N GPUs -- it never silently
+measures fewer GPUs than asked for.
 """
 import argparse
 import json
@@ -34,7 +41,9 @@ def parse_args():
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed spin of the same step before the W warm-up steps: the GPU leaves its idle "
                          "power state over tens of ms (measured: the first ~100 launches after idle run ~15%% slower)")
-    ap.add_argument("--frames", type=int, default=32, help="frames per step (per rank)")
+    ap.add_argument("--frames", type=int, default=128, help="frames per step (per rank)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (other modes, sweep, clip)")
+    ap.add_argument("--clip-frames", type=int, default=300, help="frames of the strong-scaling clip (BASELINE configs[2])")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mode", choices=["points", "mesh"], default="points")
@@ -187,22 +196,91 @@ def pmc_traffic(kernel_substr, frames, W, H):
     return best
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` outside torchrun: become N ranks, or fail loudly."""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to "
+                         "measure fewer GPUs than asked for\n")
+        sys.exit(3)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def timed_steps(step, steps, dev, torch, barrier=None):
+    """K back-to-back steps between sync points -> (wall seconds, HIP-event ms per step)."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    if barrier:
+        barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+
+
+def measure_variant(make_job, frames, W, H, dev, torch, budget_s=0.6, bytes_per_px=BYTES_PER_PX):
+    """Median over groups of launches of one prepared job (N=1 extras; not the contract's timed region)."""
+    job = make_job()
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(3):
+        job.launch(stream)
+    torch.cuda.synchronize(dev)
+    _, one = timed_steps(lambda: job.launch(stream), 3, dev, torch)
+    per_group = max(3, min(200, int(0.05 / max(one * 1e-3, 1e-6))))
+    groups = []
+    t_end = time.perf_counter() + budget_s
+    while len(groups) < 5 or (time.perf_counter() < t_end and len(groups) < 25):
+        groups.append(timed_steps(lambda: job.launch(stream), per_group, dev, torch)[1])
+    groups.sort()
+    ms = groups[len(groups) // 2]
+    byts = bytes_per_px * W * H * frames
+    return {"frames_per_launch": frames, "launch_ms": ms, "fps": frames / (ms * 1e-3),
+            "algorithmic_GBps": byts / (ms * 1e-3) / 1e9, "roofline_frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "groups": len(groups), "launches_per_group": per_group}
+
+
 def main():
     args = parse_args()
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        return relaunch_under_torchrun(args)
     import torch
     from metric_depth_video_toolbox_amd import distributed as D
     from metric_depth_video_toolbox_amd.stereo_rerender import StereoRerenderer
     from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
 
     rank, world = D.init_process_group()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.distributed.is_initialized():
+        world = torch.distributed.get_world_size()          # what RCCL actually spans, not what the env claims
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the job has {world} rank(s)\n")
+        sys.exit(3)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     W, H, N = args.width, args.height, args.frames
+    barrier = torch.distributed.barrier if torch.distributed.is_initialized() else None
+    devices = [f"{torch.cuda.get_device_name(local)} (cuda:{local})"]
+    if torch.distributed.is_initialized():
+        names = [None] * world
+        torch.distributed.all_gather_object(names, devices[0])
+        devices = names
 
     # rank 0 owns the clip parameters and broadcasts them (RCCL over xGMI when world > 1)
     clip = None
@@ -219,13 +297,21 @@ def main():
                          dont_place_points_in_edges=not bool(clip.mode_flags & 4))
     params = r.pack_params([r.frame_params(xfov=float(clip.xfov[t])) for t in range(lo, hi)], hi - lo)
 
-    # synthetic frames of this rank's range, resident in HBM before the timed region
+    # synthetic frames of this rank's range, resident in HBM before the timed region: 32 distinct scenes from the host
+    # generator, the rest of the batch the same scenes shifted by whole pixels on the device (every frame differs)
     sc = SyntheticScene(W, H, config_id=2)
-    d_np, c_np = sc.clip(hi - lo, t0=lo)
-    depth_rgb = torch.from_numpy(d_np).to(dev)
-    color_rgb = torch.from_numpy(c_np).to(dev)
-    del d_np, c_np
     n_local = hi - lo
+    n_host = min(n_local, 32)
+    d_np, c_np = sc.clip(n_host, t0=lo)
+    depth_rgb = torch.empty((n_local, H, W, 3), dtype=torch.uint8, device=dev)
+    color_rgb = torch.empty((n_local, H, W, 3), dtype=torch.uint8, device=dev)
+    depth_rgb[:n_host] = torch.from_numpy(d_np).to(dev)
+    color_rgb[:n_host] = torch.from_numpy(c_np).to(dev)
+    del d_np, c_np
+    for k in range(n_host, n_local):
+        sh = (7 * (k // n_host), 13 * (k // n_host))
+        depth_rgb[k] = torch.roll(depth_rgb[k % n_host], shifts=sh, dims=(0, 1))
+        color_rgb[k] = torch.roll(color_rgb[k % n_host], shifts=sh, dims=(0, 1))
     sbs = torch.empty((n_local, H, 2 * W, 3), dtype=torch.uint8, device=dev)
     mask = torch.empty((n_local, H, 2 * W), dtype=torch.uint8, device=dev)
 
@@ -238,38 +324,28 @@ def main():
     if args.prewarm_ms > 0:                     # clock ramp only; not part of W or K
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-            for _ in range(10):
+            for _ in range(4):
                 step()
             torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
-    if torch.distributed.is_initialized():
-        torch.distributed.barrier()
-    # HIP events on the stream the kernel is launched on (torch's current stream), bracketing the timed
-    # region: K back-to-back launches of the one kernel a step consists of -> average launch duration.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    if torch.distributed.is_initialized():
-        torch.distributed.barrier()
-    wall = time.perf_counter() - t0
+    # The timed region: EXACTLY K steps between barrier + synchronize on both sides; HIP events on the stream the
+    # kernel is launched on (torch's current stream) give the average launch duration of the one kernel a step is.
+    wall, launch_ms = timed_steps(step, args.steps, dev, torch, barrier)
     wall = D.max_over_ranks(wall, device=dev)
-    launch_ms = ev0.elapsed_time(ev1) / args.steps
     hole_px = float((mask[0] > 0).sum().item())
     stats = D.gather_rank_stats(n_local * args.steps, wall, hole_px, device=dev)
+
+    extra = {}
+    if not args.no_extra:
+        extra = extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world, dev, torch, D, barrier)
 
     if rank == 0:
         total_frames = float(stats[:, 0].sum())
         fps = total_frames / wall
         bytes_per_launch = BYTES_PER_PX * W * H * n_local
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        kname = ("k_points_rows<4, " if args.remove_edges else "k_points_rows_fast<") if args.mode == "points" else "k_mesh_rows<4, "
+        kname = ("k_points_rows<4, " if args.remove_edges else "k_points_rows_fast<") if args.mode == "points" else "k_mesh_band<"
         tr = pmc_traffic(kname, n_local, W, H)
         out = {
             "metric": "stereo frames/sec at 1920x1080 (+ achieved HBM GB/s vs roofline)",
@@ -280,12 +356,13 @@ def main():
                                    f"{' + remove_edges' if args.remove_edges else ''}, {n_local} distinct frames per step per GPU, "
                                    "inputs resident in HBM (BASELINE.json configs[1] shape, batched past the 256 MiB Infinity Cache)",
                        "frames_per_step_per_gpu": n_local, "parallelism": f"frames sharded over {world} rank(s), "
-                       "one broadcast of the parameter block, no data-path collective"},
+                       "one broadcast of the parameter block, no data-path collective", "devices": devices},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
                          "traffic_source": tr["source"] if tr else None,
                          "kernel": kname.rstrip(", "),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms},
+            "extra": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.mode, args.remove_edges, args.cpu_seconds)
@@ -295,6 +372,80 @@ def main():
     r.close()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world, dev, torch, D, barrier):
+    """Everything beside the headline line.  (a) at any N: the 300-frame clip of BASELINE configs[2], strong scaling --
+    the clip's frames are split into contiguous ranges over the ranks, every rank renders its range in batches from
+    frames resident in its HBM, time = max over ranks.  (b) at N = 1 only: the batch-size sweep of the headline kernel
+    (is 32 frames really past the Infinity Cache?), the fused ballot-compacted mask + hole counts, mesh mode (the
+    reference's default draw mode) and mesh + --infill_mask + convergence (movie_2_3D.py's default)."""
+    from metric_depth_video_toolbox_amd.stereo_rerender import StereoRerenderer
+    W, H = args.width, args.height
+    n_have = int(depth_rgb.shape[0])
+    stream = torch.cuda.current_stream(dev)
+    out = {}
+
+    # (a) the clip, strong scaling
+    NC = args.clip_frames
+    lo, hi = D.frame_range(rank, world, NC)
+    batch = min(32, n_have)
+    p1 = [r.frame_params(xfov=45.0) for _ in range(batch)]
+    jobs = {}
+
+    def clip_pass():
+        k = lo
+        while k < hi:                                   # this rank's contiguous range, batch by batch
+            n = min(batch, hi - k)
+            s = (k - lo) % max(1, n_have - n + 1)       # a window of the resident frames (no two frames of a batch equal)
+            if (s, n) not in jobs:
+                jobs[(s, n)] = r.prepare(depth_rgb[s:s + n], color_rgb[s:s + n], p1[:n], out_sbs=sbs[s:s + n], out_mask=mask[s:s + n])
+            jobs[(s, n)].launch(stream)
+            k += n
+
+    clip_pass()
+    torch.cuda.synchronize(dev)
+    walls = []
+    for _ in range(5):
+        wall, _ = timed_steps(clip_pass, 1, dev, torch, barrier)
+        walls.append(D.max_over_ranks(wall, device=dev))
+    walls.sort()
+    out["clip_c3"] = {"frames": NC, "scaling": "strong", "n_gpus": world, "seconds_median_of_5": walls[2], "fps": NC / walls[2],
+                      "mode": args.mode, "note": "BASELINE configs[2]: contiguous frame ranges per rank, frames resident in each "
+                      "rank's HBM, batches of 32, wall clock = max over ranks incl. launch overhead"}
+    if world > 1:
+        return out
+
+    # (b) N = 1 extras
+    if args.mode == "points" and not args.remove_edges:
+        sweep = {}
+        for nf in (32, 64, 128):
+            if nf > n_have:
+                continue
+            pp = [r.frame_params(xfov=45.0) for _ in range(nf)]
+            sweep[str(nf)] = measure_variant(lambda: r.prepare(depth_rgb[:nf], color_rgb[:nf], pp, out_sbs=sbs[:nf], out_mask=mask[:nf]),
+                                             nf, W, H, dev, torch)
+        out["points_batch_sweep"] = sweep
+        nf = min(32, n_have)
+        pp = [r.frame_params(xfov=45.0) for _ in range(nf)]
+        out["points_fused_maskbits_and_counts"] = measure_variant(
+            lambda: r.prepare(depth_rgb[:nf], color_rgb[:nf], pp, out_sbs=sbs[:nf], out_mask=mask[:nf], want_maskbits=True, want_hole_counts=True),
+            nf, W, H, dev, torch)
+    nf = min(32, n_have)
+    rm = StereoRerenderer(W, H, device=dev.index, pupillary_distance=65)
+    pm = [rm.frame_params(xfov=45.0) for _ in range(nf)]
+    out["mesh"] = measure_variant(lambda: rm.prepare(depth_rgb[:nf], color_rgb[:nf], pm, out_sbs=sbs[:nf], out_mask=mask[:nf]), nf, W, H, dev, torch)
+    out["mesh"]["what"] = "mesh mode (the reference's default draw mode), pure stereo shift: k_mesh_band"
+    rm.close()
+    nf = min(16, n_have)
+    rp = StereoRerenderer(W, H, device=dev.index, pupillary_distance=65, infill_mask=True)
+    pd = [rp.frame_params(xfov=45.0, convergence_distance=2.5) for _ in range(nf)]
+    out["product_default"] = measure_variant(lambda: rp.prepare(depth_rgb[:nf], color_rgb[:nf], pd, out_sbs=sbs[:nf], out_mask=mask[:nf]),
+                                             nf, W, H, dev, torch)
+    out["product_default"]["what"] = ("mesh + --infill_mask (89-degree edge filter, edge points, green key) + per-frame convergence "
+                                      "(movie_2_3D.py:433-445): the general path")
+    rp.close()
+    return out
 
 
 if __name__ == "__main__":

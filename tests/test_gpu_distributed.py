@@ -1,0 +1,88 @@
+"""The multi-rank path on real hardware: backend "nccl" (= RCCL on ROCm) with the helpers of distributed.py, and
+bench.py's refusal to measure fewer GPUs than it was asked for (the reference's analogue is one OS
+process per scene with argv parameters, movie_2_3D.py:433-452)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+_RCCL_SCRIPT = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MDVT_REPO"])
+from metric_depth_video_toolbox_amd import distributed as D
+rank, world = D.init_process_group()            # RANK / WORLD_SIZE / MASTER_* from the env -> backend nccl
+assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == world
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+N = 7
+T = np.tile(np.eye(4), (N, 1, 1)); T[:, 0, 3] = np.arange(N) * 1e-3
+clip = D.ClipParameters(1920, 1080, N, 0.065, 100.0, 45.0, 0b1110, np.linspace(40, 50, N), np.linspace(2, 3, N), T) if rank == 0 else None
+got = D.broadcast_clip_parameters(clip, src=0, device=dev)      # device tensors through RCCL
+assert (got.W, got.H, got.n_frames, got.mode_flags) == (1920, 1080, N, 0b1110)
+assert np.array_equal(got.xfov, np.linspace(40, 50, N)) and np.array_equal(got.convergence, np.linspace(2, 3, N))
+assert np.array_equal(got.transformations, T)
+st = D.gather_rank_stats(5.0 + rank, 0.25, 1234.0, device=dev)
+assert st.shape == (world, 3) and st[rank, 0] == 5.0 + rank
+assert D.max_over_ranks(1.5 + rank, device=dev) == 1.5 + (world - 1)
+t = torch.ones(1 << 20, device=dev); dist.all_reduce(t); torch.cuda.synchronize()
+assert float(t[0]) == world
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK", world)
+"""
+
+
+def test_rccl_backend_carries_the_parameter_block_and_the_rank_statistics():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               MDVT_REPO=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "RCCL_OK 1" in p.stdout, p.stdout + p.stderr
+
+
+def test_bench_never_measures_fewer_gpus_than_requested():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    ask = have + 1
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(ask), "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and f"--gpus {ask}" in p.stderr and "{" not in p.stdout, p.stdout + p.stderr
+    if have >= 2:           # on a multi-GPU node plain `python bench.py --gpus 2` becomes two RCCL ranks by itself
+        p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                            "--frames", "4", "--no-extra", "--no-cpu-baseline", "--prewarm-ms", "0"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and len(line["config"]["devices"]) == 2
+
+
+def test_bench_line_under_torchrun_with_one_rank():
+    """The driver's launch line with N = 1 ranks: the RCCL process group exists and n_gpus comes from it."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--frames", "4", "--no-cpu-baseline", "--prewarm-ms", "0", "--clip-frames", "12"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "weak" and line["roofline"]["bound"] == "hbm"
+    assert line["extra"]["clip_c3"]["frames"] == 12 and line["extra"]["clip_c3"]["scaling"] == "strong"
+    assert "mesh" in line["extra"] and "product_default" in line["extra"]
