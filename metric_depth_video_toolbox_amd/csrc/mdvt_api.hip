@@ -50,6 +50,7 @@ struct mdvt_ctx {
     unsigned long long* keys[2] = {nullptr, nullptr};
     unsigned long long* ekeys[2] = {nullptr, nullptr};
     uint4* gverts[2] = {nullptr, nullptr};
+    unsigned long long* cbuf[2] = {nullptr, nullptr};
     bool ws_gverts = false;
     bool keys_dirty = false;          // a general-path submission was interrupted between splat and resolve
     uint8_t* tri_invalid = nullptr;
@@ -198,7 +199,7 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         c->tri_invalid = nullptr; c->unused = nullptr; c->ws_edges = false;
     }
     if (grow || (need_gverts && !c->ws_gverts)) {
-        for (int e = 0; e < 2; ++e) { if (c->gverts[e]) (void)hipFree(c->gverts[e]); c->gverts[e] = nullptr; }
+        for (int e = 0; e < 2; ++e) { if (c->gverts[e]) (void)hipFree(c->gverts[e]); c->gverts[e] = nullptr; if (c->cbuf[e]) (void)hipFree(c->cbuf[e]); c->cbuf[e] = nullptr; }
         c->ws_gverts = false;
     }
     if (grow) c->ws_frames = frames;
@@ -218,7 +219,10 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         c->ws_ekeys = true;
     }
     if (need_gverts && !c->ws_gverts) {
-        for (int e = 0; e < 2; ++e) MDVT_HIP(c, hipMalloc((void**)&c->gverts[e], nf * npx * sizeof(uint4)));
+        for (int e = 0; e < 2; ++e) {
+            MDVT_HIP(c, hipMalloc((void**)&c->gverts[e], nf * npx * sizeof(uint4)));
+            MDVT_HIP(c, hipMalloc((void**)&c->cbuf[e], nf * npx * sizeof(unsigned long long)));   // validated by draw id: needs no clearing
+        }
         if (c->bigq) (void)hipFree(c->bigq);
         c->bigq = nullptr;
         // room for one large triangle per 8 pixels of a launch set (more than any scene short of white noise produces;
@@ -324,7 +328,7 @@ int mdvt_destroy(mdvt_ctx* c)
         if (sl.dev) (void)hipFree(sl.dev);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
-    for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); if (c->gverts[e]) (void)hipFree(c->gverts[e]); }
+    for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); if (c->gverts[e]) (void)hipFree(c->gverts[e]); if (c->cbuf[e]) (void)hipFree(c->cbuf[e]); }
     if (c->bigq) (void)hipFree(c->bigq);
     if (c->tri_invalid) (void)hipFree(c->tri_invalid);
     if (c->unused) (void)hipFree(c->unused);
@@ -486,6 +490,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.keys[0] = c->keys[0]; a.keys[1] = c->keys[1];
     a.ekeys[0] = c->ekeys[0]; a.ekeys[1] = c->ekeys[1];
     a.gverts[0] = c->gverts[0]; a.gverts[1] = c->gverts[1];
+    a.cbuf[0] = c->cbuf[0]; a.cbuf[1] = c->cbuf[1];
     a.tri_invalid = c->tri_invalid; a.unused = c->unused;
     if (c->bigq && getenv("MDVT_NO_BIGQ") == nullptr) {
         a.bigq = c->bigq; a.bigq_cap = c->bigq_cap; a.bigq_count = c->bigq + (size_t)c->bigq_cap * mdvt::kBigRecDwords;

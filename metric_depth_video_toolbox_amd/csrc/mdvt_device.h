@@ -191,14 +191,16 @@ __device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b,
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
 
 // iz_k = 1/Z_k of the three vertices; a vertex behind the near plane is flagged by iz == 0.
+// cull: 0 none, 1 back faces (area2 > 0 with y down: clockwise on screen), 2 front faces (mdvt_config.cull).
 __device__ __forceinline__ bool tri_setup_snapped(TriSetup& t, int X0, int Y0, float iz0, int X1, int Y1, float iz1,
-                                                  int X2, int Y2, float iz2)
+                                                  int X2, int Y2, float iz2, int cull = 0)
 {
     t.area2 = 0;
     if (!(iz0 > 0.0f && iz1 > 0.0f && iz2 > 0.0f)) return false;    // near plane: whole triangle dropped
     const i64 a2 = mul64(X1 - X0, Y2 - Y0) - mul64(Y1 - Y0, X2 - X0);
     if (a2 == 0) return false;
     const bool neg = a2 < 0;
+    if (cull && (cull == 1) != neg) return false;
     t.area2 = neg ? -a2 : a2;
     t.dx0 = neg ? X1 - X2 : X2 - X1; t.dy0 = neg ? Y1 - Y2 : Y2 - Y1;
     t.dx1 = neg ? X2 - X0 : X0 - X2; t.dy1 = neg ? Y2 - Y0 : Y0 - Y2;
@@ -210,10 +212,111 @@ __device__ __forceinline__ bool tri_setup_snapped(TriSetup& t, int X0, int Y0, f
     return true;
 }
 
-__device__ __forceinline__ bool tri_setup(TriSetup& t, const Vert& a, const Vert& b, const Vert& c)
+__device__ __forceinline__ bool tri_setup(TriSetup& t, const Vert& a, const Vert& b, const Vert& c, int cull = 0)
 {
     return tri_setup_snapped(t, snap(a.u), snap(a.v), a.ok ? rcp_exact(a.z) : 0.0f, snap(b.u), snap(b.v),
-                             b.ok ? rcp_exact(b.z) : 0.0f, snap(c.u), snap(c.v), c.ok ? rcp_exact(c.z) : 0.0f);
+                             b.ok ? rcp_exact(b.z) : 0.0f, snap(c.u), snap(c.v), c.ok ? rcp_exact(c.z) : 0.0f, cull);
+}
+
+// ---- z-buffer words and exact depth ties ------------------------------------------------------------------------
+// A z-buffer word is 64 bits, high half = ~bits(1/Z) of the fragment (1/Z > 0, so the unsigned minimum is the nearest
+// fragment; all ones = empty).  OpenGL resolves an EXACT depth tie between overlapping triangles by draw order: with
+// GL_LESS the triangle drawn first keeps the pixel, and the reference draws all tri1 row-major, then all tri2
+// (dmt:1243-1254).  Such ties are not rare (a few per 10^5 fragments on the benchmark scenes), so both kinds of
+// kernel implement that rule exactly:
+//   * global-key kernels (general path): low half = draw id = pass << 31 | i << 16 | j, so that the 64-bit minimum IS
+//     "nearest, then first drawn"; the colour is recomputed from the id by the resolve pass (deferred shading);
+//   * LDS row kernels (pure shift): low half = the shaded colour (the resolve stays a plain read); a fragment that meets
+//     its own depth with another colour in the word raises the pixel's tie bit, and a row with tie bits is rasterised
+//     twice more -- once to find the lowest draw id among the fragments at the winning depth of each tied pixel, once
+//     to let exactly that fragment write its colour (RowTies below).
+__device__ __forceinline__ uint32_t draw_id_global(int pass, int i, int j) { return ((uint32_t)pass << 31) | ((uint32_t)i << 16) | (uint32_t)j; }
+__device__ __forceinline__ uint32_t depth_bits(float iz) { return ~__float_as_uint(iz); }
+
+struct RowTies {
+    uint32_t* bits;      // LDS: one bit per pixel of the row, then one flag word (index nwords)
+    int nwords;
+    int mode;            // 0: normal pass; 1: lowest draw id at the winning depth of tied pixels; 2: that fragment's colour
+    bool force;          // test hook (MDVT_DEBUG_SKIP bit 5): every pixel that receives a second fragment counts as tied
+    __device__ __forceinline__ bool tied(int px) const { return (bits[px >> 5] >> (px & 31)) & 1u; }
+};
+
+// One shaded fragment of a row kernel.  draw = pass << 16 | cell column (one row of cells per scanline).
+__device__ __forceinline__ void post_row_fragment(u64* zb, int px, float iz, uint32_t rgb, uint32_t draw, const RowTies& t)
+{
+    const uint32_t hi = depth_bits(iz);
+    if (t.mode == 0) {
+        const u64 key = ((u64)hi << 32) | rgb;
+        const u64 old = atomicMin(&zb[px], key);
+        if (((uint32_t)(old >> 32) == hi && (uint32_t)old != rgb) || (t.force && old != kEmpty64)) {   // same depth, another colour: whoever came second sees it
+            atomicOr(&t.bits[px >> 5], 1u << (px & 31));
+            t.bits[t.nwords] = 1u;
+        }
+    } else if (t.tied(px)) {
+        if (t.mode == 1) {
+            if ((uint32_t)(zb[px] >> 32) == hi) atomicMin(&zb[px], ((u64)hi << 32) | draw);
+        } else if (zb[px] == (((u64)hi << 32) | draw)) {
+            zb[px] = ((u64)(hi & 0x7FFFFFFFu) << 32) | rgb;             // top bit cleared = final (no depth looks like this)
+        }
+    }
+}
+// between mode 0 and mode 1: a tied pixel keeps its depth and forgets its colour
+__device__ __forceinline__ void row_ties_prepare(u64* zb, int W, const RowTies& t, int tid, int nthreads)
+{
+    for (int x = tid; x < W; x += nthreads)
+        if (t.tied(x)) zb[x] |= 0xFFFFFFFFull;
+}
+// 1/Z bits of a resolved row word (the top bit of ~bits is always set; a finalised tie has it cleared)
+__device__ __forceinline__ float row_word_iz(uint32_t hi) { return __uint_as_float(~(hi | 0x80000000u)); }
+
+// ---- 32-bit twin of the triangle set-up for small triangles ---------------------------------------------------------
+// A triangle whose snapped extent is below 2^13 sub-pixels (32 px) has every edge value and its doubled area below
+// 2^27 and every factor below 2^23: the same integers as the 64-bit path from 24-bit multiplies (full rate; the
+// 32x32 -> 64 multiplies of the generic path are quarter rate) and 32-bit adds and compares.
+constexpr int kSmallTriExtent = 8192;
+struct TriSmall {
+    int dx0, dy0, dx1, dy1, dx2, dy2;   // orientation-normalised, as in TriSetup
+    int bx0, by0, bx1, by1, bx2, by2;
+    int area2;
+    float iz0, iz1, iz2;
+};
+
+__device__ __forceinline__ bool tri_small_setup(TriSmall& t, int X0, int Y0, float iz0, int X1, int Y1, float iz1,
+                                                int X2, int Y2, float iz2, int cull)
+{
+    if (!(iz0 > 0.0f && iz1 > 0.0f && iz2 > 0.0f)) return false;    // near plane: whole triangle dropped
+    const int a2 = __mul24(X1 - X0, Y2 - Y0) - __mul24(Y1 - Y0, X2 - X0);
+    if (a2 == 0) return false;
+    const bool neg = a2 < 0;
+    if (cull && (cull == 1) != neg) return false;
+    t.area2 = neg ? -a2 : a2;
+    t.dx0 = neg ? X1 - X2 : X2 - X1; t.dy0 = neg ? Y1 - Y2 : Y2 - Y1;
+    t.dx1 = neg ? X2 - X0 : X0 - X2; t.dy1 = neg ? Y2 - Y0 : Y0 - Y2;
+    t.dx2 = neg ? X0 - X1 : X1 - X0; t.dy2 = neg ? Y0 - Y1 : Y1 - Y0;
+    t.bx0 = X1; t.by0 = Y1; t.bx1 = X2; t.by1 = Y2; t.bx2 = X0; t.by2 = Y0;
+    t.iz0 = iz0; t.iz1 = iz1; t.iz2 = iz2;
+    return true;
+}
+
+struct TriWalk32 { int w0, w1, w2; };
+__device__ __forceinline__ TriWalk32 tri_small_start(const TriSmall& t, int px, int py)
+{
+    const int Xc = px * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
+    return TriWalk32{__mul24(t.dx0, Yc - t.by0) - __mul24(t.dy0, Xc - t.bx0), __mul24(t.dx1, Yc - t.by1) - __mul24(t.dy1, Xc - t.bx1),
+                     __mul24(t.dx2, Yc - t.by2) - __mul24(t.dy2, Xc - t.bx2)};
+}
+__device__ __forceinline__ void tri_small_right(const TriSmall& t, TriWalk32& w) { w.w0 -= t.dy0 * kSubpix; w.w1 -= t.dy1 * kSubpix; w.w2 -= t.dy2 * kSubpix; }
+__device__ __forceinline__ void tri_small_down(const TriSmall& t, TriWalk32& w) { w.w0 += t.dx0 * kSubpix; w.w1 += t.dx1 * kSubpix; w.w2 += t.dx2 * kSubpix; }
+__device__ __forceinline__ bool edge_in32(int w, int dx, int dy) { return w > 0 || (w == 0 && ((dy < 0) || (dy == 0 && dx > 0))); }
+__device__ __forceinline__ bool tri_small_inside(const TriSmall& t, const TriWalk32& w)
+{
+    return edge_in32(w.w0, t.dx0, t.dy0) && edge_in32(w.w1, t.dx1, t.dy1) && edge_in32(w.w2, t.dx2, t.dy2);
+}
+// q_k = (f32(w_k) * (1 / f32(area2))) * (1/Z_k): what tri_weights computes for a small triangle
+__device__ __forceinline__ void tri_small_weights(const TriSmall& t, const TriWalk32& w, float& q0, float& q1, float& q2)
+{
+    const float ra = rcp_exact((float)t.area2);
+    q0 = ((float)w.w0 * ra) * t.iz0; q1 = ((float)w.w1 * ra) * t.iz1; q2 = ((float)w.w2 * ra) * t.iz2;
 }
 
 // i64 -> f32, round to nearest even.  When the value fits int32 the single-instruction conversion

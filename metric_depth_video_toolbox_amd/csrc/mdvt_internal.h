@@ -54,6 +54,7 @@ struct RenderArgs {
     unsigned long long* keys[2]; // [slot][H*W] 64-bit z keys per eye
     unsigned long long* ekeys[2];// edge-point keys per eye
     uint4* gverts[2];            // general mesh path: per-eye projected vertices {X, Y (snapped), 1/Z', rgb}, [slot][H*W]
+    unsigned long long* cbuf[2]; // general mesh path: per-eye colour side buffer, draw id << 32 | rgb of some fragment of the pixel
     uint8_t* tri_invalid;        // [slot][2*(H-1)*(W-1)]
     uint8_t* unused;             // [slot][H*W]
     // general mesh path: queue of large triangles (records of kBigRecDwords dwords), rasterised by k_mesh_raster_big
@@ -75,7 +76,7 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
                               int n, int W, int H, int of_by_one, uint8_t* tri_invalid, size_t tri_stride,
                               uint8_t* unused, size_t unused_stride, hipStream_t s);
 
-constexpr int kBigRecDwords = 32;    // 25 used: normalised edges, base points, area, 1/Z, pixel box, colours, frame/eye
+constexpr int kBigRecDwords = 32;    // 26 used: normalised edges, base points, area, 1/Z, pixel box, draw id, colours, frame/eye
 
 struct RenderPlan {
     int mode;            // mdvt_mode

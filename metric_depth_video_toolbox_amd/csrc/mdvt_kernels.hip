@@ -839,6 +839,13 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
     for (int q = 0; q < PX; ++q) krow[q] = kEmpty64;
     uint32_t opx[PX], om[PX], spx[PX];
     float oz[PX];
+    const uint4* gv = MESH ? a.gverts[eye] + (size_t)fr * a.ws_stride_px : nullptr;
+    u64 cw[PX];
+    if (MESH) {
+        const u64* crow = a.cbuf[eye] + (size_t)fr * a.ws_stride_px + (size_t)y * W + (size_t)g * PX;
+#pragma unroll
+        for (int q = 0; q < PX; ++q) cw[q] = crow[q];
+    }
 #pragma unroll
     for (int q = 0; q < PX; ++q) {
         const bool covered = key[q] != kEmpty64;
@@ -846,8 +853,26 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
         float zval = 0.0f;
         if (covered) {
             if (MESH) {
-                rgb = (uint32_t)key[q] & 0xFFFFFFu;
+                // the key names the winning triangle (pass << 31 | i << 16 | j).  Its colour is in the side buffer unless another
+                // fragment of this pixel stored last: then its three projected vertices are read back and the fragment is
+                // evaluated exactly as the rasteriser evaluated it
+                const uint32_t id = (uint32_t)key[q];
                 if (ZOUT) zval = 1.0f / __uint_as_float(~(uint32_t)(key[q] >> 32));
+                if ((uint32_t)(cw[q] >> 32) == id && !(a.debug_skip & 64)) { rgb = (uint32_t)cw[q]; }     // (bit 6: test hook, always re-shade)
+                else {
+                const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
+                const uint4* r0 = gv + (size_t)ci * W + cj;
+                const uint4 A = r0[0];
+                const uint4 v1 = pass == 0 ? r0[W] : r0[W + 1], v2 = pass == 0 ? r0[W + 1] : r0[1];
+                TriSetup t;
+                (void)tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
+                                        (int)v2.x, (int)v2.y, __uint_as_float(v2.z));
+                float q0, q1, q2;
+                (void)tri_sample(t, g * PX + q, y, q0, q1, q2);
+                const float iz = (q0 + q1) + q2;
+                const float riz = rcp_exact(iz);
+                rgb = shade_px(q0, q1, q2, riz, A.w, v1.w, v2.w);
+                }
             } else {
                 const uint32_t src = (uint32_t)key[q];
                 rgb = load_px_bytes(cbase + (size_t)(src >> 16) * a.color_pitch, (int)(src & 0xFFFFu));
@@ -915,21 +940,31 @@ static hipError_t launch_resolve_general(const RenderPlan& plan, const RenderArg
 //   raster   per eye: one thread per cell walks the pixel centres inside its two triangles, shades each
 //            covered fragment perspective-correctly and posts
 //               key = ~bits(1/Z interpolated) << 32 | R | G<<8 | B<<16
-//            with ds_min_u64 (min == nearest; an exact 1/Z tie between overlapping triangles goes to the
-//            smaller packed colour -- the decree's order-free stand-in for draw order, which lets the
-//            fragment travel in one LDS word).  Spans longer than kShortSpan (rubber-sheet triangles
+//            with ds_min_u64 (min == nearest; an exact 1/Z tie between overlapping triangles of different
+//            colour is detected and settled by draw order in two more passes over the row -- RowTies in
+//            mdvt_device.h).  Spans longer than kShortSpan (rubber-sheet triangles
 //            across depth edges) are handed to the whole wave: one lane's triangle is broadcast with
 //            v_readlane and 64 lanes test 64 pixel centres at a time.
 //   resolve  per eye: plain LDS reads -> colour-key hole test -> coalesced dwordx3 / dword stores.
 // The z-buffer holds one eye at a time (the resolve of the left eye resets it), so LDS is
 // 2*16*W + 8*W (+4*W with edge points) bytes: 77 KB at 1080p -> two workgroups per CU.
 
-// One covered fragment -> z-buffer word.
-__device__ __forceinline__ u64 mesh_fragment_key(float q0, float q1, float q2, uint32_t c0, uint32_t c1, uint32_t c2)
+// One covered fragment of a row kernel: interpolated 1/Z and shaded colour into the row's z-buffer.
+__device__ __forceinline__ void mesh_row_fragment(u64* zb, int px, float q0, float q1, float q2, uint32_t c0, uint32_t c1, uint32_t c2,
+                                                  uint32_t draw, const RowTies& ties)
 {
     const float iz = (q0 + q1) + q2;
     const float riz = rcp_exact(iz);
-    return ((u64)(~__float_as_uint(iz)) << 32) | shade_px(q0, q1, q2, riz, c0, c1, c2);
+    post_row_fragment(zb, px, iz, shade_px(q0, q1, q2, riz, c0, c1, c2), draw, ties);
+}
+
+// One covered fragment of the global-key kernels.
+__device__ __forceinline__ void mesh_global_fragment(u64* keys, u64* cbuf, size_t o, float q0, float q1, float q2,
+                                                     uint32_t c0, uint32_t c1, uint32_t c2, uint32_t did)
+{
+    const float iz = (q0 + q1) + q2;
+    atomicMin(&keys[o], ((u64)depth_bits(iz) << 32) | did);
+    cbuf[o] = ((u64)did << 32) | shade_px(q0, q1, q2, rcp_exact(iz), c0, c1, c2);
 }
 
 struct MeshVert { int XL, XR; float iz; uint32_t rgb; };
@@ -953,13 +988,13 @@ __device__ __forceinline__ MeshVert mesh_vertex(uint32_t dpx, uint32_t cpx, int 
 
 // Triangle `pass` (0: tri1 = A,B,C; 1: tri2 = A,C,D) of cell column j for one eye from the LDS vertices.
 __device__ __forceinline__ bool mesh_tri_lds(TriSetup& t, const MeshVert& A, const MeshVert& B, const MeshVert& Cv,
-                                             const MeshVert& D, int pass, int eye, int Yt, int Yb)
+                                             const MeshVert& D, int pass, int eye, int Yt, int Yb, int cull)
 {
     const int XA = eye == 0 ? A.XL : A.XR, XB = eye == 0 ? B.XL : B.XR;
     const int XC = eye == 0 ? Cv.XL : Cv.XR, XD = eye == 0 ? D.XL : D.XR;
     // vertex order of the reference: tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]); tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
-    if (pass == 0) return tri_setup_snapped(t, XA, Yt, A.iz, XB, Yb, B.iz, XC, Yb, Cv.iz);
-    return tri_setup_snapped(t, XA, Yt, A.iz, XC, Yb, Cv.iz, XD, Yt, D.iz);
+    if (pass == 0) return tri_setup_snapped(t, XA, Yt, A.iz, XB, Yb, B.iz, XC, Yb, Cv.iz, cull);
+    return tri_setup_snapped(t, XA, Yt, A.iz, XC, Yb, Cv.iz, XD, Yt, D.iz, cull);
 }
 
 // LDS vertex array with 16-byte (colour inside) or 12-byte (colour re-read from the frame in the
@@ -995,10 +1030,11 @@ struct RegularCell {
     float izA, izB, izC, izD;
     uint32_t cA, cB, cC, cD;
     int flags;              // bit0: tri1 removed, bit1: tri2 removed (dmt:1372)
+    int j;                  // cell column (draw order)
 };
 
 __device__ __forceinline__ void regular_cell_pixel(const RegularCell& r, int px, int tt, int bb, int hh,
-                                                   i64 kcol0, i64 kcol1, i64 kdiag, u64* zb)
+                                                   i64 kcol0, i64 kcol1, i64 kdiag, u64* zb, const RowTies& ties)
 {
     const i64 hX = mul64(hh, px * kSubpix + kSubpix / 2);
     const i64 e0 = hX - kcol0, e1 = hX - kcol1, ed = hX - kdiag;
@@ -1013,7 +1049,7 @@ __device__ __forceinline__ void regular_cell_pixel(const RegularCell& r, int px,
     const i64 w2 = in1 ? e0 : ed;
     float q0, q1, q2;
     tri_weights(area2, r.izA, in1 ? r.izB : r.izC, in1 ? r.izC : r.izD, w0, w1, w2, q0, q1, q2);
-    atomicMin(&zb[px], mesh_fragment_key(q0, q1, q2, r.cA, in1 ? r.cB : r.cC, in1 ? r.cC : r.cD));
+    mesh_row_fragment(zb, px, q0, q1, q2, r.cA, in1 ? r.cB : r.cC, in1 ? r.cC : r.cD, ((in1 ? 0u : 1u) << 16) | (uint32_t)r.j, ties);
 }
 
 template <int PX, int FLAGS, int TPB, bool VRGB>
@@ -1026,7 +1062,12 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
     VertStore<VRGB> verts{(int*)(zb + W)};             // [2][W]: vertex rows c and c+1
     uint32_t* eb = (uint32_t*)(verts.base + 2 * (size_t)W * VertStore<VRGB>::kDwords);   // [W] edge-point keys (EDGEPTS)
     uint8_t* cfl = (uint8_t*)(eb + (EDGEPTS ? W : 0));  // [W] per-column flags (EDGES): bit0 tri1 removed, bit1 tri2 removed, bit2 vertex (k,j) unused
-    uint16_t* kcode = (uint16_t*)(cfl + (((size_t)W + 15) & ~(size_t)15));   // [W] 16-bit depth codes of source row k (EDGEPTS)
+    uint16_t* kcode = (uint16_t*)(cfl + (EDGES ? (((size_t)W + 15) & ~(size_t)15) : 0));   // [W] 16-bit depth codes of source row k (EDGEPTS)
+    RowTies ties;                                       // [W/32 + 1] tie bits + flag (exact depth ties, mdvt_device.h)
+    ties.bits = (uint32_t*)(((uintptr_t)(kcode + (EDGEPTS ? W : 0)) + 15) & ~(uintptr_t)15);
+    ties.nwords = (W + 31) / 32;
+    ties.mode = 0;
+    ties.force = (a.debug_skip & 32) != 0;
 
     const int fr = blockIdx.x / H;
     const int k = blockIdx.x - fr * H;                 // output row
@@ -1067,6 +1108,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
         }
     }
     for (int x = tid; x < W; x += TPB) zb[x] = kEmpty64;
+    for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
     if (EDGEPTS) for (int x = tid; x < W; x += TPB) eb[x] = kEmpty32;
     if (EDGES) {
         // removed-triangle flags of this cell row and unused-vertex flags of source row k: one coalesced pass
@@ -1086,7 +1128,9 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 
 #pragma unroll 1
     for (int eye = 0; eye < 2; ++eye) {
-        // ---- rasterise this eye ----
+        // ---- rasterise this eye (passes 1 and 2 only for a row with exact depth ties, see RowTies) ----
+#pragma unroll 1
+        for (ties.mode = 0; ties.mode < 3; ++ties.mode) {
         if (c >= 0 && !(a.debug_skip & 1)) {
             for (int j0 = 0; j0 < W - 1; j0 += TPB) {
                 const int j = j0 + tid;
@@ -1121,7 +1165,9 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                     rc.izA = A.iz; rc.izB = B.iz; rc.izC = Cv.iz; rc.izD = D.iz;
                     rc.cA = cA; rc.cB = cB; rc.cC = cC; rc.cD = cD;
                     rc.flags = (inv1 ? 1 : 0) | (inv2 ? 2 : 0);
+                    rc.j = j;
                     if (allok && XC > XB && XD > XA) {
+                        if (a.cull == 2) rc.flags = 3;                 // a regular cell is two front faces
                         if (rc.flags != 3) {
                             const i64 kcol0 = mul64(XB - XA, tt) + mul64(hh, XA);
                             const i64 kcol1 = mul64(XC - XD, tt) + mul64(hh, XD);
@@ -1141,7 +1187,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                                 lngcell = true;           // rubber-sheet cell across a vertical depth edge: whole-wave path below
                             } else if (!(a.debug_skip & 16)) {
                                 const i64 kdiag = mul64(XC - XA, tt) + mul64(hh, XA);
-                                for (int px = q0; px <= q1; ++px) regular_cell_pixel(rc, px, tt, bb, hh, kcol0, kcol1, kdiag, zb);
+                                for (int px = q0; px <= q1; ++px) regular_cell_pixel(rc, px, tt, bb, hh, kcol0, kcol1, kdiag, zb, ties);
                             }
                         }
                     } else {
@@ -1149,7 +1195,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 #pragma unroll
                         for (int pass = 0; pass < 2; ++pass) {
                             if (pass == 0 ? inv1 : inv2) continue;
-                            if (!mesh_tri_lds(t[pass], A, B, Cv, D, pass, eye, Yt, Yb)) continue;
+                            if (!mesh_tri_lds(t[pass], A, B, Cv, D, pass, eye, Yt, Yb, a.cull)) continue;
                             const TriSetup& tr = t[pass];
                             int q0p = floordiv_subpix(tr.minX - kSubpix / 2 + kSubpix - 1), q1p = floordiv_subpix(tr.maxX - kSubpix / 2);
                             if (q0p < 0) q0p = 0;
@@ -1159,7 +1205,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                             for (int px = q0p; px <= q1p; ++px) {
                                 float q0, q1, q2;
                                 if (!tri_sample(tr, px, k, q0, q1, q2)) continue;
-                                atomicMin(&zb[px], mesh_fragment_key(q0, q1, q2, col[pass][0], col[pass][1], col[pass][2]));
+                                mesh_row_fragment(zb, px, q0, q1, q2, col[pass][0], col[pass][1], col[pass][2], ((uint32_t)pass << 16) | (uint32_t)j, ties);
                             }
                         }
                     }
@@ -1174,7 +1220,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 #define MDVT_BI(fld) b.fld = __builtin_amdgcn_readlane(rc.fld, l)
 #define MDVT_BF(fld) b.fld = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rc.fld), l))
 #define MDVT_BU(fld) b.fld = (uint32_t)__builtin_amdgcn_readlane((int)rc.fld, l)
-                        MDVT_BI(XA); MDVT_BI(XB); MDVT_BI(XC); MDVT_BI(XD); MDVT_BI(flags);
+                        MDVT_BI(XA); MDVT_BI(XB); MDVT_BI(XC); MDVT_BI(XD); MDVT_BI(flags); MDVT_BI(j);
                         MDVT_BF(izA); MDVT_BF(izB); MDVT_BF(izC); MDVT_BF(izD);
                         MDVT_BU(cA); MDVT_BU(cB); MDVT_BU(cC); MDVT_BU(cD);
 #undef MDVT_BI
@@ -1184,7 +1230,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                         const i64 kcol0 = mul64(b.XB - b.XA, tt) + mul64(hh, b.XA);
                         const i64 kcol1 = mul64(b.XC - b.XD, tt) + mul64(hh, b.XD);
                         const i64 kdiag = mul64(b.XC - b.XA, tt) + mul64(hh, b.XA);
-                        for (int px = bp0 + lane; px <= bp1; px += 64) regular_cell_pixel(b, px, tt, bb, hh, kcol0, kcol1, kdiag, zb);
+                        for (int px = bp0 + lane; px <= bp1; px += 64) regular_cell_pixel(b, px, tt, bb, hh, kcol0, kcol1, kdiag, zb, ties);
                     }
                 }
                 // long spans of irregular cells: the whole wave works on one lane's triangle at a time
@@ -1209,15 +1255,17 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                         const uint32_t bc0 = __builtin_amdgcn_readlane((int)col[pass][0], l);
                         const uint32_t bc1 = __builtin_amdgcn_readlane((int)col[pass][1], l);
                         const uint32_t bc2 = __builtin_amdgcn_readlane((int)col[pass][2], l);
+                        const int bj = __builtin_amdgcn_readlane(j, l);
                         for (int px = bp0 + lane; px <= bp1; px += 64) {
                             float q0, q1, q2;
                             if (!tri_sample(b, px, k, q0, q1, q2)) continue;
-                            atomicMin(&zb[px], mesh_fragment_key(q0, q1, q2, bc0, bc1, bc2));
+                            mesh_row_fragment(zb, px, q0, q1, q2, bc0, bc1, bc2, ((uint32_t)pass << 16) | (uint32_t)bj, ties);
                         }
                     }
                 }
             }
         }
+        if (ties.mode == 0) {
         // ---- edge points of source row k (sr:589-606, 745-781): vertices of removed triangles ----
         if (EDGEPTS) {
             const uint8_t* drow_k = a.depth + (size_t)f * a.depth_stride + (size_t)k * a.depth_pitch;
@@ -1238,7 +1286,16 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                 }
             }
         }
+        }
         __syncthreads();
+        if (ties.mode == 0) {
+            if (ties.bits[ties.nwords] == 0u) break;
+            row_ties_prepare(zb, W, ties, tid, TPB);
+            __syncthreads();
+        }
+        }
+        const bool had_ties = ties.mode == 3;            // the loop ran to its end (a row without ties leaves it at mode 0)
+        ties.mode = 0;
 
         // ---- resolve this eye ----
         uint8_t* orow = a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)k * a.rgb_pitch;
@@ -1256,7 +1313,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                 const bool covered = key != kEmpty64;
                 const uint32_t rgb = covered ? (uint32_t)key & 0xFFFFFFu : 0u;
                 float zval = 0.0f;
-                if (ZOUT && covered) zval = 1.0f / __uint_as_float(~(uint32_t)(key >> 32));
+                if (ZOUT && covered) zval = 1.0f / row_word_iz((uint32_t)(key >> 32));
                 const bool hole = !covered || rgb == a.key_rgb;
                 uint32_t out = hole ? 0u : rgb;
                 uint32_t esrc = ~0u;
@@ -1276,6 +1333,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
             if (ZOUT && zrow) RowIO<PX>::store_z(zrow, g, oz);
             if (SEED && a.seed[eye]) RowIO<PX>::store_rgb(a.seed[eye] + (size_t)f * a.seed_stride + (size_t)k * a.seed_pitch, g, spx);
         }
+        if (had_ties) for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
         if (eye == 0) __syncthreads();
     }
 }
@@ -1283,7 +1341,15 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 // =================================================================================================
 // MESH MODE, general (pose / convergence): triangles rasterised into global 64-bit z keys
 // =================================================================================================
-//   key = ~bits(1/Z') << 32 | R | G<<8 | B<<16     (the shaded fragment travels in the key, see above)
+//   key = ~bits(1/Z') << 32 | draw id (pass << 31 | i << 16 | j): the 64-bit minimum is "nearest, then first drawn" = GL_LESS
+//   with the reference's draw order (dmt:1243-1254).  The colour travels beside it: EVERY fragment also leaves
+//   draw id << 32 | rgb in a side buffer with a plain 64-bit store.  Fragments of one pixel overwrite each other in no
+//   particular order, so the resolve pass takes the side buffer's colour only if its id is the winner's -- always the
+//   case for the ~97 % of pixels that received one fragment -- and otherwise shades the winner from its id (three vertex
+//   records read back).  Measured and rejected: (1) shading every pixel in the resolve (deferred shading proper): the
+//   three 16-byte gathers per pixel make the resolve pass HBM-bound at 58 us per 1080p frame against 26; (2) storing the
+//   colour only when the fragment takes the pixel: the returning atomic that needs stalls the rasteriser (product
+//   default 2508 us per 16 frames against 2392 for (1)).
 
 // Stage 1: every vertex is projected ONCE per eye (decode, unproject, 3x4 transform, pinhole, snap, 1/Z')
 // into a 16-byte record; the rasteriser then reads four records per cell instead of recomputing each
@@ -1404,6 +1470,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
 #pragma unroll 1
     for (int eye = 0; eye < 2; ++eye) {
         u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
+        u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
         uint4 A = make_uint4(0, 0, 0, 0), B = A, Cv = A, D = A;
         if (act) {
             const int t = threadIdx.x;
@@ -1413,12 +1480,13 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
         for (int pass = 0; pass < 2; ++pass) {
             // tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]); tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])   (dmt:1243-1254)
             const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
+            const uint32_t did = draw_id_global(pass, i, j);
             TriSetup t;
             bool big = false;
             int px0 = 0, px1 = -1, py0 = 0, py1 = -1;
             if (act && !inv[pass] &&
                 tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
-                                  (int)v2.x, (int)v2.y, __uint_as_float(v2.z))) {
+                                  (int)v2.x, (int)v2.y, __uint_as_float(v2.z), a.cull)) {
                 px0 = floordiv_subpix(t.minX - kSubpix / 2 + kSubpix - 1); px1 = floordiv_subpix(t.maxX - kSubpix / 2);
                 py0 = floordiv_subpix(t.minY - kSubpix / 2 + kSubpix - 1); py1 = floordiv_subpix(t.maxY - kSubpix / 2);
                 if (px0 < 0) px0 = 0;
@@ -1442,7 +1510,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                                 for (int px = lo; px <= hi; ++px) {
                                     float q0, q1, q2;
                                     if (!tri_sample(t, px, py, q0, q1, q2)) continue;
-                                    atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, A.w, v1.w, v2.w));
+                                    mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
                                 }
                             }
                     } else if (!(a.debug_skip & 16)) {
@@ -1452,7 +1520,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                             for (int px = px0; px <= px1; ++px) {
                                 float q0, q1, q2;
                                 if (tri_walk_sample(t, w, q0, q1, q2))
-                                    atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, A.w, v1.w, v2.w));
+                                    mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
                                 tri_walk_right(t, w);
                             }
                             tri_walk_down(t, row);
@@ -1481,8 +1549,8 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                         rec[12] = (uint32_t)t.area2; rec[13] = (uint32_t)((u64)t.area2 >> 32);
                         rec[14] = __float_as_uint(t.iz0); rec[15] = __float_as_uint(t.iz1); rec[16] = __float_as_uint(t.iz2);
                         rec[17] = (uint32_t)px0; rec[18] = (uint32_t)px1; rec[19] = (uint32_t)py0; rec[20] = (uint32_t)py1;
-                        rec[21] = A.w; rec[22] = v1.w; rec[23] = v2.w;
-                        rec[24] = (uint32_t)fr * 2u + (uint32_t)eye;
+                        rec[21] = did; rec[22] = A.w; rec[23] = v1.w; rec[24] = v2.w;
+                        rec[25] = (uint32_t)fr * 2u + (uint32_t)eye;
                         big = false;
                     }
                 }
@@ -1504,6 +1572,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                 b.iz2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.iz2), l));
                 const int bx0 = __builtin_amdgcn_readlane(px0, l), bx1 = __builtin_amdgcn_readlane(px1, l);
                 const int by0 = __builtin_amdgcn_readlane(py0, l), by1 = __builtin_amdgcn_readlane(py1, l);
+                const uint32_t bid = (uint32_t)__builtin_amdgcn_readlane((int)did, l);
                 const uint32_t c0 = __builtin_amdgcn_readlane((int)A.w, l), c1 = __builtin_amdgcn_readlane((int)v1.w, l);
                 const uint32_t c2 = __builtin_amdgcn_readlane((int)v2.w, l);
                 const int bw = bx1 - bx0 + 1;
@@ -1514,7 +1583,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
                 for (i64 idx = lane; idx < total; idx += 64) {
                     float q0, q1, q2;
                     if (tri_sample(b, px, py, q0, q1, q2))
-                        atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, c0, c1, c2));
+                        mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, c0, c1, c2, bid);
                     px += sx; py += sy;
                     if (px > bx1) { px -= bw; ++py; }
                 }
@@ -1540,8 +1609,9 @@ __global__ void __launch_bounds__(256) k_mesh_raster_big(RenderArgs a)
         b.area2 = (i64)(((u64)rec[13] << 32) | rec[12]);
         b.iz0 = __uint_as_float(rec[14]); b.iz1 = __uint_as_float(rec[15]); b.iz2 = __uint_as_float(rec[16]);
         const int bx0 = (int)rec[17], bx1 = (int)rec[18], by0 = (int)rec[19], by1 = (int)rec[20];
-        const uint32_t c0 = rec[21], c1 = rec[22], c2 = rec[23];
-        u64* keys = a.keys[rec[24] & 1u] + (size_t)(rec[24] >> 1) * a.ws_stride_px;
+        const uint32_t bid = rec[21], c0 = rec[22], c1 = rec[23], c2 = rec[24];
+        u64* keys = a.keys[rec[25] & 1u] + (size_t)(rec[25] >> 1) * a.ws_stride_px;
+        u64* cbuf = a.cbuf[rec[25] & 1u] + (size_t)(rec[25] >> 1) * a.ws_stride_px;
         const int bw = bx1 - bx0 + 1;
         const i64 npix = (i64)bw * (by1 - by0 + 1);
         int px = bx0 + lane % bw, py = by0 + lane / bw;        // lanes walk the box in row-major order, 64 pixel centres per step
@@ -1549,7 +1619,7 @@ __global__ void __launch_bounds__(256) k_mesh_raster_big(RenderArgs a)
         for (i64 idx = lane; idx < npix; idx += 64) {
             float q0, q1, q2;
             if (tri_sample(b, px, py, q0, q1, q2))
-                atomicMin(&keys[(size_t)py * W + (size_t)px], mesh_fragment_key(q0, q1, q2, c0, c1, c2));
+                mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, c0, c1, c2, bid);
             px += sx; py += sy;
             if (px > bx1) { px -= bw; ++py; }
         }
@@ -2249,6 +2319,8 @@ bool render_fits_lds(const RenderPlan& plan, int W)
     return render_lds_bytes(p, W) <= kMaxLds;
 }
 
+static size_t mesh_rows_tie_bytes(int W) { return (((size_t)W + 31) / 32 + 1) * sizeof(uint32_t) + 32; }     // RowTies + alignment slack
+
 size_t render_lds_bytes(const RenderPlan& plan, int W)
 {
     if (plan.general) return 0;
@@ -2258,7 +2330,7 @@ size_t render_lds_bytes(const RenderPlan& plan, int W)
         return b;
     }
     const size_t extra = (size_t)W * sizeof(u64) + (plan.edge_points ? (size_t)W * sizeof(uint32_t) + 2 * (size_t)W + 16 : 0) +
-                         (plan.remove_edges ? (((size_t)W + 15) & ~(size_t)15) : 0);
+                         (plan.remove_edges ? (((size_t)W + 15) & ~(size_t)15) : 0) + mesh_rows_tie_bytes(W);
     size_t b = 2 * (size_t)W * 16 + extra;              // 16-byte vertices (colour in LDS)
     if (b > kMaxLds) b = 2 * (size_t)W * 12 + extra;    // 12-byte vertices (colour re-read in the resolve)
     return b;
@@ -2407,7 +2479,7 @@ static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a_i
     const size_t lds = render_lds_bytes(plan, a.W);
     if (lds > kMaxLds) return hipErrorNotSupported;         // W > ~4300 with edge points (5120 without)
     const bool vrgb = lds == 2 * (size_t)a.W * 16 + (size_t)a.W * 8 + (plan.edge_points ? (size_t)a.W * 4 + 2 * (size_t)a.W + 16 : 0) +
-                             (plan.remove_edges ? (((size_t)a.W + 15) & ~(size_t)15) : 0);
+                             (plan.remove_edges ? (((size_t)a.W + 15) & ~(size_t)15) : 0) + mesh_rows_tie_bytes(a.W);
     // two 512-thread workgroups per CU when two fit in the 160 KB LDS, otherwise one 1024-thread workgroup:
     // either way 16 waves per CU
     int tpb = (2 * lds <= kMaxLds) ? 512 : 1024;

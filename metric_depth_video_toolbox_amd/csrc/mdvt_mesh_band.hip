@@ -88,7 +88,7 @@ __device__ __forceinline__ RowGeom row_geometry(int k, const RowCell* __restrict
 // kcol0 / kcol1: the scanline crossings of the cell's two column edges (see the header).
 __device__ __forceinline__ void cell_pixel(int XA, int XB, int XC, int XD, float izA, float izB, float izC, float izD,
                                            uint32_t cA, uint32_t cB, uint32_t cC, uint32_t cD, int kcol0, int kcol1, int px,
-                                           const RowGeom& g, u64* zb)
+                                           int j, const RowGeom& g, u64* zb, const RowTies& ties)
 {
     const int kdiag = mad24(XC - XA, g.tt, mul24(g.hh, XA));
     const int hX = mul24(g.hh, px * kSubpix + kSubpix / 2);
@@ -111,7 +111,7 @@ __device__ __forceinline__ void cell_pixel(int XA, int XB, int XC, int XD, float
     const float iz = (q0 + q1) + q2;
     const float riz = rcp_exact(iz);
     const uint32_t rgb = shade_px(q0, q1, q2, riz, cA, in1 ? cB : cC, in1 ? cC : cD);
-    atomicMin(&zb[px], ((u64)(~__float_as_uint(iz)) << 32) | rgb);
+    post_row_fragment(zb, px, iz, rgb, ((in1 ? 0u : 1u) << 16) | (uint32_t)j, ties);
 }
 
 // lane i <- lane i + 1 of the wave (lane 63 gets 0)
@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_
 // Generic 64-bit path for one exotic cell, rasterised by the whole wave (uniform arguments).
 __device__ __forceinline__ void exotic_cell_wave(int XA, int XB, int XC, int XD, float izA, float izB, float izC, float izD,
                                               uint32_t cA, uint32_t cB, uint32_t cC, uint32_t cD, uint32_t skip, int Yt, int Yb,
-                                              int k, int W, int lane, u64* zb)
+                                              int k, int W, int lane, int j, u64* zb, const RowTies& ties)
 {
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void exotic_cell_wave(int XA, int XB, int XC, int XD,
             if (!tri_sample(t, px, k, q0, q1, q2)) continue;
             const float iz = (q0 + q1) + q2;
             const float riz = rcp_exact(iz);
-            atomicMin(&zb[px], ((u64)(~__float_as_uint(iz)) << 32) | shade_px(q0, q1, q2, riz, cA, c1, c2));
+            post_row_fragment(zb, px, iz, shade_px(q0, q1, q2, riz, cA, c1, c2), ((uint32_t)pass << 16) | (uint32_t)j, ties);
         }
     }
 }
@@ -158,7 +158,12 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
     const int W = a.W, H = a.H, W4 = W >> 2;
     u64* zb = (u64*)smem;                                   // [W] z keys of the eye being rendered
     int4* verts = (int4*)(zb + W);                          // [2][W]: vertex row i lives in slot i & 1
-    uint32_t* queue = (uint32_t*)(verts + 2 * (size_t)W);   // [NW][kQueueWave]
+    uint32_t* queue = (uint32_t*)(verts + 2 * (size_t)W);   // [TPB/64][kQueueWave]
+    RowTies ties;                                           // [W/32 + 1] exact-depth-tie bits + flag (mdvt_device.h)
+    ties.bits = queue + (TPB / 64) * kQueueWave;
+    ties.nwords = (W + 31) / 32;
+    ties.mode = 0;
+    ties.force = (a.debug_skip & 32) != 0;
 
     const int fr = blockIdx.x / nbands;
     const int band = blockIdx.x - fr * nbands;
@@ -202,6 +207,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
     };
 
     for (int x = tid; x < W; x += TPB) zb[x] = kEmpty64;
+    for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
 
     // The loop starts one row early: that prologue pass only stages the two vertex rows of scanline k0 (so that the
     // staging code exists once).
@@ -224,6 +230,9 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
 
 #pragma unroll 1
         for (int eye = 0; eye < 2; ++eye) {
+            // (passes 1 and 2 only for a row with exact depth ties between different colours: RowTies in mdvt_device.h)
+#pragma unroll 1
+            for (ties.mode = 0; ties.mode < 3; ++ties.mode) {
             if (g.c >= 0 && !(a.debug_skip & 1)) {
                 int qn = 0;                                          // items on this wave's stack (uniform)
                 // A wave takes 63 consecutive cells per pass: lane l works out column c0 + l (its crossing of the scanline and
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                     const int plo = regular ? pA : pD;
                     int n = drawn ? (regular ? pD - pA : pA - pD) : 0;
                     if (n > 0 && !(a.debug_skip & 16))
-                        cell_pixel(XA, XB, XC, XD, izA, izB, izC, izD, cA, cB, cC, cD, kcol0, kcol1, plo, g, zb);
+                        cell_pixel(XA, XB, XC, XD, izA, izB, izC, izD, cA, cB, cC, cD, kcol0, kcol1, plo, j, g, zb, ties);
                     // Further pixels of the cell become (cell, pixel) items on the wave's stack, shaded 64 at a time: first
                     // one item per lane and round (spans of up to 4 px), then the long spans (rubber sheet across a depth
                     // edge), one cell at a time written by the whole wave.  One loop, so that the shading code exists once.
@@ -277,7 +286,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                                     const int iXA = eye == 0 ? A.x : A.y, iXB = eye == 0 ? B.x : B.y, iXC = eye == 0 ? Cv.x : Cv.y, iXD = eye == 0 ? D.x : D.y;
                                     cell_pixel(iXA, iXB, iXC, iXD, __int_as_float(A.z), __int_as_float(B.z), __int_as_float(Cv.z), __int_as_float(D.z),
                                                (uint32_t)A.w, (uint32_t)B.w, (uint32_t)Cv.w, (uint32_t)D.w,
-                                               mad24(iXB - iXA, g.tt, mul24(g.hh, iXA)), mad24(iXC - iXD, g.tt, mul24(g.hh, iXD)), px, g, zb);
+                                               mad24(iXB - iXA, g.tt, mul24(g.hh, iXA)), mad24(iXC - iXD, g.tt, mul24(g.hh, iXD)), px, ij, g, zb, ties);
                                 }
                                 continue;
                             }
@@ -322,7 +331,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                             if ((cull == 1u) == back2 && bXA != bXD) sk |= 2u;
                         }
                         exotic_cell_wave(bXA, bXB, bXC, bXD, MDVT_BF(izA), MDVT_BF(izB), MDVT_BF(izC), MDVT_BF(izD),
-                                         MDVT_BU(cA), MDVT_BU(cB), MDVT_BU(cC), MDVT_BU(cD), sk, g.Yt, g.Yb, k, W, lane, zb);
+                                         MDVT_BU(cA), MDVT_BU(cB), MDVT_BU(cC), MDVT_BU(cD), sk, g.Yt, g.Yb, k, W, lane, MDVT_BI(j), zb, ties);
 #undef MDVT_BI
 #undef MDVT_BF
 #undef MDVT_BU
@@ -330,6 +339,14 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                 }
             }
             __syncthreads();
+            if (ties.mode == 0) {
+                if (ties.bits[ties.nwords] == 0u) break;
+                row_ties_prepare(zb, W, ties, tid, TPB);
+                __syncthreads();
+            }
+            }
+            const bool had_ties = ties.mode == 3;        // the loop ran to its end (a row without ties leaves it at mode 0)
+            ties.mode = 0;
 
             // the next scanline's vertex row replaces the one no longer needed (its last reader was the raster above)
             if (eye == 1 && k + 1 < k1 && gn.c >= 0) {
@@ -349,12 +366,12 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                 float oz[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const bool covered = !(hi[q] == ~0u && lo[q] == ~0u);
+                    const bool covered = !(hi[q] == ~0u && lo[q] == ~0u);          // (a settled tie has the top bit of hi cleared)
                     const uint32_t rgb = lo[q] & 0xFFFFFFu;
                     const bool hole = !covered || rgb == a.key_rgb;          // sr:740
                     o[q] = hole ? 0u : rgb;                                  // sr:793
                     mw |= hole ? (0xFFu << (8 * q)) : 0u;
-                    if (ZOUT) oz[q] = covered ? 1.0f / __uint_as_float(~hi[q]) : 0.0f;
+                    if (ZOUT) oz[q] = covered ? 1.0f / row_word_iz(hi[q]) : 0.0f;
                 }
                 uint32_t* op = (uint32_t*)(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)k * a.rgb_pitch) + 3 * tid;
                 __builtin_nontemporal_store(__builtin_amdgcn_perm(o[1], o[0], 0x04020100u), op);
@@ -367,6 +384,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                     __builtin_nontemporal_store(v, (f32x4*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)k * a.zout_pitch) + tid);
                 }
             }
+            if (had_ties) for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
             __syncthreads();
         }
         g = gn;
@@ -375,7 +393,8 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
 
 size_t mesh_band_lds_bytes(int W, int tpb)
 {
-    return (size_t)W * sizeof(u64) + 2 * (size_t)W * 16 + (size_t)(tpb / 64) * kQueueWave * sizeof(uint32_t);
+    return (size_t)W * sizeof(u64) + 2 * (size_t)W * 16 + (size_t)(tpb / 64) * kQueueWave * sizeof(uint32_t) +
+           (((size_t)W + 31) / 32 + 1) * sizeof(uint32_t);
 }
 
 // Can the band kernel render this launch?  (4-byte aligned rows, no edge removal, LDS for one row.)

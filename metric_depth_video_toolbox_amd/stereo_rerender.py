@@ -250,12 +250,14 @@ class StereoRerenderer:
       remove_edges / infill_mask / do_basic_infill   turn the 89-degree edge filter on (sr:568-570)
       dont_remove_edges                              overrides the above (sr:572-573)
       dont_place_points_in_edges                     no edge points (sr:589)
+      cull                                           0 draw both faces of the mesh (default), 1 cull back faces, 2 front faces
+                                                     (dmt:1507-1556 leaves Open3D's mesh_show_back_face at its default)
     """
 
     def __init__(self, width: int, height: int, *, device: Optional[int] = None, pupillary_distance=63,
                  max_depth=100, master_xfov: float = 45.0, render_as_pointcloud: bool = False,
                  remove_edges: bool = False, infill_mask: bool = False, do_basic_infill: bool = False,
-                 dont_remove_edges: bool = False, dont_place_points_in_edges: bool = False):
+                 dont_remove_edges: bool = False, dont_place_points_in_edges: bool = False, cull: int = 0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no ROCm GPU visible: the stereo-rerender path has no CPU fallback")
@@ -278,6 +280,8 @@ class StereoRerenderer:
         cfg.mode = self.mode
         cfg.remove_edges = int(self.remove_edges)
         cfg.edge_points = (2 if self.do_basic_infill else 1) if self.edge_points else 0
+        cfg.cull = int(cull)
+        self.cull = int(cull)
         cfg.ipd_m = self.pupillary_distance / 1000                         # sr:458-459
         cfg.max_depth = float(self.max_depth)
         for k in range(3):

@@ -18,7 +18,7 @@ class OrcParams(C.Structure):
     _fields_ = [
         ("W", C.c_int32), ("H", C.c_int32),
         ("mode", C.c_int32), ("remove_edges", C.c_int32), ("edge_points", C.c_int32),
-        ("general", C.c_int32), ("has_T", C.c_int32), ("_pad", C.c_int32),
+        ("general", C.c_int32), ("has_T", C.c_int32), ("cull", C.c_int32),
         ("K", C.c_double * 4), ("Kr", C.c_double * 4),
         ("ipd_m", C.c_double), ("max_depth", C.c_double), ("depth_scale", C.c_double),
         ("conv_angle", C.c_double),
@@ -58,6 +58,10 @@ def lib():
         L.orc_edge_filter.restype = None
         L.orc_convergence_angle.argtypes = [C.c_double, C.c_double]
         L.orc_convergence_angle.restype = C.c_double
+        L.orc_stats_reset.argtypes = []
+        L.orc_stats_reset.restype = None
+        L.orc_stats_get.argtypes = [C.POINTER(C.c_int64)]
+        L.orc_stats_get.restype = None
         L.orc_render_stereo.argtypes = [C.POINTER(OrcParams), u8p, u8p, u8p, u8p, u8p, u8p, f32p, f32p]
         L.orc_render_stereo.restype = C.c_int
         L.orc_render_stereo_seed.argtypes = [C.POINTER(OrcParams), u8p, u8p, u8p, u8p, u8p, u8p, f32p, f32p, u8p, u8p]
@@ -147,11 +151,12 @@ def convergence_angle(distance: float, ipd_m: float) -> float:
 
 def make_params(W, H, K, *, Kr=None, ipd_m=0.065, max_depth=100.0, depth_scale=1.0, mode=MODE_POINTS,
                 remove_edges=False, edge_points=False, conv_angle=0.0, T=None, key_rgb=(0, 0, 0),
-                force_general=False) -> OrcParams:
+                force_general=False, cull=0) -> OrcParams:
     p = OrcParams()
     p.W, p.H = int(W), int(H)
     p.mode = int(mode)
     p.remove_edges = int(bool(remove_edges))
+    p.cull = int(cull)
     p.edge_points = int(edge_points)
     kk = k4(K)
     kr = kk if Kr is None else k4(Kr)
@@ -171,6 +176,20 @@ def make_params(W, H, K, *, Kr=None, ipd_m=0.065, max_depth=100.0, depth_scale=1
     for i in range(3):
         p.key_rgb[i] = int(key_rgb[i])
     return p
+
+
+STAT_NAMES = ("near_partial", "near_all", "depth_ties", "fragments", "culled")
+
+
+def stats_reset():
+    lib().orc_stats_reset()
+
+
+def stats():
+    """Rasteriser counters since stats_reset(): dict of STAT_NAMES (see mdvt_oracle.h)."""
+    v = (C.c_int64 * 5)()
+    lib().orc_stats_get(v)
+    return dict(zip(STAT_NAMES, [int(x) for x in v]))
 
 
 def render_stereo(p: OrcParams, depth_rgb: np.ndarray, color_rgb: np.ndarray, want_depth: bool = False, want_seed: bool = False):

@@ -321,15 +321,25 @@ static inline int orc_edge_in(int64_t w, int64_t dx, int64_t dy)
     return (dy < 0) || (dy == 0 && dx > 0);    /* top-left rule, clockwise (y down) orientation */
 }
 
+static int64_t g_stats[5];
+void orc_stats_reset(void) { memset(g_stats, 0, sizeof g_stats); }
+void orc_stats_get(int64_t out[5]) { memcpy(out, g_stats, sizeof g_stats); }
+
 static void orc_raster_tri(orc_target* t, const orc_vert* a, const orc_vert* b, const orc_vert* c,
-                           const uint8_t* ca, const uint8_t* cb, const uint8_t* cc)
+                           const uint8_t* ca, const uint8_t* cb, const uint8_t* cc, int cull)
 {
-    if (!(a->ok && b->ok && c->ok)) return;     /* near-plane: drop the whole triangle (decree) */
+    if (!(a->ok && b->ok && c->ok)) {           /* near-plane: drop the whole triangle (decree) */
+        g_stats[(a->ok || b->ok || c->ok) ? 0 : 1]++;
+        return;
+    }
     const int64_t X0 = orc_snap(a->u), Y0 = orc_snap(a->v);
     const int64_t X1 = orc_snap(b->u), Y1 = orc_snap(b->v);
     const int64_t X2 = orc_snap(c->u), Y2 = orc_snap(c->v);
     int64_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
     if (area2 == 0) return;
+    /* y runs down: the grid's own triangles (dmt:1243-1254) have negative area2 here and appear counter-clockwise on
+     * screen -- GL's default front face */
+    if ((cull == 1 && area2 > 0) || (cull == 2 && area2 < 0)) { g_stats[4]++; return; }
     const int64_t s = area2 > 0 ? 1 : -1;
     area2 *= s;
     int64_t minX = X0 < X1 ? X0 : X1; if (X2 < minX) minX = X2;
@@ -364,7 +374,11 @@ static void orc_raster_tri(orc_target* t, const orc_vert* a, const orc_vert* b, 
             const float q0 = l0 * iz0, q1 = l1 * iz1, q2 = l2 * iz2;
             const float iz = (q0 + q1) + q2;
             const size_t o = (size_t)py * t->W + (size_t)px;
-            if (iz < t->zbuf[o]) continue;             /* GL_LESS on depth == GREATER on 1/Z */
+            g_stats[3]++;
+            if (t->covered[o] && iz == t->zbuf[o]) g_stats[2]++;
+            /* GL_LESS on depth == strictly GREATER on 1/Z: on an exact tie the triangle drawn first keeps the pixel
+             * (draw order = all tri1 row-major, then all tri2, dmt:1243-1254) */
+            if (t->covered[o] && !(iz > t->zbuf[o])) continue;
             const float riz = 1.0f / iz;               /* one division per fragment; also the depth plane value */
             uint8_t frag[3];
             for (int ch = 0; ch < 3; ++ch) {
@@ -373,15 +387,6 @@ static void orc_raster_tri(orc_target* t, const orc_vert* a, const orc_vert* b, 
                 if (!(val >= 0.0f)) val = 0.0f;
                 if (val > 255.0f) val = 255.0f;
                 frag[ch] = (uint8_t)val;
-            }
-            if (iz == t->zbuf[o]) {
-                /* exact tie in interpolated 1/Z between overlapping triangles (decree): the fragment with
-                 * the smaller packed colour R | G<<8 | B<<16 wins -- a deterministic, order-free stand-in
-                 * for GL's draw order that lets the z-buffer word carry the colour. */
-                const uint32_t mine = frag[0] | ((uint32_t)frag[1] << 8) | ((uint32_t)frag[2] << 16);
-                const uint8_t* cur = t->rgb + 3 * o;
-                const uint32_t theirs = cur[0] | ((uint32_t)cur[1] << 8) | ((uint32_t)cur[2] << 16);
-                if (!t->covered[o] || !(mine < theirs)) continue;
             }
             t->zbuf[o] = iz;
             t->covered[o] = 1;
@@ -469,7 +474,7 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
                     const size_t i1 = (size_t)i * W + j, i2 = (size_t)(i + 1) * W + j;
                     const size_t i3 = (size_t)(i + 1) * W + j + 1, i4 = (size_t)i * W + j + 1;
                     const size_t v0 = i1, v1 = pass == 0 ? i2 : i3, v2 = pass == 0 ? i3 : i4;
-                    orc_raster_tri(&t, &V[v0], &V[v1], &V[v2], color + 3 * v0, color + 3 * v1, color + 3 * v2);
+                    orc_raster_tri(&t, &V[v0], &V[v1], &V[v2], color + 3 * v0, color + 3 * v1, color + 3 * v2, p->cull);
                 }
         if (out_depth)
             for (size_t k = 0; k < n; ++k) out_depth[k] = t.covered[k] ? t.zinv[k] : 0.0f;

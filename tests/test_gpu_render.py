@@ -1,6 +1,9 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
 inputs, and against the committed golden fixtures.  Bar: bit-exact hole mask, RGB and depth planes
 (the <= 1 LSB RGB allowance of the north star is not needed: both sides follow one arithmetic decree).
+
+Exact depth ties between overlapping triangles go to the triangle drawn first (GL_LESS + the draw order of
+dmt:1243-1254) on both sides; test_exact_depth_ties_follow_the_draw_order builds scenes that are full of them.
 """
 import numpy as np
 import pytest
@@ -27,7 +30,7 @@ def _oracle(orc, r, p, depth_rgb, color, T=None, want_depth=True):
                          depth_scale=p.depth_scale,
                          mode=orc.MODE_POINTS if r.mode == 0 else orc.MODE_MESH,
                          remove_edges=r.remove_edges, edge_points=r.edge_points,
-                         conv_angle=p.convergence_angle, T=T, key_rgb=r.key_rgb)
+                         conv_angle=p.convergence_angle, T=T, key_rgb=r.key_rgb, cull=getattr(r, "cull", 0))
     return orc.render_stereo(op, depth_rgb, color, want_depth=want_depth)
 
 
@@ -193,6 +196,78 @@ def test_mesh_general_path(mods, orc, case, infill_mask):
     got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
     _compare(got, _oracle(orc, r, p, depth_rgb, color, T=T), W, f"mesh general/{case}")
     r.close()
+
+
+@pytest.mark.parametrize("cull", [1, 2])
+@pytest.mark.parametrize("variant", ["band", "rows_odd_width", "rows_edges", "general", "general_edges", "wide_global"])
+def test_mesh_face_culling(mods, orc, cull, variant, monkeypatch):
+    """mdvt_config.cull: Open3D's legacy mesh_show_back_face defaults to off and dmt:1507-1556 never sets it; whether that
+    means GL_CULL_FACE cannot be observed here, so both candidates exist.  The grid's own winding is the front face:
+    culling back faces removes the fold-over triangles of the rubber sheet, culling front faces leaves only those."""
+    _lib, sr, synthetic = mods
+    W, H = (250, 61) if variant == "rows_odd_width" else (256, 64)
+    depth_rgb, color = _scene(synthetic, W, H, seed=90 + cull)
+    if variant == "wide_global":
+        monkeypatch.setenv("MDVT_FORCE_GLOBAL", "1")
+    kw = dict(infill_mask=True) if variant in ("rows_edges", "general_edges") else {}
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, cull=cull, **kw)
+    T = synthetic.synthetic_pose_track(40)[21] if variant.startswith("general") else None
+    p = r.frame_params(xfov=45.0, convergence_distance=2.0 if variant.startswith("general") else None, transformation=T)
+    got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+    want = _oracle(orc, r, p, depth_rgb, color, T=T)
+    _compare(got, want, W, f"cull={cull} {variant}")
+    both = sr.StereoRerenderer(W, H, pupillary_distance=65, **kw)
+    ref = both.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p)
+    if cull == 2:        # only the fold-over triangles are left: almost everything becomes a hole
+        assert float((got["mask"] > 0).float().mean()) > 0.8
+    else:                # back faces lie behind the surface that folds over them: removing them uncovers nothing ...
+        assert bool(((got["mask"] > 0) | (ref["mask"] == 0)).all())
+    r.close(); both.close()
+
+
+def test_exact_depth_ties_follow_the_draw_order(mods, orc, monkeypatch):
+    """GL_LESS keeps the triangle drawn first on an exact depth tie (draw order: all tri1 row-major, then all tri2,
+    dmt:1243-1254).  C4's contention band (hundreds of cells folded onto a few pixels) produces such ties between
+    differently coloured fragments even under the pure shift: the oracle counts them, and every kernel family must agree
+    with it pixel for pixel -- the band kernel and k_mesh_rows (which settle a tie in two more passes over the row) and
+    the global-key kernels (draw id in the z-buffer word, colour recomputed from it).  MDVT_DEBUG_SKIP=32 additionally
+    makes the row kernels treat every pixel that received a second fragment as tied, so the extra passes run on every
+    fold: the images must not change."""
+    from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
+    _lib, sr, synthetic = mods
+    ties = 0
+    for (W, H, t, kw, force_global) in ((256, 96, 180, {}, False), (256, 96, 60, dict(cull=2), False), (250, 64, 299, {}, False),
+                                        (256, 96, 180, {}, True), (256, 64, 299, dict(dont_place_points_in_edges=True, remove_edges=True), False)):
+        K = compute_camera_matrix(45.0, None, W, H)
+        sc = synthetic.SyntheticScene(W, H, config_id=4)
+        z = synthetic.contention_band(sc.depth_m(t), K[0, 0], 0.065, row0=H // 3, rows=H // 3)
+        depth_rgb = synthetic.quantise_depth_to_rgb(z)
+        _, color = sc.frame(t)
+        if force_global:
+            monkeypatch.setenv("MDVT_FORCE_GLOBAL", "1")
+        r = sr.StereoRerenderer(W, H, pupillary_distance=65, **kw)
+        p = r.frame_params(xfov=45.0)
+        orc.stats_reset()
+        want = _oracle(orc, r, p, depth_rgb, color)
+        ties += orc.stats()["depth_ties"]
+        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+        _compare(got, want, W, f"ties {W}x{H} t={t} {kw} global={force_global}")
+        if force_global:     # ... and with the resolve pass distrusting the colour side buffer: every pixel re-shaded from its draw id
+            monkeypatch.setenv("MDVT_DEBUG_SKIP", "64")
+            got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+            _compare(got, want, W, "ties, re-shaded")
+            monkeypatch.delenv("MDVT_DEBUG_SKIP")
+        monkeypatch.delenv("MDVT_FORCE_GLOBAL", raising=False)
+        r.close()
+    assert ties >= 10, f"only {ties} exact depth ties in the oracle: the scenes no longer test the rule"
+    monkeypatch.setenv("MDVT_DEBUG_SKIP", "32")
+    for kw, (w, h) in ((dict(), (256, 64)), (dict(), (250, 37)), (dict(infill_mask=True), (256, 64)), (dict(cull=1), (256, 64))):
+        depth_rgb, color = _scene(synthetic, w, h, seed=3)
+        r = sr.StereoRerenderer(w, h, pupillary_distance=65, **kw)
+        p = r.frame_params(xfov=45.0)
+        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+        _compare(got, _oracle(orc, r, p, depth_rgb, color), w, f"forced tie passes {kw} {w}x{h}")
+        r.close()
 
 
 def test_mesh_batch(mods, orc):

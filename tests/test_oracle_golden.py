@@ -312,3 +312,49 @@ def test_level_synchronous_order_vs_sequential_fast_marching(orc):
     # both fill every hole pixel and leave the seeds alone
     assert np.array_equal(fmm[mask == 0], seed[mask == 0]) and np.array_equal(lev[mask == 0], seed[mask == 0])
     assert not np.all(fmm[green] == (0, 255, 0), -1).any()
+
+
+def test_rasteriser_statistics_near_plane_ties_and_culling(orc):
+    """What the decree's known deviations from OpenGL amount to on the benchmark content:
+    * near plane: OpenGL clips a triangle that crosses z = 1e-4 (dmt:1520), the decree drops it whole.  Config C4's
+      synthetic camera track (BASELINE configs[3]: yaw / pitch / 2 mm per frame over 300 frames) never produces one,
+      nor does any frame without depth code 0 -- a vertex reaches the near plane only through Z = 0 (a pixel of code 0
+      sits AT the camera) or a pose that carries the camera through the scene;
+    * exact 1/Z ties between overlapping triangles DO happen (a few per 10^5 fragments here): the oracle keeps the
+      triangle drawn first, as GL_LESS does, and the kernels implement the same rule (tests/test_gpu_render.py);
+    * culling: the fold-over triangles exist and are exactly what `cull=1` removes."""
+    from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene, synthetic_pose_track, contention_band, quantise_depth_to_rgb
+    W, H = 480, 270
+    K = compute_camera_matrix(45.0, None, W, H)
+    sc = SyntheticScene(W, H, config_id=4)
+    track = synthetic_pose_track(300)
+    ties = 0
+    for t in (0, 1, 150, 299):
+        z = contention_band(sc.depth_m(t), K[0, 0], 0.065, row0=100, rows=32)
+        depth_rgb = quantise_depth_to_rgb(z)
+        _, color = sc.frame(t)
+        p = orc.make_params(W, H, K, ipd_m=0.065, mode=orc.MODE_MESH, T=track[t])
+        orc.stats_reset()
+        orc.render_stereo(p, depth_rgb, color)
+        st = orc.stats()
+        assert st["near_partial"] == 0 and st["near_all"] == 0, (t, st)
+        assert st["depth_ties"] < 1e-3 * st["fragments"] and st["fragments"] > 2 * W * H * 0.9, (t, st)
+        ties += st["depth_ties"]
+    assert ties > 0, "the posed frames of this scene used to contain exact depth ties; has the scene changed?"
+    # a Z = 0 patch is the one way to the near plane: its triangles are dropped whole (decree), and counted
+    depth_rgb = quantise_depth_to_rgb(sc.depth_m(0))
+    depth_rgb[40:44, 60:70] = 0
+    _, color = sc.frame(0)
+    orc.stats_reset()
+    orc.render_stereo(orc.make_params(W, H, K, ipd_m=0.065, mode=orc.MODE_MESH), depth_rgb, color)
+    st = orc.stats()
+    assert st["near_partial"] > 0 and st["near_all"] > 0
+    # culling
+    got = {}
+    for cull in (0, 1, 2):
+        orc.stats_reset()
+        got[cull] = orc.render_stereo(orc.make_params(W, H, K, ipd_m=0.065, mode=orc.MODE_MESH, cull=cull), quantise_depth_to_rgb(sc.depth_m(0)), color)
+        got[cull]["culled"] = orc.stats()["culled"]
+    assert got[0]["culled"] == 0 and 0 < got[1]["culled"] < got[2]["culled"]
+    assert (got[2]["left_mask"] > 0).mean() > 0.9 and (got[1]["left_mask"] > 0).sum() >= (got[0]["left_mask"] > 0).sum()
