@@ -8,7 +8,8 @@ a device-side FFV1 codec is out of scope, so this driver works on raw frame dump
   depth dump            the same layout holding the 16-bit RGB depth code of dfh:48-61 (RGB order)
   <depth>_stereo.npy    uint8 [N, H, 2W, 3] left | right (sr:918), written as <depth>_tmp_stereo.npy and
                         renamed only when every frame was written (the reference's verify_and_move,
-                        dfh:163-179)
+                        dfh:163-179); <depth>_Touchly0.npy / <depth>_Touchly1.npy with --touchly0 / --touchly1
+                        (sr:411-418; the side outputs follow the main name, as the reference's do)
   <depth>_stereo.npy_holemask.npy   uint8 [N, H, 2W]   255 = hole (sr:740 / 854)
   <depth>_stereo.npy_depth.npy      uint8 [N, H, 2W, 3] B,G,R 16-bit depth code of both eyes (sr:930-939)
   <depth>_stereo.npy_infillmask.npy uint8 [N, H, 2W, 3] with --infill_mask (sr:787-808, 921-928; RGB order): the
@@ -28,8 +29,9 @@ Side-cars are the reference's own JSON formats: xfov list (sr:351-359), converge
 (sr:343-349), transformations list of 4x4 (sr:362-373).
 
 Pipelining: per batch, H2D on a copy stream from pinned staging -> render on the compute stream ->
-D2H on a second copy stream into pinned staging, HIP events order them; the host copies into and out of the pinned
-staging run on helper threads one batch ahead of / behind the submitting thread; three staging sets rotate.
+D2H on a second copy stream into pinned staging, HIP events order them; the file <-> pinned-staging copies are
+pread / pwrite calls (no mapping, no intermediate array) fanned out over helper threads in frame sub-ranges, one batch
+ahead of / behind the submitting thread; three staging sets rotate.
 """
 from __future__ import annotations
 
@@ -48,8 +50,11 @@ def load_clip_parameters(n_frames: int, W: int, H: int, *, xfov=None, xfov_file=
                          transformation_file=None, transformation_lock_frame: int = 0, pupillary_distance=63,
                          max_depth=100, master_xfov: float = 45.0, render_as_pointcloud=False, remove_edges=False,
                          infill_mask=False, dont_place_points_in_edges=False, vr180=False, touchly0=False,
-                         touchly1=False, touchly_max_depth=5.0, touchly_min_depth=0.0, do_basic_infill=False) -> D.ClipParameters:
-    """What sr:318-373 does before the loop, on rank 0."""
+                         touchly1=False, touchly_max_depth=5.0, touchly_min_depth=0.0, do_basic_infill=False,
+                         dont_remove_edges=False, n_use: Optional[int] = None) -> D.ClipParameters:
+    """What sr:318-373 does before the loop, on rank 0.  n_frames is the length of the input clip: the side-cars are
+    checked against it and the convergence curve is smoothed over all of it, as the reference does (sr:343-349, 403);
+    n_use (--max_frames) then keeps the first frames only."""
     if xfov is None and xfov_file is None:
         raise ValueError("Error: Either --xfov_file, --xfov or --yfov must be provided.")            # sr:319-320
     if xfov_file is not None:
@@ -71,8 +76,9 @@ def load_clip_parameters(n_frames: int, W: int, H: int, *, xfov=None, xfov_file=
         with open(convergence_file) as fh:
             vals = fill_nan_with_closest([float(v) for v in json.load(fh)])                            # sr:348
         conv = np.asarray(curve_fit(vals), np.float64)                                                 # sr:349
-        if len(conv) != n_frames:
-            raise ValueError("convergence file must have one value per frame")
+        if len(conv) < n_frames:            # (the reference indexes the list by frame, sr:709: a short list fails there)
+            raise ValueError("convergence file has fewer entries than frames")
+        conv = conv[:n_frames]
     T = None
     if transformation_file is not None:
         if not os.path.isfile(transformation_file):
@@ -82,7 +88,12 @@ def load_clip_parameters(n_frames: int, W: int, H: int, *, xfov=None, xfov_file=
         if len(T) < n_frames:
             raise ValueError("transformation file has fewer entries than frames")
         T = T[:n_frames]
-    rm = bool(infill_mask or remove_edges or do_basic_infill)                                          # sr:568-570
+    if n_use is not None and n_use < n_frames:
+        xfovs, conv = xfovs[:n_use], conv[:n_use]
+        if T is not None:
+            T = T[:n_use]
+        n_frames = n_use
+    rm = bool(infill_mask or remove_edges or do_basic_infill) and not dont_remove_edges                # sr:568-573
     flags = (1 if render_as_pointcloud else 0) | (2 if rm else 0) | (4 if (rm and not dont_place_points_in_edges) else 0) \
         | (8 if infill_mask else 0)
     if touchly0:
@@ -117,7 +128,7 @@ def renderer_for(clip: D.ClipParameters, device: Optional[int] = None) -> Stereo
                             max_depth=clip.max_depth, master_xfov=clip.master_xfov,
                             render_as_pointcloud=bool(f & 1), remove_edges=bool(f & 2) and not bool(f & 8),
                             infill_mask=bool(f & 8), dont_place_points_in_edges=not bool(f & 4),
-                            do_basic_infill=bool(f & 128), dont_remove_edges=not bool(f & 2))
+                            do_basic_infill=bool(f & 128) and bool(f & 2), dont_remove_edges=not bool(f & 2))
 
 
 def frame_param_records(r: StereoRerenderer, clip: D.ClipParameters, lo: int, hi: int):
@@ -177,6 +188,50 @@ def _post_touchly1(r, clip, scales, d_depth_in, d_color_in, d_sbs, d_mask, d_z, 
     return d_post[:n]
 
 
+class _RawFrames:
+    """Frame dumps that live in a file (np.load(..., mmap_mode=...) / open_memmap arrays) are read and written with
+    pread / pwrite straight between the file and the pinned staging buffers: one kernel copy per batch and direction,
+    no page-fault storm through a mapping and no intermediate NumPy array.  Anything else (plain arrays, lists) is
+    indexed the ordinary way."""
+
+    def __init__(self, arr, writable: bool):
+        self.arr = arr
+        self.fd = -1
+        if isinstance(arr, np.memmap) and arr.flags["C_CONTIGUOUS"] and getattr(arr, "filename", None) and arr.ndim >= 2:
+            try:
+                self.fd = os.open(str(arr.filename), os.O_RDWR if writable else os.O_RDONLY)
+                self.base = int(arr.offset)
+                self.frame_bytes = int(arr[0].nbytes)
+            except OSError:
+                self.fd = -1
+
+    def read_into(self, dst: np.ndarray, a: int, n: int):
+        if self.fd < 0:
+            dst[...] = self.arr[a:a + n]
+            return
+        mv = memoryview(dst).cast("B")
+        off, done, total = self.base + a * self.frame_bytes, 0, n * self.frame_bytes
+        while done < total:
+            got = os.preadv(self.fd, [mv[done:total]], off + done)
+            if got <= 0:
+                raise IOError("short read from a frame dump")
+            done += got
+
+    def write_from(self, src: np.ndarray, a: int, n: int):
+        if self.fd < 0:
+            self.arr[a:a + n] = src
+            return
+        mv = memoryview(src).cast("B")
+        off, done, total = self.base + a * self.frame_bytes, 0, n * self.frame_bytes
+        while done < total:
+            done += os.pwritev(self.fd, [mv[done:total]], off + done)
+
+    def close(self):
+        if self.fd >= 0:
+            os.close(self.fd)
+            self.fd = -1
+
+
 def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParameters, *, lo: int = 0,
                 hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, out_infill=None, green_and_black: bool = False,
                 device: Optional[int] = None):
@@ -198,7 +253,10 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     skip_render = touchly1 and not posed                      # sr:548-552: "fast path we can skip the full render pass"
     want_z = want_zrgb or touchly0 or (touchly1 and posed)
     basic_infill = bool(clip.mode_flags & 128) and not touchly1
-    want_infill = out_infill is not None
+    want_infill = out_infill is not None and not skip_render   # (the reference writes no infill-mask frame on its fast path)
+    if not (clip.mode_flags & 2):
+        green_and_black = True       # --infill_mask --dont_remove_edges: no normals to show, the mask is the key colour at holes
+        basic_infill = False
     want_seed = ((want_infill and not green_and_black) or basic_infill) and bool(clip.mode_flags & 2)
     # without --infill_mask the key colour is black and every black pixel counts as "to fill" (sr:803-805): the front
     # then has to cross the whole frame, as the reference's own cv2.inpaint call does
@@ -215,7 +273,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         sets.append({
             "h_d": pinned((B, H, W, 3), torch.uint8), "h_c": pinned((B, H, W, 3), torch.uint8),
             "h_sbs": pinned((B, oH, oW, 3), torch.uint8), "h_mask": pinned((B, H, 2 * W), torch.uint8),
-            "h_counts": pinned((B, 2), torch.int32),
+            "h_counts": pinned((B, 2), torch.int32), "h_rem": pinned((2, B), torch.int32),
             "h_zrgb": pinned((B, H, 2 * W, 3), torch.uint8) if want_zrgb else None,
             "h_seed": pinned((B, H, 2 * W, 3), torch.uint8) if want_infill else None,
             "d_infill": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if (want_seed or want_infill) else None,
@@ -236,28 +294,54 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     # dumps; 29 MB per 1080p frame, NumPy drops the GIL inside them) run on helper threads, one batch ahead / behind
     # the thread that feeds the GPU.  Three staging sets keep the three stages out of each other's buffers.
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=4)
+    pool = ThreadPoolExecutor(max_workers=4)        # one task per batch and direction ...
+    io_pool = ThreadPoolExecutor(max_workers=12)    # ... each of which fans its file copies out in frame sub-ranges
+
+    def fan(fn, host, a, n, parts):
+        """fn(host[k0:k1], a + k0, k1 - k0) over `parts` frame sub-ranges in parallel: one thread moves ~2-3 GB/s into
+        fresh page-cache pages, a 1080p batch needs several."""
+        parts = max(1, min(parts, n))
+        edges = [(n * k) // parts for k in range(parts + 1)]
+        return [io_pool.submit(fn, host[edges[k]:edges[k + 1]], a + edges[k], edges[k + 1] - edges[k]) for k in range(parts)]
+
+    f_depth, f_color = _RawFrames(depth_frames, False), _RawFrames(color_frames, False)
+    f_sbs, f_mask = _RawFrames(out_sbs, True), _RawFrames(out_mask, True)
+    f_zrgb = _RawFrames(out_depth_rgb, True) if out_depth_rgb is not None else None
+    f_infill = _RawFrames(out_infill, True) if out_infill is not None else None
+
+    trace = [] if os.environ.get("MDVT_CLIP_TRACE") else None
 
     def load(st, a, n):
+        t_l = time.perf_counter()
         st["in_done"].synchronize()                 # the H2D copies that last read these pinned buffers are done
-        st["h_d"][:n].numpy()[...] = depth_frames[a:a + n]
-        st["h_c"][:n].numpy()[...] = color_frames[a:a + n]
-
-    def store_main(st, a, n):
-        out_sbs[a:a + n] = st["h_sbs"][:n].numpy()
+        t_l1 = time.perf_counter()
+        jobs = fan(f_color.read_into, st["h_c"][:n].numpy(), a, n, 2) + fan(f_depth.read_into, st["h_d"][:n].numpy(), a, n, 2)
+        for j in jobs:
+            j.result()
+        if trace is not None:
+            trace.append(("load", a, t_l - t0, t_l1 - t_l, time.perf_counter() - t_l1))
 
     def store(st, a, n):
+        t_s = time.perf_counter()
         st["out_done"].synchronize()
-        side = pool.submit(store_main, st, a, n)    # the largest output on its own thread
-        out_mask[a:a + n] = st["h_mask"][:n].numpy()
+        t_s1 = time.perf_counter()
+        jobs = fan(f_sbs.write_from, st["h_sbs"][:n].numpy(), a, n, 6) + fan(f_mask.write_from, st["h_mask"][:n].numpy(), a, n, 1)
         h = int(st["h_counts"][:n].sum())           # hole pixels, counted on the device (mdvt_io.hole_counts)
+        if st.get("check_rem") and int(st["h_rem"][:, :n].sum()) != 0:
+            redo.append((a, n))                     # a hole deeper than the default 256 levels: finished again below
         if want_zrgb:
-            out_depth_rgb[a:a + n] = st["h_zrgb"][:n].numpy()
+            jobs += fan(f_zrgb.write_from, st["h_zrgb"][:n].numpy(), a, n, 3)
         if want_infill:
-            out_infill[a:a + n] = st["h_seed"][:n].numpy()
-        side.result()
+            jobs += fan(f_infill.write_from, st["h_seed"][:n].numpy(), a, n, 3)
+        for j in jobs:
+            j.result()
+        store_done.append(time.perf_counter())
+        if trace is not None:
+            trace.append(("store", a, t_s - t0, t_s1 - t_s, time.perf_counter() - t_s1))
         return h
 
+    redo = []
+    store_done = []
     starts = list(range(lo, hi, B))
     t0 = time.perf_counter()
     if starts:
@@ -291,7 +375,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             for f in range(n):
                 dfh.encode_depth_frame(st["d_z"][f], clip.max_depth, bgr=True, out=st["d_zrgb"][f])
         if want_seed and res is not None:              # sr:803-808: finish the normal-coloured mask on the device, per eye
-            r.finish_infill_mask_sbs(res["seed"], out=st["d_infill"][:n], max_rounds=telea_rounds)
+            _, st["d_rem"] = r.finish_infill_mask_sbs(res["seed"], out=st["d_infill"][:n], max_rounds=telea_rounds, want_remaining=True)
             if basic_infill:                           # sr:809-812: march along the normals into the holes
                 from .stereo_rerender import infill_using_normals
                 for f in range(n):
@@ -321,13 +405,49 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
                 st["h_zrgb"][:n].copy_(st["d_zrgb"][:n], non_blocking=True)
             if want_infill and res is not None:
                 st["h_seed"][:n].copy_(st["d_infill"][:n], non_blocking=True)
+            if st.get("d_rem") is not None:
+                st["h_rem"][:, :n].copy_(st["d_rem"], non_blocking=True)
+                st["d_rem"].record_stream(s_out)
+                st["check_rem"] = True
             st["out_done"].record(s_out)
         st["stored"] = pool.submit(store, st, a, n)
         stores.append(st["stored"])
     holes = sum(f.result() for f in stores)
     torch.cuda.synchronize(dev)
+    # steady-state rate: from the moment the first batch has left the pipeline (the first render call pays the one-time
+    # code-object load, ~0.2 s) to the moment the last one has
+    if len(store_done) >= 3:
+        render_clip.last_steady_fps = (hi - lo - min(B, hi - lo)) / max(store_done[-1] - store_done[0], 1e-9)
+    else:
+        render_clip.last_steady_fps = float("nan")
+    for a, n in redo:
+        # cv2.inpaint fills every masked pixel (sr:806).  The default 256 levels did not reach the bottom of a hole of this
+        # batch: render it again and let the front travel as far as the frame is large (W + H levels always suffice).
+        st = sets[0]
+        st["d_d"][:n].copy_(torch.from_numpy(np.ascontiguousarray(depth_frames[a:a + n])))
+        st["d_c"][:n].copy_(torch.from_numpy(np.ascontiguousarray(color_frames[a:a + n])))
+        res = r.render(st["d_d"][:n], st["d_c"][:n], recs[a - lo:a - lo + n], out_sbs=st["d_sbs"][:n], out_mask=st["d_mask"][:n], want_seed=True)
+        r.finish_infill_mask_sbs(res["seed"], out=st["d_infill"][:n], max_rounds=W + H)
+        if basic_infill:
+            from .stereo_rerender import infill_using_normals
+            for f in range(n):
+                for eye in range(2):
+                    sl = slice(eye * W, (eye + 1) * W)
+                    normals = (st["d_infill"][f, :, sl].to(torch.float32) / 255.0) * 2 - 1
+                    st["d_sbs"][f, :, sl] = infill_using_normals(st["d_sbs"][f, :, sl], st["d_mask"][f, :, sl] > 0, normals)
+            if not post:
+                f_sbs.write_from(st["d_sbs"][:n].cpu().numpy(), a, n)
+        if want_infill:
+            f_infill.write_from(st["d_infill"][:n].cpu().numpy(), a, n)
     dt = time.perf_counter() - t0
+    if trace is not None:
+        for ev in sorted(trace, key=lambda e: e[2]):
+            print("clip trace: %-5s frame %4d  t=%7.1f ms  wait %6.1f ms  copy %6.1f ms" % (ev[0], ev[1], ev[2] * 1e3, ev[3] * 1e3, ev[4] * 1e3))
     pool.shutdown()
+    io_pool.shutdown()
+    for f in (f_depth, f_color, f_sbs, f_mask, f_zrgb, f_infill):
+        if f is not None:
+            f.close()
     r.close()
     return hi - lo, dt, holes
 
@@ -354,18 +474,20 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
         raise ValueError(f"Depth video and Color video must have the same dimensions "
                          f"(Depth: {depth.shape[2]}x{depth.shape[1]} vs Color {color.shape[2]}x{color.shape[1]}).")   # sr:387-388
     N, H, W = depth.shape[:3]
+    n_total = N
     if max_frames >= 0:
         N = min(N, max_frames)      # the reference processes max_frames+1 and then fails its own check: dropped
-    clip = load_clip_parameters(N, W, H, **clip_kwargs) if rank == 0 else None
+    clip = load_clip_parameters(n_total, W, H, n_use=N, **clip_kwargs) if rank == 0 else None
     clip = D.broadcast_clip_parameters(clip, src=0)
-    final = depth_path + "_stereo.npy"
-    tmp = depth_path + "_tmp_stereo.npy"
+    kind = "Touchly1" if clip.mode_flags & 64 else ("Touchly0" if clip.mode_flags & 32 else "stereo")     # sr:411-422
+    final = depth_path + f"_{kind}.npy"
+    tmp = depth_path + f"_tmp_{kind}.npy"
     oH, oW = output_shape(clip)
     names = {"sbs": (tmp, final, (N, oH, oW, 3)),
              "mask": (tmp + "_holemask.npy", final + "_holemask.npy", (N, H, 2 * W))}
     if create_sbs_depth_video:
         names["depth"] = (tmp + "_depth.npy", final + "_depth.npy", (N, H, 2 * W, 3))
-    if clip_kwargs.get("infill_mask"):
+    if clip_kwargs.get("infill_mask") and not ((clip.mode_flags & 64) and clip.transformations is None):
         names["infill"] = (tmp + "_infillmask.npy", final + "_infillmask.npy", (N, H, 2 * W, 3))
     if rank == 0:
         for t, _, shape in names.values():

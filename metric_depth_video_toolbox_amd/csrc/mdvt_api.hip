@@ -180,7 +180,9 @@ int stage_params(mdvt_ctx* c, const std::vector<FrameDev>& v, hipStream_t s, con
     return MDVT_OK;
 }
 
-int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, bool need_edges, bool need_gverts)
+// (the EMPTY fill of fresh key buffers goes on the caller's stream: PyTorch's pool streams do not synchronise with the
+//  legacy null stream, so a fill issued there could land after the first splat)
+int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, bool need_edges, bool need_gverts, hipStream_t s)
 {
     const size_t npx = (size_t)c->W * c->H;
     const size_t ntri = 2 * (size_t)(c->W - 1) * (c->H - 1);
@@ -207,14 +209,14 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     if (need_keys && !c->ws_keys) {
         for (int e = 0; e < 2; ++e) {
             MDVT_HIP(c, hipMalloc((void**)&c->keys[e], nf * npx * sizeof(unsigned long long)));
-            MDVT_HIP(c, hipMemset(c->keys[e], 0xFF, nf * npx * sizeof(unsigned long long)));     // EMPTY; resolve keeps them so
+            MDVT_HIP(c, hipMemsetAsync(c->keys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));     // EMPTY; resolve keeps them so
         }
         c->ws_keys = true;
     }
     if (need_ekeys && !c->ws_ekeys) {
         for (int e = 0; e < 2; ++e) {
             MDVT_HIP(c, hipMalloc((void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long)));
-            MDVT_HIP(c, hipMemset(c->ekeys[e], 0xFF, nf * npx * sizeof(unsigned long long)));
+            MDVT_HIP(c, hipMemsetAsync(c->ekeys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));
         }
         c->ws_ekeys = true;
     }
@@ -460,7 +462,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         if ((r.general || plan.remove_edges) && ch > ws_frames) ws_frames = ch;
         if (ch > count_frames) count_frames = ch;
     }
-    if (ws_frames && (rc = ensure_workspace(c, ws_frames, need_keys, need_ekeys, plan.remove_edges, need_gverts)) != MDVT_OK) return rc;
+    if (ws_frames && (rc = ensure_workspace(c, ws_frames, need_keys, need_ekeys, plan.remove_edges, need_gverts, s)) != MDVT_OK) return rc;
 
     RenderArgs a{};
     a.depth = io->depth_rgb; a.depth_pitch = io->depth_pitch; a.depth_stride = io->depth_stride;

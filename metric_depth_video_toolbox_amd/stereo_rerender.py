@@ -509,11 +509,11 @@ def main(argv=None):
                             transformation_lock_frame=args.transformation_lock_frame,
                             pupillary_distance=args.pupillary_distance, max_depth=args.max_depth,
                             master_xfov=args.master_xfov, render_as_pointcloud=args.render_as_pointcloud,
-                            remove_edges=(args.remove_edges and not args.dont_remove_edges),
-                            infill_mask=(args.infill_mask and not args.dont_remove_edges),
+                            remove_edges=args.remove_edges, dont_remove_edges=args.dont_remove_edges,
+                            infill_mask=args.infill_mask,
                             dont_place_points_in_edges=args.dont_place_points_in_edges,
                             vr180=args.vr180, touchly0=args.touchly0, touchly1=args.touchly1,
-                            do_basic_infill=(args.do_basic_infill and not args.dont_remove_edges),
+                            do_basic_infill=args.do_basic_infill,
                             touchly_max_depth=args.touchly_max_depth, touchly_min_depth=args.touchly_min_depth)
     if int(os.environ.get("RANK", "0")) == 0:
         frames, secs = float(stats[:, 0].sum()), float(stats[:, 1].max())

@@ -37,7 +37,7 @@ def render_scene(dfh, dmt, sr, sc, depth_rgb, color, T):
     cam = dmt.compute_camera_matrix(sc["xfov"], None, W, H)                                   # sr:515-525
     depth = dfh.decode_rgb_depth_frame(depth_rgb, 100, True)                                  # sr:512
     scale = 1.0 / (np.tan(np.radians(45.0 / 2)) / np.tan(np.radians(sc["xfov"] / 2)))        # sr:537-538, master_xfov 45
-    depth = depth * np.float32(1.0) if scale == 1.0 else depth * scale                        # sr:541
+    depth *= scale                                                                            # sr:541
     bg = np.array([0.0, 1.0, 0.0]) if sc["remove_edges"] else np.array([0.0, 0.0, 0.0])       # sr:555-558 (--infill_mask)
     mesh, unused, normals = dmt.get_mesh_from_depth_map(depth, cam, color, None, remove_edges=sc["remove_edges"],
                                                         of_by_one=not sc["pointcloud"], return_normals_of_removed=True)   # sr:583

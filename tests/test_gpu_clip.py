@@ -165,8 +165,13 @@ def test_touchly1_clip(mods, orc, tmp_path, posed):
         (tmp_path / "T.json").write_text(json.dumps(synthetic.synthetic_pose_track(N).tolist()))
         kw["transformation_file"] = str(tmp_path / "T.json")
     stats, final = clip.run(dp, cp, batch=2, **kw)
+    assert final == dp + "_Touchly1.npy" and not os.path.exists(dp + "_tmp_Touchly1.npy")       # sr:411-413
+    assert os.path.exists(final + "_infillmask.npy") == posed
     out = np.load(final)
     assert out.shape == (N, 2 * H, W, 3)
+    if not posed:       # the fast path (sr:548-552) writes no infill-mask frames even when one is asked for
+        stats, final2 = clip.run(dp, cp, batch=2, **dict(kw, infill_mask=True))
+        assert not os.path.exists(final2 + "_infillmask.npy") and np.array_equal(np.load(final2), out)
     cl = clip.load_clip_parameters(N, W, H, **kw)
     r = clip.renderer_for(cl)
     recs = clip.frame_param_records(r, cl, 0, N)
@@ -199,6 +204,7 @@ def test_vr180_clip(mods, orc, tmp_path, touchly0):
     (tmp_path / "xfov.json").write_text(json.dumps([90.0, 70.0]))                 # per-frame fov: 90 -> render fov 90, 70 -> 75
     kw.pop("xfov"); kw["xfov_file"] = str(tmp_path / "xfov.json")
     stats, final = clip.run(dp, cp, batch=2, **kw)
+    assert final == dp + ("_Touchly0.npy" if touchly0 else "_stereo.npy")                          # sr:414-422
     out = np.load(final)
     assert out.shape == (N, H, (3 if touchly0 else 2) * W, 3)
     cl = clip.load_clip_parameters(N, W, H, **kw)
@@ -257,4 +263,38 @@ def test_infill_mask_clip(mods, orc, tmp_path, basic):
                 wn = ((wfin.astype(np.float32) / np.float32(255.0)) * 2 - 1).astype(np.float32)
                 wimg = orc.infill_using_normals(wimg, want[eye + "_mask"] > 0, wn)
             assert np.array_equal(sbs[t][:, sl], wimg), (t, eye)
+    r.close()
+
+
+def test_max_frames_with_full_length_side_cars_and_unremoved_edges(mods, orc, tmp_path):
+    """(a) --max_frames with side-cars that cover the whole clip: the reference checks the xfov list against the video's
+    frame count (sr:403) and indexes the convergence list by frame, so this combination works upstream and must here.
+    (b) --infill_mask --dont_remove_edges: only remove_edges is cleared (sr:572-573) -- the background stays green and
+    the infill-mask output is still written (sr:555-558, 921-928), with nothing but the key colour in it."""
+    clip, sr, synthetic = mods
+    W, H, N = 128, 72, 6
+    d, c = synthetic.SyntheticScene(W, H, config_id=3, n_fg=5).clip(N)
+    dp, cp = str(tmp_path / "d.npy"), str(tmp_path / "c.npy")
+    np.save(dp, d); np.save(cp, c)
+    (tmp_path / "xfov.json").write_text(json.dumps([44.0 + k for k in range(N)]))
+    (tmp_path / "conv.json").write_text(json.dumps([2.0, float("nan"), 2.2, 2.4, 2.1, 2.0]))
+    stats, final = clip.run(dp, cp, batch=4, max_frames=3, xfov_file=str(tmp_path / "xfov.json"),
+                            convergence_file=str(tmp_path / "conv.json"), pupillary_distance=65, infill_mask=True,
+                            dont_remove_edges=True)
+    sbs, mask, im = np.load(final), np.load(final + "_holemask.npy"), np.load(final + "_infillmask.npy")
+    assert sbs.shape[0] == 3 and im.shape == sbs.shape
+    cl = clip.load_clip_parameters(N, W, H, n_use=3, xfov_file=str(tmp_path / "xfov.json"), convergence_file=str(tmp_path / "conv.json"),
+                                   pupillary_distance=65, infill_mask=True, dont_remove_edges=True)
+    full = clip.load_clip_parameters(N, W, H, xfov_file=str(tmp_path / "xfov.json"), convergence_file=str(tmp_path / "conv.json"),
+                                     pupillary_distance=65, infill_mask=True, dont_remove_edges=True)
+    assert cl.n_frames == 3 and np.array_equal(cl.convergence, full.convergence[:3]) and not (cl.mode_flags & 2) and (cl.mode_flags & 8)
+    r = clip.renderer_for(cl)
+    assert r.key_rgb == (0, 255, 0) and not r.remove_edges
+    recs = clip.frame_param_records(r, cl, 0, 3)
+    for t in range(3):
+        want = _oracle_frame(orc, cl, r, recs[t], d[t], c[t], None)
+        assert np.array_equal(mask[t, :, :W], want["left_mask"]) and np.array_equal(sbs[t, :, W:], want["right_rgb"]), t
+        green = np.zeros((H, 2 * W, 3), np.uint8)
+        green[mask[t] > 0] = (0, 255, 0)
+        assert np.array_equal(im[t], green), t
     r.close()

@@ -33,4 +33,5 @@ dt = time.perf_counter() - t0
 if int(os.environ.get("RANK", "0")) == 0:
     print(f"C3 clip: {N} frames 1080p, {'mesh' if a.mesh else 'points'}{'+infill' if a.infill else ''}: "
           f"{stats[:, 0].sum() / stats[:, 1].max():.1f} frames/s in the render loop incl. host copies and PCIe, "
-          f"{N / dt:.1f} frames/s wall incl. output file creation; holes {int(stats[:, 2].sum())}")
+          f"{N / dt:.1f} frames/s wall incl. output file creation; steady state after the first batch "
+          f"{getattr(clip.render_clip, 'last_steady_fps', float('nan')):.1f} frames/s; holes {int(stats[:, 2].sum())}")
