@@ -227,11 +227,11 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         }
         if (c->bigq) (void)hipFree(c->bigq);
         c->bigq = nullptr;
-        // room for one large triangle per 8 pixels of a launch set (more than any scene short of white noise produces;
-        // beyond that the owning workgroup rasterises them itself)
-        const size_t cap = nf * npx / 8 + 1024;
-        c->bigq_cap = cap > 0x3FFFFFFFu ? 0x3FFFFFFFu : (uint32_t)cap;
-        MDVT_HIP(c, hipMalloc((void**)&c->bigq, ((size_t)c->bigq_cap * mdvt::kBigRecDwords + 1) * sizeof(uint32_t)));
+        // one segment per (frame slot, cell row), each with room for all four triangles of every cell of the row (8 bytes
+        // per triangle) and its own counter: the queue cannot overflow
+        const size_t cap = nf * npx * 4;
+        c->bigq_cap = cap > 0xFFFFFFF0u ? 0xFFFFFFF0u : (uint32_t)cap;
+        MDVT_HIP(c, hipMalloc((void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 1) * sizeof(uint32_t)));   // entries, counters, prefix sums
         c->ws_gverts = true;
     }
     if (need_edges && !c->ws_edges) {
@@ -494,7 +494,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.gverts[0] = c->gverts[0]; a.gverts[1] = c->gverts[1];
     a.cbuf[0] = c->cbuf[0]; a.cbuf[1] = c->cbuf[1];
     a.tri_invalid = c->tri_invalid; a.unused = c->unused;
-    if (c->bigq && getenv("MDVT_NO_BIGQ") == nullptr) {
+    if (c->bigq) {
         a.bigq = c->bigq; a.bigq_cap = c->bigq_cap; a.bigq_count = c->bigq + (size_t)c->bigq_cap * mdvt::kBigRecDwords;
     }
     a.ws_stride_px = (size_t)W * H;

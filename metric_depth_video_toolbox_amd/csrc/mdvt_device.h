@@ -377,6 +377,29 @@ __device__ __forceinline__ bool tri_walk_sample(const TriSetup& t, const TriWalk
     return true;
 }
 
+// Conservative pixel-column range [lo, hi] of a triangle on pixel row py: each orientation-normalised edge
+// w_k = A_k - dy_k * X >= 0 bounds X from above (dy_k > 0) or below (dy_k < 0); the crossings are estimated
+// in float and widened by one pixel (they are good to ~0.1 px inside the snap range), so the range is a
+// superset of the covered pixels and the exact integer test still decides.  Returns false for an empty row.
+__device__ __forceinline__ bool tri_row_range(const TriSetup& t, int py, int px0, int px1, int& lo, int& hi)
+{
+    const int Yc = py * kSubpix + kSubpix / 2;
+    float flo = -3.0e9f, fhi = 3.0e9f;
+    const int dxs[3] = {t.dx0, t.dx1, t.dx2}, dys[3] = {t.dy0, t.dy1, t.dy2};
+    const int bxs[3] = {t.bx0, t.bx1, t.bx2}, bys[3] = {t.by0, t.by1, t.by2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const i64 A = mul64(dxs[k], Yc - bys[k]) + mul64(dys[k], bxs[k]);
+        if (dys[k] == 0) { if (A < 0) return false; continue; }
+        const float x = (float)A / (float)dys[k];
+        if (dys[k] > 0) fhi = fminf(fhi, x); else flo = fmaxf(flo, x);
+    }
+    const float l = floorf((flo - 128.0f) * (1.0f / 256.0f)) - 1.0f, h = floorf((fhi - 128.0f) * (1.0f / 256.0f)) + 1.0f;
+    lo = l < (float)px0 ? px0 : (l > (float)px1 ? px1 + 1 : (int)l);
+    hi = h > (float)px1 ? px1 : (h < (float)px0 ? px0 - 1 : (int)h);
+    return lo <= hi;
+}
+
 // Perspective-correct colour, rounded half-even to u8 (decree): rint(((q0 c0 + q1 c1) + q2 c2) * (1/iz)) clamped to
 // [0, 255], NaN -> 0.  v_cvt_pk_u8_f32 IS that conversion (round to nearest even, saturating, NaN -> 0 -- checked for
 // every f32 by mdvt_selftest) and packs the byte in place; R and G travel as one v_pk_mul/add_f32 pair (two IEEE f32

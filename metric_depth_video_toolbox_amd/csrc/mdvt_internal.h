@@ -57,7 +57,7 @@ struct RenderArgs {
     unsigned long long* cbuf[2]; // general mesh path: per-eye colour side buffer, draw id << 32 | rgb of some fragment of the pixel
     uint8_t* tri_invalid;        // [slot][2*(H-1)*(W-1)]
     uint8_t* unused;             // [slot][H*W]
-    // general mesh path: queue of large triangles (records of kBigRecDwords dwords), rasterised by k_mesh_raster_big
+    // general mesh path: queue of the triangles that are not small (kBigRecDwords dwords each), rasterised by k_mesh_raster_queue
     uint32_t* bigq; uint32_t* bigq_count; uint32_t bigq_cap;
     size_t ws_stride_px;         // H*W (elements) between slots
     size_t ws_stride_tri;        // 2*(H-1)*(W-1)
@@ -76,7 +76,7 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
                               int n, int W, int H, int of_by_one, uint8_t* tri_invalid, size_t tri_stride,
                               uint8_t* unused, size_t unused_stride, hipStream_t s);
 
-constexpr int kBigRecDwords = 32;    // 26 used: normalised edges, base points, area, 1/Z, pixel box, draw id, colours, frame/eye
+constexpr int kBigRecDwords = 2;     // a queued triangle: draw id, frame slot << 1 | eye
 
 struct RenderPlan {
     int mode;            // mdvt_mode
@@ -91,6 +91,8 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 // mdvt_mesh_band.hip: the pure-shift mesh rows as bands (no edge removal)
 bool mesh_band_supported(const RenderPlan& plan, const RenderArgs& a);
 hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+// mdvt_mesh_general.hip: the rasteriser of the general mesh path (between the vertex pass and the resolve pass)
+hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const uint8_t* hole, size_t hole_pitch,
                                  const float* normal, size_t normal_pitch, uint8_t* out, size_t out_pitch, int W, int H,
                                  int max_steps, hipStream_t s);

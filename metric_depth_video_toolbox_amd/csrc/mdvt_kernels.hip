@@ -958,15 +958,6 @@ __device__ __forceinline__ void mesh_row_fragment(u64* zb, int px, float q0, flo
     post_row_fragment(zb, px, iz, shade_px(q0, q1, q2, riz, c0, c1, c2), draw, ties);
 }
 
-// One covered fragment of the global-key kernels.
-__device__ __forceinline__ void mesh_global_fragment(u64* keys, u64* cbuf, size_t o, float q0, float q1, float q2,
-                                                     uint32_t c0, uint32_t c1, uint32_t c2, uint32_t did)
-{
-    const float iz = (q0 + q1) + q2;
-    atomicMin(&keys[o], ((u64)depth_bits(iz) << 32) | did);
-    cbuf[o] = ((u64)did << 32) | shade_px(q0, q1, q2, rcp_exact(iz), c0, c1, c2);
-}
-
 struct MeshVert { int XL, XR; float iz; uint32_t rgb; };
 static_assert(sizeof(MeshVert) == 16, "MeshVert is one ds_read_b128");
 constexpr int kShortSpan = 4;
@@ -1405,226 +1396,6 @@ __global__ void __launch_bounds__(256) k_mesh_vertices_general(RenderArgs a)
     }
 }
 
-// Conservative pixel-column range [lo, hi] of a triangle on pixel row py: each orientation-normalised edge
-// w_k = A_k - dy_k * X >= 0 bounds X from above (dy_k > 0) or below (dy_k < 0); the crossings are estimated
-// in float and widened by one pixel (they are good to ~0.1 px inside the snap range), so the range is a
-// superset of the covered pixels and the exact integer test still decides.  Returns false for an empty row.
-__device__ __forceinline__ bool tri_row_range(const TriSetup& t, int py, int px0, int px1, int& lo, int& hi)
-{
-    const int Yc = py * kSubpix + kSubpix / 2;
-    float flo = -3.0e9f, fhi = 3.0e9f;
-    const int dxs[3] = {t.dx0, t.dx1, t.dx2}, dys[3] = {t.dy0, t.dy1, t.dy2};
-    const int bxs[3] = {t.bx0, t.bx1, t.bx2}, bys[3] = {t.by0, t.by1, t.by2};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const i64 A = mul64(dxs[k], Yc - bys[k]) + mul64(dys[k], bxs[k]);
-        if (dys[k] == 0) { if (A < 0) return false; continue; }
-        const float x = (float)A / (float)dys[k];
-        if (dys[k] > 0) fhi = fminf(fhi, x); else flo = fmaxf(flo, x);
-    }
-    const float l = floorf((flo - 128.0f) * (1.0f / 256.0f)) - 1.0f, h = floorf((fhi - 128.0f) * (1.0f / 256.0f)) + 1.0f;
-    lo = l < (float)px0 ? px0 : (l > (float)px1 ? px1 + 1 : (int)l);
-    hi = h > (float)px1 ? px1 : (h < (float)px0 ? px0 - 1 : (int)h);
-    return lo <= hi;
-}
-
-constexpr int kSmallBox = 12;      // bounding boxes up to this many pixel centres are walked by the owning lane
-constexpr int kBigQueueMinPix = 256;  // boxes from this many pixel centres on go to the queue of k_mesh_raster_big
-
-// Stage 2: one thread per cell, both triangles, both eyes.  Triangles with a large bounding box (rubber
-// sheet across depth edges, sheared cells) are broadcast lane by lane and rasterised by the whole wave.
-template <int FLAGS>
-__global__ void __launch_bounds__(128) k_mesh_raster_general(RenderArgs a)
-{
-    constexpr bool EDGES = FLAGS & 2;
-    const int W = a.W, H = a.H;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    const int fr = blockIdx.z;
-    const int lane = threadIdx.x & 63;
-    const bool act = j < W - 1;
-    const size_t ncell = (size_t)(W - 1) * (H - 1);
-    // The 2 x 129 vertex records of both eyes are fetched once per workgroup, all loads in flight together: at
-    // 4 waves per SIMD the kernel is latency-limited in this prologue, and per-thread loads (four per eye, each
-    // record fetched by four threads, the eyes one after the other) cost two round trips instead of one.
-    __shared__ uint4 sv[2][2][129];
-    uint32_t inv0 = 0, inv1 = 0;
-    {
-        const int t = threadIdx.x;
-        const int j0 = blockIdx.x * blockDim.x;
-        const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
-        const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);      // (clamped: columns past the row end are never used)
-        uint4 rx = make_uint4(0, 0, 0, 0);                                  // the 129th column, issued first so that
-        if (t < 4) rx = (t & 2 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t & 1) * W + jx];   // wave 0 does not pay a second round trip
-        const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
-        const uint4 r2 = a.gverts[1][base + jc], r3 = a.gverts[1][base + W + jc];
-        if (EDGES && act) {                                                 // (issued behind the record loads, not before)
-            const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
-            inv0 = tinv[0]; inv1 = tinv[ncell];
-        }
-        if (t < 4) sv[t >> 1][t & 1][128] = rx;
-        sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
-    }
-    __syncthreads();
-    const bool inv[2] = {inv0 != 0, inv1 != 0};
-#pragma unroll 1
-    for (int eye = 0; eye < 2; ++eye) {
-        u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
-        u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
-        uint4 A = make_uint4(0, 0, 0, 0), B = A, Cv = A, D = A;
-        if (act) {
-            const int t = threadIdx.x;
-            A = sv[eye][0][t]; D = sv[eye][0][t + 1]; B = sv[eye][1][t]; Cv = sv[eye][1][t + 1];
-        }
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            // tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]); tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])   (dmt:1243-1254)
-            const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
-            const uint32_t did = draw_id_global(pass, i, j);
-            TriSetup t;
-            bool big = false;
-            int px0 = 0, px1 = -1, py0 = 0, py1 = -1;
-            if (act && !inv[pass] &&
-                tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
-                                  (int)v2.x, (int)v2.y, __uint_as_float(v2.z), a.cull)) {
-                px0 = floordiv_subpix(t.minX - kSubpix / 2 + kSubpix - 1); px1 = floordiv_subpix(t.maxX - kSubpix / 2);
-                py0 = floordiv_subpix(t.minY - kSubpix / 2 + kSubpix - 1); py1 = floordiv_subpix(t.maxY - kSubpix / 2);
-                if (px0 < 0) px0 = 0;
-                if (py0 < 0) py0 = 0;
-                if (px1 > W - 1) px1 = W - 1;
-                if (py1 > H - 1) py1 = H - 1;
-                if (px1 >= px0 && py1 >= py0) {
-                    if ((px1 - px0 + 1) * (i64)(py1 - py0 + 1) > kSmallBox) {
-                        // large box: most are thin slivers (cells sheared across a depth edge) -- walk the rows by
-                        // their own x-range; only triangles that are large in area go to the whole-wave path
-                        int total = py1 - py0 > 8 ? kSmallBox + 1 : 0;
-                        for (int py = py0; py <= py1 && total <= kSmallBox; ++py) {
-                            int lo, hi;
-                            if (tri_row_range(t, py, px0, px1, lo, hi)) total += hi - lo + 1;
-                        }
-                        if (total > kSmallBox) big = true;
-                        else if (!(a.debug_skip & 16))
-                            for (int py = py0; py <= py1; ++py) {
-                                int lo, hi;
-                                if (!tri_row_range(t, py, px0, px1, lo, hi)) continue;
-                                for (int px = lo; px <= hi; ++px) {
-                                    float q0, q1, q2;
-                                    if (!tri_sample(t, px, py, q0, q1, q2)) continue;
-                                    mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
-                                }
-                            }
-                    } else if (!(a.debug_skip & 16)) {
-                        TriWalk row = tri_walk_start(t, px0, py0);
-                        for (int py = py0; py <= py1; ++py) {
-                            TriWalk w = row;
-                            for (int px = px0; px <= px1; ++px) {
-                                float q0, q1, q2;
-                                if (tri_walk_sample(t, w, q0, q1, q2))
-                                    mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
-                                tri_walk_right(t, w);
-                            }
-                            tri_walk_down(t, row);
-                        }
-                    }
-                }
-            }
-            // Large triangles cluster (a horizontal depth edge under vertical parallax turns a whole row of cells into
-            // them), so the workgroups that own them used to run far longer than the rest.  They go to a queue instead,
-            // which k_mesh_raster_big spreads over the whole chip; only if the queue is full are they rasterised here.
-            if (a.bigq && !(a.debug_skip & 8)) {
-                // (a box of a few hundred pixel centres is cheaper to finish here than to write out and read back)
-                const bool toq = big && (i64)(px1 - px0 + 1) * (py1 - py0 + 1) >= kBigQueueMinPix;
-                const u64 mq = __ballot(toq);
-                if (mq) {
-                    uint32_t base = 0;
-                    const int first = __ffsll((long long)mq) - 1;
-                    if (lane == first) base = atomicAdd(a.bigq_count, (uint32_t)__popcll(mq));
-                    base = __shfl(base, first);
-                    const uint32_t slot = base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
-                    if (toq && slot < a.bigq_cap) {
-                        uint32_t* rec = a.bigq + (size_t)slot * kBigRecDwords;
-                        rec[0] = (uint32_t)t.dx0; rec[1] = (uint32_t)t.dy0; rec[2] = (uint32_t)t.dx1; rec[3] = (uint32_t)t.dy1;
-                        rec[4] = (uint32_t)t.dx2; rec[5] = (uint32_t)t.dy2; rec[6] = (uint32_t)t.bx0; rec[7] = (uint32_t)t.by0;
-                        rec[8] = (uint32_t)t.bx1; rec[9] = (uint32_t)t.by1; rec[10] = (uint32_t)t.bx2; rec[11] = (uint32_t)t.by2;
-                        rec[12] = (uint32_t)t.area2; rec[13] = (uint32_t)((u64)t.area2 >> 32);
-                        rec[14] = __float_as_uint(t.iz0); rec[15] = __float_as_uint(t.iz1); rec[16] = __float_as_uint(t.iz2);
-                        rec[17] = (uint32_t)px0; rec[18] = (uint32_t)px1; rec[19] = (uint32_t)py0; rec[20] = (uint32_t)py1;
-                        rec[21] = did; rec[22] = A.w; rec[23] = v1.w; rec[24] = v2.w;
-                        rec[25] = (uint32_t)fr * 2u + (uint32_t)eye;
-                        big = false;
-                    }
-                }
-            }
-            u64 m = (a.debug_skip & 8) ? 0ull : __ballot(big);
-            while (m) {
-                const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-                m &= m - 1;
-                TriSetup b;
-#define MDVT_BCAST(fld) b.fld = __builtin_amdgcn_readlane(t.fld, l)
-                MDVT_BCAST(dx0); MDVT_BCAST(dy0); MDVT_BCAST(dx1); MDVT_BCAST(dy1); MDVT_BCAST(dx2); MDVT_BCAST(dy2);
-                MDVT_BCAST(bx0); MDVT_BCAST(by0); MDVT_BCAST(bx1); MDVT_BCAST(by1); MDVT_BCAST(bx2); MDVT_BCAST(by2);
-#undef MDVT_BCAST
-                const uint32_t alo = __builtin_amdgcn_readlane((int)(uint32_t)t.area2, l);
-                const uint32_t ahi = __builtin_amdgcn_readlane((int)(uint32_t)((u64)t.area2 >> 32), l);
-                b.area2 = (i64)(((u64)ahi << 32) | alo);
-                b.iz0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.iz0), l));
-                b.iz1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.iz1), l));
-                b.iz2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.iz2), l));
-                const int bx0 = __builtin_amdgcn_readlane(px0, l), bx1 = __builtin_amdgcn_readlane(px1, l);
-                const int by0 = __builtin_amdgcn_readlane(py0, l), by1 = __builtin_amdgcn_readlane(py1, l);
-                const uint32_t bid = (uint32_t)__builtin_amdgcn_readlane((int)did, l);
-                const uint32_t c0 = __builtin_amdgcn_readlane((int)A.w, l), c1 = __builtin_amdgcn_readlane((int)v1.w, l);
-                const uint32_t c2 = __builtin_amdgcn_readlane((int)v2.w, l);
-                const int bw = bx1 - bx0 + 1;
-                const i64 total = (i64)bw * (by1 - by0 + 1);
-                // lanes walk the box in row-major order, 64 pixel centres per step
-                int px = bx0 + lane % bw, py = by0 + lane / bw;
-                const int sx = 64 % bw, sy = 64 / bw;
-                for (i64 idx = lane; idx < total; idx += 64) {
-                    float q0, q1, q2;
-                    if (tri_sample(b, px, py, q0, q1, q2))
-                        mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, c0, c1, c2, bid);
-                    px += sx; py += sy;
-                    if (px > bx1) { px -= bw; ++py; }
-                }
-            }
-        }
-    }
-}
-
-
-
-// The queued large triangles of one launch, one wave per triangle at a time, dealt round-robin to every wave of the grid.
-__global__ void __launch_bounds__(256) k_mesh_raster_big(RenderArgs a)
-{
-    const int W = a.W;
-    const uint32_t total = min(*a.bigq_count, a.bigq_cap);
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t k = wave; k < total; k += nwaves) {
-        const uint32_t* rec = a.bigq + (size_t)k * kBigRecDwords;
-        TriSetup b;
-        b.dx0 = (int)rec[0]; b.dy0 = (int)rec[1]; b.dx1 = (int)rec[2]; b.dy1 = (int)rec[3]; b.dx2 = (int)rec[4]; b.dy2 = (int)rec[5];
-        b.bx0 = (int)rec[6]; b.by0 = (int)rec[7]; b.bx1 = (int)rec[8]; b.by1 = (int)rec[9]; b.bx2 = (int)rec[10]; b.by2 = (int)rec[11];
-        b.area2 = (i64)(((u64)rec[13] << 32) | rec[12]);
-        b.iz0 = __uint_as_float(rec[14]); b.iz1 = __uint_as_float(rec[15]); b.iz2 = __uint_as_float(rec[16]);
-        const int bx0 = (int)rec[17], bx1 = (int)rec[18], by0 = (int)rec[19], by1 = (int)rec[20];
-        const uint32_t bid = rec[21], c0 = rec[22], c1 = rec[23], c2 = rec[24];
-        u64* keys = a.keys[rec[25] & 1u] + (size_t)(rec[25] >> 1) * a.ws_stride_px;
-        u64* cbuf = a.cbuf[rec[25] & 1u] + (size_t)(rec[25] >> 1) * a.ws_stride_px;
-        const int bw = bx1 - bx0 + 1;
-        const i64 npix = (i64)bw * (by1 - by0 + 1);
-        int px = bx0 + lane % bw, py = by0 + lane / bw;        // lanes walk the box in row-major order, 64 pixel centres per step
-        const int sx = 64 % bw, sy = 64 / bw;
-        for (i64 idx = lane; idx < npix; idx += 64) {
-            float q0, q1, q2;
-            if (tri_sample(b, px, py, q0, q1, q2))
-                mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, c0, c1, c2, bid);
-            px += sx; py += sy;
-            if (px > bx1) { px -= bw; ++py; }
-        }
-    }
-}
 // =================================================================================================
 // infill_using_normals (sr:155-240): one thread per pixel, lock-step free ray march
 // =================================================================================================
@@ -2503,15 +2274,7 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
         else hipLaunchKernelGGL(k_mesh_vertices_general<false>, grid_v, dim3(256), 0, s, a);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
-    if (a.bigq && (e = hipMemsetAsync(a.bigq_count, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
-    if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_general<2>), grid_c, dim3(128), 0, s, a);
-    else hipLaunchKernelGGL((k_mesh_raster_general<0>), grid_c, dim3(128), 0, s, a);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (a.bigq) {
-        hipLaunchKernelGGL(k_mesh_raster_big, dim3(2048), dim3(256), 0, s, a);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
+    if ((e = launch_mesh_raster_general(plan, a, s)) != hipSuccess) return e;
     if (edge) {
         if (a.W % 4 == 0) {
             const dim3 grid_s((a.W / 4 + 255) / 256, a.H, plan.n);

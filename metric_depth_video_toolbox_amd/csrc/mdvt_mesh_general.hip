@@ -1,0 +1,212 @@
+// mdvt_mesh_general.hip -- MESH MODE, general path (pose / convergence / K != Krender, and pure-shift frames too wide
+// for the LDS row kernels): the rasteriser stage between k_mesh_vertices_general and k_resolve_general.
+//
+//   replaces dmt.render (dmt:1422-1572) for the triangles of dmt:1243-1254 after the transforms of sr:615-619,
+//   724-725, 832-836; z-buffer words and tie rule: see mdvt_device.h.
+//
+// The grid mesh is ~4 million triangles per 1080p eye, of which all but ~0.5 % cover a handful of pixel centres: the
+// rest are the rubber sheet across depth edges.  The kernel that owns a cell therefore only knows ONE kind of
+// triangle: snapped extent below 2^13 sub-pixels (32 px) and at most kSmallBox pixel centres in its box.  For that
+// kind every edge value fits 32 bits and every product is a 24-bit multiply (mdvt_device.h, TriSmall) -- the
+// 32x32 -> 64 multiplies of the generic set-up are quarter rate and were two thirds of this kernel's instructions.
+// Everything else goes to a queue as 8 bytes (draw id, frame slot / eye); k_mesh_raster_queue reads the three vertex
+// records of a queued triangle back and rasterises it generically, 16 lanes per triangle.  The queue is one segment
+// per (frame slot, cell row) with its own counter -- a single counter for the launch serialised ~10^5 returning
+// atomics per frame on one address (150 us per 1080p frame when the rubber sheet is not filtered out) -- and every
+// segment holds all four triangles of every cell of its row, so nothing can overflow.
+#include "mdvt_device.h"
+
+namespace mdvt {
+
+namespace {
+
+constexpr int kSmallBox = 12;      // pixel centres in the bounding box of a triangle the owning lane walks itself
+
+__device__ __forceinline__ void mesh_global_fragment(u64* keys, u64* cbuf, size_t o, float q0, float q1, float q2,
+                                                     uint32_t c0, uint32_t c1, uint32_t c2, uint32_t did)
+{
+    const float iz = (q0 + q1) + q2;
+    atomicMin(&keys[o], ((u64)depth_bits(iz) << 32) | did);
+    cbuf[o] = ((u64)did << 32) | shade_px(q0, q1, q2, rcp_exact(iz), c0, c1, c2);
+}
+
+}  // namespace
+
+// One thread per cell, both triangles, both eyes.
+template <int FLAGS>
+__global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
+{
+    constexpr bool EDGES = FLAGS & 2;
+    const int W = a.W, H = a.H;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    const int fr = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const bool act = j < W - 1;
+    const size_t ncell = (size_t)(W - 1) * (H - 1);
+    // the 2 x 129 vertex records of both eyes, fetched once per workgroup with all loads in flight together
+    __shared__ uint4 sv[2][2][129];
+    uint32_t inv0 = 0, inv1 = 0;
+    {
+        const int t = threadIdx.x;
+        const int j0 = blockIdx.x * blockDim.x;
+        const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
+        const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);      // (clamped: columns past the row end are never used)
+        uint4 rx = make_uint4(0, 0, 0, 0);
+        if (t < 4) rx = (t & 2 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t & 1) * W + jx];
+        const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
+        const uint4 r2 = a.gverts[1][base + jc], r3 = a.gverts[1][base + W + jc];
+        if (EDGES && act) {
+            const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
+            inv0 = tinv[0]; inv1 = tinv[ncell];
+        }
+        if (t < 4) sv[t >> 1][t & 1][128] = rx;
+        sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int eye = 0; eye < 2; ++eye) {
+        u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
+        u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
+        uint4 A = make_uint4(0, 0, 0, 0), B = A, Cv = A, D = A;
+        if (act) {
+            const int t = threadIdx.x;
+            A = sv[eye][0][t]; D = sv[eye][0][t + 1]; B = sv[eye][1][t]; Cv = sv[eye][1][t + 1];
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            // tri1 = (v[i,j], v[i+1,j], v[i+1,j+1]); tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])   (dmt:1243-1254)
+            const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
+            const uint32_t did = draw_id_global(pass, i, j);
+            bool toq = false;
+            if (act && !(pass == 0 ? inv0 : inv1)) {
+                const int X0 = (int)A.x, Y0 = (int)A.y, X1 = (int)v1.x, Y1 = (int)v1.y, X2 = (int)v2.x, Y2 = (int)v2.y;
+                const float iz0 = __uint_as_float(A.z), iz1 = __uint_as_float(v1.z), iz2 = __uint_as_float(v2.z);
+                if (iz0 > 0.0f && iz1 > 0.0f && iz2 > 0.0f) {          // else: near plane, whole triangle dropped
+                    const int mnX = min3i(X0, X1, X2), mxX = max3i(X0, X1, X2), mnY = min3i(Y0, Y1, Y2), mxY = max3i(Y0, Y1, Y2);
+                    int bx0 = floordiv_subpix(mnX - kSubpix / 2 + kSubpix - 1), bx1 = floordiv_subpix(mxX - kSubpix / 2);
+                    int by0 = floordiv_subpix(mnY - kSubpix / 2 + kSubpix - 1), by1 = floordiv_subpix(mxY - kSubpix / 2);
+                    bx0 = max(bx0, 0); by0 = max(by0, 0); bx1 = min(bx1, W - 1); by1 = min(by1, H - 1);
+                    if (bx1 >= bx0 && by1 >= by0) {                      // else: no pixel centre in the box
+                        if (max(mxX - mnX, mxY - mnY) >= kSmallTriExtent || (i64)(bx1 - bx0 + 1) * (by1 - by0 + 1) > kSmallBox) {
+                            toq = true;
+                        } else {
+                            TriSmall ts;
+                            if (tri_small_setup(ts, X0, Y0, iz0, X1, Y1, iz1, X2, Y2, iz2, a.cull) && !(a.debug_skip & 16)) {
+                                TriWalk32 row = tri_small_start(ts, bx0, by0);
+                                for (int py = by0; py <= by1; ++py) {
+                                    TriWalk32 w = row;
+                                    for (int px = bx0; px <= bx1; ++px) {
+                                        if (tri_small_inside(ts, w)) {
+                                            float q0, q1, q2;
+                                            tri_small_weights(ts, w, q0, q1, q2);
+                                            mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
+                                        }
+                                        tri_small_right(ts, w);
+                                    }
+                                    tri_small_down(ts, row);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            const u64 mq = __ballot(toq);
+            if (mq) {
+                const size_t seg = (size_t)fr * H + i;                    // this row's segment: 4 (W - 1) entries at most
+                uint32_t base = 0;
+                const int first = __ffsll((long long)mq) - 1;
+                if (lane == first) base = atomicAdd(&a.bigq_count[seg], (uint32_t)__popcll(mq));
+                base = __shfl(base, first);
+                if (toq) {
+                    uint2* q = (uint2*)a.bigq + seg * (size_t)(4 * W);
+                    q[base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = make_uint2(did, (uint32_t)fr * 2u + (uint32_t)eye);
+                }
+            }
+        }
+    }
+}
+
+// Exclusive prefix sums of the segment counters (n <= a few 10^4): one workgroup.  prefix[n] = number of queued triangles.
+__global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ prefix, int n)
+{
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024, lo = min(t * per, n), hi = min(lo + per, n);
+    uint32_t sum = 0;
+    for (int k = lo; k < hi; ++k) sum += counts[k];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int k = lo; k < hi; ++k) { prefix[k] = run; run += counts[k]; }
+    if (t == 1023) prefix[n] = part[1023];
+}
+
+// The queued triangles, dealt over the whole chip (a horizontal depth edge under vertical parallax turns an entire row
+// of cells into large triangles: one workgroup per segment would leave that segment's workgroup running alone): 16 lanes
+// per triangle, generic 64-bit set-up, rows walked by their own column range.
+__global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nseg)
+{
+    const int W = a.W, H = a.H;
+    const uint32_t* prefix = a.bigq_count + nseg;
+    const uint32_t total = prefix[nseg];
+    const int sub = threadIdx.x & 15;
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = (gridDim.x * blockDim.x) >> 4;
+    for (uint32_t g = group; g < total; g += ngroups) {
+        int lo_s = 0, hi_s = nseg - 1;                              // the segment holding global entry g: last s with prefix[s] <= g
+        while (lo_s < hi_s) {
+            const int mid = (lo_s + hi_s + 1) >> 1;
+            if (prefix[mid] <= g) lo_s = mid; else hi_s = mid - 1;
+        }
+        const uint2* q = (const uint2*)a.bigq + (size_t)lo_s * (size_t)(4 * W);
+        const uint32_t k = g - prefix[lo_s];
+
+        const uint2 e = q[k];
+        const uint32_t id = e.x;
+        const int eye = (int)(e.y & 1u), slot = (int)(e.y >> 1);
+        const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
+        const uint4* r0 = a.gverts[eye] + (size_t)slot * a.ws_stride_px + (size_t)ci * W + cj;
+        const uint4 A = r0[0];
+        const uint4 v1 = pass == 0 ? r0[W] : r0[W + 1], v2 = pass == 0 ? r0[W + 1] : r0[1];
+        TriSetup t;
+        if (!tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
+                               (int)v2.x, (int)v2.y, __uint_as_float(v2.z), a.cull))
+            continue;
+        int px0 = floordiv_subpix(t.minX - kSubpix / 2 + kSubpix - 1), px1 = floordiv_subpix(t.maxX - kSubpix / 2);
+        int py0 = floordiv_subpix(t.minY - kSubpix / 2 + kSubpix - 1), py1 = floordiv_subpix(t.maxY - kSubpix / 2);
+        px0 = max(px0, 0); py0 = max(py0, 0); px1 = min(px1, W - 1); py1 = min(py1, H - 1);
+        u64* keys = a.keys[eye] + (size_t)slot * a.ws_stride_px;
+        u64* cbuf = a.cbuf[eye] + (size_t)slot * a.ws_stride_px;
+        for (int py = py0; py <= py1; ++py) {
+            int lo, hi;
+            if (!tri_row_range(t, py, px0, px1, lo, hi)) continue;
+            for (int px = lo + sub; px <= hi; px += 16) {
+                float q0, q1, q2;
+                if (tri_sample(t, px, py, q0, q1, q2))
+                    mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
+            }
+        }
+    }
+}
+
+hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(a.bigq_count, 0, (size_t)plan.n * a.H * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
+    if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2>), grid_c, dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((k_mesh_raster_small<0>), grid_c, dim3(128), 0, s, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const int nseg = plan.n * a.H;
+    hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg);
+    hipLaunchKernelGGL(k_mesh_raster_queue, dim3(2048), dim3(256), 0, s, a, nseg);
+    return hipGetLastError();
+}
+
+}  // namespace mdvt
