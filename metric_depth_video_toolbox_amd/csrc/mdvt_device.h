@@ -298,25 +298,31 @@ __device__ __forceinline__ bool tri_small_setup(TriSmall& t, int X0, int Y0, flo
     return true;
 }
 
+// The walk carries BIASED edge values: w_k + 1 where the top-left rule admits w_k == 0 (edge_in), w_k otherwise, so
+// "inside" is min(w0, w1, w2) > 0 -- two instructions per pixel centre instead of a dozen compares.
 struct TriWalk32 { int w0, w1, w2; };
+__device__ __forceinline__ int edge_bias(int dx, int dy) { return ((dy < 0) || (dy == 0 && dx > 0)) ? 1 : 0; }
 __device__ __forceinline__ TriWalk32 tri_small_start(const TriSmall& t, int px, int py)
 {
     const int Xc = px * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
-    return TriWalk32{__mul24(t.dx0, Yc - t.by0) - __mul24(t.dy0, Xc - t.bx0), __mul24(t.dx1, Yc - t.by1) - __mul24(t.dy1, Xc - t.bx1),
-                     __mul24(t.dx2, Yc - t.by2) - __mul24(t.dy2, Xc - t.bx2)};
+    return TriWalk32{__mul24(t.dx0, Yc - t.by0) - __mul24(t.dy0, Xc - t.bx0) + edge_bias(t.dx0, t.dy0),
+                     __mul24(t.dx1, Yc - t.by1) - __mul24(t.dy1, Xc - t.bx1) + edge_bias(t.dx1, t.dy1),
+                     __mul24(t.dx2, Yc - t.by2) - __mul24(t.dy2, Xc - t.bx2) + edge_bias(t.dx2, t.dy2)};
 }
 __device__ __forceinline__ void tri_small_right(const TriSmall& t, TriWalk32& w) { w.w0 -= t.dy0 * kSubpix; w.w1 -= t.dy1 * kSubpix; w.w2 -= t.dy2 * kSubpix; }
 __device__ __forceinline__ void tri_small_down(const TriSmall& t, TriWalk32& w) { w.w0 += t.dx0 * kSubpix; w.w1 += t.dx1 * kSubpix; w.w2 += t.dx2 * kSubpix; }
-__device__ __forceinline__ bool edge_in32(int w, int dx, int dy) { return w > 0 || (w == 0 && ((dy < 0) || (dy == 0 && dx > 0))); }
-__device__ __forceinline__ bool tri_small_inside(const TriSmall& t, const TriWalk32& w)
-{
-    return edge_in32(w.w0, t.dx0, t.dy0) && edge_in32(w.w1, t.dx1, t.dy1) && edge_in32(w.w2, t.dx2, t.dy2);
-}
+__device__ __forceinline__ bool tri_small_inside(const TriSmall& t, const TriWalk32& w) { return min3i(w.w0, w.w1, w.w2) > 0; }
 // q_k = (f32(w_k) * (1 / f32(area2))) * (1/Z_k): what tri_weights computes for a small triangle
+// (half the small triangles cover no pixel centre at all, so 1/area2 is worked out here, per fragment -- the empty asm
+//  keeps the compiler from hoisting it, with both branches of rcp_exact, into every triangle's set-up)
 __device__ __forceinline__ void tri_small_weights(const TriSmall& t, const TriWalk32& w, float& q0, float& q1, float& q2)
 {
-    const float ra = rcp_exact((float)t.area2);
-    q0 = ((float)w.w0 * ra) * t.iz0; q1 = ((float)w.w1 * ra) * t.iz1; q2 = ((float)w.w2 * ra) * t.iz2;
+    float fa = (float)t.area2;
+    asm volatile("" : "+v"(fa));
+    const float ra = rcp_exact(fa);
+    q0 = ((float)(w.w0 - edge_bias(t.dx0, t.dy0)) * ra) * t.iz0;
+    q1 = ((float)(w.w1 - edge_bias(t.dx1, t.dy1)) * ra) * t.iz1;
+    q2 = ((float)(w.w2 - edge_bias(t.dx2, t.dy2)) * ra) * t.iz2;
 }
 
 // i64 -> f32, round to nearest even.  When the value fits int32 the single-instruction conversion

@@ -25,6 +25,7 @@ constexpr int kSmallBox = 12;      // pixel centres in the bounding box of a tri
 __device__ __forceinline__ void mesh_global_fragment(u64* keys, u64* cbuf, size_t o, float q0, float q1, float q2,
                                                      uint32_t c0, uint32_t c1, uint32_t c2, uint32_t did)
 {
+    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));     // (the colour conversions belong to the fragment, not to every triangle's set-up)
     const float iz = (q0 + q1) + q2;
     atomicMin(&keys[o], ((u64)depth_bits(iz) << 32) | did);
     cbuf[o] = ((u64)did << 32) | shade_px(q0, q1, q2, rcp_exact(iz), c0, c1, c2);
@@ -88,7 +89,8 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
                     int by0 = floordiv_subpix(mnY - kSubpix / 2 + kSubpix - 1), by1 = floordiv_subpix(mxY - kSubpix / 2);
                     bx0 = max(bx0, 0); by0 = max(by0, 0); bx1 = min(bx1, W - 1); by1 = min(by1, H - 1);
                     if (bx1 >= bx0 && by1 >= by0) {                      // else: no pixel centre in the box
-                        if (max(mxX - mnX, mxY - mnY) >= kSmallTriExtent || (i64)(bx1 - bx0 + 1) * (by1 - by0 + 1) > kSmallBox) {
+                        // (a small extent bounds the box at 33 x 33: the count fits any integer)
+                        if (max(mxX - mnX, mxY - mnY) >= kSmallTriExtent || (bx1 - bx0 + 1) * (by1 - by0 + 1) > kSmallBox) {
                             toq = true;
                         } else {
                             TriSmall ts;
