@@ -63,6 +63,7 @@ struct mdvt_ctx {
     // infill-mask completion: per image stamp u16 + T f32 + work image u8x3, and the per-image counters
     int telea_images = 0, telea_rounds = 0;
     mdvt::TeleaWorkspace telea{};
+    uint32_t* telea_levels_host = nullptr;      // pinned: the deepest level of a pass, read back once per pass
 };
 
 namespace {
@@ -314,7 +315,7 @@ int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flag
 static void free_telea(mdvt_ctx* c)
 {
     mdvt::TeleaWorkspace& w = c->telea;
-    void* ptrs[] = {w.stamp, w.T, w.img, w.queued, w.need, w.list, w.nlist, w.counts, w.remaining, w.last_round};   // offs / ncounts live inside counts
+    void* ptrs[] = {w.stamp, w.T, w.img, w.need, w.list, w.nlist, w.counts, w.remaining, w.last_round};   // offs / ncounts / cursor live inside counts
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = mdvt::TeleaWorkspace{};
     c->telea_images = 0; c->telea_rounds = 0;
@@ -336,6 +337,7 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->unused) (void)hipFree(c->unused);
     if (c->row_counts) (void)hipFree(c->row_counts);
     if (c->rowcell) (void)hipFree(c->rowcell);
+    if (c->telea_levels_host) (void)hipHostFree(c->telea_levels_host);
     free_telea(c);
     delete c;
     return MDVT_OK;
@@ -743,17 +745,18 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
         MDVT_HIP(c, hipMalloc((void**)&w.stamp, (size_t)images * npx * sizeof(uint16_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.T, (size_t)images * npx * sizeof(float)));
         MDVT_HIP(c, hipMalloc((void**)&w.img, (size_t)images * npx * 3 + 4));      // + 4: pixels are fetched as unaligned dwords
-        MDVT_HIP(c, hipMalloc((void**)&w.queued, (size_t)images * npx * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.need, (size_t)images * npx));
         MDVT_HIP(c, hipMalloc((void**)&w.list, (size_t)images * npx * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.nlist, (size_t)images * npx * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.counts, 3 * ((size_t)rounds + 2) * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.counts, 4 * ((size_t)rounds + 2) * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.remaining, (size_t)kTeleaChunk * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.last_round, (size_t)kTeleaChunk * sizeof(uint32_t)));
         c->telea_images = images; c->telea_rounds = rounds;
     }
     c->telea.offs = c->telea.counts + (max_rounds + 2);
     c->telea.ncounts = c->telea.offs + (max_rounds + 2);
+    c->telea.cursor = c->telea.ncounts + (max_rounds + 2);
+    if (!c->telea_levels_host) MDVT_HIP(c, hipHostMalloc((void**)&c->telea_levels_host, sizeof(uint32_t), hipHostMallocDefault));
     const uint32_t key = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     const mdvt::BlurKernel K = masked_blur_kernel();
     const int eyes = d_seed_right ? 2 : 1;
@@ -764,8 +767,8 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
                                   d_seed_right ? d_seed_right - d_seed : 0, nf};
         const mdvt::ImageSet out{d_out + (size_t)f0 * out_stride, out_pitch, out_stride, d_out_right ? d_out_right - d_out : 0, nf};
         const mdvt::ImageSet work{c->telea.img, (size_t)3 * W, 3 * npx, 0, n};
-        MDVT_HIP(c, launch_telea_init(seed, c->telea, n, W, H, max_rounds, key, s));
-        MDVT_HIP(c, launch_telea_rounds(c->telea, W, H, max_rounds, key, s));                               // sr:806, inpaintRadius = 3
+        MDVT_HIP(c, launch_telea_init(seed, c->telea, n, W, H, max_rounds, key, c->telea_levels_host, s));
+        MDVT_HIP(c, launch_telea_rounds(c->telea, W, H, (int)*c->telea_levels_host, key, s));               // sr:806, inpaintRadius = 3
         MDVT_HIP(c, launch_masked_blur(work, &seed, out, n, W, H, K, key, s));                              // sr:807-808
         if (d_remaining) {      // image order of the result: left eyes of all frames, then right eyes
             for (int e = 0; e < eyes; ++e)

@@ -108,18 +108,19 @@ struct ImageSet {
     __host__ __device__ uint8_t* image(int im) const { return base + (size_t)(im % per_eye) * stride + (ptrdiff_t)(im / per_eye) * eye_offset; }
 };
 
-struct TeleaWorkspace {              // per image pixel: stamp u16, T f32, work image u8x3, queued u32, need u8, list u32, nlist u32
-    uint16_t* stamp; float* T; uint8_t* img; uint32_t* queued; uint8_t* need; uint32_t* list; uint32_t* nlist;
+struct TeleaWorkspace {              // per image pixel: stamp u16, T f32, work image u8x3, need u8, list u32, nlist u32
+    uint16_t* stamp; float* T; uint8_t* img; uint8_t* need; uint32_t* list; uint32_t* nlist;
     uint32_t* counts;                // [max_rounds + 2], followed by
-    uint32_t* offs;                  // [max_rounds + 2] and
-    uint32_t* ncounts;               // [max_rounds + 2] (one allocation: offs = counts + max_rounds + 2, ncounts = offs + max_rounds + 2)
+    uint32_t* offs;                  // [max_rounds + 2],
+    uint32_t* ncounts;               // [max_rounds + 2] and
+    uint32_t* cursor;                // [max_rounds + 2] (one allocation of 4 x (max_rounds + 2) words)
     uint32_t* remaining;             // [images]
     uint32_t* last_round;            // [images]
 };
 constexpr int kTeleaMaxImages = 32;  // images per pass
 hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int n, int W, int H, int max_rounds, uint32_t key_rgb,
-                             hipStream_t s);
-hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int max_rounds, uint32_t key_rgb, hipStream_t s);
+                             uint32_t* h_levels, hipStream_t s);
+hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int levels, uint32_t key_rgb, hipStream_t s);
 hipError_t launch_swap_rb(const ImageSet& src, const ImageSet& dst, int n, int W, int H, hipStream_t s);
 struct BlurKernel { float k[36]; };      // masked_blur's 6x6 Gaussian, f32, row major (built on the host in f64)
 hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const ImageSet& out, int n, int W, int H,

@@ -1593,21 +1593,26 @@ hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t sr
 // same round (stamp = r) are never observed: one launch = one Jacobi step, no double buffering.
 constexpr uint16_t kTeleaUnknown = 0xFFFFu;
 
-// Three passes over the same levels, so that the expensive estimate only runs where the result can reach a hole:
-//   A  k_telea_levels  r = 1 .. R   breadth-first levels: stamp = r for every unknown pixel with a 4-neighbour known
-//                                   before round r; the pixels of level r are list[off[r] .. off[r]+counts[r]) of one
-//                                   append-only list (a pixel filled in round r appends its unknown neighbours for
-//                                   r+1, once: `queued`).  Per image the levels stop after the round in which its last
-//                                   key-coloured pixel was reached (last_round, written by the thread whose atomicSub
-//                                   takes `remaining` to zero, so every thread of that round still runs: deterministic).
+// The level of a pixel -- the round in which the level-synchronous front reaches it -- is its 4-connected distance to the
+// nearest known pixel: an L1 distance transform, two separable passes (A) instead of one dependent launch per level.
+// Then, level by level, so that the expensive estimate only runs where the result can reach a hole:
+//   A  k_telea_dt_rows / k_telea_dt_cols   stamp = L1 distance to the nearest known pixel (0 = known), capped at max_rounds;
+//                                   per image last_round = the level of its deepest key-coloured pixel (later levels
+//                                   are never needed) and remaining = key-coloured pixels beyond max_rounds;
+//      k_telea_count / _scan / _scatter    the pixels of level r become list[off[r] .. off[r] + counts[r]) (counting sort).
 //   B  k_telea_need    r = R .. 1   which estimates are needed: key-coloured pixels, and every pixel of a lower
-//                                   level that a needed pixel reads (its radius-3 disc and their 4-neighbours).
-//   C  k_telea_fill    r = 1 .. R   Telea's estimate for the needed pixels of level r, reading levels < r.
+//                                   level that a needed pixel reads (its radius-3 disc and their 4-neighbours) -- which
+//                                   also closes the set under "T of a pixel needs T of its lower 4-neighbours".
+//   C  k_telea_fill    r = 1 .. R   T (FastMarching_solve over the four quadrants) and Telea's estimate for the needed
+//                                   pixels of level r, reading levels < r.
 // A black (non-hole) pixel that no key-coloured pixel depends on is never estimated -- it returns to black at
-// sr:807 anyway -- which removes ~90 % of the estimates of a front that also grows outwards from the holes.
+// sr:807 anyway -- which removes ~90 % of the estimates (and T solves) of a front that also grows outwards from the
+// holes.  R (the deepest level any image needs) is read back by the host after pass A: passes B and C are launched
+// for exactly the levels that exist (round 1 launched all max_rounds levels of all three passes, 768 launches of which
+// ~620 found nothing to do).
 struct TeleaArgs {
     uint16_t* stamp; float* T; uint8_t* img;      // [n][H*W] / [n][H*W*3]
-    uint32_t* queued;                             // [n][H*W] nonzero once a pixel has been appended to a level
+    uint32_t* cursor;                             // [max_rounds + 2] next free slot of each level (counting sort)
     uint8_t* need;                                // [n][H*W]
     uint32_t* list;                               // all levels back to back, capacity n*H*W
     uint32_t* nlist;                              // the needed pixels of each level, compacted (same offsets as `list`)
@@ -1620,91 +1625,211 @@ struct TeleaArgs {
     uint32_t key_rgb;
 };
 
-// Appends `idx` to `list` for every lane with `want`, one atomicAdd per wave.
-__device__ __forceinline__ void telea_append(bool want, uint32_t idx, uint32_t* list, uint32_t* count)
-{
-    const u64 m = __ballot(want);
-    if (!m) return;
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (uint32_t)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
-}
+constexpr int kDtInf = 1 << 20;          // "no known pixel in this direction" (any real distance is < 2^17)
 
-// T and `queued` are zeroed with memsets beforehand; this pass writes the level stamps, the need flags, the work image
-// and level 1 (one list append per block, not per wave: same-address atomics serialise).
+// T is zeroed with a memset beforehand; this pass writes 0 (known) / 0xFFFF (to fill) stamps, the need flags (key-coloured
+// pixels) and the work image.
 __global__ void __launch_bounds__(256) k_telea_init(ImageSet seed, TeleaArgs a)
 {
-    const size_t seed_pitch = seed.pitch;
-    const uint32_t key_rgb = a.key_rgb;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
     const int W = a.W, H = a.H;
-    const bool in = x < W;
-    bool green = false, front = false;
-    const size_t o = (size_t)im * W * H + (size_t)y * W + (in ? x : 0);
-    if (in) {
-        const uint8_t* sim = seed.image(im);
-        auto masked = [&](int xx, int yy) {                   // sr:803-805: key-coloured or black = to inpaint
-            const uint32_t p = load_px_bytes(sim + (size_t)yy * seed_pitch, xx);
-            return p == key_rgb || p == 0u;
-        };
-        const uint32_t px = load_px_bytes(sim + (size_t)y * seed_pitch, x);
-        green = px == key_rgb;
-        const bool unk = green || px == 0u;
-        a.stamp[o] = unk ? kTeleaUnknown : (uint16_t)0;
-        a.need[o] = green ? 1 : 0;
-        store_px_bytes(a.img + 3 * ((size_t)im * W * H + (size_t)y * W), x, px);
-        front = unk && ((x > 0 && !masked(x - 1, y)) || (x + 1 < W && !masked(x + 1, y)) ||
-                        (y > 0 && !masked(x, y - 1)) || (y + 1 < H && !masked(x, y + 1)));
-        if (front) a.queued[o] = 1u;
+    if (x >= W) return;
+    const size_t o = (size_t)im * W * H + (size_t)y * W + x;
+    const uint32_t px = load_px_bytes(seed.image(im) + (size_t)y * seed.pitch, x);
+    const bool green = px == a.key_rgb;
+    a.stamp[o] = (green || px == 0u) ? kTeleaUnknown : (uint16_t)0;        // sr:803-805: key-coloured or black = to inpaint
+    a.need[o] = green ? 1 : 0;
+    store_px_bytes(a.img + 3 * ((size_t)im * W * H + (size_t)y * W), x, px);
+}
+
+// Pass A, rows: stamp[x] = distance to the nearest known pixel of the same row (0xFFFF: none), in place.  One workgroup per
+// (row, image); a thread owns a contiguous segment, the nearest known pixels outside it come from a block-wide scan.
+__global__ void __launch_bounds__(256) k_telea_dt_rows(uint16_t* __restrict__ stamp, int W, int H)
+{
+    __shared__ int sl[256], sf[256];
+    uint16_t* d = stamp + ((size_t)blockIdx.y * H + blockIdx.x) * W;
+    const int t = threadIdx.x;
+    const int seg = (W + 255) / 256, x0 = min(t * seg, W), x1 = min(x0 + seg, W);
+    int last = -kDtInf, first = kDtInf;
+    for (int x = x0; x < x1; ++x)
+        if (d[x] == 0) { last = x; if (first == kDtInf) first = x; }
+    sl[t] = last; sf[t] = first;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {            // inclusive prefix max of `last`, inclusive suffix min of `first`
+        const int vl = t >= off ? sl[t - off] : -kDtInf, vf = t + off < 256 ? sf[t + off] : kDtInf;
+        __syncthreads();
+        sl[t] = max(sl[t], vl); sf[t] = min(sf[t], vf);
+        __syncthreads();
     }
-    __shared__ uint32_t wave_front[4], wave_green[4], block_base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 mf = __ballot(front), mg = __ballot(green);
-    if (lane == 0) { wave_front[wave] = (uint32_t)__popcll(mf); wave_green[wave] = (uint32_t)__popcll(mg); }
+    int run = t > 0 ? sl[t - 1] : -kDtInf;                // nearest known pixel left of the segment
+    for (int x = x0; x < x1; ++x) {
+        if (d[x] == 0) run = x;
+        const int v = x - run;
+        d[x] = (uint16_t)(v < 0xFFFF ? v : 0xFFFF);
+    }
+    run = t < 255 ? sf[t + 1] : kDtInf;                   // ... and right of it
+    for (int x = x1 - 1; x >= x0; --x) {
+        if (d[x] == 0) run = x;
+        const int v = run - x;
+        if (v < (int)d[x]) d[x] = (uint16_t)v;
+    }
+}
+
+// Pass A, columns: the two sweeps of the L1 transform (down: D[y] = min(D[y-1] + 1, d[y]); up the same from below), in
+// place.  One workgroup = 64 columns x 16 row segments; the value entering a segment comes from a scan over the segments'
+// exit values.  The last sweep also caps the level at max_rounds and collects, per image, the deepest key-coloured level
+// (last_round) and the number of key-coloured pixels beyond the cap (remaining).
+__global__ void __launch_bounds__(1024) k_telea_dt_cols(TeleaArgs a, uint32_t max_rounds)
+{
+    __shared__ int ex[16][64], carry[16][64];
+    __shared__ uint32_t s_rem, s_max;
+    const int W = a.W, H = a.H;
+    const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + cx, im = blockIdx.y;
+    const bool act = x < W;
+    const int seglen = (H + 15) / 16, y0 = min(sg * seglen, H), y1 = min(y0 + seglen, H);
+    const size_t base = (size_t)im * W * H + (act ? x : 0);
+    uint16_t* d = a.stamp + base;
+    if (threadIdx.x == 0) { s_rem = 0u; s_max = 0u; }
+    auto val = [&](int y) { const int v = d[(size_t)y * W]; return v == 0xFFFF ? kDtInf : v; };
+    auto put = [&](int y, int v) { d[(size_t)y * W] = (uint16_t)(v < 0xFFFF ? v : 0xFFFF); };
+    // ---- down ----
+    int run = kDtInf;
+    if (act) for (int y = y0; y < y1; ++y) run = min(run + 1, val(y));
+    ex[sg][cx] = run;
+    __syncthreads();
+    if (sg == 0) {
+        int c = kDtInf;
+        for (int q = 0; q < 16; ++q) {
+            carry[q][cx] = c;
+            const int len = min((q + 1) * seglen, H) - min(q * seglen, H);
+            c = min(ex[q][cx], c + len);
+        }
+    }
+    __syncthreads();
+    run = carry[sg][cx];
+    if (act) for (int y = y0; y < y1; ++y) { run = min(run + 1, val(y)); put(y, run); }
+    __syncthreads();            // (a column's segments are all in this workgroup: its writes above are visible below)
+    // ---- up ----
+    run = kDtInf;
+    if (act) for (int y = y1 - 1; y >= y0; --y) run = min(run + 1, val(y));
+    ex[sg][cx] = run;
+    __syncthreads();
+    if (sg == 0) {
+        int c = kDtInf;
+        for (int q = 15; q >= 0; --q) {
+            carry[q][cx] = c;
+            const int len = min((q + 1) * seglen, H) - min(q * seglen, H);
+            c = min(ex[q][cx], c + len);
+        }
+    }
+    __syncthreads();
+    run = carry[sg][cx];
+    uint32_t rem = 0, lmax = 0;
+    if (act) {
+        const uint8_t* key = a.need + base;
+        for (int y = y1 - 1; y >= y0; --y) {
+            run = min(run + 1, val(y));
+            const bool reached = run <= (int)max_rounds;
+            d[(size_t)y * W] = reached ? (uint16_t)run : kTeleaUnknown;
+            if (key[(size_t)y * W]) { if (reached) lmax = max(lmax, (uint32_t)run); else ++rem; }
+        }
+    }
+    if (rem) atomicAdd(&s_rem, rem);
+    if (lmax) atomicMax(&s_max, lmax);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t nf = wave_front[0] + wave_front[1] + wave_front[2] + wave_front[3];
-        const uint32_t ng = wave_green[0] + wave_green[1] + wave_green[2] + wave_green[3];
-        block_base = nf ? atomicAdd(&a.counts[1], nf) : 0u;                 // level 1 starts at offset 0
-        if (ng) atomicAdd(&a.remaining[im], ng);
+        if (s_rem) atomicAdd(&a.remaining[im], s_rem);
+        if (s_max) atomicMax(&a.last_round[im], s_max);
+    }
+}
+
+// counts[0] = the deepest level any image needs (the host reads it back: passes B and C get exactly that many launches)
+__global__ void k_telea_rmax(TeleaArgs a)
+{
+    uint32_t m = 0;
+    for (int im = 0; im < a.n; ++im) m = max(m, a.last_round[im]);
+    a.counts[0] = m;
+}
+
+// Counting sort of the pixels by level.  A workgroup takes 4096 consecutive pixels of one image; levels below
+// kLevelBins are counted in LDS first (one global atomic per occupied level and workgroup), deeper ones directly.
+constexpr int kLevelBins = 4096;
+constexpr int kSortPixels = 4096;
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
+{
+    __shared__ uint32_t hist[kLevelBins];
+    __shared__ uint32_t slot[SCATTER ? kLevelBins : 1];
+    const int im = blockIdx.y;
+    const uint32_t lr = a.last_round[im];
+    if (lr == 0u) return;                                   // nothing key-coloured (or nothing reachable): nothing to do
+    const uint32_t npx = (uint32_t)a.W * (uint32_t)a.H;
+    const uint32_t p0 = blockIdx.x * kSortPixels;
+    const uint16_t* st = a.stamp + (size_t)im * npx;
+    for (int b = threadIdx.x; b < kLevelBins; b += 256) hist[b] = 0u;
+    __syncthreads();
+    uint32_t lv[kSortPixels / 256];
+#pragma unroll
+    for (int k = 0; k < kSortPixels / 256; ++k) {
+        const uint32_t o = p0 + k * 256 + threadIdx.x;
+        const uint32_t sv = o < npx ? (uint32_t)st[o] : 0u;
+        lv[k] = (sv >= 1u && sv <= lr) ? sv : 0u;
+        if (lv[k] && lv[k] < (uint32_t)kLevelBins) atomicAdd(&hist[lv[k]], 1u);
+        else if (lv[k] && !SCATTER) atomicAdd(&a.counts[lv[k]], 1u);
     }
     __syncthreads();
-    if (front) {
-        uint32_t pos = block_base + (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) pos += wave_front[w];
-        a.list[pos] = (uint32_t)o;
+    for (int b = threadIdx.x; b < kLevelBins; b += 256) {
+        const uint32_t c = hist[b];
+        if (!c) continue;
+        if (SCATTER) { slot[b] = atomicAdd(&a.cursor[b], c); hist[b] = 0u; }
+        else atomicAdd(&a.counts[b], c);
+    }
+    if (!SCATTER) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortPixels / 256; ++k) {
+        if (!lv[k]) continue;
+        const uint32_t e = (uint32_t)im * npx + p0 + k * 256 + threadIdx.x;
+        const uint32_t pos = lv[k] < (uint32_t)kLevelBins ? slot[lv[k]] + atomicAdd(&hist[lv[k]], 1u) : atomicAdd(&a.cursor[lv[k]], 1u);
+        a.list[pos] = e;
     }
 }
 
-__global__ void k_telea_begin(TeleaArgs a)
+// offs[r] = counts[1] + ... + counts[r-1] for r = 1 .. n_levels + 1 (level 1 starts at 0); cursor = offs.  One workgroup.
+__global__ void __launch_bounds__(1024) k_telea_scan(TeleaArgs a, int n_levels)
 {
-    const int im = blockIdx.x * blockDim.x + threadIdx.x;
-    if (im < a.n) a.last_round[im] = a.remaining[im] ? 0xFFFFFFFFu : 0u;     // nothing key-coloured: nothing to do
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x, n = n_levels + 1;             // entries 1 .. n
+    const int per = (n + 1023) / 1024, lo = min(1 + t * per, n + 1), hi = min(lo + per, n + 1);
+    uint32_t sum = 0;
+    for (int k = lo; k < hi; ++k) sum += a.counts[k];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int k = lo; k < hi; ++k) { a.offs[k] = run; a.cursor[k] = run; run += a.counts[k]; }
 }
 
-struct TeleaView {
-    const uint16_t* stamp; const float* T; const uint8_t* img; int W, H; uint32_t r;
-    __device__ __forceinline__ bool known(int x, int y) const
-    {
-        return x >= 0 && x < W && y >= 0 && y < H && (uint32_t)stamp[(size_t)y * W + x] < r;
-    }
-    __device__ __forceinline__ float t(int x, int y) const { return T[(size_t)y * W + x]; }
-    __device__ float solve(int x1, int y1, int x2, int y2) const
-    {
-        const bool k1 = known(x1, y1), k2 = known(x2, y2);
-        const double a11 = k1 ? (double)t(x1, y1) : 1.0e6, a22 = k2 ? (double)t(x2, y2) : 1.0e6;
-        const double m12 = a11 < a22 ? a11 : a22;
-        double sol;
-        if (k1) {
-            if (k2) sol = fabs(a11 - a22) >= 1.0 ? 1.0 + m12 : (a11 + a22 + sqrt(2.0 - (a11 - a22) * (a11 - a22))) * 0.5;
-            else sol = 1.0 + a11;
-        } else if (k2) sol = 1.0 + a22;
-        else sol = 1.0 + m12;
-        return (float)sol;
-    }
-};
+// OpenCV's FastMarching_solve for one quadrant: k = the neighbour is known (in the image, filled before this level), t = its T.
+__device__ __forceinline__ float telea_solve(bool k1, float t1, bool k2, float t2)
+{
+    const double a11 = k1 ? (double)t1 : 1.0e6, a22 = k2 ? (double)t2 : 1.0e6;
+    const double m12 = a11 < a22 ? a11 : a22;
+    double sol;
+    if (k1) {
+        if (k2) sol = fabs(a11 - a22) >= 1.0 ? 1.0 + m12 : (a11 + a22 + sqrt(2.0 - (a11 - a22) * (a11 - a22))) * 0.5;
+        else sol = 1.0 + a11;
+    } else if (k2) sol = 1.0 + a22;
+    else sol = 1.0 + m12;
+    return (float)sol;
+}
 
 // Decodes list entry idx of level r.
 struct TeleaEntry { uint32_t e, im, o; int x, y; };
@@ -1715,85 +1840,6 @@ __device__ __forceinline__ TeleaEntry telea_entry(const TeleaArgs& a, uint32_t o
     t.e = a.list[off + idx]; t.im = t.e / npx; t.o = t.e - t.im * npx;
     t.y = (int)(t.o / (uint32_t)a.W); t.x = (int)(t.o - (uint32_t)t.y * (uint32_t)a.W);
     return t;
-}
-
-__global__ void __launch_bounds__(256) k_telea_levels(TeleaArgs a, uint32_t r)
-{
-    const uint32_t count = a.counts[r], off = a.offs[r], off_next = off + count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.offs[r + 1] = off_next;
-    const int W = a.W, H = a.H;
-    const uint32_t npx = (uint32_t)W * (uint32_t)H;
-    // candidates of one block iteration are compacted in LDS and appended with ONE atomicAdd on the level counter
-    // (thousands of same-address atomics per round serialise in L2: that alone cost 300 us per round)
-    __shared__ uint32_t cand[4 * 256];
-    __shared__ uint32_t wave_cnt[4], wave_off[4], block_base;
-    __shared__ uint32_t reached[kTeleaMaxImages];          // key-coloured pixels this block reached, per image
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = threadIdx.x; k < kTeleaMaxImages; k += blockDim.x) reached[k] = 0u;
-    __syncthreads();
-    for (uint32_t bbase = blockIdx.x * blockDim.x; bbase < count; bbase += gridDim.x * blockDim.x) {   // block-uniform trip count
-        const uint32_t idx = bbase + threadIdx.x;
-        bool act = idx < count;
-        TeleaEntry t{};
-        if (act) {
-            t = telea_entry(a, off, idx);
-            act = r <= a.last_round[t.im];                                  // the image's holes were all reached earlier
-        }
-        if (act) {
-            // T of the pixel (FastMarching_solve over the four quadrants) depends on levels and earlier T only, not on
-            // colours: computed here, once, by one lane -- the fill pass just reads it
-            const size_t ib = (size_t)t.im * npx;
-            const TeleaView s{a.stamp + ib, a.T + ib, a.img + 3 * ib, W, H, r};
-            float tv = s.solve(t.x, t.y - 1, t.x - 1, t.y);
-            tv = fminf(tv, s.solve(t.x, t.y + 1, t.x - 1, t.y));
-            tv = fminf(tv, s.solve(t.x, t.y - 1, t.x + 1, t.y));
-            tv = fminf(tv, s.solve(t.x, t.y + 1, t.x + 1, t.y));
-            a.T[t.e] = tv;
-            a.stamp[t.e] = (uint16_t)r;
-            const bool green = load_px_bytes(a.img + 3 * ib, (int)t.o) == a.key_rgb;
-            if (green) atomicAdd(&reached[t.im], 1u);                       // LDS; one global atomic per (block, image) at the end
-        }
-        const int nx[4] = {t.x - 1, t.x + 1, t.x, t.x}, ny[4] = {t.y, t.y, t.y - 1, t.y + 1};
-        uint32_t q[4];
-        bool want[4];
-        uint32_t mine = 0;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            want[d] = act && nx[d] >= 0 && nx[d] < W && ny[d] >= 0 && ny[d] < H;
-            q[d] = 0;
-            if (want[d]) {
-                q[d] = t.im * npx + (uint32_t)ny[d] * (uint32_t)W + (uint32_t)nx[d];
-                want[d] = a.stamp[q[d]] == kTeleaUnknown && atomicMax(&a.queued[q[d]], r + 1u) == 0u;     // never appended before
-            }
-            mine += want[d] ? 1u : 0u;
-        }
-        // exclusive prefix of `mine` inside the wave, wave totals through LDS
-        uint32_t pre = mine;
-#pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) { const uint32_t v = __shfl_up(pre, sh); if (lane >= sh) pre += v; }
-        if (lane == 63) wave_cnt[wave] = pre;
-        pre -= mine;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < 4; ++w) { wave_off[w] = tot; tot += wave_cnt[w]; }
-            block_base = tot ? atomicAdd(&a.counts[r + 1], tot) : 0u;
-            wave_cnt[0] = tot;
-        }
-        __syncthreads();
-        uint32_t pos = wave_off[wave] + pre;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) if (want[d]) cand[pos++] = q[d];
-        const uint32_t tot = wave_cnt[0], gbase = block_base;
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < tot; k += blockDim.x) a.list[off_next + gbase + k] = cand[k];
-        __syncthreads();
-    }
-    // the thread whose subtraction takes an image's counter to zero closes the image after this round
-    if ((int)threadIdx.x < a.n) {
-        const uint32_t got = reached[threadIdx.x];
-        if (got && atomicSub(&a.remaining[threadIdx.x], got) == got) a.last_round[threadIdx.x] = r;
-    }
 }
 
 __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
@@ -1848,7 +1894,7 @@ __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
 __device__ __constant__ const int8_t kDiscDx[32] = {0, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2, -3, -2, -1, 1, 2, 3, -2, -1, 0, 1, 2, -2, -1, 0, 1, 2, 0, 0, 0, 0, 0};
 __device__ __constant__ const int8_t kDiscDy[32] = {-3, -2, -2, -2, -2, -2, -1, -1, -1, -1, -1, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 0, 0, 0, 0};
 
-// Pass C, lane-parallel: one half-wave (32 lanes) per needed pixel, lane j < 28 = disc pixel j.  Every lane fetches
+// Pass C, lane-parallel: one half-wave (32 lanes) per needed pixel, lane j < 28 = disc pixel j (T first, see below).  Every lane fetches
 // and weighs its own disc pixel (a dozen loads, ~300 instructions instead of one lane walking all 28: the level's
 // latency is what bounds this pass, not its throughput); the 10 running sums (Ia, Jx, Jy per channel and the
 // weight) are then added up in the oracle's order j = 0..27 by 10 lanes reading the terms from LDS -- the same
@@ -1891,8 +1937,13 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
 #define WK(dx, dy) (wkn[hw][((dy) + 4) * 9 + (dx) + 4] != 0)
 #define WT(dx, dy) (wt[hw][((dy) + 4) * 9 + (dx) + 4])
 #define WC(dx, dy) (wcol[hw][((dy) + 4) * 9 + (dx) + 4])
-            // T of the pixel (from the levels pass) and its gradient
-            const float t = WT(0, 0);
+            // T of the pixel (FastMarching_solve over the four quadrants; every lane of the half-wave computes the same
+            // value, lane 0 keeps it for the levels above) and its gradient
+            float t = telea_solve(WK(0, -1), WT(0, -1), WK(-1, 0), WT(-1, 0));
+            t = fminf(t, telea_solve(WK(0, 1), WT(0, 1), WK(-1, 0), WT(-1, 0)));
+            t = fminf(t, telea_solve(WK(0, -1), WT(0, -1), WK(1, 0), WT(1, 0)));
+            t = fminf(t, telea_solve(WK(0, 1), WT(0, 1), WK(1, 0), WT(1, 0)));
+            if (lane32 == 0) a.T[e] = t;
             float gtx, gty;
             if (WK(1, 0)) gtx = WK(-1, 0) ? (WT(1, 0) - WT(-1, 0)) * 0.5f : WT(1, 0) - t;
             else gtx = WK(-1, 0) ? t - WT(-1, 0) : 0.0f;
@@ -2010,39 +2061,51 @@ __global__ void __launch_bounds__(256) k_masked_blur(ImageSet imgs, ImageSet see
 
 static TeleaArgs telea_args(const TeleaWorkspace& ws, int n, int W, int H, uint32_t key_rgb)
 {
-    return TeleaArgs{ws.stamp, ws.T, ws.img, ws.queued, ws.need, ws.list, ws.nlist, ws.counts, ws.offs, ws.ncounts, ws.remaining, ws.last_round,
+    return TeleaArgs{ws.stamp, ws.T, ws.img, ws.cursor, ws.need, ws.list, ws.nlist, ws.counts, ws.offs, ws.ncounts, ws.remaining, ws.last_round,
                      W, H, n, key_rgb};
 }
 
-// Per-call part: reset the counters, copy the seeds into the work image, build level 1.
+// Per-call part: reset the counters, copy the seeds into the work image, pass A (levels by distance transform, level
+// lists by counting sort).  h_levels (pinned host word) receives the deepest level any image needs -- the call waits for
+// it, once per pass, so that passes B and C can be launched for exactly the levels that exist.
 hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int n, int W, int H, int max_rounds, uint32_t key_rgb,
-                             hipStream_t s)
+                             uint32_t* h_levels, hipStream_t s)
 {
     const TeleaArgs a = telea_args(ws, n, W, H, key_rgb);
     hipError_t e = hipMemsetAsync(ws.remaining, 0, (size_t)kTeleaMaxImages * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws.counts, 0, 3 * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts, offs and ncounts (adjacent)
+    if ((e = hipMemsetAsync(ws.last_round, 0, (size_t)kTeleaMaxImages * sizeof(uint32_t), s)) != hipSuccess) return e;
+    e = hipMemsetAsync(ws.counts, 0, 4 * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts, offs, ncounts and cursor (adjacent)
     if (e != hipSuccess) return e;
     const size_t npx = (size_t)n * W * H;
     if ((e = hipMemsetAsync(ws.T, 0, npx * sizeof(float), s)) != hipSuccess) return e;           // T = 0 at every known pixel
-    if ((e = hipMemsetAsync(ws.queued, 0, npx * sizeof(uint32_t), s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_telea_init, dim3((W + 255) / 256, H, n), dim3(256), 0, s, seed, a);
-    hipLaunchKernelGGL(k_telea_begin, dim3((n + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_telea_dt_rows, dim3(H, n), dim3(256), 0, s, ws.stamp, W, H);
+    hipLaunchKernelGGL(k_telea_dt_cols, dim3((W + 63) / 64, n), dim3(1024), 0, s, a, (uint32_t)max_rounds);
+    hipLaunchKernelGGL(k_telea_rmax, dim3(1), dim3(1), 0, s, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(h_levels, ws.counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    const int R = (int)*h_levels;
+    if (R == 0) return hipSuccess;
+    if ((e = hipMemsetAsync(ws.counts, 0, sizeof(uint32_t), s)) != hipSuccess) return e;         // counts[0] carried R; level 0 is empty
+    const dim3 grid_s((unsigned)(((size_t)W * H + kSortPixels - 1) / kSortPixels), n);
+    hipLaunchKernelGGL((k_telea_sort<false>), grid_s, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_telea_scan, dim3(1), dim3(1024), 0, s, a, R);
+    hipLaunchKernelGGL((k_telea_sort<true>), grid_s, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
-// The 3 x max_rounds level launches (replaying them from a captured HIP graph was measured: no gain, the ~4 us
-// between dependent kernels is the device's, not the host's).
-hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int max_rounds, uint32_t key_rgb, hipStream_t s)
+// Passes B and C: one launch per existing level each (a captured HIP graph replays them no faster: the ~4 us between
+// dependent kernels is the device's, not the host's; one cooperative launch with grid-wide barriers is 3 x slower).
+hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int levels, uint32_t key_rgb, hipStream_t s)
 {
     const TeleaArgs a = telea_args(ws, kTeleaMaxImages, W, H, key_rgb);
-    // fixed, modest grids: a level is a few 10^4 pixels per image, and an exhausted level costs one near-empty launch
     int nb = 512;
     if (const char* e = getenv("MDVT_TELEA_BLOCKS")) { const int v = atoi(e); if (v > 0) nb = v; }      // tuning hook
     const dim3 grid(nb), block(256);
-    for (int r = 1; r <= max_rounds; ++r) hipLaunchKernelGGL(k_telea_levels, grid, block, 0, s, a, (uint32_t)r);
-    for (int r = max_rounds; r >= 1; --r) hipLaunchKernelGGL(k_telea_need, grid, block, 0, s, a, (uint32_t)r);
-    for (int r = 1; r <= max_rounds; ++r) hipLaunchKernelGGL(k_telea_fill, dim3(4 * nb), block, 0, s, a, (uint32_t)r);
+    for (int r = levels; r >= 1; --r) hipLaunchKernelGGL(k_telea_need, grid, block, 0, s, a, (uint32_t)r);
+    for (int r = 1; r <= levels; ++r) hipLaunchKernelGGL(k_telea_fill, dim3(4 * nb), block, 0, s, a, (uint32_t)r);
     return hipGetLastError();
 }
 
