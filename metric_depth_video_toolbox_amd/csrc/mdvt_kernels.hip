@@ -1752,10 +1752,13 @@ __global__ void k_telea_rmax(TeleaArgs a)
     a.counts[0] = m;
 }
 
-// Counting sort of the pixels by level.  A workgroup takes 4096 consecutive pixels of one image; levels below
-// kLevelBins are counted in LDS first (one global atomic per occupied level and workgroup), deeper ones directly.
+// Counting sort of the pixels by level.  A workgroup takes a 64 x 64 tile of one image -- so that the pixels of a level
+// stay together tile by tile in the list, and the half-waves that later work through consecutive list entries read
+// overlapping 9 x 9 neighbourhoods --; levels below kLevelBins are counted in LDS first (one global atomic per occupied
+// level and workgroup), deeper ones directly.
 constexpr int kLevelBins = 4096;
-constexpr int kSortPixels = 4096;
+constexpr int kSortTile = 64;
+constexpr int kSortPixels = kSortTile * kSortTile;
 
 template <bool SCATTER>
 __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
@@ -1766,15 +1769,19 @@ __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
     const uint32_t lr = a.last_round[im];
     if (lr == 0u) return;                                   // nothing key-coloured (or nothing reachable): nothing to do
     const uint32_t npx = (uint32_t)a.W * (uint32_t)a.H;
-    const uint32_t p0 = blockIdx.x * kSortPixels;
+    const int tiles_x = (a.W + kSortTile - 1) / kSortTile;
+    const int tx0 = (int)(blockIdx.x % tiles_x) * kSortTile, ty0 = (int)(blockIdx.x / tiles_x) * kSortTile;
+    const int lx = threadIdx.x & (kSortTile - 1), ly0 = threadIdx.x >> 6;          // 64 columns x 4 rows per step
     const uint16_t* st = a.stamp + (size_t)im * npx;
     for (int b = threadIdx.x; b < kLevelBins; b += 256) hist[b] = 0u;
     __syncthreads();
     uint32_t lv[kSortPixels / 256];
 #pragma unroll
     for (int k = 0; k < kSortPixels / 256; ++k) {
-        const uint32_t o = p0 + k * 256 + threadIdx.x;
-        const uint32_t sv = o < npx ? (uint32_t)st[o] : 0u;
+        const int px = tx0 + lx, py = ty0 + ly0 + 4 * k;
+        const bool in = px < a.W && py < a.H;
+        const uint32_t o = in ? (uint32_t)py * (uint32_t)a.W + (uint32_t)px : 0u;
+        const uint32_t sv = in ? (uint32_t)st[o] : 0u;
         lv[k] = (sv >= 1u && sv <= lr) ? sv : 0u;
         if (lv[k] && lv[k] < (uint32_t)kLevelBins) atomicAdd(&hist[lv[k]], 1u);
         else if (lv[k] && !SCATTER) atomicAdd(&a.counts[lv[k]], 1u);
@@ -1791,7 +1798,7 @@ __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
 #pragma unroll
     for (int k = 0; k < kSortPixels / 256; ++k) {
         if (!lv[k]) continue;
-        const uint32_t e = (uint32_t)im * npx + p0 + k * 256 + threadIdx.x;
+        const uint32_t e = (uint32_t)im * npx + (uint32_t)(ty0 + ly0 + 4 * k) * (uint32_t)a.W + (uint32_t)(tx0 + lx);
         const uint32_t pos = lv[k] < (uint32_t)kLevelBins ? slot[lv[k]] + atomicAdd(&hist[lv[k]], 1u) : atomicAdd(&a.cursor[lv[k]], 1u);
         a.list[pos] = e;
     }
@@ -2089,7 +2096,7 @@ hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int
     const int R = (int)*h_levels;
     if (R == 0) return hipSuccess;
     if ((e = hipMemsetAsync(ws.counts, 0, sizeof(uint32_t), s)) != hipSuccess) return e;         // counts[0] carried R; level 0 is empty
-    const dim3 grid_s((unsigned)(((size_t)W * H + kSortPixels - 1) / kSortPixels), n);
+    const dim3 grid_s((unsigned)(((W + kSortTile - 1) / kSortTile) * ((H + kSortTile - 1) / kSortTile)), n);
     hipLaunchKernelGGL((k_telea_sort<false>), grid_s, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_telea_scan, dim3(1), dim3(1024), 0, s, a, R);
     hipLaunchKernelGGL((k_telea_sort<true>), grid_s, dim3(256), 0, s, a);
