@@ -53,6 +53,7 @@ struct mdvt_ctx {
     unsigned long long* cbuf[2] = {nullptr, nullptr};
     bool ws_gverts = false;
     bool keys_dirty = false;          // a general-path submission was interrupted between splat and resolve
+    uint32_t* ebuf = nullptr;         // edge-point keys of the pure-shift mesh rows (allocated with the edge-filter workspace)
     uint8_t* tri_invalid = nullptr;
     uint8_t* unused = nullptr;
     uint32_t* bigq = nullptr;         // general mesh path: queue of large triangles + its counter (last dword)
@@ -199,7 +200,8 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     if (grow || (need_edges && !c->ws_edges)) {
         if (c->tri_invalid) (void)hipFree(c->tri_invalid);
         if (c->unused) (void)hipFree(c->unused);
-        c->tri_invalid = nullptr; c->unused = nullptr; c->ws_edges = false;
+        if (c->ebuf) (void)hipFree(c->ebuf);
+        c->tri_invalid = nullptr; c->unused = nullptr; c->ebuf = nullptr; c->ws_edges = false;
     }
     if (grow || (need_gverts && !c->ws_gverts)) {
         for (int e = 0; e < 2; ++e) { if (c->gverts[e]) (void)hipFree(c->gverts[e]); c->gverts[e] = nullptr; if (c->cbuf[e]) (void)hipFree(c->cbuf[e]); c->cbuf[e] = nullptr; }
@@ -238,6 +240,10 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     if (need_edges && !c->ws_edges) {
         MDVT_HIP(c, hipMalloc((void**)&c->tri_invalid, nf * ntri));
         MDVT_HIP(c, hipMalloc((void**)&c->unused, nf * npx));
+        if (c->cfg.mode == MDVT_MODE_MESH && c->cfg.edge_points) {
+            MDVT_HIP(c, hipMalloc((void**)&c->ebuf, 2 * nf * npx * sizeof(uint32_t)));                // [slot][eye][H*W]
+            MDVT_HIP(c, hipMemsetAsync(c->ebuf, 0xFF, 2 * nf * npx * sizeof(uint32_t), s));      // EMPTY; the kernel keeps it so
+        }
         c->ws_edges = true;
     }
     return MDVT_OK;
@@ -335,6 +341,7 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->bigq) (void)hipFree(c->bigq);
     if (c->tri_invalid) (void)hipFree(c->tri_invalid);
     if (c->unused) (void)hipFree(c->unused);
+    if (c->ebuf) (void)hipFree(c->ebuf);
     if (c->row_counts) (void)hipFree(c->row_counts);
     if (c->rowcell) (void)hipFree(c->rowcell);
     if (c->telea_levels_host) (void)hipHostFree(c->telea_levels_host);
@@ -455,6 +462,9 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         if (!(r.general || plan.remove_edges)) return n;                  // no workspace: the whole run in one launch
         int ws_chunk = (r.general && plan.mode == MDVT_MODE_POINTS) ? 2 : kWorkspaceChunk;
         if (r.general && plan.mode == MDVT_MODE_MESH) ws_chunk = 2 * kWorkspaceChunk;      // 16: measured -4 % (convergence) / -11 % (pose) vs 8
+        // pure-shift mesh rows with edge removal: a launch is (frames x 135 bands) workgroups for 512 slots -- 8 frames
+        // leave the chip 30 % idle in the last wave of workgroups (476 -> see DESIGN.md); the workspace is 11 B/px per frame
+        if (!r.general && plan.mode == MDVT_MODE_MESH) ws_chunk = 4 * kWorkspaceChunk;
         if (tuned_chunk) ws_chunk = tuned_chunk;
         return n < ws_chunk ? n : ws_chunk;
     };
@@ -495,7 +505,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.ekeys[0] = c->ekeys[0]; a.ekeys[1] = c->ekeys[1];
     a.gverts[0] = c->gverts[0]; a.gverts[1] = c->gverts[1];
     a.cbuf[0] = c->cbuf[0]; a.cbuf[1] = c->cbuf[1];
-    a.tri_invalid = c->tri_invalid; a.unused = c->unused;
+    a.tri_invalid = c->tri_invalid; a.unused = c->unused; a.ebuf = c->ebuf;
     if (c->bigq) {
         a.bigq = c->bigq; a.bigq_cap = c->bigq_cap; a.bigq_count = c->bigq + (size_t)c->bigq_cap * mdvt::kBigRecDwords;
     }

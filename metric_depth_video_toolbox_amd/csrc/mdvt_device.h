@@ -436,4 +436,90 @@ __device__ __forceinline__ uint32_t shade_channel_reference(float v)
     return (uint32_t)val;
 }
 
+// ---- f64 vertex of the 89-degree filter (dmt:1117-1128 as NumPy >= 2 evaluates it) ----
+__device__ __forceinline__ void vertex_f64(const FrameDev& f, int i, int j, int of_by_one, float z, double (&p)[3])
+{
+    const double x = of_by_one ? (double)((float)j * f.sx) : (double)j;   // dmt:1117-1122 (f32 grid)
+    const double y = of_by_one ? (double)((float)i * f.sy) : (double)i;
+    p[0] = (x - f.Kd[2]) * (double)z / f.Kd[0];
+    p[1] = (y - f.Kd[3]) * (double)z / f.Kd[1];
+    p[2] = (double)z;
+}
+
+
+// =================================================================================================
+// infill-mask seed image (sr:787-803): colour of one hole pixel
+// =================================================================================================
+
+// Unit normal (f64) of the LAST triangle in the reference's draw order that contains vertex (i,j) -- what
+// the last-writer-wins scatter of dmt:1358-1364 leaves in normals_of_vertexes -- and the vertex itself.
+static __device__ void removed_vertex_normal(const RenderArgs& a, const FrameDev& fp, int f, int i, int j, int of_by_one,
+                                      double (&n)[3], double (&p)[3])
+{
+    const int W = a.W, H = a.H;
+    int ci, cj, pass;
+    if (i <= H - 2 && j <= W - 2) { pass = 1; ci = i; cj = j; }               // tri2(i,j): vertex is A
+    else if (i <= H - 2 && j >= 1) { pass = 1; ci = i; cj = j - 1; }          // tri2(i,j-1): D
+    else if (i >= 1 && j >= 1) { pass = 1; ci = i - 1; cj = j - 1; }          // tri2(i-1,j-1): C
+    else { pass = 0; ci = i - 1; cj = j; }                                    // only (H-1, 0): tri1(H-2,0): B
+    const int vi[3] = {ci, ci + 1, pass == 0 ? ci + 1 : ci};
+    const int vj[3] = {cj, pass == 0 ? cj : cj + 1, cj + 1};
+    double v[3][3];
+    const uint8_t* dbase = a.depth + (size_t)f * a.depth_stride;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float z = decode_z(code16_of(load_px_bytes(dbase + (size_t)vi[k] * a.depth_pitch, vj[k])), fp.mult, fp.scale);
+        vertex_f64(fp, vi[k], vj[k], of_by_one, z, v[k]);
+    }
+    const double e1x = v[1][0] - v[0][0], e1y = v[1][1] - v[0][1], e1z = v[1][2] - v[0][2];
+    const double e2x = v[2][0] - v[0][0], e2y = v[2][1] - v[0][1], e2z = v[2][2] - v[0][2];
+    const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const double len = sqrt((nx * nx + ny * ny) + nz * nz);
+    if (len > 0.0) { n[0] = nx / len; n[1] = ny / len; n[2] = nz / len; }
+    else { n[0] = n[1] = n[2] = 1.0; }                                        // dmt:1348-1353
+    const float zp = decode_z(code16_of(load_px_bytes(dbase + (size_t)i * a.depth_pitch, j)), fp.mult, fp.scale);
+    vertex_f64(fp, i, j, of_by_one, zp, p);
+}
+
+// (n'+1)/2*255 truncated, n' = M(n + p) - M(S p) normalised (sr:596-600, 727-733, 777-802).
+static __device__ uint32_t edge_normal_colour(const RenderArgs& a, const FrameDev& fp, int f, int eye, int i, int j, int of_by_one)
+{
+    double n[3], p[3];
+    removed_vertex_normal(a, fp, f, i, j, of_by_one, n, p);
+    const double sW = ((double)a.W - 1.0) / (double)a.W, sH = ((double)a.H - 1.0) / (double)a.H;
+    const double pa[3] = {n[0] + p[0], n[1] + p[1], n[2] + p[2]};
+    const double q[3] = {p[0] * sW, p[1] * sH, p[2]};
+    double d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double* M = fp.Md[eye] + 4 * r;
+        const double ar = ((M[0] * pa[0] + M[1] * pa[1]) + M[2] * pa[2]) + M[3];
+        const double qr = ((M[0] * q[0] + M[1] * q[1]) + M[2] * q[2]) + M[3];
+        d[r] = ar - qr;
+    }
+    const double len = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    uint32_t rgb = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double c = ((d[r] / len) + 1.0) / 2.0 * 255.0;
+        rgb |= ((c >= 0.0 && c < 256.0) ? (uint32_t)c : 0u) << (8 * r);
+    }
+    return rgb;
+}
+
+// Seed colour of output pixel (x,y): black outside holes; in holes the edge point's normal colour if one
+// was splatted there (esrc = i<<16 | j of the winning edge vertex, or ~0u), else border normals / key colour.
+__device__ __forceinline__ uint32_t seed_pixel(const RenderArgs& a, const FrameDev& fp, int f, int eye, int x, int y,
+                                               bool hole, uint32_t esrc, int of_by_one)
+{
+    if (!hole) return 0u;
+    if (esrc != ~0u) return edge_normal_colour(a, fp, f, eye, (int)(esrc >> 16), (int)(esrc & 0xFFFFu), of_by_one);
+    if (x == 0) return 255u | (127u << 8) | (127u << 16);             // sr:796 normal pointing right
+    if (x == a.W - 1) return 0u | (127u << 8) | (127u << 16);         // sr:797 pointing left
+    if (y == 0) return 127u | (127u << 8) | (0u << 16);               // sr:798 pointing down
+    if (y == a.H - 1) return 127u | (127u << 8) | (255u << 16);       // sr:799 pointing up
+    return a.key_rgb;
+}
+
+
 }  // namespace mdvt

@@ -55,6 +55,7 @@ struct RenderArgs {
     unsigned long long* ekeys[2];// edge-point keys per eye
     uint4* gverts[2];            // general mesh path: per-eye projected vertices {X, Y (snapped), 1/Z', rgb}, [slot][H*W]
     unsigned long long* cbuf[2]; // general mesh path: per-eye colour side buffer, draw id << 32 | rgb of some fragment of the pixel
+    uint32_t* ebuf;              // pure-shift mesh rows with edge points: [slot][eye][H*W] edge-point keys code16 << 16 | column, EMPTY between uses
     uint8_t* tri_invalid;        // [slot][2*(H-1)*(W-1)]
     uint8_t* unused;             // [slot][H*W]
     // general mesh path: queue of the triangles that are not small (kBigRecDwords dwords each), rasterised by k_mesh_raster_queue

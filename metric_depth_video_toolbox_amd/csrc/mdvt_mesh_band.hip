@@ -42,6 +42,7 @@ __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
 
 // One vertex of the grid: decode, 1/Z and dl/Z (correctly rounded), snapped x of both eyes.
+// (cpx may carry per-vertex flags in its top byte: they ride along in the record's colour word)
 __device__ __forceinline__ int4 band_vertex(uint32_t dpx, uint32_t cpx, int j, const FrameDev& fp, bool dl_ok)
 {
     const float z = decode_z(code16_of(dpx), fp.mult, fp.scale);
@@ -85,15 +86,16 @@ __device__ __forceinline__ RowGeom row_geometry(int k, const RowCell* __restrict
 }
 
 // One pixel of a fast-path cell (both triangles in one orientation, all coordinates bounded, no near-plane vertex).
-// kcol0 / kcol1: the scanline crossings of the cell's two column edges (see the header).
+// kcol0 / kcol1: the scanline crossings of the cell's two column edges (see the header); skip: bit 0 tri1 / bit 1 tri2 draws nothing.
 __device__ __forceinline__ void cell_pixel(int XA, int XB, int XC, int XD, float izA, float izB, float izC, float izD,
                                            uint32_t cA, uint32_t cB, uint32_t cC, uint32_t cD, int kcol0, int kcol1, int px,
-                                           int j, const RowGeom& g, u64* zb, const RowTies& ties)
+                                           int j, uint32_t skip, const RowGeom& g, u64* zb, const RowTies& ties)
 {
     const int kdiag = mad24(XC - XA, g.tt, mul24(g.hh, XA));
     const int hX = mul24(g.hh, px * kSubpix + kSubpix / 2);
     const bool regular = XD > XA;
     const bool in1 = (hX < kdiag) == regular;
+    if (skip & (in1 ? 1u : 2u)) return;                      // that triangle was removed by the 89-degree filter (dmt:1372)
     int wd = in1 ? XC - XB : XD - XA;
     wd = wd < 0 ? -wd : wd;
     const int area2 = mul24(g.hh, wd);
@@ -148,11 +150,13 @@ __device__ __forceinline__ void exotic_cell_wave(int XA, int XB, int XC, int XD,
 
 }  // namespace
 
-// FLAGS bit 0: depth planes.  (remove_edges variants are rendered by k_mesh_rows.)
+// FLAGS bit 0: depth planes; bit 1: triangles removed by the 89-degree filter draw nothing (remove_edges; tri_invalid /
+// unused come from k_edge_filter); bit 2: the vertices of removed triangles are splatted into the holes (sr:589-606,
+// 745-781); bit 3: the infill-mask seed image (sr:787-803).
 template <int FLAGS, int TPB>
-__global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per_band, int nbands)
+__global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderArgs a, int rows_per_band, int nbands)
 {
-    constexpr bool ZOUT = FLAGS & 1;
+    constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4, SEED = FLAGS & 8;
     const uint32_t cull = (uint32_t)a.cull;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = a.W, H = a.H, W4 = W >> 2;
@@ -164,6 +168,11 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
     ties.nwords = (W + 31) / 32;
     ties.mode = 0;
     ties.force = (a.debug_skip & 32) != 0;
+    // With edge removal a vertex record's colour word carries three flags in its top byte: bit 24 / 25 = tri1 / tri2 of the
+    // cell whose top-left corner the vertex is were removed (dmt:1372), bit 26 = the vertex belongs to a removed triangle
+    // (its edge point is splatted, sr:589-606).  The edge-point keys of a (scanline, eye) (code16 << 16 | column, nearest wins)
+    // live in a row of a global buffer, not in LDS (read back only where the render left a hole, reset by the lanes that wrote them): with them in LDS only one workgroup fits a CU, which costs this
+    // barrier-heavy row loop a factor of two; the ~100 atomics and 8 B/px of extra traffic per row do not show.
 
     const int fr = blockIdx.x / nbands;
     const int band = blockIdx.x - fr * nbands;
@@ -182,6 +191,8 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
     int have0 = -1, have1 = -1;                 // vertex row held by slot 0 / 1 (uniform)
     int pf_row = -1;                            // vertex row sitting in the prefetch registers (uniform)
     uint32_t pd0 = 0, pd1 = 0, pd2 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
+    uint32_t pfl = 0;                            // EDGES: the four columns' flags of that row, one byte each
+    int etx[4] = {-1, -1, -1, -1};               // EDGEPTS: the pixels this thread's edge points touched in the current (row, eye)
 
     auto fetch_row = [&](int r) {
         if (act4) {
@@ -189,6 +200,19 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
             const uint32_t* cp = (const uint32_t*)(cbase + (size_t)r * a.color_pitch) + 3 * tid;
             pd0 = dp[0]; pd1 = dp[1]; pd2 = dp[2];
             pc0 = cp[0]; pc1 = cp[1]; pc2 = cp[2];
+            if (EDGES) {
+                const size_t ncell_ = (size_t)(W - 1) * (H - 1);
+                const uint8_t* ti = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)r * (W - 1) + 4 * tid;
+                const uint8_t* ur = a.unused + (size_t)fr * a.ws_stride_px + (size_t)r * W + 4 * tid;
+                pfl = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t fl = 0;
+                    if (r <= H - 2 && 4 * tid + q < W - 1) fl = (ti[q] ? 1u : 0u) | (ti[ncell_ + q] ? 2u : 0u);
+                    if (EDGEPTS && ur[q]) fl |= 4u;
+                    pfl |= fl << (8 * q);
+                }
+            }
         }
         pf_row = r;
     };
@@ -198,6 +222,10 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
             uint32_t dpx[4], cpx[4];
             unpack4(pd0, pd1, pd2, dpx);
             unpack4(pc0, pc1, pc2, cpx);
+            if (EDGES) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cpx[q] |= ((pfl >> (8 * q)) & 0xFFu) << 24;
+            }
             int4* dst = verts + (size_t)(r & 1) * W + 4 * tid;
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = band_vertex(dpx[q], cpx[q], 4 * tid + q, fp, dl_ok);
@@ -208,7 +236,6 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
 
     for (int x = tid; x < W; x += TPB) zb[x] = kEmpty64;
     for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
-
     // The loop starts one row early: that prologue pass only stages the two vertex rows of scanline k0 (so that the
     // staging code exists once).
     RowGeom g = row_geometry(k0, a.rowcell);
@@ -249,7 +276,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                     const int4 A = vt[jc], B = vb[jc];
                     const int XA = eye == 0 ? A.x : A.y, XB = eye == 0 ? B.x : B.y;
                     const float izA = __int_as_float(A.z), izB = __int_as_float(B.z);
-                    const uint32_t cA = (uint32_t)A.w, cB = (uint32_t)B.w;
+                    const uint32_t cA = (uint32_t)A.w & 0xFFFFFFu, cB = (uint32_t)B.w & 0xFFFFFFu;
                     const int colok = (izA > 0.0f && izB > 0.0f && (((uint32_t)(XA + kCoordBound) | (uint32_t)(XB + kCoordBound)) >> 21) == 0u) ? 1 : 0;
                     const int kcol0 = mad24(XB - XA, g.tt, mul24(g.hh, XA));
                     const int pA = first_pixel(kcol0, g.c128, g.D, g.rD, W);
@@ -263,11 +290,12 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                     const bool fast = cell && colok && okD && ((s1 > 0 && s2 > 0) || (s1 < 0 && s2 < 0));
                     const bool exotic = cell && !fast;
                     // culling (mdvt_config.cull): the grid's own orientation is the front face
-                    const bool drawn = fast && !(cull && (cull == 1u) != regular);
+                    const uint32_t skip = EDGES ? ((uint32_t)A.w >> 24) & 3u : 0u;                        // dmt:1372
+                    const bool drawn = fast && skip != 3u && !(cull && (cull == 1u) != regular);
                     const int plo = regular ? pA : pD;
                     int n = drawn ? (regular ? pD - pA : pA - pD) : 0;
                     if (n > 0 && !(a.debug_skip & 16))
-                        cell_pixel(XA, XB, XC, XD, izA, izB, izC, izD, cA, cB, cC, cD, kcol0, kcol1, plo, j, g, zb, ties);
+                        cell_pixel(XA, XB, XC, XD, izA, izB, izC, izD, cA, cB, cC, cD, kcol0, kcol1, plo, j, skip, g, zb, ties);
                     // Further pixels of the cell become (cell, pixel) items on the wave's stack, shaded 64 at a time: first
                     // one item per lane and round (spans of up to 4 px), then the long spans (rubber sheet across a depth
                     // edge), one cell at a time written by the whole wave.  One loop, so that the shading code exists once.
@@ -285,8 +313,9 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                                     const int4 A = vt[ij], D = vt[ij + 1], B = vb[ij], Cv = vb[ij + 1];
                                     const int iXA = eye == 0 ? A.x : A.y, iXB = eye == 0 ? B.x : B.y, iXC = eye == 0 ? Cv.x : Cv.y, iXD = eye == 0 ? D.x : D.y;
                                     cell_pixel(iXA, iXB, iXC, iXD, __int_as_float(A.z), __int_as_float(B.z), __int_as_float(Cv.z), __int_as_float(D.z),
-                                               (uint32_t)A.w, (uint32_t)B.w, (uint32_t)Cv.w, (uint32_t)D.w,
-                                               mad24(iXB - iXA, g.tt, mul24(g.hh, iXA)), mad24(iXC - iXD, g.tt, mul24(g.hh, iXD)), px, ij, g, zb, ties);
+                                               (uint32_t)A.w & 0xFFFFFFu, (uint32_t)B.w & 0xFFFFFFu, (uint32_t)Cv.w & 0xFFFFFFu, (uint32_t)D.w & 0xFFFFFFu,
+                                               mad24(iXB - iXA, g.tt, mul24(g.hh, iXA)), mad24(iXC - iXD, g.tt, mul24(g.hh, iXD)), px, ij,
+                                               EDGES ? ((uint32_t)A.w >> 24) & 3u : 0u, g, zb, ties);
                                 }
                                 continue;
                             }
@@ -323,7 +352,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
 #define MDVT_BI(v) __builtin_amdgcn_readlane(v, l)
 #define MDVT_BF(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l))
 #define MDVT_BU(v) (uint32_t)__builtin_amdgcn_readlane((int)(v), l)
-                        uint32_t sk = 0;
+                        uint32_t sk = MDVT_BU(skip);
                         const int bXA = MDVT_BI(XA), bXB = MDVT_BI(XB), bXC = MDVT_BI(XC), bXD = MDVT_BI(XD);
                         if (cull) {        // per triangle: area2 of tri1 = hh (XB - XC), of tri2 = -hh (XD - XA); front = negative
                             const bool back1 = bXB > bXC, back2 = bXA > bXD;
@@ -331,10 +360,38 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                             if ((cull == 1u) == back2 && bXA != bXD) sk |= 2u;
                         }
                         exotic_cell_wave(bXA, bXB, bXC, bXD, MDVT_BF(izA), MDVT_BF(izB), MDVT_BF(izC), MDVT_BF(izD),
-                                         MDVT_BU(cA), MDVT_BU(cB), MDVT_BU(cC), MDVT_BU(cD), sk, g.Yt, g.Yb, k, W, lane, MDVT_BI(j), zb, ties);
+                                         MDVT_BU(cA), MDVT_BU(cB), MDVT_BU(cC), MDVT_BU(cD), sk, g.Yt, g.Yb, k, W, lane, MDVT_BI(j), zb, ties);      // (cA.. are already masked)
 #undef MDVT_BI
 #undef MDVT_BF
 #undef MDVT_BU
+                    }
+                }
+            }
+            // ---- edge points of source row k (sr:589-606, 745-781): the vertices of removed triangles, nearest wins ----
+            if (EDGEPTS && ties.mode == 0 && k >= k0) {
+                const uint8_t* drow_k = dbase + (size_t)k * a.depth_pitch;
+                const float fW = (float)W;
+                // (source row k is one of the two staged vertex rows: c(k) is k or k - 1)
+                const int4* vk = ((k & 1) ? have1 : have0) == k ? verts + (size_t)(k & 1) * W : nullptr;
+                uint32_t* eb = a.ebuf + ((size_t)fr * 2 + eye) * a.ws_stride_px + (size_t)k * W;     // this (row, eye)'s keys
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                          // W <= 4 * TPB (launcher)
+                    const int jj = tid + q * TPB;
+                    etx[q] = -1;
+                    if (jj >= W) continue;
+                    const bool un = vk ? (((uint32_t)vk[jj].w >> 26) & 1u) != 0u
+                                       : a.unused[(size_t)fr * a.ws_stride_px + (size_t)k * W + jj] != 0;
+                    if (!un) continue;
+                    const uint32_t code = code16_of(load_px_bytes(drow_k, jj));
+                    const float z = decode_z(code, fp.mult, fp.scale);
+                    if (!(z > kNear)) continue;
+                    const float d = fp.dl / z;
+                    const float gx = (float)jj * fp.sx;
+                    const float ex = ((gx - fp.cx) * fp.sW) + fp.cx;                      // sr:599-600
+                    const float u = eye == 0 ? ex + d : ex - d;
+                    if (u > -1.0f && u < fW + 1.0f) {
+                        const int x = (int)rintf(u);                                      // np.round (sr:746)
+                        if (x >= 0 && x < W) { atomicMin(&eb[x], (code << 16) | (uint32_t)jj); etx[q] = x; }
                     }
                 }
             }
@@ -362,8 +419,23 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                 zq[0] = make_uint4(~0u, ~0u, ~0u, ~0u); zq[1] = make_uint4(~0u, ~0u, ~0u, ~0u);
                 const uint32_t hi[4] = {k01.y, k01.w, k23.y, k23.w};
                 const uint32_t lo[4] = {k01.x, k01.z, k23.x, k23.z};
-                uint32_t o[4], mw = 0;
+                uint32_t o[4], mw = 0, spx[4];
                 float oz[4];
+                uint4 ek4 = make_uint4(~0u, ~0u, ~0u, ~0u);
+                bool any_hole = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) any_hole |= (hi[q] == ~0u && lo[q] == ~0u) || (lo[q] & 0xFFFFFFu) == a.key_rgb;
+                if (EDGEPTS && any_hole) {        // an edge point only matters where the render left a hole (sr:776): ~3 % of the pixels
+                    // (device-scope loads: the keys were written by atomics, which live in L2, by other lanes of this workgroup
+                    //  before the barrier -- a plain load could be served from this CU's L1)
+                    uint32_t* ep = a.ebuf + ((size_t)fr * 2 + eye) * a.ws_stride_px + (size_t)k * W + 4 * tid;
+                    ek4.x = __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ek4.y = __hip_atomic_load(ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ek4.z = __hip_atomic_load(ep + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ek4.w = __hip_atomic_load(ep + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const uint32_t ek[4] = {ek4.x, ek4.y, ek4.z, ek4.w};
+                const uint8_t* crow_k = cbase + (size_t)k * a.color_pitch;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const bool covered = !(hi[q] == ~0u && lo[q] == ~0u);          // (a settled tie has the top bit of hi cleared)
@@ -372,6 +444,18 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
                     o[q] = hole ? 0u : rgb;                                  // sr:793
                     mw |= hole ? (0xFFu << (8 * q)) : 0u;
                     if (ZOUT) oz[q] = covered ? 1.0f / row_word_iz(hi[q]) : 0.0f;
+                    uint32_t esrc = ~0u;
+                    if (EDGEPTS && hole && ek[q] != kEmpty32) {              // sr:776, 813-814: only where the render left a hole
+                        if (a.edge_paint) o[q] = load_px_bytes(crow_k, (int)(ek[q] & 0xFFFFu));
+                        esrc = ((uint32_t)k << 16) | (ek[q] & 0xFFFFu);
+                    }
+                    if (SEED && a.seed[eye]) spx[q] = seed_pixel(a, fp, f, eye, 4 * tid + q, k, hole, esrc, 1);
+                }
+                if (SEED && a.seed[eye]) {
+                    uint32_t* sp = (uint32_t*)(a.seed[eye] + (size_t)f * a.seed_stride + (size_t)k * a.seed_pitch) + 3 * tid;
+                    sp[0] = __builtin_amdgcn_perm(spx[1], spx[0], 0x04020100u);
+                    sp[1] = __builtin_amdgcn_perm(spx[2], spx[1], 0x05040201u);
+                    sp[2] = __builtin_amdgcn_perm(spx[3], spx[2], 0x06050402u);
                 }
                 uint32_t* op = (uint32_t*)(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)k * a.rgb_pitch) + 3 * tid;
                 __builtin_nontemporal_store(__builtin_amdgcn_perm(o[1], o[0], 0x04020100u), op);
@@ -386,40 +470,58 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_band(RenderArgs a, int rows_per
             }
             if (had_ties) for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
             __syncthreads();
+            if (EDGEPTS && k >= k0) {             // the keys of this (row, eye) have been read: EMPTY again for the next submission
+                uint32_t* eb = a.ebuf + ((size_t)fr * 2 + eye) * a.ws_stride_px + (size_t)k * W;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (etx[q] >= 0) eb[etx[q]] = kEmpty32;
+            }
         }
         g = gn;
     }
 }
 
-size_t mesh_band_lds_bytes(int W, int tpb)
+size_t mesh_band_lds_bytes(int W, int tpb, bool, bool)
 {
     return (size_t)W * sizeof(u64) + 2 * (size_t)W * 16 + (size_t)(tpb / 64) * kQueueWave * sizeof(uint32_t) +
            (((size_t)W + 31) / 32 + 1) * sizeof(uint32_t);
 }
 
-// Can the band kernel render this launch?  (4-byte aligned rows, no edge removal, LDS for one row.)
+static int mesh_band_tpb(const RenderPlan& plan, int W)
+{
+    // two 512-thread workgroups per CU when two fit in the 160 KB LDS, otherwise one of 1024 threads: 16 waves per CU either way
+    return (W / 4 <= 512 && 2 * mesh_band_lds_bytes(W, 512, plan.remove_edges, plan.edge_points) <= 160 * 1024) ? 512 : 1024;
+}
+
+// Can the band kernel render this launch?  (4-byte aligned rows, LDS for one row.)
 bool mesh_band_supported(const RenderPlan& plan, const RenderArgs& a)
 {
-    if (!plan.vec4 || plan.general || plan.remove_edges || a.seed[0]) return false;
+    if (!plan.vec4 || plan.general) return false;
+    if (plan.edge_points && !a.ebuf) return false;
     if (a.W < 8 || a.W > 4096 || a.W > 4 * 1024) return false;       // 1024 threads x 4 px; the 24-bit fast path assumes W*256 <= 2^20
-    return mesh_band_lds_bytes(a.W, a.W / 4 <= 512 ? 512 : 1024) <= 160 * 1024;
+    return mesh_band_lds_bytes(a.W, mesh_band_tpb(plan, a.W), plan.remove_edges, plan.edge_points) <= 160 * 1024;
 }
 
 template <int TPB>
 static hipError_t launch_mesh_band_tpb(const RenderPlan& plan, const RenderArgs& a, int rows, hipStream_t s)
 {
-    size_t lds = mesh_band_lds_bytes(a.W, TPB);
+    size_t lds = mesh_band_lds_bytes(a.W, TPB, plan.remove_edges, plan.edge_points);
     if (const char* e = getenv("MDVT_LDS_PAD")) lds += (size_t)atoi(e);      // occupancy probe (tools/kbench.py)
     const int nbands = (a.H + rows - 1) / rows;
     const dim3 grid((unsigned)(plan.n * nbands)), block(TPB);
     const bool zout = a.zout[0] || a.zout[1];
-    if (zout) {
-        (void)hipFuncSetAttribute((const void*)k_mesh_band<1, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_mesh_band<1, TPB>), grid, block, lds, s, a, rows, nbands);
-    } else {
-        (void)hipFuncSetAttribute((const void*)k_mesh_band<0, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_mesh_band<0, TPB>), grid, block, lds, s, a, rows, nbands);
+    const int flags = (zout ? 1 : 0) | (plan.remove_edges ? 2 : 0) | (plan.remove_edges && plan.edge_points ? 4 : 0) |
+                      (plan.remove_edges && a.seed[0] ? 8 : 0);
+#define MDVT_CASE(F)                                                                                                        \
+    case F:                                                                                                                 \
+        (void)hipFuncSetAttribute((const void*)k_mesh_band<F, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL((k_mesh_band<F, TPB>), grid, block, lds, s, a, rows, nbands);                                   \
+        break;
+    switch (flags) {
+        MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(2) MDVT_CASE(3) MDVT_CASE(6) MDVT_CASE(7)
+        MDVT_CASE(10) MDVT_CASE(11) MDVT_CASE(14) MDVT_CASE(15)
+        default: return hipErrorInvalidValue;
     }
+#undef MDVT_CASE
     return hipGetLastError();
 }
 
@@ -430,7 +532,7 @@ hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a_in, hipS
     int rows = 8;
     if (const char* e = getenv("MDVT_MESH_BAND")) { const int v = atoi(e); if (v > 0) rows = v; }     // tuning hook
     if (rows > a.H) rows = a.H;
-    if (a.W / 4 <= 512) return launch_mesh_band_tpb<512>(plan, a, rows, s);
+    if (mesh_band_tpb(plan, a.W) == 512) return launch_mesh_band_tpb<512>(plan, a, rows, s);
     return launch_mesh_band_tpb<1024>(plan, a, rows, s);
 }
 
