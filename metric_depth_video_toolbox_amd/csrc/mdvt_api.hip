@@ -321,7 +321,7 @@ int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flag
 static void free_telea(mdvt_ctx* c)
 {
     mdvt::TeleaWorkspace& w = c->telea;
-    void* ptrs[] = {w.stamp, w.T, w.img, w.need, w.list, w.nlist, w.counts, w.remaining, w.last_round};   // offs / ncounts / cursor live inside counts
+    void* ptrs[] = {w.stamp, w.T, w.img, w.need, w.nlist, w.counts, w.remaining, w.last_round};   // offs / ncounts live inside counts
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = mdvt::TeleaWorkspace{};
     c->telea_images = 0; c->telea_rounds = 0;
@@ -697,7 +697,7 @@ mdvt::BlurKernel masked_blur_kernel()
     for (int y = 0; y < 6; ++y) for (int x = 0; x < 6; ++x) K.k[6 * y + x] = (float)(g[y] * g[x]);
     return K;
 }
-constexpr int kTeleaChunk = mdvt::kTeleaMaxImages;      // images per pass (18 B/px of workspace each)
+constexpr int kTeleaChunk = mdvt::kTeleaMaxImages;      // images per pass (14 B/px of workspace each)
 
 }  // namespace
 
@@ -756,16 +756,14 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
         MDVT_HIP(c, hipMalloc((void**)&w.T, (size_t)images * npx * sizeof(float)));
         MDVT_HIP(c, hipMalloc((void**)&w.img, (size_t)images * npx * 3 + 4));      // + 4: pixels are fetched as unaligned dwords
         MDVT_HIP(c, hipMalloc((void**)&w.need, (size_t)images * npx));
-        MDVT_HIP(c, hipMalloc((void**)&w.list, (size_t)images * npx * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.nlist, (size_t)images * npx * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.counts, 4 * ((size_t)rounds + 2) * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.counts, 3 * ((size_t)rounds + 2) * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.remaining, (size_t)kTeleaChunk * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.last_round, (size_t)kTeleaChunk * sizeof(uint32_t)));
         c->telea_images = images; c->telea_rounds = rounds;
     }
     c->telea.offs = c->telea.counts + (max_rounds + 2);
     c->telea.ncounts = c->telea.offs + (max_rounds + 2);
-    c->telea.cursor = c->telea.ncounts + (max_rounds + 2);
     if (!c->telea_levels_host) MDVT_HIP(c, hipHostMalloc((void**)&c->telea_levels_host, sizeof(uint32_t), hipHostMallocDefault));
     const uint32_t key = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     const mdvt::BlurKernel K = masked_blur_kernel();

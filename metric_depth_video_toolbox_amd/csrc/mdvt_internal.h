@@ -109,12 +109,11 @@ struct ImageSet {
     __host__ __device__ uint8_t* image(int im) const { return base + (size_t)(im % per_eye) * stride + (ptrdiff_t)(im / per_eye) * eye_offset; }
 };
 
-struct TeleaWorkspace {              // per image pixel: stamp u16, T f32, work image u8x3, need u8, list u32, nlist u32
-    uint16_t* stamp; float* T; uint8_t* img; uint8_t* need; uint32_t* list; uint32_t* nlist;
+struct TeleaWorkspace {              // per image pixel: stamp u16, T f32, work image u8x3, need u8, nlist u32 (14 B)
+    uint16_t* stamp; float* T; uint8_t* img; uint8_t* need; uint32_t* nlist;
     uint32_t* counts;                // [max_rounds + 2], followed by
-    uint32_t* offs;                  // [max_rounds + 2],
-    uint32_t* ncounts;               // [max_rounds + 2] and
-    uint32_t* cursor;                // [max_rounds + 2] (one allocation of 4 x (max_rounds + 2) words)
+    uint32_t* offs;                  // [max_rounds + 2] and
+    uint32_t* ncounts;               // [max_rounds + 2] (one allocation of 3 x (max_rounds + 2) words)
     uint32_t* remaining;             // [images]
     uint32_t* last_round;            // [images]
 };
