@@ -20,7 +20,8 @@ for name in ("fetch", "write"):
     for r in rows(f"pmc_{name}/**/*counter_collection.csv"):
         if "mdvt::" in r["Kernel_Name"]:
             pmc.setdefault((r["Kernel_Name"].split("(")[0], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
-launches = max(len(v) for v in dur.values()) if dur else 1
+launches = int(sys.argv[5]) if len(sys.argv) > 5 else 16      # submissions: profile_kbench.sh runs 1 warm-up + 3 rounds x 5 calls;
+                                                                # a submission may be split into several launches (frame chunks)
 with open(os.path.join(repo, "profiles", f"{tag}_summary.md"), "w") as fo:
     fo.write(f"# rocprofv3 summary `{tag}`\n\n{what}\n\nCommand: `bash tools/profile_kbench.sh {tag} ...` (kernel trace + separate "
              f"FETCH_SIZE / WRITE_SIZE passes); {frames} frames per submission.  HBM bytes as MI355X_MICROARCH.md prescribes "
@@ -28,10 +29,7 @@ with open(os.path.join(repo, "profiles", f"{tag}_summary.md"), "w") as fo:
     fo.write("| kernel | launches | avg us per launch | us per frame | HBM read MB per frame | HBM write MB per frame |\n|---|---|---|---|---|---|\n")
     tot = 0.0
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-        per_sub = len(v) / launches            # launches of this kernel per submission (chunks)
-        us_frame = statistics.mean(v) / 1e3 * per_sub / frames * (launches / launches)
-        # a submission may be split into chunks: frames per submission / launches per submission frames per launch
-        us_frame = sum(v) / 1e3 / (launches * frames) * (launches / max(1, launches))
+        us_frame = sum(v) / 1e3 / (launches * frames)
         f, w = pmc.get((k, "FETCH_SIZE")), pmc.get((k, "WRITE_SIZE"))
         rd = 2.0 * sum(f) * 1024 / 1e6 / (launches * frames) if f else float("nan")
         wr = sum(w) * 1024 / 1e6 / (launches * frames) if w else float("nan")
