@@ -906,6 +906,27 @@ def test_finish_infill_mask_matches_the_oracle(mods, orc, W, H):
     rb.close()
 
 
+@pytest.mark.parametrize("blocks", ["1", "3"])
+def test_finish_infill_mask_with_a_starved_grid(mods, orc, monkeypatch, blocks):
+    """The level passes of the completion with 1 / 3 workgroups (MDVT_TELEA_BLOCKS, re-read per call): every workgroup then
+    loops over many list entries and marks far more pixels per target level than its LDS stage holds, so the direct
+    append path, the multi-iteration loops and appends racing between workgroups all run -- same bits as the oracle."""
+    _lib, sr, synthetic = mods
+    monkeypatch.setenv("MDVT_TELEA_BLOCKS", blocks)
+    W, H = 320, 180
+    rng = np.random.default_rng(77)
+    seeds = np.stack([_synthetic_seed(rng, W, H) for _ in range(2)])
+    seeds[1, 40:140, 60:260] = (0, 255, 0)                  # one hole 100 x 200: 50 levels, thousands of needed pixels per level
+    seeds[1, 40:140:7, 60] = (200, 90, 30); seeds[1, 139, 61:260:5] = (10, 220, 140)
+    r = sr.StereoRerenderer(W, H, infill_mask=True)
+    got, rem = r.finish_infill_mask(torch.from_numpy(seeds).cuda(), want_remaining=True)
+    for k in range(2):
+        want, wrem = orc.finish_infill_mask(seeds[k])
+        assert np.array_equal(got[k].cpu().numpy(), want), k
+        assert int(rem[k]) == wrem == 0
+    r.close()
+
+
 @pytest.mark.parametrize("mode,conv", [("mesh", None), ("mesh", 2.5), ("points", None)])
 def test_infill_mask_and_basic_infill_from_a_render(mods, orc, mode, conv):
     """The product-default chain on real seeds: render(--infill_mask) -> seed -> finished mask, and the
