@@ -1798,18 +1798,33 @@ __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
         const uint32_t e = a.nlist[off + idx], im = e / npx, o = e - im * npx;
         const int y = (int)(o / (uint32_t)W), x = (int)(o - (uint32_t)y * (uint32_t)W);
         const size_t ib = (size_t)im * npx;
-        for (int q = sub; q < kNeedOffsets.n; q += kNeedLanes) {
-            const int xx = x + kNeedOffsets.dx[q], yy = y + kNeedOffsets.dy[q];
-            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-            const size_t u = ib + (size_t)yy * W + xx;
-            const uint32_t su = a.stamp[u];
-            if (su == 0u || su >= r || a.need[u]) continue;
-            const uint32_t bit = 1u << (8u * (uint32_t)(u & 3));
-            if (atomicOr(need_words + (u >> 2), bit) & bit) continue;          // somebody else was first
-            const uint32_t d = r - 1u - su;
-            const uint32_t k = d < 5u ? atomicAdd(&cnt[d], 1u) : (uint32_t)kNeedStage;
-            if (k < (uint32_t)kNeedStage) stage[d][k] = (uint32_t)u;
-            else a.nlist[a.offs[su] + atomicAdd(&a.ncounts[su], 1u)] = (uint32_t)u;
+        // three rounds with everything of a round in flight together (a loop over the lane's offsets with the flag test, the
+        // atomic and the append inside is seven dependent round trips to L2 per entry: the floor of a level's launch)
+        constexpr int kPer = (56 + kNeedLanes - 1) / kNeedLanes;
+        static_assert(kPer * kNeedLanes >= 56, "every offset has a lane");
+        uint32_t uu[kPer], su[kPer], nd[kPer], old[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int q = sub + k * kNeedLanes;
+            const int xx = x + kNeedOffsets.dx[q < kNeedOffsets.n ? q : 0], yy = y + kNeedOffsets.dy[q < kNeedOffsets.n ? q : 0];
+            const bool in = q < kNeedOffsets.n && xx >= 0 && xx < W && yy >= 0 && yy < H;
+            uu[k] = in ? (uint32_t)(ib + (size_t)yy * W + xx) : e;           // (the entry itself: level r, never marked)
+            su[k] = a.stamp[uu[k]];
+            nd[k] = a.need[uu[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t bit = 1u << (8u * (uu[k] & 3u));
+            old[k] = bit;                                                      // "already set"
+            if (su[k] != 0u && su[k] < r && !nd[k]) old[k] = atomicOr(need_words + (uu[k] >> 2), bit);
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (old[k] & (1u << (8u * (uu[k] & 3u)))) continue;               // flag was set: somebody else appends (or has appended) it
+            const uint32_t d = r - 1u - su[k];
+            const uint32_t pos = d < 5u ? atomicAdd(&cnt[d], 1u) : (uint32_t)kNeedStage;
+            if (pos < (uint32_t)kNeedStage) stage[d][pos] = uu[k];
+            else a.nlist[a.offs[su[k]] + atomicAdd(&a.ncounts[su[k]], 1u)] = uu[k];
         }
     }
     __syncthreads();
