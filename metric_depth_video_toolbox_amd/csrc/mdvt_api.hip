@@ -777,7 +777,8 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
         const mdvt::ImageSet work{c->telea.img, (size_t)3 * W, 3 * npx, 0, n};
         MDVT_HIP(c, launch_telea_init(seed, c->telea, n, W, H, max_rounds, key, c->telea_levels_host, s));
         MDVT_HIP(c, launch_telea_rounds(c->telea, W, H, (int)*c->telea_levels_host, key, s));               // sr:806, inpaintRadius = 3
-        MDVT_HIP(c, launch_masked_blur(work, &seed, out, n, W, H, K, key, s));                              // sr:807-808
+        // (the level lists and T are done with: their storage serves the blur's per-row pixel lists and row counters)
+        MDVT_HIP(c, launch_masked_blur(work, &seed, out, n, W, H, K, key, s, c->telea.nlist, reinterpret_cast<uint32_t*>(c->telea.T)));   // sr:807-808
         if (d_remaining) {      // image order of the result: left eyes of all frames, then right eyes
             for (int e = 0; e < eyes; ++e)
                 MDVT_HIP(c, hipMemcpyAsync(d_remaining + (size_t)e * n_frames + f0, c->telea.remaining + (size_t)e * nf,

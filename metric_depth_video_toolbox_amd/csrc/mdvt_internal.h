@@ -124,7 +124,7 @@ hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int level
 hipError_t launch_swap_rb(const ImageSet& src, const ImageSet& dst, int n, int W, int H, hipStream_t s);
 struct BlurKernel { float k[36]; };      // masked_blur's 6x6 Gaussian, f32, row major (built on the host in f64)
 hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const ImageSet& out, int n, int W, int H,
-                              const BlurKernel& K, uint32_t key_rgb, hipStream_t s);
+                              const BlurKernel& K, uint32_t key_rgb, hipStream_t s, uint32_t* list = nullptr, uint32_t* count = nullptr);
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_selftest(int which, unsigned long long seed, unsigned long long* d_mism, hipStream_t s);

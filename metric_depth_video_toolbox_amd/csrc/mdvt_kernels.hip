@@ -1976,20 +1976,18 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
 
 // sr:807: only the key-coloured pixels take the inpainted value, black ones go back to black; then masked_blur.
 // Both in one pass: the 36 taps read the work image and zero it on the fly where the seed was black.
-__global__ void __launch_bounds__(256) k_masked_blur(ImageSet imgs, ImageSet seeds, ImageSet outs, int W, int H, BlurKernel K,
-                                                     uint32_t key_rgb)
+struct BlurSrc { const uint8_t* ibase; const uint8_t* sbase; size_t img_pitch, seed_pitch; bool masked; };
+
+__device__ __forceinline__ uint32_t blur_px(const BlurSrc& b, int x, int y)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
-    if (x >= W) return;
-    const size_t img_pitch = imgs.pitch, seed_pitch = seeds.pitch, out_pitch = outs.pitch;
-    const uint8_t* ibase = imgs.image(im);
-    const uint8_t* sbase = seeds.base ? seeds.image(im) : nullptr;
-    uint8_t* out = outs.image(im);
-    {   // a black pixel stays black whatever surrounds it (sr:151) -- and outside the holes the mask is black
-        uint32_t c = load_px_bytes(ibase + (size_t)y * img_pitch, x);
-        if (sbase && key_rgb != 0u && load_px_bytes(sbase + (size_t)y * seed_pitch, x) == 0u) c = 0u;
-        if (c == 0u) { store_px_bytes(out + (size_t)y * out_pitch, x, 0u); return; }
-    }
+    uint32_t c = load_px_bytes(b.ibase + (size_t)y * b.img_pitch, x);
+    if (b.masked && load_px_bytes(b.sbase + (size_t)y * b.seed_pitch, x) == 0u) c = 0u;
+    return c;
+}
+
+// The 6 x 6 correlation around a non-black pixel (a black pixel stays black whatever surrounds it, sr:151).
+__device__ __forceinline__ uint32_t masked_blur_pixel(const BlurSrc& b, int x, int y, int W, int H, const BlurKernel& K)
+{
     float acc[3] = {0.0f, 0.0f, 0.0f}, wsum = 0.0f;
     uint32_t centre = 0;
 #pragma unroll
@@ -2000,8 +1998,7 @@ __global__ void __launch_bounds__(256) k_masked_blur(ImageSet imgs, ImageSet see
         for (int kx = 0; kx < 6; ++kx) {
             const int sx = x + kx - 3;
             if (sx < 0 || sx >= W) continue;
-            uint32_t px = load_px_bytes(ibase + (size_t)sy * img_pitch, sx);
-            if (sbase && key_rgb != 0u && load_px_bytes(sbase + (size_t)sy * seed_pitch, sx) == 0u) px = 0u;
+            const uint32_t px = blur_px(b, sx, sy);
             const float k = K.k[6 * ky + kx];
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[c] = acc[c] + k * (float)((px >> (8 * c)) & 0xFF);
@@ -2016,7 +2013,87 @@ __global__ void __launch_bounds__(256) k_masked_blur(ImageSet imgs, ImageSet see
         v = fminf(fmaxf(v, 0.0f), 255.0f);
         o |= (uint32_t)v << (8 * c);
     }
-    store_px_bytes(out + (size_t)y * out_pitch, x, o);
+    return o;
+}
+
+__device__ __forceinline__ BlurSrc blur_src(const ImageSet& imgs, const ImageSet& seeds, int im, uint32_t key_rgb)
+{
+    return BlurSrc{imgs.image(im), seeds.base ? seeds.image(im) : nullptr, imgs.pitch, seeds.pitch, seeds.base != nullptr && key_rgb != 0u};
+}
+
+__global__ void __launch_bounds__(256) k_masked_blur(ImageSet imgs, ImageSet seeds, ImageSet outs, int W, int H, BlurKernel K,
+                                                     uint32_t key_rgb)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
+    if (x >= W) return;
+    const BlurSrc b = blur_src(imgs, seeds, im, key_rgb);
+    uint8_t* orow = outs.image(im) + (size_t)y * outs.pitch;
+    if (blur_px(b, x, y) == 0u) { store_px_bytes(orow, x, 0u); return; }
+    store_px_bytes(orow, x, masked_blur_pixel(b, x, y, W, H, K));
+}
+
+// The same in two passes, for images that are mostly black (an infill mask is: ~4 % of its pixels are not, in strips a few
+// pixels wide -- a wave of 64 consecutive pixels that meets one runs all 36 taps for a handful of lanes): the first pass
+// writes the black pixels and lists the columns of the others row by row (a counter per image row: one counter for the whole
+// pass serialised 3 * 10^5 atomics on one address, 1.2 ms), the second gives every lane of a row's wave a listed pixel.
+template <int PX>      // 4: rows addressable as dwords (12 bytes per lane), 1: any width / alignment
+__global__ void __launch_bounds__(128) k_masked_blur_scan(ImageSet imgs, ImageSet seeds, ImageSet outs, int W, int H, uint32_t key_rgb,
+                                                          uint32_t* __restrict__ list, uint32_t* __restrict__ row_count)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
+    uint32_t c[PX];
+#pragma unroll
+    for (int q = 0; q < PX; ++q) c[q] = 0u;
+    const bool in = g * PX < W;
+    uint8_t* orow = outs.image(im) + (size_t)y * outs.pitch;
+    if (in) {
+        RowIO<PX>::load(imgs.image(im) + (size_t)y * imgs.pitch, g, c);
+        if (seeds.base && key_rgb != 0u) {
+            uint32_t sd[PX];
+            RowIO<PX>::load(seeds.image(im) + (size_t)y * seeds.pitch, g, sd);
+#pragma unroll
+            for (int q = 0; q < PX; ++q) if (sd[q] == 0u) c[q] = 0u;
+        }
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < PX; ++q) any |= c[q] != 0u;
+        if (!any) { const uint32_t z[PX] = {}; RowIO<PX>::store_rgb(orow, g, z); }
+        else {
+#pragma unroll
+            for (int q = 0; q < PX; ++q) if (c[q] == 0u) store_px_bytes(orow, g * PX + q, 0u);
+        }
+    }
+    u64 m[PX];
+    uint32_t total = 0;
+#pragma unroll
+    for (int q = 0; q < PX; ++q) { m[q] = __ballot(c[q] != 0u); total += (uint32_t)__popcll(m[q]); }
+    if (total) {
+        const size_t row = (size_t)im * H + y;
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&row_count[row], total);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            if (c[q] != 0u) list[row * (size_t)W + base + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull))] = (uint32_t)(g * PX + q);
+            base += (uint32_t)__popcll(m[q]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_masked_blur_list(ImageSet imgs, ImageSet seeds, ImageSet outs, int W, int H, BlurKernel K,
+                                                         uint32_t key_rgb, const uint32_t* __restrict__ list, const uint32_t* __restrict__ row_count)
+{
+    const int y = blockIdx.x, im = blockIdx.y;
+    const size_t row = (size_t)im * H + y;
+    const uint32_t n = row_count[row];
+    if (n == 0u) return;
+    const BlurSrc b = blur_src(imgs, seeds, im, key_rgb);
+    uint8_t* orow = outs.image(im) + (size_t)y * outs.pitch;
+    for (uint32_t k = threadIdx.x; k < n; k += 64) {
+        const int x = (int)list[row * (size_t)W + k];
+        store_px_bytes(orow, x, masked_blur_pixel(b, x, y, W, H, K));
+    }
 }
 
 static TeleaArgs telea_args(const TeleaWorkspace& ws, int n, int W, int H, uint32_t key_rgb)
@@ -2078,10 +2155,21 @@ hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int level
 }
 
 hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const ImageSet& out, int n, int W, int H,
-                              const BlurKernel& K, uint32_t key_rgb, hipStream_t s)
+                              const BlurKernel& K, uint32_t key_rgb, hipStream_t s, uint32_t* list, uint32_t* count)
 {
     const dim3 grid((W + 255) / 256, H, n), block(256);
     const ImageSet none{nullptr, 0, 0, 0, 1};
+    if (list && count && getenv("MDVT_BLUR_ONE_PASS") == nullptr) {          // list: n * W * H entries, count: n * H row counters
+        hipError_t e = hipMemsetAsync(count, 0, (size_t)n * H * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        auto dwords = [](const ImageSet& i) { return !i.base || (((uintptr_t)i.base | i.pitch | i.stride | (size_t)i.eye_offset) & 3) == 0; };
+        if (W % 4 == 0 && dwords(img) && dwords(out) && (!seed || dwords(*seed)))
+            hipLaunchKernelGGL(k_masked_blur_scan<4>, dim3((W / 4 + 127) / 128, H, n), dim3(128), 0, s, img, seed ? *seed : none, out, W, H, key_rgb, list, count);
+        else
+            hipLaunchKernelGGL(k_masked_blur_scan<1>, dim3((W + 127) / 128, H, n), dim3(128), 0, s, img, seed ? *seed : none, out, W, H, key_rgb, list, count);
+        hipLaunchKernelGGL(k_masked_blur_list, dim3(H, n), dim3(64), 0, s, img, seed ? *seed : none, out, W, H, K, key_rgb, list, count);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_masked_blur, grid, block, 0, s, img, seed ? *seed : none, out, W, H, K, key_rgb);
     return hipGetLastError();
 }
