@@ -1549,17 +1549,33 @@ constexpr int kDtInf = 1 << 20;          // "no known pixel in this direction" (
 
 // T is zeroed with a memset beforehand; this pass writes 0 (known) / 0xFFFF (to fill) stamps, the need flags (key-coloured
 // pixels) and the work image.
-__global__ void __launch_bounds__(256) k_telea_init(ImageSet seed, TeleaArgs a)
+template <int PX>
+__global__ void __launch_bounds__(128) k_telea_init(ImageSet seed, TeleaArgs a)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, im = blockIdx.z;
     const int W = a.W, H = a.H;
-    if (x >= W) return;
-    const size_t o = (size_t)im * W * H + (size_t)y * W + x;
-    const uint32_t px = load_px_bytes(seed.image(im) + (size_t)y * seed.pitch, x);
-    const bool green = px == a.key_rgb;
-    a.stamp[o] = (green || px == 0u) ? kTeleaUnknown : (uint16_t)0;        // sr:803-805: key-coloured or black = to inpaint
-    a.need[o] = green ? 1 : 0;
-    store_px_bytes(a.img + 3 * ((size_t)im * W * H + (size_t)y * W), x, px);
+    if (g * PX >= W) return;
+    const size_t o = (size_t)im * W * H + (size_t)y * W + (size_t)g * PX;
+    uint32_t px[PX];
+    RowIO<PX>::load(seed.image(im) + (size_t)y * seed.pitch, g, px);
+    uint32_t st = 0, nd = 0;
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+        const bool green = px[q] == a.key_rgb;
+        if (green || px[q] == 0u) {                                        // sr:803-805: key-coloured or black = to inpaint
+            if (PX == 4) { if (q < 2) st |= (uint32_t)kTeleaUnknown << (16 * q); }
+            else a.stamp[o + q] = kTeleaUnknown;
+        } else if (PX != 4) a.stamp[o + q] = 0;
+        if (PX == 4) nd |= (green ? 1u : 0u) << (8 * q); else a.need[o + q] = green ? 1 : 0;
+    }
+    if (PX == 4) {
+        uint32_t st1 = 0;
+#pragma unroll
+        for (int q = 2; q < 4; ++q) if (px[q] == a.key_rgb || px[q] == 0u) st1 |= (uint32_t)kTeleaUnknown << (16 * (q - 2));
+        *reinterpret_cast<uint2*>(a.stamp + o) = make_uint2(st, st1);
+        *reinterpret_cast<uint32_t*>(a.need + o) = nd;
+    }
+    RowIO<PX>::store_rgb(a.img + 3 * ((size_t)im * W * H + (size_t)y * W), g, px);
 }
 
 // Pass A, rows: stamp[x] = distance to the nearest known pixel of the same row (0xFFFF: none), in place.  One workgroup per
@@ -1592,6 +1608,58 @@ __global__ void __launch_bounds__(256) k_telea_dt_rows(uint16_t* __restrict__ st
         if (d[x] == 0) run = x;
         const int v = run - x;
         if (v < (int)d[x]) d[x] = (uint16_t)v;
+    }
+}
+
+// The same with 16-byte row accesses: a thread owns 8 * VEC consecutive pixels (W % 8 == 0, W <= 2048 * VEC).
+template <int VEC>
+__global__ void __launch_bounds__(256) k_telea_dt_rows_vec(uint16_t* __restrict__ stamp, int W, int H)
+{
+    __shared__ int sl[256], sf[256];
+    uint16_t* d = stamp + ((size_t)blockIdx.y * H + blockIdx.x) * W;
+    const int t = threadIdx.x;
+    constexpr int N = 8 * VEC;
+    const int x0 = t * N;
+    uint32_t w[4 * VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        uint4 q = make_uint4(~0u, ~0u, ~0u, ~0u);                       // past the row end: "unknown", never a zero
+        if (x0 + 8 * v < W) q = *reinterpret_cast<const uint4*>(d + x0 + 8 * v);
+        w[4 * v] = q.x; w[4 * v + 1] = q.y; w[4 * v + 2] = q.z; w[4 * v + 3] = q.w;
+    }
+    auto val = [&](int k) { return (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu; };
+    int last = -kDtInf, first = kDtInf;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        if (val(k) == 0u) { last = x0 + k; if (first == kDtInf) first = x0 + k; }
+    sl[t] = last; sf[t] = first;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {            // inclusive prefix max of `last`, inclusive suffix min of `first`
+        const int vl = t >= off ? sl[t - off] : -kDtInf, vf = t + off < 256 ? sf[t + off] : kDtInf;
+        __syncthreads();
+        sl[t] = max(sl[t], vl); sf[t] = min(sf[t], vf);
+        __syncthreads();
+    }
+    int out[N];
+    int run = t > 0 ? sl[t - 1] : -kDtInf;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (val(k) == 0u) run = x0 + k;
+        out[k] = min(x0 + k - run, 0xFFFF);
+    }
+    run = t < 255 ? sf[t + 1] : kDtInf;
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+        if (val(k) == 0u) run = x0 + k;
+        out[k] = min(out[k], run - (x0 + k));
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        if (x0 + 8 * v >= W) continue;
+        uint4 q;
+        q.x = (uint32_t)out[8 * v] | ((uint32_t)out[8 * v + 1] << 16); q.y = (uint32_t)out[8 * v + 2] | ((uint32_t)out[8 * v + 3] << 16);
+        q.z = (uint32_t)out[8 * v + 4] | ((uint32_t)out[8 * v + 5] << 16); q.w = (uint32_t)out[8 * v + 6] | ((uint32_t)out[8 * v + 7] << 16);
+        *reinterpret_cast<uint4*>(d + x0 + 8 * v) = q;
     }
 }
 
@@ -1654,6 +1722,82 @@ __global__ void __launch_bounds__(1024) k_telea_dt_cols(TeleaArgs a, uint32_t ma
             d[(size_t)y * W] = reached ? (uint16_t)run : kTeleaUnknown;
             if (key[(size_t)y * W]) { if (reached) lmax = max(lmax, (uint32_t)run); else ++rem; }
         }
+    }
+    if (rem) atomicAdd(&s_rem, rem);
+    if (lmax) atomicMax(&s_max, lmax);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_rem) atomicAdd(&a.remaining[im], s_rem);
+        if (s_max) atomicMax(&a.last_round[im], s_max);
+    }
+}
+
+// The same with a column segment held in registers between the sweeps (H <= 16 * SEG): the stamps are read once and
+// written once instead of four times and twice.
+template <int SEG>
+__global__ void __launch_bounds__(1024) k_telea_dt_cols_reg(TeleaArgs a, uint32_t max_rounds)
+{
+    __shared__ int ex[16][64], carry[16][64];
+    __shared__ uint32_t s_rem, s_max;
+    const int W = a.W, H = a.H;
+    const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + cx, im = blockIdx.y;
+    const bool act = x < W;
+    const int seglen = (H + 15) / 16, y0 = min(sg * seglen, H), y1 = min(y0 + seglen, H);
+    const int len = act ? y1 - y0 : 0;
+    const size_t base = (size_t)im * W * H + (act ? x : 0);
+    uint16_t* d = a.stamp + base;
+    if (threadIdx.x == 0) { s_rem = 0u; s_max = 0u; }
+    int v[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) {
+        v[k] = kDtInf;
+        if (k < len) { const int q = d[(size_t)(y0 + k) * W]; v[k] = q == 0xFFFF ? kDtInf : q; }
+    }
+    // ---- down ----
+    int run = kDtInf;
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) if (k < len) run = min(run + 1, v[k]);
+    ex[sg][cx] = run;
+    __syncthreads();
+    if (sg == 0) {
+        int c = kDtInf;
+        for (int q = 0; q < 16; ++q) {
+            carry[q][cx] = c;
+            const int l = min((q + 1) * seglen, H) - min(q * seglen, H);
+            c = min(ex[q][cx], c + l);
+        }
+    }
+    __syncthreads();
+    run = carry[sg][cx];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) if (k < len) { run = min(run + 1, v[k]); v[k] = run; }
+    __syncthreads();
+    // ---- up ----
+    run = kDtInf;
+#pragma unroll
+    for (int k = SEG - 1; k >= 0; --k) if (k < len) run = min(run + 1, v[k]);
+    ex[sg][cx] = run;
+    __syncthreads();
+    if (sg == 0) {
+        int c = kDtInf;
+        for (int q = 15; q >= 0; --q) {
+            carry[q][cx] = c;
+            const int l = min((q + 1) * seglen, H) - min(q * seglen, H);
+            c = min(ex[q][cx], c + l);
+        }
+    }
+    __syncthreads();
+    run = carry[sg][cx];
+    uint32_t rem = 0, lmax = 0;
+    const uint8_t* key = a.need + base;
+#pragma unroll
+    for (int k = SEG - 1; k >= 0; --k) {
+        if (k >= len) continue;
+        run = min(run + 1, v[k]);
+        const bool reached = run <= (int)max_rounds;
+        d[(size_t)(y0 + k) * W] = reached ? (uint16_t)run : kTeleaUnknown;
+        if (key[(size_t)(y0 + k) * W]) { if (reached) lmax = max(lmax, (uint32_t)run); else ++rem; }
     }
     if (rem) atomicAdd(&s_rem, rem);
     if (lmax) atomicMax(&s_max, lmax);
@@ -2115,9 +2259,15 @@ hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int
     if (e != hipSuccess) return e;
     const size_t npx = (size_t)n * W * H;
     if ((e = hipMemsetAsync(ws.T, 0, npx * sizeof(float), s)) != hipSuccess) return e;           // T = 0 at every known pixel
-    hipLaunchKernelGGL(k_telea_init, dim3((W + 255) / 256, H, n), dim3(256), 0, s, seed, a);
-    hipLaunchKernelGGL(k_telea_dt_rows, dim3(H, n), dim3(256), 0, s, ws.stamp, W, H);
-    hipLaunchKernelGGL(k_telea_dt_cols, dim3((W + 63) / 64, n), dim3(1024), 0, s, a, (uint32_t)max_rounds);
+    if (W % 4 == 0 && (((uintptr_t)seed.base | seed.pitch | seed.stride | (size_t)seed.eye_offset) & 3) == 0)
+        hipLaunchKernelGGL(k_telea_init<4>, dim3((W / 4 + 127) / 128, H, n), dim3(128), 0, s, seed, a);
+    else
+        hipLaunchKernelGGL(k_telea_init<1>, dim3((W + 127) / 128, H, n), dim3(128), 0, s, seed, a);
+    if (W % 8 == 0 && W <= 2048) hipLaunchKernelGGL(k_telea_dt_rows_vec<1>, dim3(H, n), dim3(256), 0, s, ws.stamp, W, H);
+    else if (W % 8 == 0 && W <= 4096) hipLaunchKernelGGL(k_telea_dt_rows_vec<2>, dim3(H, n), dim3(256), 0, s, ws.stamp, W, H);
+    else hipLaunchKernelGGL(k_telea_dt_rows, dim3(H, n), dim3(256), 0, s, ws.stamp, W, H);
+    if (H <= 16 * 68) hipLaunchKernelGGL(k_telea_dt_cols_reg<68>, dim3((W + 63) / 64, n), dim3(1024), 0, s, a, (uint32_t)max_rounds);
+    else hipLaunchKernelGGL(k_telea_dt_cols, dim3((W + 63) / 64, n), dim3(1024), 0, s, a, (uint32_t)max_rounds);
     hipLaunchKernelGGL(k_telea_rmax, dim3(1), dim3(1), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(h_levels, ws.counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
