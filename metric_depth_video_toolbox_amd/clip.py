@@ -500,8 +500,8 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     frames, secs, holes = render_clip(depth, color, outs["sbs"], outs["mask"], clip, lo=lo, hi=hi, batch=batch,
                                       out_depth_rgb=outs.get("depth"),
                                       out_infill=outs.get("infill"), green_and_black=green_and_black_infill_mask)
-    for o in outs.values():
-        o.flush()
+    # (no msync: the dumps were written through the page cache, which every later reader shares; forcing 6 GB of dirty pages
+    #  to the disk before the rename is what the reference's writers do not do either, and costs seconds on a container fs)
     stats = D.gather_rank_stats(frames, secs, holes)
     if world > 1:
         import torch.distributed as dist

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How far the level-synchronous infill order (the device's, = orc_telea_levels) is from the sequential fast-marching order
 of cv2.inpaint (restated as orc_telea_fmm; same estimator, same decrees) on rendered seed images.  CPU only (oracle).
-usage: python tools/infill_order_report.py [--out profiles/r02_infill_order_vs_fmm.md]"""
+usage: python tests/report_infill_order.py [--out profiles/r02_infill_order_vs_fmm.md]"""
 import argparse, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,7 +34,7 @@ hdr = ("| frame size | frame | eye | hole px | mean | p50 | p90 | p99 | share wi
        "|---|---|---|---|---|---|---|---|---|---|---|\n")
 body = "".join(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]} | {r[4]:.2f} | {r[5]:.0f} | {r[6]:.0f} | {r[7]:.0f} | {r[8]:.2f} | {r[9]:.2f} | {r[10]:.0f} |\n" for r in rows)
 text = ("# Infill-mask completion: level-synchronous order vs sequential fast marching\n\n"
-        "`python tools/infill_order_report.py` (CPU, oracle only).  Per hole pixel, max over channels of |orc_telea_levels - orc_telea_fmm| in LSB:\n"
+        "`python tests/report_infill_order.py` (CPU, oracle only).  Per hole pixel, max over channels of |orc_telea_levels - orc_telea_fmm| in LSB:\n"
         "the device's order (breadth-first levels = L1 distance to the nearest known pixel) against the heap order of `cv2.inpaint`\n"
         "(restated; OpenCV itself is not installed), same estimator and decrees.  Seeds: product-default render (mesh, edge removal,\n"
         "edge points, green key) of the synthetic clip.\n\n" + hdr + body)
