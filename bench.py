@@ -444,7 +444,35 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
                                              nf, W, H, dev, torch)
     out["product_default"]["what"] = ("mesh + --infill_mask (89-degree edge filter, edge points, green key) + per-frame convergence "
                                       "(movie_2_3D.py:433-445): the general path")
+    # the finished infill-mask image of the same frames (sr:803-808): render with the seed image, then the completion
+    res = rp.render(depth_rgb[:nf], color_rgb[:nf], pd, want_seed=True)
+    seed = res["seed"]
+    fin = torch.empty_like(seed)
+    rp.finish_infill_mask_sbs(seed, out=fin)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ms = []
+    for _ in range(5):
+        torch.cuda.synchronize(dev)
+        ev[0].record()
+        rp.finish_infill_mask_sbs(seed, out=fin)
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+        ms.append(ev[0].elapsed_time(ev[1]))
+    ms.sort()
+    out["infill_mask_completion"] = {"frames_per_call": nf, "ms_per_call_median_of_5": ms[2], "ms_per_frame": ms[2] / nf,
+                                     "what": "mdvt_finish_infill_mask_stereo on the product-default seed images of both eyes "
+                                             "(level-synchronous Telea inpaint + masked blur, one host read-back per pass)"}
+    out["product_default_with_finished_infill_mask"] = {
+        "fps": 1.0 / (1.0 / out["product_default"]["fps"] + ms[2] * 1e-3 / nf),
+        "what": "render + completion, per-frame times added"}
     rp.close()
+    rme = StereoRerenderer(W, H, device=dev.index, pupillary_distance=65, infill_mask=True)
+    nf = min(32, n_have)
+    pme = [rme.frame_params(xfov=45.0) for _ in range(nf)]
+    out["mesh_infill_mask"] = measure_variant(lambda: rme.prepare(depth_rgb[:nf], color_rgb[:nf], pme, out_sbs=sbs[:nf], out_mask=mask[:nf]),
+                                              nf, W, H, dev, torch)
+    out["mesh_infill_mask"]["what"] = "mesh + --infill_mask, pure stereo shift: k_edge_filter + k_mesh_band with edge removal / edge points / seed"
+    rme.close()
     return out
 
 

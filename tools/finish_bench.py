@@ -17,12 +17,14 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--rounds", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--config", type=int, default=3, help="synthetic scene id (bench.py uses 2)")
+ap.add_argument("--conv", type=float, default=0.0, help="convergence distance in metres (0: none)")
 ap.add_argument("--per-eye", action="store_true", help="one call per eye instead of the stereo entry point")
 a = ap.parse_args()
 W, H, N = a.width, a.height, a.frames
-d, c = synthetic.SyntheticScene(W, H, config_id=3).clip(N)
+d, c = synthetic.SyntheticScene(W, H, config_id=a.config).clip(N)
 r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
-p = r.frame_params(xfov=45.0)
+p = r.frame_params(xfov=45.0, **({'convergence_distance': a.conv} if a.conv > 0 else {}))
 res = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), p, want_seed=True)
 seed = res["seed"]
 out = torch.empty_like(seed)

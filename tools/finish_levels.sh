@@ -2,7 +2,7 @@
 # Per-level durations of the infill-mask completion's need / fill launches and per-kernel totals of one pass (GPU box).
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pf
-rocprofv3 --kernel-trace --output-format csv -d /tmp/pf -o t -- python $GRAFT_REPO_ROOT/tools/finish_bench.py --frames ${1:-16} --reps 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/pf -o t -- python $GRAFT_REPO_ROOT/tools/finish_bench.py --frames ${1:-16} --reps 1 ${@:2} > /dev/null 2>&1
 f=$(find /tmp/pf -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
