@@ -49,6 +49,7 @@ struct mdvt_ctx {
     bool ws_keys = false, ws_ekeys = false, ws_edges = false;
     unsigned long long* keys[2] = {nullptr, nullptr};
     unsigned long long* ekeys[2] = {nullptr, nullptr};
+    uint32_t* elist = nullptr;        // written edge-key words per (slot, source row) + counters (behind the entries)
     uint4* gverts[2] = {nullptr, nullptr};
     unsigned long long* cbuf[2] = {nullptr, nullptr};
     bool ws_gverts = false;
@@ -195,6 +196,8 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     }
     if (grow || (need_ekeys && !c->ws_ekeys)) {
         for (int e = 0; e < 2; ++e) { if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); c->ekeys[e] = nullptr; }
+        if (c->elist) (void)hipFree(c->elist);
+        c->elist = nullptr;
         c->ws_ekeys = false;
     }
     if (grow || (need_edges && !c->ws_edges)) {
@@ -221,6 +224,8 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
             MDVT_HIP(c, hipMalloc((void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long)));
             MDVT_HIP(c, hipMemsetAsync(c->ekeys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));
         }
+        MDVT_HIP(c, hipMalloc((void**)&c->elist, (nf * 2 * npx + nf * (size_t)c->H) * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMemsetAsync(c->elist + nf * 2 * npx, 0, nf * (size_t)c->H * sizeof(uint32_t), s));   // counters; the reset pass keeps them 0
         c->ws_ekeys = true;
     }
     if (need_gverts && !c->ws_gverts) {
@@ -342,6 +347,7 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->tri_invalid) (void)hipFree(c->tri_invalid);
     if (c->unused) (void)hipFree(c->unused);
     if (c->ebuf) (void)hipFree(c->ebuf);
+    if (c->elist) (void)hipFree(c->elist);
     if (c->row_counts) (void)hipFree(c->row_counts);
     if (c->rowcell) (void)hipFree(c->rowcell);
     if (c->telea_levels_host) (void)hipHostFree(c->telea_levels_host);
@@ -503,6 +509,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.key_rgb = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     a.keys[0] = c->keys[0]; a.keys[1] = c->keys[1];
     a.ekeys[0] = c->ekeys[0]; a.ekeys[1] = c->ekeys[1];
+    a.elist = c->elist; a.elist_count = c->elist ? c->elist + (size_t)c->ws_frames * 2 * (size_t)W * H : nullptr;
     a.gverts[0] = c->gverts[0]; a.gverts[1] = c->gverts[1];
     a.cbuf[0] = c->cbuf[0]; a.cbuf[1] = c->cbuf[1];
     a.tri_invalid = c->tri_invalid; a.unused = c->unused; a.ebuf = c->ebuf;
@@ -519,6 +526,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                 if (c->keys[e]) MDVT_HIP(c, hipMemsetAsync(c->keys[e], 0xFF, bytes, s));
                 if (c->ekeys[e]) MDVT_HIP(c, hipMemsetAsync(c->ekeys[e], 0xFF, bytes, s));
             }
+            if (c->elist) MDVT_HIP(c, hipMemsetAsync(a.elist_count, 0, (size_t)c->ws_frames * H * sizeof(uint32_t), s));
         }
         c->keys_dirty = true;
     }

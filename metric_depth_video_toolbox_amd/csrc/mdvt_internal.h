@@ -53,6 +53,8 @@ struct RenderArgs {
     // workspace (general path / edge filter); per frame-in-flight slices
     unsigned long long* keys[2]; // [slot][H*W] 64-bit z keys per eye
     unsigned long long* ekeys[2];// edge-point keys per eye
+    uint32_t* elist;             // the edge-key words written since the last resolve, one segment of 2 W entries (eye << 31 | pixel) per
+    uint32_t* elist_count;       //   (slot, source row) and its counter: k_edge_keys_reset empties exactly those words
     uint4* gverts[2];            // general mesh path: per-eye projected vertices {X, Y (snapped), 1/Z', rgb}, [slot][H*W]
     unsigned long long* cbuf[2]; // general mesh path: per-eye colour side buffer, draw id << 32 | rgb of some fragment of the pixel
     uint32_t* ebuf;              // pure-shift mesh rows with edge points: [slot][eye][H*W] edge-point keys code16 << 16 | column, EMPTY between uses

@@ -652,6 +652,34 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
 // =================================================================================================
 //   key = f32 bits of Z' << 32 | i << 16 | j      (Z' > 0, so the bit pattern orders like the value)
 
+// An edge point's key into the general paths' edge-key plane.  Whoever finds the word EMPTY also lists it (segment of the
+// point's source row: at most one word per vertex and eye, so 2 W entries hold them all): the resolve pass then reads the
+// edge keys only where the render left a hole, and k_edge_keys_reset empties exactly the written words -- instead of the
+// resolve rewriting the whole plane (8 B/px per eye) for the ~3 % of the words that were touched.
+__device__ __forceinline__ void post_edge_key(const RenderArgs& a, int eye, int fr, int src_row, size_t pix, u64 key)
+{
+    const u64 old = atomicMin(&a.ekeys[eye][(size_t)fr * a.ws_stride_px + pix], key);
+    if (old == kEmpty64) {
+        const size_t seg = (size_t)fr * a.H + src_row;
+        const uint32_t k = atomicAdd(&a.elist_count[seg], 1u);
+        a.elist[seg * (size_t)(2 * a.W) + k] = ((uint32_t)eye << 31) | (uint32_t)pix;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_edge_keys_reset(RenderArgs a)
+{
+    const int fr = blockIdx.y;
+    const size_t seg = (size_t)fr * a.H + blockIdx.x;
+    const uint32_t n = a.elist_count[seg];
+    if (n == 0u) return;
+    const uint32_t* list = a.elist + seg * (size_t)(2 * a.W);
+    for (uint32_t k = threadIdx.x; k < n; k += 64) {
+        const uint32_t e = list[k];
+        a.ekeys[e >> 31][(size_t)fr * a.ws_stride_px + (e & 0x7FFFFFFFu)] = kEmpty64;
+    }
+    if (threadIdx.x == 0) a.elist_count[seg] = 0u;           // (every lane of the one wave has read n)
+}
+
 template <int FLAGS>
 __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
 {
@@ -693,7 +721,7 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
             const int px = (int)rintf(v.u), py = (int)rintf(v.v);   // np.round (sr:746)
             if (px < 0 || px >= W || py < 0 || py >= H) continue;
             const u64 key = ((u64)__float_as_uint(v.z) << 32) | src;
-            atomicMin(&a.ekeys[eye][(size_t)fr * a.ws_stride_px + (size_t)py * W + px], key);
+            post_edge_key(a, eye, fr, i, (size_t)py * W + px, key);
         }
     }
 }
@@ -729,13 +757,13 @@ __global__ void __launch_bounds__(256) k_edge_points_splat4(RenderArgs a)
             const int px = (int)rintf(v.u), py = (int)rintf(v.v);   // np.round (sr:746)
             if (px < 0 || px >= W || py < 0 || py >= H) continue;
             const u64 key = ((u64)__float_as_uint(v.z) << 32) | src;
-            atomicMin(&a.ekeys[eye][(size_t)fr * a.ws_stride_px + (size_t)py * W + px], key);
+            post_edge_key(a, eye, fr, i, (size_t)py * W + px, key);
         }
     }
 }
 
-// Resolve of both general paths: PX pixels per thread, coalesced key reads, the keys are reset to EMPTY
-// on the way out (so the next submission needs no clearing pass), colour from the key (mesh) or gathered
+// Resolve of both general paths: PX pixels per thread, coalesced key reads, the z keys are reset to EMPTY
+// on the way out (so the next submission needs no clearing pass; the edge keys: k_edge_keys_reset), colour from the key (mesh) or gathered
 // from the source frame by the winning source index (points).
 template <int PX, int FLAGS, bool MESH>
 __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
@@ -812,10 +840,6 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
         oz[q] = zval;
         if (SEED && a.seed[eye]) spx[q] = seed_pixel(a, a.fp[f], f, eye, g * PX + q, y, hole, esrc, MESH ? 1 : 0);
     }
-    if (EDGE) {                      // the edge keys are reset for the next submission whether they were read or not
-#pragma unroll
-        for (int q = 0; q < PX; ++q) erow[q] = kEmpty64;
-    }
     if (SEED && a.seed[eye]) RowIO<PX>::store_rgb(a.seed[eye] + (size_t)f * a.seed_stride + (size_t)y * a.seed_pitch, g, spx);
     RowIO<PX>::store_rgb(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)y * a.rgb_pitch, g, opx);
     RowIO<PX>::store_mask(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch, g, om);
@@ -840,6 +864,7 @@ static hipError_t launch_resolve_general(const RenderPlan& plan, const RenderArg
         MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(4) MDVT_CASE(5) MDVT_CASE(8) MDVT_CASE(9) MDVT_CASE(12) MDVT_CASE(13)
     }
 #undef MDVT_CASE
+    if (edge) hipLaunchKernelGGL(k_edge_keys_reset, dim3(a.H, plan.n), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
