@@ -54,6 +54,7 @@ struct mdvt_ctx {
     unsigned long long* cbuf[2] = {nullptr, nullptr};
     bool ws_gverts = false;
     bool keys_dirty = false;          // a general-path submission was interrupted between splat and resolve
+    uint32_t key_parity = 0;          // bit s: parity of the next use of z-key slot s (mdvt_device.h, parity scheme)
     uint32_t* ebuf = nullptr;         // edge-point keys of the pure-shift mesh rows (allocated with the edge-filter workspace)
     uint8_t* tri_invalid = nullptr;
     uint8_t* unused = nullptr;
@@ -215,8 +216,9 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     if (need_keys && !c->ws_keys) {
         for (int e = 0; e < 2; ++e) {
             MDVT_HIP(c, hipMalloc((void**)&c->keys[e], nf * npx * sizeof(unsigned long long)));
-            MDVT_HIP(c, hipMemsetAsync(c->keys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));     // EMPTY; resolve keeps them so
+            MDVT_HIP(c, hipMemsetAsync(c->keys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));     // parity 0's empty value
         }
+        c->key_parity = 0;
         c->ws_keys = true;
     }
     if (need_ekeys && !c->ws_ekeys) {
@@ -472,6 +474,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         // leave the chip 30 % idle in the last wave of workgroups (476 -> see DESIGN.md); the workspace is 11 B/px per frame
         if (!r.general && plan.mode == MDVT_MODE_MESH) ws_chunk = 4 * kWorkspaceChunk;
         if (tuned_chunk) ws_chunk = tuned_chunk;
+        if (r.general && ws_chunk > 32) ws_chunk = 32;        // one parity bit per z-key slot (uint32_t key_parity)
         return n < ws_chunk ? n : ws_chunk;
     };
     int ws_frames = 0, count_frames = 0;
@@ -527,6 +530,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                 if (c->ekeys[e]) MDVT_HIP(c, hipMemsetAsync(c->ekeys[e], 0xFF, bytes, s));
             }
             if (c->elist) MDVT_HIP(c, hipMemsetAsync(a.elist_count, 0, (size_t)c->ws_frames * H * sizeof(uint32_t), s));
+            c->key_parity = 0;
         }
         c->keys_dirty = true;
     }
@@ -542,7 +546,9 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                                            plan.mode == MDVT_MODE_MESH, c->tri_invalid, a.ws_stride_tri,
                                            c->unused, a.ws_stride_px, s));
         }
+        a.key_parity = c->key_parity;
         hipError_t e = launch_render(plan, a, s);
+        if (r.general && e == hipSuccess) c->key_parity ^= plan.n >= 32 ? 0xFFFFFFFFu : ((1u << plan.n) - 1u);   // these slots' next use has the other parity
         if (e == hipErrorNotSupported) return fail(c, MDVT_ERR_UNSUPPORTED, "render mode %d is not built yet", plan.mode);
         if (e != hipSuccess) return fail(c, MDVT_ERR_HIP, "render launch failed: %s", hipGetErrorString(e));
         if ((want_bits || io->hole_counts) && !plan.fused_bits) MDVT_HIP(c, launch_pack_mask(a, plan.n, s));

@@ -233,6 +233,34 @@ __device__ __forceinline__ bool tri_setup(TriSetup& t, const Vert& a, const Vert
 __device__ __forceinline__ uint32_t draw_id_global(int pass, int i, int j) { return ((uint32_t)pass << 31) | ((uint32_t)i << 16) | (uint32_t)j; }
 __device__ __forceinline__ uint32_t depth_bits(float iz) { return ~__float_as_uint(iz); }
 
+// ---- z keys of the general paths (global memory), parity scheme ------------------------------------------------------
+// A slot of the key planes is used with alternating parity.  Parity 0: keys have the top bit clear and are posted with
+// atomicMin; parity 1: keys have it set and are posted with atomicMax.  "Covered by this use" is then simply "top bit ==
+// parity": whatever the previous use (other parity) left in a word loses to every fragment of this one and does not count as
+// covered, so the resolve pass only has to rewrite the words this use left UNcovered (the holes, a few per cent) with the
+// next parity's empty value -- not reset the whole plane (8 B/px per eye) after every use.
+//   payload (63 bits) = 31-bit order key of the depth << 32 | 32-bit tie breaker, arranged so that the winner is the
+//   nearest fragment, ties to the smaller tie breaker (first drawn triangle / lower source index).
+__device__ __forceinline__ u64 zkey_empty(uint32_t parity) { return parity ? 0ull : ~0ull; }
+__device__ __forceinline__ bool zkey_covered(u64 key, uint32_t parity) { return (uint32_t)(key >> 63) == parity; }
+// `nearer_is_larger`: the 31-bit value grows towards the camera (1/Z bits: mesh) or away from it (Z bits: points)
+template <bool NEARER_IS_LARGER>
+__device__ __forceinline__ void zkey_post(u64* word, uint32_t parity, uint32_t depth31, uint32_t tie)
+{
+    // parity 0 / atomicMin wants "nearer = smaller, first = smaller"; parity 1 / atomicMax the opposite
+    const uint32_t d_min = NEARER_IS_LARGER ? 0x7FFFFFFFu - depth31 : depth31;
+    if (parity == 0u) atomicMin(word, ((u64)d_min << 32) | tie);
+    else atomicMax(word, (1ull << 63) | ((u64)(0x7FFFFFFFu - d_min) << 32) | (uint32_t)~tie);
+}
+template <bool NEARER_IS_LARGER>
+__device__ __forceinline__ void zkey_decode(u64 key, uint32_t parity, uint32_t& depth31, uint32_t& tie)
+{
+    const uint32_t hi = (uint32_t)(key >> 32) & 0x7FFFFFFFu;
+    const uint32_t d_min = parity ? 0x7FFFFFFFu - hi : hi;
+    depth31 = NEARER_IS_LARGER ? 0x7FFFFFFFu - d_min : d_min;
+    tie = parity ? ~(uint32_t)key : (uint32_t)key;
+}
+
 struct RowTies {
     uint32_t* bits;      // LDS: one bit per pixel of the row, then one flag word (index nwords)
     int nwords;

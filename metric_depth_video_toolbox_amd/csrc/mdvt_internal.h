@@ -51,7 +51,8 @@ struct RenderArgs {
     int32_t frame0;              // first frame of this launch within the batch
     uint32_t key_rgb;            // R | G<<8 | B<<16
     // workspace (general path / edge filter); per frame-in-flight slices
-    unsigned long long* keys[2]; // [slot][H*W] 64-bit z keys per eye
+    unsigned long long* keys[2]; // [slot][H*W] 64-bit z keys per eye (parity scheme: mdvt_device.h)
+    uint32_t key_parity;         // bit s = parity of slot s in this launch
     unsigned long long* ekeys[2];// edge-point keys per eye
     uint32_t* elist;             // the edge-key words written since the last resolve, one segment of 2 W entries (eye << 31 | pixel) per
     uint32_t* elist_count;       //   (slot, source row) and its counter: k_edge_keys_reset empties exactly those words

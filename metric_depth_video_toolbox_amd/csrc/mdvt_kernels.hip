@@ -709,8 +709,7 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
             if (!v.ok) continue;
             if (!(v.u >= 0.0f && v.u < (float)W && v.v >= 0.0f && v.v < (float)H)) continue;
             const int px = (int)floorf(v.u), py = (int)floorf(v.v);
-            const u64 key = ((u64)__float_as_uint(v.z) << 32) | src;
-            atomicMin(&a.keys[eye][(size_t)fr * a.ws_stride_px + (size_t)py * W + px], key);
+            zkey_post<false>(&a.keys[eye][(size_t)fr * a.ws_stride_px + (size_t)py * W + px], (a.key_parity >> fr) & 1u, __float_as_uint(v.z), src);   // v.z > 0
         }
     } else if (EDGE) {
 #pragma unroll
@@ -762,8 +761,8 @@ __global__ void __launch_bounds__(256) k_edge_points_splat4(RenderArgs a)
     }
 }
 
-// Resolve of both general paths: PX pixels per thread, coalesced key reads, the z keys are reset to EMPTY
-// on the way out (so the next submission needs no clearing pass; the edge keys: k_edge_keys_reset), colour from the key (mesh) or gathered
+// Resolve of both general paths: PX pixels per thread, coalesced key reads; the z keys need no clearing pass (parity
+// scheme, mdvt_device.h: only the uncovered words are rewritten; the edge keys: k_edge_keys_reset), colour from the key (mesh) or gathered
 // from the source frame by the winning source index (points).
 template <int PX, int FLAGS, bool MESH>
 __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
@@ -778,11 +777,13 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
     const uint8_t* cbase = a.color + (size_t)f * a.color_stride;
     u64* krow = a.keys[eye] + (size_t)fr * a.ws_stride_px + (size_t)y * W + (size_t)g * PX;
     u64* erow = EDGE ? a.ekeys[eye] + (size_t)fr * a.ws_stride_px + (size_t)y * W + (size_t)g * PX : nullptr;
+    const uint32_t parity = (a.key_parity >> fr) & 1u;
     u64 key[PX];
 #pragma unroll
     for (int q = 0; q < PX; ++q) key[q] = krow[q];
 #pragma unroll
-    for (int q = 0; q < PX; ++q) krow[q] = kEmpty64;
+    for (int q = 0; q < PX; ++q)                               // only what this use left uncovered needs the next use's empty value
+        if (!zkey_covered(key[q], parity)) krow[q] = zkey_empty(parity ^ 1u);
     uint32_t opx[PX], om[PX], spx[PX];
     float oz[PX];
     const uint4* gv = MESH ? a.gverts[eye] + (size_t)fr * a.ws_stride_px : nullptr;
@@ -794,16 +795,18 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
     }
 #pragma unroll
     for (int q = 0; q < PX; ++q) {
-        const bool covered = key[q] != kEmpty64;
+        const bool covered = zkey_covered(key[q], parity);
         uint32_t rgb = 0;
         float zval = 0.0f;
+        uint32_t kdepth = 0, ktie = 0;
         if (covered) {
+            if (MESH) zkey_decode<true>(key[q], parity, kdepth, ktie); else zkey_decode<false>(key[q], parity, kdepth, ktie);
             if (MESH) {
                 // the key names the winning triangle (pass << 31 | i << 16 | j).  Its colour is in the side buffer unless another
                 // fragment of this pixel stored last: then its three projected vertices are read back and the fragment is
                 // evaluated exactly as the rasteriser evaluated it
-                const uint32_t id = (uint32_t)key[q];
-                if (ZOUT) zval = 1.0f / __uint_as_float(~(uint32_t)(key[q] >> 32));
+                const uint32_t id = ktie;
+                if (ZOUT) zval = 1.0f / __uint_as_float(kdepth);
                 if ((uint32_t)(cw[q] >> 32) == id && !(a.debug_skip & 64)) { rgb = (uint32_t)cw[q]; }     // (bit 6: test hook, always re-shade)
                 else {
                 const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
@@ -820,9 +823,9 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
                 rgb = shade_px(q0, q1, q2, riz, A.w, v1.w, v2.w);
                 }
             } else {
-                const uint32_t src = (uint32_t)key[q];
+                const uint32_t src = ktie;
                 rgb = load_px_bytes(cbase + (size_t)(src >> 16) * a.color_pitch, (int)(src & 0xFFFFu));
-                if (ZOUT) zval = __uint_as_float((uint32_t)(key[q] >> 32));
+                if (ZOUT) zval = __uint_as_float(kdepth);
             }
         }
         const bool hole = !covered || rgb == a.key_rgb;

@@ -22,12 +22,12 @@ namespace {
 
 constexpr int kSmallBox = 12;      // pixel centres in the bounding box of a triangle the owning lane walks itself
 
-__device__ __forceinline__ void mesh_global_fragment(u64* keys, u64* cbuf, size_t o, float q0, float q1, float q2,
+__device__ __forceinline__ void mesh_global_fragment(u64* keys, u64* cbuf, uint32_t parity, size_t o, float q0, float q1, float q2,
                                                      uint32_t c0, uint32_t c1, uint32_t c2, uint32_t did)
 {
     asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));     // (the colour conversions belong to the fragment, not to every triangle's set-up)
     const float iz = (q0 + q1) + q2;
-    atomicMin(&keys[o], ((u64)depth_bits(iz) << 32) | did);
+    zkey_post<true>(&keys[o], parity, __float_as_uint(iz), did);          // iz > 0: its bits are a 31-bit order key
     cbuf[o] = ((u64)did << 32) | shade_px(q0, q1, q2, rcp_exact(iz), c0, c1, c2);
 }
 
@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
     const int fr = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
+    const uint32_t parity = (a.key_parity >> fr) & 1u;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     // the 2 x 129 vertex records of both eyes, fetched once per workgroup with all loads in flight together
     __shared__ uint4 sv[2][2][129];
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
                                         if (tri_small_inside(ts, w)) {
                                             float q0, q1, q2;
                                             tri_small_weights(ts, w, q0, q1, q2);
-                                            mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
+                                            mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
                                         }
                                         tri_small_right(ts, w);
                                     }
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nse
             for (int px = lo + sub; px <= hi; px += 16) {
                 float q0, q1, q2;
                 if (tri_sample(t, px, py, q0, q1, q2))
-                    mesh_global_fragment(keys, cbuf, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
+                    mesh_global_fragment(keys, cbuf, (a.key_parity >> slot) & 1u, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
             }
         }
     }
