@@ -27,16 +27,18 @@ ap.add_argument("--conv", type=float, default=None)
 ap.add_argument("--pose", action="store_true")
 ap.add_argument("--bits", action="store_true")
 ap.add_argument("--counts", action="store_true")
+ap.add_argument("--edges", action="store_true", help="remove_edges without --infill_mask (edge points painted, no seed image)")
+ap.add_argument("--noedgepts", action="store_true", help="with --edges / --infill: dont_place_points_in_edges")
 a = ap.parse_args()
 W, H, N = a.width, a.height, a.frames
 if os.environ.get('KB_ORDER'):
-    r = StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not a.mesh, infill_mask=a.infill)
+    r = StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not a.mesh, infill_mask=a.infill, remove_edges=a.edges or a.infill, dont_place_points_in_edges=a.noedgepts)
     d, c = SyntheticScene(W, H, config_id=2).clip(N)
     d, c = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
 else:
     d, c = SyntheticScene(W, H, config_id=2).clip(N)
     d, c = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
-    r = StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not a.mesh, infill_mask=a.infill)
+    r = StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not a.mesh, infill_mask=a.infill, remove_edges=a.edges or a.infill, dont_place_points_in_edges=a.noedgepts)
 from metric_depth_video_toolbox_amd.synthetic import synthetic_pose_track
 Ts = synthetic_pose_track(N) if a.pose else [None] * N
 p = [r.frame_params(xfov=45.0, convergence_distance=a.conv, transformation=Ts[k]) for k in range(N)]
