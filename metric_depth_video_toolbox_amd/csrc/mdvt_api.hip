@@ -55,7 +55,6 @@ struct mdvt_ctx {
     bool ws_gverts = false;
     bool keys_dirty = false;          // a general-path submission was interrupted between splat and resolve
     uint32_t key_parity = 0;          // bit s: parity of the next use of z-key slot s (mdvt_device.h, parity scheme)
-    uint32_t* ebuf = nullptr;         // edge-point keys of the pure-shift mesh rows (allocated with the edge-filter workspace)
     uint8_t* tri_invalid = nullptr;
     uint8_t* unused = nullptr;
     uint32_t* bigq = nullptr;         // general mesh path: queue of large triangles + its counter (last dword)
@@ -204,8 +203,7 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     if (grow || (need_edges && !c->ws_edges)) {
         if (c->tri_invalid) (void)hipFree(c->tri_invalid);
         if (c->unused) (void)hipFree(c->unused);
-        if (c->ebuf) (void)hipFree(c->ebuf);
-        c->tri_invalid = nullptr; c->unused = nullptr; c->ebuf = nullptr; c->ws_edges = false;
+        c->tri_invalid = nullptr; c->unused = nullptr; c->ws_edges = false;
     }
     if (grow || (need_gverts && !c->ws_gverts)) {
         for (int e = 0; e < 2; ++e) { if (c->gverts[e]) (void)hipFree(c->gverts[e]); c->gverts[e] = nullptr; if (c->cbuf[e]) (void)hipFree(c->cbuf[e]); c->cbuf[e] = nullptr; }
@@ -247,10 +245,6 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     if (need_edges && !c->ws_edges) {
         MDVT_HIP(c, hipMalloc((void**)&c->tri_invalid, nf * ntri));
         MDVT_HIP(c, hipMalloc((void**)&c->unused, nf * npx));
-        if (c->cfg.mode == MDVT_MODE_MESH && c->cfg.edge_points) {
-            MDVT_HIP(c, hipMalloc((void**)&c->ebuf, 2 * nf * npx * sizeof(uint32_t)));                // [slot][eye][H*W]
-            MDVT_HIP(c, hipMemsetAsync(c->ebuf, 0xFF, 2 * nf * npx * sizeof(uint32_t), s));      // EMPTY; the kernel keeps it so
-        }
         c->ws_edges = true;
     }
     return MDVT_OK;
@@ -348,7 +342,6 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->bigq) (void)hipFree(c->bigq);
     if (c->tri_invalid) (void)hipFree(c->tri_invalid);
     if (c->unused) (void)hipFree(c->unused);
-    if (c->ebuf) (void)hipFree(c->ebuf);
     if (c->elist) (void)hipFree(c->elist);
     if (c->row_counts) (void)hipFree(c->row_counts);
     if (c->rowcell) (void)hipFree(c->rowcell);
@@ -515,7 +508,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.elist = c->elist; a.elist_count = c->elist ? c->elist + (size_t)c->ws_frames * 2 * (size_t)W * H : nullptr;
     a.gverts[0] = c->gverts[0]; a.gverts[1] = c->gverts[1];
     a.cbuf[0] = c->cbuf[0]; a.cbuf[1] = c->cbuf[1];
-    a.tri_invalid = c->tri_invalid; a.unused = c->unused; a.ebuf = c->ebuf;
+    a.tri_invalid = c->tri_invalid; a.unused = c->unused;
     if (c->bigq) {
         a.bigq = c->bigq; a.bigq_cap = c->bigq_cap; a.bigq_count = c->bigq + (size_t)c->bigq_cap * mdvt::kBigRecDwords;
     }

@@ -58,7 +58,6 @@ struct RenderArgs {
     uint32_t* elist_count;       //   (slot, source row) and its counter: k_edge_keys_reset empties exactly those words
     uint4* gverts[2];            // general mesh path: per-eye projected vertices {X, Y (snapped), 1/Z', rgb}, [slot][H*W]
     unsigned long long* cbuf[2]; // general mesh path: per-eye colour side buffer, draw id << 32 | rgb of some fragment of the pixel
-    uint32_t* ebuf;              // pure-shift mesh rows with edge points: [slot][eye][H*W] edge-point keys code16 << 16 | column, EMPTY between uses
     uint8_t* tri_invalid;        // [slot][2*(H-1)*(W-1)]
     uint8_t* unused;             // [slot][H*W]
     // general mesh path: queue of the triangles that are not small (kBigRecDwords dwords each), rasterised by k_mesh_raster_queue

@@ -192,7 +192,8 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
     int pf_row = -1;                            // vertex row sitting in the prefetch registers (uniform)
     uint32_t pd0 = 0, pd1 = 0, pd2 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
     uint32_t pfl = 0;                            // EDGES: the four columns' flags of that row, one byte each
-    int etx[4] = {-1, -1, -1, -1};               // EDGEPTS: the pixels this thread's edge points touched in the current (row, eye)
+    int etx[4] = {-1, -1, -1, -1};               // EDGEPTS: where this thread's edge points of the current (row, eye) land,
+    uint32_t ekey[4] = {0, 0, 0, 0};             //          and their keys code16 << 16 | source column
 
     auto fetch_row = [&](int r) {
         if (act4) {
@@ -367,13 +368,14 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                     }
                 }
             }
-            // ---- edge points of source row k (sr:589-606, 745-781): the vertices of removed triangles, nearest wins ----
+            // ---- edge points of source row k (sr:589-606, 745-781): the vertices of removed triangles, nearest wins.  They land
+            //      on scanline k itself, the scanline this workgroup is rendering: their keys go into the z-buffer row's own
+            //      memory once its words have been read out (below); here only position and key are worked out ----
             if (EDGEPTS && ties.mode == 0 && k >= k0) {
                 const uint8_t* drow_k = dbase + (size_t)k * a.depth_pitch;
                 const float fW = (float)W;
                 // (source row k is one of the two staged vertex rows: c(k) is k or k - 1)
                 const int4* vk = ((k & 1) ? have1 : have0) == k ? verts + (size_t)(k & 1) * W : nullptr;
-                uint32_t* eb = a.ebuf + ((size_t)fr * 2 + eye) * a.ws_stride_px + (size_t)k * W;     // this (row, eye)'s keys
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                          // W <= 4 * TPB (launcher)
                     const int jj = tid + q * TPB;
@@ -391,7 +393,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                     const float u = eye == 0 ? ex + d : ex - d;
                     if (u > -1.0f && u < fW + 1.0f) {
                         const int x = (int)rintf(u);                                      // np.round (sr:746)
-                        if (x >= 0 && x < W) { atomicMin(&eb[x], (code << 16) | (uint32_t)jj); etx[q] = x; }
+                        if (x >= 0 && x < W) { etx[q] = x; ekey[q] = (code << 16) | (uint32_t)jj; }
                     }
                 }
             }
@@ -413,27 +415,32 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
             }
 
             // ---- resolve this eye: LDS keys -> colour-key hole test -> coalesced stores; the keys are reset on the way ----
-            if (act4 && k >= k0 && !(a.debug_skip & 2)) {
+            const bool resolving = act4 && k >= k0 && !(a.debug_skip & 2);
+            uint4 k01 = make_uint4(~0u, ~0u, ~0u, ~0u), k23 = k01, ek4 = k01;
+            if (resolving) {
                 uint4* zq = (uint4*)zb + 2 * tid;
-                const uint4 k01 = zq[0], k23 = zq[1];
+                k01 = zq[0]; k23 = zq[1];
                 zq[0] = make_uint4(~0u, ~0u, ~0u, ~0u); zq[1] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            }
+            if (EDGEPTS && k >= k0) {            // (workgroup-uniform)
+                // the row's words are in registers and EMPTY in LDS: its first W dwords now hold the edge keys, ds_min_u32 each,
+                // are read back four per thread and left EMPTY again by their readers
+                uint32_t* eb = reinterpret_cast<uint32_t*>(zb);
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (etx[q] >= 0) atomicMin(&eb[etx[q]], ekey[q]);
+                __syncthreads();
+                if (resolving) {
+                    uint4* eq = reinterpret_cast<uint4*>(eb) + tid;
+                    ek4 = *eq;
+                    *eq = make_uint4(~0u, ~0u, ~0u, ~0u);
+                }
+            }
+            if (resolving) {
                 const uint32_t hi[4] = {k01.y, k01.w, k23.y, k23.w};
                 const uint32_t lo[4] = {k01.x, k01.z, k23.x, k23.z};
                 uint32_t o[4], mw = 0, spx[4];
                 float oz[4];
-                uint4 ek4 = make_uint4(~0u, ~0u, ~0u, ~0u);
-                bool any_hole = false;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) any_hole |= (hi[q] == ~0u && lo[q] == ~0u) || (lo[q] & 0xFFFFFFu) == a.key_rgb;
-                if (EDGEPTS && any_hole) {        // an edge point only matters where the render left a hole (sr:776): ~3 % of the pixels
-                    // (device-scope loads: the keys were written by atomics, which live in L2, by other lanes of this workgroup
-                    //  before the barrier -- a plain load could be served from this CU's L1)
-                    uint32_t* ep = a.ebuf + ((size_t)fr * 2 + eye) * a.ws_stride_px + (size_t)k * W + 4 * tid;
-                    ek4.x = __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ek4.y = __hip_atomic_load(ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ek4.z = __hip_atomic_load(ep + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ek4.w = __hip_atomic_load(ep + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
                 const uint32_t ek[4] = {ek4.x, ek4.y, ek4.z, ek4.w};
                 const uint8_t* crow_k = cbase + (size_t)k * a.color_pitch;
 #pragma unroll
@@ -470,11 +477,6 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
             }
             if (had_ties) for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
             __syncthreads();
-            if (EDGEPTS && k >= k0) {             // the keys of this (row, eye) have been read: EMPTY again for the next submission
-                uint32_t* eb = a.ebuf + ((size_t)fr * 2 + eye) * a.ws_stride_px + (size_t)k * W;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (etx[q] >= 0) eb[etx[q]] = kEmpty32;
-            }
         }
         g = gn;
     }
@@ -496,7 +498,6 @@ static int mesh_band_tpb(const RenderPlan& plan, int W)
 bool mesh_band_supported(const RenderPlan& plan, const RenderArgs& a)
 {
     if (!plan.vec4 || plan.general) return false;
-    if (plan.edge_points && !a.ebuf) return false;
     if (a.W < 8 || a.W > 4096 || a.W > 4 * 1024) return false;       // 1024 threads x 4 px; the 24-bit fast path assumes W*256 <= 2^20
     return mesh_band_lds_bytes(a.W, mesh_band_tpb(plan, a.W), plan.remove_edges, plan.edge_points) <= 160 * 1024;
 }
