@@ -198,6 +198,31 @@ def test_mesh_general_path(mods, orc, case, infill_mask):
     r.close()
 
 
+@pytest.mark.parametrize("mode", ["mesh", "points"])
+def test_general_paths_reuse_their_key_planes_across_submissions(mods, orc, mode):
+    """The z-key planes of the general paths are never cleared between submissions: a slot's uses alternate in parity
+    (atomicMin / atomicMax), the resolve rewrites only the words a use left uncovered, the edge-key words are emptied from a
+    list.  One renderer, a sequence of submissions of different batch sizes, scenes, poses and hole patterns -- every slot
+    sees both parities, slots see different numbers of uses -- each compared bit for bit with the oracle."""
+    _lib, sr, synthetic = mods
+    W, H = 96, 64
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True, render_as_pointcloud=(mode == "points"))
+    track = synthetic.synthetic_pose_track(40)
+    step = 0
+    for n, conv in ((3, 2.5), (1, 1.2), (5, None), (2, 4.0), (5, 2.0), (1, None), (4, 0.8)):
+        frames = [_scene(synthetic, W, H, seed=300 + 7 * step + k, n_fg=2 + (step + k) % 4) for k in range(n)]
+        Ts = [track[(5 * step + 3 * k) % 40] if (conv is None or k % 2) else None for k in range(n)]
+        ps = [r.frame_params(xfov=45.0, convergence_distance=conv, transformation=Ts[k]) for k in range(n)]
+        d = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+        c = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+        got = r.render(d, c, ps, want_depth=True)
+        for k in range(n):
+            one = {key: (v[k] if hasattr(v, "shape") and v.dim() > 0 and v.shape[0] == n else v) for key, v in got.items()}
+            _compare(one, _oracle(orc, r, ps[k], frames[k][0], frames[k][1], T=Ts[k]), W, f"{mode} submission {step} frame {k}")
+        step += 1
+    r.close()
+
+
 @pytest.mark.parametrize("cull", [1, 2])
 @pytest.mark.parametrize("variant", ["band", "rows_odd_width", "rows_edges", "general", "general_edges", "wide_global"])
 def test_mesh_face_culling(mods, orc, cull, variant, monkeypatch):
