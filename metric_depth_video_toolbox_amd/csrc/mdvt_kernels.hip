@@ -2322,11 +2322,12 @@ hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int level
     const dim3 grid(nb), block(256);
     for (int r = levels; r >= 2; --r) hipLaunchKernelGGL(k_telea_need, grid, block, 0, s, a, (uint32_t)r);
     for (int r = 1; r <= levels; ++r) hipLaunchKernelGGL(k_telea_fill, dim3(4 * nb), block, 0, s, a, (uint32_t)r);
-    if (getenv("MDVT_TELEA_DUMP")) {
+    if (getenv("MDVT_TELEA_DUMP")) {         // tuning hook: level sizes / needed pixels of this pass on stderr
         std::vector<uint32_t> c(levels + 2), nc(levels + 2);
-        hipStreamSynchronize(s);
-        hipMemcpy(c.data(), ws.counts, c.size() * 4, hipMemcpyDeviceToHost);
-        hipMemcpy(nc.data(), ws.ncounts, nc.size() * 4, hipMemcpyDeviceToHost);
+        hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipMemcpy(c.data(), ws.counts, c.size() * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(nc.data(), ws.ncounts, nc.size() * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
         for (int r = 1; r <= levels; ++r) fprintf(stderr, "level %d count %u need %u\n", r, c[r], nc[r]);
     }
     return hipGetLastError();
