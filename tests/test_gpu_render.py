@@ -931,6 +931,28 @@ def test_finish_infill_mask_matches_the_oracle(mods, orc, W, H):
     rb.close()
 
 
+def test_finish_infill_mask_wide_and_tall_images(mods, orc):
+    """Rows beyond 2048 pixels take the two-vector row pass of the distance transform, images taller than 1088 rows the
+    column pass that does not keep its segment in registers: one image that needs both, and an odd width beside it."""
+    _lib, sr, synthetic = mods
+    for W, H in ((2056, 1100), (2050, 40)):
+        rng = np.random.default_rng(W)
+        seed = np.zeros((H, W, 3), np.uint8)
+        for _ in range(12):
+            x0, y0 = int(rng.integers(1, W - 70)), int(rng.integers(1, H - 30))
+            w, h = int(rng.integers(4, 60)), int(rng.integers(4, 28))
+            seed[y0:y0 + h, x0:x0 + w] = (0, 255, 0)
+            seed[y0:y0 + h:3, x0] = rng.integers(1, 255, 3)
+            seed[y0 + h - 1, x0:x0 + w:4] = rng.integers(1, 255, 3)
+        seed[H - 9:, W - 40:] = (0, 255, 0); seed[H - 9:, W - 41] = (9, 200, 77)         # a hole in the last rows / columns
+        r = sr.StereoRerenderer(W, H, infill_mask=True)
+        got, rem = r.finish_infill_mask(torch.from_numpy(seed).cuda(), want_remaining=True)
+        want, wrem = orc.finish_infill_mask(seed)
+        assert np.array_equal(got.cpu().numpy(), want), (W, H)
+        assert int(rem[0]) == wrem == 0
+        r.close()
+
+
 @pytest.mark.parametrize("blocks", ["1", "3"])
 def test_finish_infill_mask_with_a_starved_grid(mods, orc, monkeypatch, blocks):
     """The level passes of the completion with 1 / 3 workgroups (MDVT_TELEA_BLOCKS, re-read per call): every workgroup then
