@@ -6,7 +6,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_IN
            "SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCC_EA_WRREQ_sum TCC_EA_RDREQ_sum TCP_TCC_READ_REQ_sum" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmf/p$i -o p -- python $ROOT/tools/finish_bench.py --frames 16 --reps 2 > /dev/null 2> /tmp/pmf_$i.log
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmf/p$i -o p -- python $ROOT/tools/finish_bench.py --frames 16 --reps 2 "$@" > /dev/null 2> /tmp/pmf_$i.log
 done
 python3 - <<'PY'
 import csv, glob, collections
