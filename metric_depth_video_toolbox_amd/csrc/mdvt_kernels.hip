@@ -1959,14 +1959,18 @@ __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
     __shared__ uint32_t cnt[5], base[5];
     const uint32_t count = a.ncounts[r], off = a.offs[r];
     constexpr uint32_t per_block = 256 / kNeedLanes;
-    if (blockIdx.x * per_block >= count) return;                       // (workgroup-uniform)
+    // XCD-aware dealing (workgroup b runs on XCD b % 8, each XCD has its own L2): every XCD walks one contiguous eighth of the
+    // level's list -- neighbouring entries are neighbouring pixels, whose 9 x 9 windows share their cache lines
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const uint32_t per_xcd = (count + 7u) >> 3, lo_x = xcd * per_xcd, hi_x = min(lo_x + per_xcd, count);
+    if (lo_x + slot * per_block >= hi_x) return;                       // (workgroup-uniform)
     const int W = a.W, H = a.H;
     const uint32_t npx = (uint32_t)W * (uint32_t)H;
     if (threadIdx.x < 5) cnt[threadIdx.x] = 0u;
     __syncthreads();
     const int sub = threadIdx.x & (kNeedLanes - 1);
     uint32_t* need_words = reinterpret_cast<uint32_t*>(a.need);
-    for (uint32_t idx = blockIdx.x * per_block + threadIdx.x / kNeedLanes; idx < count; idx += gridDim.x * per_block) {
+    for (uint32_t idx = lo_x + slot * per_block + threadIdx.x / kNeedLanes; idx < hi_x; idx += nslot * per_block) {
         const uint32_t e = a.nlist[off + idx], im = e / npx, o = e - im * npx;
         const int y = (int)(o / (uint32_t)W), x = (int)(o - (uint32_t)y * (uint32_t)W);
         const size_t ib = (size_t)im * npx;
@@ -2053,7 +2057,10 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
     const DiscPixel dp = kDisc[lane32];
     const int qv = 4 + ((lane32 & 1) ? 9 : -9), qh = 4 * 9 + 4 + ((lane32 & 2) ? 1 : -1);     // this lane's quadrant: cells (0, +-1) and (+-1, 0)
     // every entry of nlist is a pixel to estimate: they are dealt round-robin to all half-waves of the grid
-    for (uint32_t k = blockIdx.x * 8 + hw; k < nneed; k += gridDim.x * 8) {                 // half-wave uniform
+    // (XCD-aware dealing as in the need pass: one contiguous eighth of the list per XCD)
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const uint32_t per_xcd = (nneed + 7u) >> 3, lo_x = xcd * per_xcd, hi_x = min(lo_x + per_xcd, nneed);
+    for (uint32_t k = lo_x + slot * 8 + hw; k < hi_x; k += nslot * 8) {                     // half-wave uniform
         const uint32_t e = a.nlist[off + k], im = e / npx, o = e - im * npx;
         const int y = (int)(o / (uint32_t)W), x = (int)(o - (uint32_t)y * (uint32_t)W);
         const size_t ib = (size_t)im * npx;
@@ -2318,7 +2325,7 @@ hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int level
     // both passes wait on memory, not on arithmetic (PMC: `need` spends 90 % of its wave cycles waiting): a grid large enough
     // for one entry per thread takes 7.1 -> 5.8 ms off a 32-image pass compared with 512 workgroups looping
     int nb = 2048;
-    if (const char* e = getenv("MDVT_TELEA_BLOCKS")) { const int v = atoi(e); if (v > 0) nb = v; }      // tuning hook
+    if (const char* e = getenv("MDVT_TELEA_BLOCKS")) { const int v = atoi(e); if (v > 0) nb = (v + 7) & ~7; }      // tuning hook (a multiple of 8: XCDs)
     const dim3 grid(nb), block(256);
     for (int r = levels; r >= 2; --r) hipLaunchKernelGGL(k_telea_need, grid, block, 0, s, a, (uint32_t)r);
     for (int r = 1; r <= levels; ++r) hipLaunchKernelGGL(k_telea_fill, dim3(4 * nb), block, 0, s, a, (uint32_t)r);
