@@ -2226,12 +2226,17 @@ __global__ void __launch_bounds__(128) k_masked_blur_scan(ImageSet imgs, ImageSe
     const bool in = g * PX < W;
     uint8_t* orow = outs.image(im) + (size_t)y * outs.pitch;
     if (in) {
-        RowIO<PX>::load(imgs.image(im) + (size_t)y * imgs.pitch, g, c);
+        uint8_t* irow = imgs.image(im) + (size_t)y * imgs.pitch;
+        RowIO<PX>::load(irow, g, c);
         if (seeds.base && key_rgb != 0u) {
             uint32_t sd[PX];
             RowIO<PX>::load(seeds.image(im) + (size_t)y * seeds.pitch, g, sd);
 #pragma unroll
-            for (int q = 0; q < PX; ++q) if (sd[q] == 0u) c[q] = 0u;
+            for (int q = 0; q < PX; ++q)
+                if (sd[q] == 0u && c[q] != 0u) {           // an estimate nobody keeps (sr:807): black in the work image too, so that the
+                    c[q] = 0u;                              // second pass reads one image per tap instead of two
+                    store_px_bytes(irow, g * PX + q, 0u);
+                }
         }
         bool any = false;
 #pragma unroll
@@ -2267,7 +2272,7 @@ __global__ void __launch_bounds__(64) k_masked_blur_list(ImageSet imgs, ImageSet
     const size_t row = (size_t)im * H + y;
     const uint32_t n = row_count[row];
     if (n == 0u) return;
-    const BlurSrc b = blur_src(imgs, seeds, im, key_rgb);
+    const BlurSrc b{imgs.image(im), nullptr, imgs.pitch, 0, false};          // (the scan pass has merged the seed's black pixels into the work image)
     uint8_t* orow = outs.image(im) + (size_t)y * outs.pitch;
     for (uint32_t k = threadIdx.x; k < n; k += 64) {
         const int x = (int)list[row * (size_t)W + k];
