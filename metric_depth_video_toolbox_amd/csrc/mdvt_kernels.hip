@@ -1545,7 +1545,7 @@ constexpr uint16_t kTeleaUnknown = 0xFFFFu;
 //   A  k_telea_dt_rows / k_telea_dt_cols   stamp = L1 distance to the nearest known pixel (0 = known), capped at max_rounds;
 //                                   per image last_round = the level of its deepest key-coloured pixel (later levels
 //                                   are never needed) and remaining = key-coloured pixels beyond max_rounds;
-//      k_telea_sort<false> / _scan / k_telea_sort<true>   level sizes (every pixel), offsets, and the key-coloured pixels
+//      (level sizes: last sweep of the transform) / k_telea_scan / k_telea_sort   offsets, and the key-coloured pixels
 //                                   of level r appended to nlist[offs[r] ..) -- the first needed pixels of each level.
 //   B  k_telea_need    r = R .. 2   which estimates are needed: key-coloured pixels, and every pixel of a lower
 //                                   level that a needed pixel reads (its radius-3 disc and their 4-neighbours) -- which
@@ -1691,6 +1691,8 @@ __global__ void __launch_bounds__(256) k_telea_dt_rows_vec(uint16_t* __restrict_
     }
 }
 
+constexpr int kLevelBins = 4096;      // levels counted / slotted in LDS; deeper ones go straight to the global counters
+
 // Pass A, columns: the two sweeps of the L1 transform (down: D[y] = min(D[y-1] + 1, d[y]); up the same from below), in
 // place.  One workgroup = 64 columns x 16 row segments; the value entering a segment comes from a scan over the segments'
 // exit values.  The last sweep also caps the level at max_rounds and collects, per image, the deepest key-coloured level
@@ -1699,6 +1701,7 @@ __global__ void __launch_bounds__(1024) k_telea_dt_cols(TeleaArgs a, uint32_t ma
 {
     __shared__ int ex[16][64], carry[16][64];
     __shared__ uint32_t s_rem, s_max;
+    __shared__ uint32_t hist[kLevelBins];          // the level sizes (every reached pixel), added to a.counts at the end
     const int W = a.W, H = a.H;
     const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + cx, im = blockIdx.y;
@@ -1707,6 +1710,7 @@ __global__ void __launch_bounds__(1024) k_telea_dt_cols(TeleaArgs a, uint32_t ma
     const size_t base = (size_t)im * W * H + (act ? x : 0);
     uint16_t* d = a.stamp + base;
     if (threadIdx.x == 0) { s_rem = 0u; s_max = 0u; }
+    for (int b = threadIdx.x; b < kLevelBins; b += 1024) hist[b] = 0u;
     auto val = [&](int y) { const int v = d[(size_t)y * W]; return v == 0xFFFF ? kDtInf : v; };
     auto put = [&](int y, int v) { d[(size_t)y * W] = (uint16_t)(v < 0xFFFF ? v : 0xFFFF); };
     // ---- down ----
@@ -1748,6 +1752,7 @@ __global__ void __launch_bounds__(1024) k_telea_dt_cols(TeleaArgs a, uint32_t ma
             run = min(run + 1, val(y));
             const bool reached = run <= (int)max_rounds;
             d[(size_t)y * W] = reached ? (uint16_t)run : kTeleaUnknown;
+            if (reached && run >= 1) { if (run < kLevelBins) atomicAdd(&hist[run], 1u); else atomicAdd(&a.counts[run], 1u); }
             if (key[(size_t)y * W]) { if (reached) lmax = max(lmax, (uint32_t)run); else ++rem; }
         }
     }
@@ -1758,6 +1763,8 @@ __global__ void __launch_bounds__(1024) k_telea_dt_cols(TeleaArgs a, uint32_t ma
         if (s_rem) atomicAdd(&a.remaining[im], s_rem);
         if (s_max) atomicMax(&a.last_round[im], s_max);
     }
+    for (int b = threadIdx.x; b < kLevelBins; b += 1024)
+        if (hist[b]) atomicAdd(&a.counts[b], hist[b]);
 }
 
 // The same with a column segment held in registers between the sweeps (H <= 16 * SEG): the stamps are read once and
@@ -1767,6 +1774,7 @@ __global__ void __launch_bounds__(1024) k_telea_dt_cols_reg(TeleaArgs a, uint32_
 {
     __shared__ int ex[16][64], carry[16][64];
     __shared__ uint32_t s_rem, s_max;
+    __shared__ uint32_t hist[kLevelBins];          // the level sizes (every reached pixel), added to a.counts at the end
     const int W = a.W, H = a.H;
     const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + cx, im = blockIdx.y;
@@ -1776,6 +1784,7 @@ __global__ void __launch_bounds__(1024) k_telea_dt_cols_reg(TeleaArgs a, uint32_
     const size_t base = (size_t)im * W * H + (act ? x : 0);
     uint16_t* d = a.stamp + base;
     if (threadIdx.x == 0) { s_rem = 0u; s_max = 0u; }
+    for (int b = threadIdx.x; b < kLevelBins; b += 1024) hist[b] = 0u;
     int v[SEG];
 #pragma unroll
     for (int k = 0; k < SEG; ++k) {
@@ -1825,6 +1834,7 @@ __global__ void __launch_bounds__(1024) k_telea_dt_cols_reg(TeleaArgs a, uint32_
         run = min(run + 1, v[k]);
         const bool reached = run <= (int)max_rounds;
         d[(size_t)(y0 + k) * W] = reached ? (uint16_t)run : kTeleaUnknown;
+        if (reached && run >= 1) { if (run < kLevelBins) atomicAdd(&hist[run], 1u); else atomicAdd(&a.counts[run], 1u); }
         if (key[(size_t)(y0 + k) * W]) { if (reached) lmax = max(lmax, (uint32_t)run); else ++rem; }
     }
     if (rem) atomicAdd(&s_rem, rem);
@@ -1834,6 +1844,8 @@ __global__ void __launch_bounds__(1024) k_telea_dt_cols_reg(TeleaArgs a, uint32_
         if (s_rem) atomicAdd(&a.remaining[im], s_rem);
         if (s_max) atomicMax(&a.last_round[im], s_max);
     }
+    for (int b = threadIdx.x; b < kLevelBins; b += 1024)
+        if (hist[b]) atomicAdd(&a.counts[b], hist[b]);
 }
 
 // counts[0] = the deepest level any image needs (the host reads it back: passes B and C get exactly that many launches)
@@ -1844,20 +1856,18 @@ __global__ void k_telea_rmax(TeleaArgs a)
     a.counts[0] = m;
 }
 
-// Level sizes (SCATTER = false: every pixel of levels 1 .. last_round) and the first entries of the level lists (SCATTER =
-// true: the key-coloured pixels).  A workgroup takes a 64 x 64 tile of one image -- so that the pixels of a level stay
-// together tile by tile in the list, and the half-waves that later work through consecutive list entries read overlapping
-// 9 x 9 neighbourhoods --; levels below kLevelBins are counted in LDS first (one global atomic per occupied level and
-// workgroup), deeper ones directly.
-constexpr int kLevelBins = 4096;
+// The first entries of the level lists: the key-coloured pixels.  (The level sizes -- every reached pixel of a level, the room
+// its list may need -- are counted by the last sweep of the distance transform.)  A workgroup takes a 64 x 64 tile of one
+// image -- so that the pixels of a level stay together tile by tile in the list, and the half-waves that later work through
+// consecutive list entries read overlapping 9 x 9 neighbourhoods --; levels below kLevelBins are slotted in LDS first (one
+// global atomic per occupied level and workgroup), deeper ones directly.
 constexpr int kSortTile = 64;
 constexpr int kSortPixels = kSortTile * kSortTile;
 
-template <bool SCATTER>
 __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
 {
     __shared__ uint32_t hist[kLevelBins];
-    __shared__ uint32_t slot[SCATTER ? kLevelBins : 1];
+    __shared__ uint32_t slot[kLevelBins];
     const int im = blockIdx.y;
     const uint32_t lr = a.last_round[im];
     if (lr == 0u) return;                                   // nothing key-coloured (or nothing reachable): nothing to do
@@ -1866,6 +1876,7 @@ __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
     const int tx0 = (int)(blockIdx.x % tiles_x) * kSortTile, ty0 = (int)(blockIdx.x / tiles_x) * kSortTile;
     const int lx = threadIdx.x & (kSortTile - 1), ly0 = threadIdx.x >> 6;          // 64 columns x 4 rows per step
     const uint16_t* st = a.stamp + (size_t)im * npx;
+    const uint8_t* nd = a.need + (size_t)im * npx;
     for (int b = threadIdx.x; b < kLevelBins; b += 256) hist[b] = 0u;
     __syncthreads();
     uint32_t lv[kSortPixels / 256];
@@ -1874,20 +1885,17 @@ __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
         const int px = tx0 + lx, py = ty0 + ly0 + 4 * k;
         const bool in = px < a.W && py < a.H;
         const uint32_t o = in ? (uint32_t)py * (uint32_t)a.W + (uint32_t)px : 0u;
-        const uint32_t sv = in ? (uint32_t)st[o] : 0u;
+        const bool key = in && nd[o] != 0;                  // (~4 % of the pixels: only those look their level up)
+        const uint32_t sv = key ? (uint32_t)st[o] : 0u;
         lv[k] = (sv >= 1u && sv <= lr) ? sv : 0u;
-        if (SCATTER && lv[k] && !a.need[(size_t)im * npx + o]) lv[k] = 0u;
         if (lv[k] && lv[k] < (uint32_t)kLevelBins) atomicAdd(&hist[lv[k]], 1u);
-        else if (lv[k] && !SCATTER) atomicAdd(&a.counts[lv[k]], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < kLevelBins; b += 256) {
         const uint32_t c = hist[b];
         if (!c) continue;
-        if (SCATTER) { slot[b] = atomicAdd(&a.ncounts[b], c); hist[b] = 0u; }
-        else atomicAdd(&a.counts[b], c);
+        slot[b] = atomicAdd(&a.ncounts[b], c); hist[b] = 0u;
     }
-    if (!SCATTER) return;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kSortPixels / 256; ++k) {
@@ -2316,9 +2324,8 @@ hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int
     if (R == 0) return hipSuccess;
     if ((e = hipMemsetAsync(ws.counts, 0, sizeof(uint32_t), s)) != hipSuccess) return e;         // counts[0] carried R; level 0 is empty
     const dim3 grid_s((unsigned)(((W + kSortTile - 1) / kSortTile) * ((H + kSortTile - 1) / kSortTile)), n);
-    hipLaunchKernelGGL((k_telea_sort<false>), grid_s, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_telea_scan, dim3(1), dim3(1024), 0, s, a, R);
-    hipLaunchKernelGGL((k_telea_sort<true>), grid_s, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_telea_sort, grid_s, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
