@@ -1534,7 +1534,7 @@ hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t sr
 // =================================================================================================
 // infill-mask completion (sr:803-808, 114-153): level-synchronous Telea inpaint + masked Gaussian
 // =================================================================================================
-// State per image: stamp u16 (0 known from the start, 0xFFFF unknown, r = filled in round r), T f32, the work
+// State per image: stamp u16 (0 known from the start, 0xFFFF unknown, r = filled in round r), T f32 (written by the fill pass only: known pixels read as 0), the work
 // image (seed copy, filled in place).  Round r reads only pixels with stamp < r, so the in-place writes of the
 // same round (stamp = r) are never observed: one launch = one Jacobi step, no double buffering.
 constexpr uint16_t kTeleaUnknown = 0xFFFFu;
@@ -2083,9 +2083,10 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
             const size_t oo = (size_t)(inb ? yy : y) * W + (inb ? xx : x);
             uint32_t c;
             __builtin_memcpy(&c, img + 3 * oo, 4);          // unaligned dword: the work image is padded by 4 bytes
+            const uint32_t sv = stamp[oo];
             wcol[hw][q] = c & 0xFFFFFFu;
-            wt[hw][q] = Tm[oo];
-            wkn[hw][q] = (inb && (uint32_t)stamp[oo] < r) ? 1 : 0;
+            wt[hw][q] = sv == 0u ? 0.0f : Tm[oo];           // T = 0 at every originally known pixel (nobody writes it there)
+            wkn[hw][q] = (inb && sv < r) ? 1 : 0;
         }
         __builtin_amdgcn_wave_barrier();                   // LDS is in order within a wave: the reads below see these writes
         const uint8_t* kn = wkn[hw];
@@ -2305,8 +2306,6 @@ hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int
     if ((e = hipMemsetAsync(ws.last_round, 0, (size_t)kTeleaMaxImages * sizeof(uint32_t), s)) != hipSuccess) return e;
     e = hipMemsetAsync(ws.counts, 0, 3 * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts, offs and ncounts (adjacent)
     if (e != hipSuccess) return e;
-    const size_t npx = (size_t)n * W * H;
-    if ((e = hipMemsetAsync(ws.T, 0, npx * sizeof(float), s)) != hipSuccess) return e;           // T = 0 at every known pixel
     if (W % 4 == 0 && (((uintptr_t)seed.base | seed.pitch | seed.stride | (size_t)seed.eye_offset) & 3) == 0)
         hipLaunchKernelGGL(k_telea_init<4>, dim3((W / 4 + 127) / 128, H, n), dim3(128), 0, s, seed, a);
     else
