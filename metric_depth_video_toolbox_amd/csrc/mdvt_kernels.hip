@@ -1862,7 +1862,6 @@ __global__ void k_telea_rmax(TeleaArgs a)
 // consecutive list entries read overlapping 9 x 9 neighbourhoods --; levels below kLevelBins are slotted in LDS first (one
 // global atomic per occupied level and workgroup), deeper ones directly.
 constexpr int kSortTile = 64;
-constexpr int kSortPixels = kSortTile * kSortTile;
 
 __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
 {
@@ -1874,21 +1873,39 @@ __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
     const uint32_t npx = (uint32_t)a.W * (uint32_t)a.H;
     const int tiles_x = (a.W + kSortTile - 1) / kSortTile;
     const int tx0 = (int)(blockIdx.x % tiles_x) * kSortTile, ty0 = (int)(blockIdx.x / tiles_x) * kSortTile;
-    const int lx = threadIdx.x & (kSortTile - 1), ly0 = threadIdx.x >> 6;          // 64 columns x 4 rows per step
+    // a thread takes four consecutive pixels of a row (one dword of need flags where the row allows it): 16 threads per tile
+    // row, 16 rows per step, 4 steps
+    const int lx = (threadIdx.x & 15) * 4, ly0 = threadIdx.x >> 4;
     const uint16_t* st = a.stamp + (size_t)im * npx;
     const uint8_t* nd = a.need + (size_t)im * npx;
+    const bool dwords = (a.W & 3) == 0;                     // (then every row starts on a dword of the flag plane)
     for (int b = threadIdx.x; b < kLevelBins; b += 256) hist[b] = 0u;
     __syncthreads();
-    uint32_t lv[kSortPixels / 256];
+    constexpr int kSteps = kSortTile / 16;
+    uint32_t lv[kSteps][4];
 #pragma unroll
-    for (int k = 0; k < kSortPixels / 256; ++k) {
-        const int px = tx0 + lx, py = ty0 + ly0 + 4 * k;
-        const bool in = px < a.W && py < a.H;
-        const uint32_t o = in ? (uint32_t)py * (uint32_t)a.W + (uint32_t)px : 0u;
-        const bool key = in && nd[o] != 0;                  // (~4 % of the pixels: only those look their level up)
-        const uint32_t sv = key ? (uint32_t)st[o] : 0u;
-        lv[k] = (sv >= 1u && sv <= lr) ? sv : 0u;
-        if (lv[k] && lv[k] < (uint32_t)kLevelBins) atomicAdd(&hist[lv[k]], 1u);
+    for (int k = 0; k < kSteps; ++k) {
+        const int px = tx0 + lx, py = ty0 + ly0 + 16 * k;
+        const uint32_t o = (uint32_t)py * (uint32_t)a.W + (uint32_t)px;
+        uint32_t flags = 0;
+        if (py < a.H) {
+            if (dwords && px + 3 < a.W) flags = *reinterpret_cast<const uint32_t*>(nd + o);
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (px + q < a.W && nd[o + q]) flags |= 1u << (8 * q);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lv[k][q] = 0u;
+            if ((flags >> (8 * q)) & 0xFFu) {               // key-coloured (~4 % of the pixels): only those look their level up
+                const uint32_t sv = st[o + q];
+                if (sv >= 1u && sv <= lr) {
+                    lv[k][q] = sv;
+                    if (sv < (uint32_t)kLevelBins) atomicAdd(&hist[sv], 1u);
+                }
+            }
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < kLevelBins; b += 256) {
@@ -1898,12 +1915,15 @@ __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kSortPixels / 256; ++k) {
-        if (!lv[k]) continue;
-        const uint32_t e = (uint32_t)im * npx + (uint32_t)(ty0 + ly0 + 4 * k) * (uint32_t)a.W + (uint32_t)(tx0 + lx);
-        const uint32_t pos = lv[k] < (uint32_t)kLevelBins ? slot[lv[k]] + atomicAdd(&hist[lv[k]], 1u) : atomicAdd(&a.ncounts[lv[k]], 1u);
-        a.nlist[a.offs[lv[k]] + pos] = e;
-    }
+    for (int k = 0; k < kSteps; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t l = lv[k][q];
+            if (!l) continue;
+            const uint32_t e = (uint32_t)im * npx + (uint32_t)(ty0 + ly0 + 16 * k) * (uint32_t)a.W + (uint32_t)(tx0 + lx + q);
+            const uint32_t pos = l < (uint32_t)kLevelBins ? slot[l] + atomicAdd(&hist[l], 1u) : atomicAdd(&a.ncounts[l], 1u);
+            a.nlist[a.offs[l] + pos] = e;
+        }
 }
 
 // offs[r] = counts[1] + ... + counts[r-1] for r = 1 .. n_levels + 1 (level 1 starts at 0).  One workgroup.
