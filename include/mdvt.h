@@ -193,7 +193,7 @@ int mdvt_masked_blur(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, uint
  * to black, then masked_blur.  The inpaint uses Telea's weights as OpenCV publishes them but fills LEVEL BY LEVEL
  * (round r = every unknown pixel with a 4-neighbour known before round r), not in OpenCV's one-pixel-at-a-time
  * heap order -- the parallel form of the fast-marching front; it is not bit-identical to cv2.inpaint.
- * max_rounds (<= 0: 256, at most 65000) bounds the front's travel, in pixels of 4-neighbour distance from the nearest
+ * max_rounds (<= 0: 256, at most 32766) bounds the front's travel, in pixels of 4-neighbour distance from the nearest
  * seed; the rounds stop at the level of the deepest key-coloured pixel, and d_remaining (optional, n_images x uint32)
  * receives the number of key-coloured pixels beyond max_rounds.  Up to 32 images share one pass (14 B/px of workspace
  * each).  Unlike the other entry points this one WAITS on the stream once per pass: the levels come from a distance

@@ -744,7 +744,7 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
     if (seed_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
     if (d_seed == d_out || (d_seed_right && d_seed_right == d_out_right)) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias d_seed");
     if (max_rounds <= 0) max_rounds = 256;
-    if (max_rounds > 65000) return fail(c, MDVT_ERR_INVALID_ARG, "max_rounds must be <= 65000");
+    if (max_rounds > 32766) return fail(c, MDVT_ERR_INVALID_ARG, "max_rounds must be <= 32766");
     DeviceGuard g(c->device);
     hipStream_t s = (hipStream_t)stream;
     const int W = c->W, H = c->H;

@@ -1538,6 +1538,8 @@ hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t sr
 // image (seed copy, filled in place).  Round r reads only pixels with stamp < r, so the in-place writes of the
 // same round (stamp = r) are never observed: one launch = one Jacobi step, no double buffering.
 constexpr uint16_t kTeleaUnknown = 0xFFFFu;
+constexpr uint32_t kTeleaNeedBit = 0x8000u;        // from the list scatter on: top bit of a level word = "this pixel's estimate is needed"
+constexpr uint32_t kTeleaLevelMask = 0x7FFFu;      // (levels stay below 32767: max_rounds <= 32766)
 
 // The level of a pixel -- the round in which the level-synchronous front reaches it -- is its 4-connected distance to the
 // nearest known pixel: an L1 distance transform, two separable passes (A) instead of one dependent launch per level.
@@ -1902,6 +1904,7 @@ __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
                 const uint32_t sv = st[o + q];
                 if (sv >= 1u && sv <= lr) {
                     lv[k][q] = sv;
+                    a.stamp[(size_t)im * npx + o + q] = (uint16_t)(sv | kTeleaNeedBit);      // needed from the start
                     if (sv < (uint32_t)kLevelBins) atomicAdd(&hist[sv], 1u);
                 }
             }
@@ -1997,7 +2000,8 @@ __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
     if (threadIdx.x < 5) cnt[threadIdx.x] = 0u;
     __syncthreads();
     const int sub = threadIdx.x & (kNeedLanes - 1);
-    uint32_t* need_words = reinterpret_cast<uint32_t*>(a.need);
+    // (from the list scatter on, "needed" is the top bit of a pixel's level word: one load tells level and flag)
+    uint32_t* stamp_words = reinterpret_cast<uint32_t*>(a.stamp);
     for (uint32_t idx = lo_x + slot * per_block + threadIdx.x / kNeedLanes; idx < hi_x; idx += nslot * per_block) {
         const uint32_t e = a.nlist[off + idx], im = e / npx, o = e - im * npx;
         const int y = (int)(o / (uint32_t)W), x = (int)(o - (uint32_t)y * (uint32_t)W);
@@ -2006,25 +2010,27 @@ __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
         // atomic and the append inside is seven dependent round trips to L2 per entry: the floor of a level's launch)
         constexpr int kPer = (56 + kNeedLanes - 1) / kNeedLanes;
         static_assert(kPer * kNeedLanes >= 56, "every offset has a lane");
-        uint32_t uu[kPer], su[kPer], nd[kPer], old[kPer];
+        uint32_t uu[kPer], su[kPer], old[kPer];
+        bool want[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int q = sub + k * kNeedLanes;
             const int xx = x + kNeedOffsets.dx[q < kNeedOffsets.n ? q : 0], yy = y + kNeedOffsets.dy[q < kNeedOffsets.n ? q : 0];
             const bool in = q < kNeedOffsets.n && xx >= 0 && xx < W && yy >= 0 && yy < H;
             uu[k] = in ? (uint32_t)(ib + (size_t)yy * W + xx) : e;           // (the entry itself: level r, never marked)
-            su[k] = a.stamp[uu[k]];
-            nd[k] = a.need[uu[k]];
+            const uint32_t sw = a.stamp[uu[k]];
+            su[k] = sw & kTeleaLevelMask;
+            want[k] = su[k] != 0u && su[k] < r && !(sw & kTeleaNeedBit);
         }
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-            const uint32_t bit = 1u << (8u * (uu[k] & 3u));
+            const uint32_t bit = kTeleaNeedBit << (16u * (uu[k] & 1u));
             old[k] = bit;                                                      // "already set"
-            if (su[k] != 0u && su[k] < r && !nd[k]) old[k] = atomicOr(need_words + (uu[k] >> 2), bit);
+            if (want[k]) old[k] = atomicOr(stamp_words + (uu[k] >> 1), bit);
         }
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-            if (old[k] & (1u << (8u * (uu[k] & 3u)))) continue;               // flag was set: somebody else appends (or has appended) it
+            if (old[k] & (kTeleaNeedBit << (16u * (uu[k] & 1u)))) continue;    // flag was set: somebody else appends (or has appended) it
             const uint32_t d = r - 1u - su[k];
             const uint32_t pos = d < 5u ? atomicAdd(&cnt[d], 1u) : (uint32_t)kNeedStage;
             if (pos < (uint32_t)kNeedStage) stage[d][pos] = uu[k];
@@ -2103,7 +2109,7 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
             const size_t oo = (size_t)(inb ? yy : y) * W + (inb ? xx : x);
             uint32_t c;
             __builtin_memcpy(&c, img + 3 * oo, 4);          // unaligned dword: the work image is padded by 4 bytes
-            const uint32_t sv = stamp[oo];
+            const uint32_t sv = stamp[oo] & kTeleaLevelMask;       // (an unreached pixel, 0xFFFF, stays beyond every level)
             wcol[hw][q] = c & 0xFFFFFFu;
             wt[hw][q] = sv == 0u ? 0.0f : Tm[oo];           // T = 0 at every originally known pixel (nobody writes it there)
             wkn[hw][q] = (inb && sv < r) ? 1 : 0;
