@@ -2094,26 +2094,52 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
     // (XCD-aware dealing as in the need pass: one contiguous eighth of the list per XCD)
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const uint32_t per_xcd = (nneed + 7u) >> 3, lo_x = xcd * per_xcd, hi_x = min(lo_x + per_xcd, nneed);
-    for (uint32_t k = lo_x + slot * 8 + hw; k < hi_x; k += nslot * 8) {                     // half-wave uniform
-        const uint32_t e = a.nlist[off + k], im = e / npx, o = e - im * npx;
+    // Software pipeline over a half-wave's pixels: the neighbourhood of pixel i + 1 (loads into registers) and the list index of
+    // pixel i + 2 are in flight while pixel i is worked out from LDS -- pixels of one level never read each other's results.
+    struct Cells { uint32_t c[3]; float t[3]; uint32_t sv[3]; bool inb[3]; };
+    auto fetch = [&](uint32_t e, Cells& p) {
+        const uint32_t im = e / npx, o = e - im * npx;
         const int y = (int)(o / (uint32_t)W), x = (int)(o - (uint32_t)y * (uint32_t)W);
         const size_t ib = (size_t)im * npx;
         const uint16_t* stamp = a.stamp + ib;
         const float* Tm = a.T + ib;
         const uint8_t* img = a.img + 3 * ib;
 #pragma unroll
-        for (int q = lane32; q < 81; q += 32) {
+        for (int it = 0; it < 3; ++it) {
+            const int q = min(lane32 + 32 * it, 80);                  // (lanes past cell 80 repeat it: their values are not committed)
             const int wy = q / 9, wx = q - 9 * wy;
             const int xx = x - 4 + wx, yy = y - 4 + wy;
-            const bool inb = xx >= 0 && xx < W && yy >= 0 && yy < H;
-            const size_t oo = (size_t)(inb ? yy : y) * W + (inb ? xx : x);
-            uint32_t c;
-            __builtin_memcpy(&c, img + 3 * oo, 4);          // unaligned dword: the work image is padded by 4 bytes
-            const uint32_t sv = stamp[oo] & kTeleaLevelMask;       // (an unreached pixel, 0xFFFF, stays beyond every level)
-            wcol[hw][q] = c & 0xFFFFFFu;
-            wt[hw][q] = sv == 0u ? 0.0f : Tm[oo];           // T = 0 at every originally known pixel (nobody writes it there)
-            wkn[hw][q] = (inb && sv < r) ? 1 : 0;
+            p.inb[it] = xx >= 0 && xx < W && yy >= 0 && yy < H;
+            const size_t oo = (size_t)(p.inb[it] ? yy : y) * W + (p.inb[it] ? xx : x);
+            __builtin_memcpy(&p.c[it], img + 3 * oo, 4);              // unaligned dword: the work image is padded by 4 bytes
+            p.sv[it] = stamp[oo];
+            p.t[it] = Tm[oo];
         }
+    };
+    auto commit = [&](const Cells& p) {
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int q = lane32 + 32 * it;
+            if (q >= 81) continue;
+            const uint32_t sv = p.sv[it] & kTeleaLevelMask;           // (an unreached pixel, 0xFFFF, stays beyond every level)
+            wcol[hw][q] = p.c[it] & 0xFFFFFFu;
+            wt[hw][q] = sv == 0u ? 0.0f : p.t[it];                    // T = 0 at every originally known pixel (nobody writes it there)
+            wkn[hw][q] = (p.inb[it] && sv < r) ? 1 : 0;
+        }
+    };
+    const uint32_t stride = nslot * 8;
+    uint32_t k = lo_x + slot * 8 + hw;
+    uint32_t e_cur = k < hi_x ? a.nlist[off + k] : 0u;
+    uint32_t e_next = k + stride < hi_x ? a.nlist[off + k + stride] : 0u;
+    Cells cells;
+    if (k < hi_x) fetch(e_cur, cells);
+    for (; k < hi_x; k += stride) {                                                         // half-wave uniform
+        const uint32_t e = e_cur, im = e / npx, o = e - im * npx;
+        const size_t ib = (size_t)im * npx;
+        commit(cells);
+        e_cur = e_next;
+        if (k + stride < hi_x) fetch(e_cur, cells);
+        if (k + 2 * stride < hi_x) e_next = a.nlist[off + k + 2 * stride];
         __builtin_amdgcn_wave_barrier();                   // LDS is in order within a wave: the reads below see these writes
         const uint8_t* kn = wkn[hw];
         const float* tt = wt[hw];
