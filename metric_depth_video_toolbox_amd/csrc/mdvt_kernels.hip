@@ -2002,8 +2002,11 @@ __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
     const int sub = threadIdx.x & (kNeedLanes - 1);
     // (from the list scatter on, "needed" is the top bit of a pixel's level word: one load tells level and flag)
     uint32_t* stamp_words = reinterpret_cast<uint32_t*>(a.stamp);
-    for (uint32_t idx = lo_x + slot * per_block + threadIdx.x / kNeedLanes; idx < hi_x; idx += nslot * per_block) {
-        const uint32_t e = a.nlist[off + idx], im = e / npx, o = e - im * npx;
+    uint32_t idx = lo_x + slot * per_block + threadIdx.x / kNeedLanes;
+    uint32_t e_next = idx < hi_x ? a.nlist[off + idx] : 0u;
+    for (; idx < hi_x; idx += nslot * per_block) {
+        const uint32_t e = e_next, im = e / npx, o = e - im * npx;
+        if (idx + nslot * per_block < hi_x) e_next = a.nlist[off + idx + nslot * per_block];     // (in flight during this entry)
         const int y = (int)(o / (uint32_t)W), x = (int)(o - (uint32_t)y * (uint32_t)W);
         const size_t ib = (size_t)im * npx;
         // three rounds with everything of a round in flight together (a loop over the lane's offsets with the flag test, the
