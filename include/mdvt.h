@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 8
+#define MDVT_VERSION_MINOR 9
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
