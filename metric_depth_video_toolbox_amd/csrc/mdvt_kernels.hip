@@ -733,15 +733,27 @@ __global__ void __launch_bounds__(256) k_edge_points_splat4(RenderArgs a)
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     const int fr = blockIdx.z;
-    if (g >= W / 4) return;
-    const uint32_t flags = *(const uint32_t*)(a.unused + (size_t)fr * a.ws_stride_px + (size_t)i * W + (size_t)g * 4);
-    if (!flags) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint16_t cols[4][256];                 // per wave: the columns of its flagged vertices, compacted
+    uint32_t flags = 0;
+    if (g < W / 4) flags = *(const uint32_t*)(a.unused + (size_t)fr * a.ws_stride_px + (size_t)i * W + (size_t)g * 4);
+    // The flagged vertices of the wave's 256 columns are gathered into its first lanes: the vertex programme below then runs
+    // once per 64 of them instead of once per flag position with a lane or two alive.
+    uint32_t total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool on = ((flags >> (8 * q)) & 0xFFu) != 0u;
+        const u64 m = __ballot(on);
+        if (on) cols[wave][total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(g * 4 + q);
+        total += (uint32_t)__popcll(m);
+    }
+    if (total == 0u) return;                          // (wave-uniform)
+    __builtin_amdgcn_wave_barrier();
     const int f = a.frame0 + fr;
     const FrameDev& fp = a.fp[f];
     const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
-    for (int q = 0; q < 4; ++q) {
-        if (!((flags >> (8 * q)) & 0xFFu)) continue;
-        const int j = g * 4 + q;
+    for (uint32_t k = lane; k < total; k += 64) {
+        const int j = cols[wave][k];
         const float z = decode_z(code16_of(load_px_bytes(drow, j)), fp.mult, fp.scale);
         if (!(z > kNear)) continue;
         const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
