@@ -198,11 +198,19 @@ class _RawFrames:
         self.arr = arr
         self.fd = -1
         if isinstance(arr, np.memmap) and arr.flags["C_CONTIGUOUS"] and getattr(arr, "filename", None) and arr.ndim >= 2:
+            # A slice of a memmap (depth[k:]) is still an np.memmap with the parent's filename AND the parent's `offset`:
+            # the file position of its first byte is the root mapping's offset plus the distance of the data pointers.
+            root = arr
+            while isinstance(getattr(root, "base", None), np.memmap):
+                root = root.base
             try:
+                delta = int(arr.__array_interface__["data"][0]) - int(root.__array_interface__["data"][0])
+                if delta < 0 or len(arr) == 0:
+                    raise OSError("not a forward slice of its mapping")
                 self.fd = os.open(str(arr.filename), os.O_RDWR if writable else os.O_RDONLY)
-                self.base = int(arr.offset)
+                self.base = int(root.offset) + delta
                 self.frame_bytes = int(arr[0].nbytes)
-            except OSError:
+            except (OSError, KeyError, TypeError):
                 self.fd = -1
 
     def read_into(self, dst: np.ndarray, a: int, n: int):
@@ -234,9 +242,10 @@ class _RawFrames:
 
 def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParameters, *, lo: int = 0,
                 hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, out_infill=None, green_and_black: bool = False,
-                device: Optional[int] = None):
+                device: Optional[int] = None, out_base: int = 0, io_threads: int = 12):
     """Render frames [lo, hi) of a clip.  depth_frames / color_frames / out_*: array-likes indexed
-    [frame] (NumPy arrays or memmaps, uint8).  Returns (frames, seconds, hole_pixels)."""
+    [frame] (NumPy arrays or memmaps, uint8); frame t is written to out_*[t - out_base] (a rank that owns the output
+    segment [lo, hi) passes out_base = lo).  Returns (frames, seconds, hole_pixels)."""
     import time
     import torch
     from . import depth_frames_helper as dfh
@@ -295,7 +304,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     # the thread that feeds the GPU.  Three staging sets keep the three stages out of each other's buffers.
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=4)        # one task per batch and direction ...
-    io_pool = ThreadPoolExecutor(max_workers=12)    # ... each of which fans its file copies out in frame sub-ranges
+    io_pool = ThreadPoolExecutor(max_workers=max(2, int(io_threads)))    # ... each of which fans its file copies out in frame sub-ranges
 
     def fan(fn, host, a, n, parts):
         """fn(host[k0:k1], a + k0, k1 - k0) over `parts` frame sub-ranges in parallel: one thread moves ~2-3 GB/s into
@@ -325,20 +334,56 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         t_s = time.perf_counter()
         st["out_done"].synchronize()
         t_s1 = time.perf_counter()
-        jobs = fan(f_sbs.write_from, st["h_sbs"][:n].numpy(), a, n, 6) + fan(f_mask.write_from, st["h_mask"][:n].numpy(), a, n, 1)
+        o = a - out_base
+        jobs = fan(f_sbs.write_from, st["h_sbs"][:n].numpy(), o, n, 6) + fan(f_mask.write_from, st["h_mask"][:n].numpy(), o, n, 1)
         h = int(st["h_counts"][:n].sum())           # hole pixels, counted on the device (mdvt_io.hole_counts)
         if st.get("check_rem") and int(st["h_rem"][:, :n].sum()) != 0:
             redo.append((a, n))                     # a hole deeper than the default 256 levels: finished again below
         if want_zrgb:
-            jobs += fan(f_zrgb.write_from, st["h_zrgb"][:n].numpy(), a, n, 3)
+            jobs += fan(f_zrgb.write_from, st["h_zrgb"][:n].numpy(), o, n, 3)
         if want_infill:
-            jobs += fan(f_infill.write_from, st["h_seed"][:n].numpy(), a, n, 3)
+            jobs += fan(f_infill.write_from, st["h_seed"][:n].numpy(), o, n, 3)
         for j in jobs:
             j.result()
         store_done.append(time.perf_counter())
         if trace is not None:
             trace.append(("store", a, t_s - t0, t_s1 - t_s, time.perf_counter() - t_s1))
         return h
+
+    def device_stage(st, a, n, rounds, count_holes):
+        """Everything the compute stream does for one batch once its inputs are on the device (sr:512-941 minus file I/O):
+        render, SBS depth code, infill-mask completion, basic infill, green / black mask, VR180 / Touchly post.  Shared by
+        the streaming loop and the re-do of batches whose holes were deeper than the default level budget."""
+        brecs = recs[a - lo:a - lo + n]
+        res = None
+        if skip_render:
+            st["d_mask"][:n].zero_()
+        else:
+            res = r.render(st["d_d"][:n], st["d_c"][:n], brecs, out_sbs=st["d_sbs"][:n],
+                           out_mask=st["d_mask"][:n], want_depth=want_z, out_depth=st["d_z"][:n] if want_z else None,
+                           want_seed=want_seed, want_hole_counts=count_holes)
+        if want_zrgb:                               # sr:930-939: both eyes through the 16-bit code, B,G,R
+            for f in range(n):
+                dfh.encode_depth_frame(st["d_z"][f], clip.max_depth, bgr=True, out=st["d_zrgb"][f])
+        st["d_rem"] = None
+        if want_seed and res is not None:              # sr:803-808: finish the normal-coloured mask on the device, per eye
+            _, st["d_rem"] = r.finish_infill_mask_sbs(res["seed"], out=st["d_infill"][:n], max_rounds=rounds, want_remaining=True)
+            if basic_infill:                           # sr:809-812: march along the normals into the holes
+                from .stereo_rerender import infill_using_normals
+                for f in range(n):
+                    for eye in range(2):
+                        sl = slice(eye * W, (eye + 1) * W)
+                        normals = (st["d_infill"][f, :, sl].to(torch.float32) / 255.0) * 2 - 1
+                        st["d_sbs"][f, :, sl] = infill_using_normals(st["d_sbs"][f, :, sl], st["d_mask"][f, :, sl] > 0, normals)
+        if want_infill and green_and_black and res is not None:      # sr:787-793: the key colour at holes, black elsewhere
+            key = torch.tensor(r.key_rgb, dtype=torch.uint8, device=dev)
+            torch.mul((st["d_mask"][:n] > 0)[..., None], key, out=st["d_infill"][:n])
+        main = st["d_sbs"][:n]
+        if touchly1:
+            main = _post_touchly1(r, clip, [rec.depth_scale for rec in brecs], st["d_d"], st["d_c"], st["d_sbs"], st["d_mask"], st["d_z"], st["d_post"], n, posed)
+        elif vr180:
+            main = _post_vr180(r, clip, brecs, st["d_sbs"], st["d_z"], st["d_post"], n)
+        return res, main
 
     redo = []
     store_done = []
@@ -363,34 +408,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             st["in_done"].record(s_in)
         s_cmp.wait_event(st["in_done"])
         s_cmp.wait_event(st["out_done"])            # device outputs free again
-        brecs = recs[a - lo:a - lo + n]
-        res = None
-        if skip_render:
-            st["d_mask"][:n].zero_()
-        else:
-            res = r.render(st["d_d"][:n], st["d_c"][:n], brecs, out_sbs=st["d_sbs"][:n],
-                           out_mask=st["d_mask"][:n], want_depth=want_z, out_depth=st["d_z"][:n] if want_z else None,
-                           want_seed=want_seed, want_hole_counts=True)
-        if want_zrgb:                               # sr:930-939: both eyes through the 16-bit code, B,G,R
-            for f in range(n):
-                dfh.encode_depth_frame(st["d_z"][f], clip.max_depth, bgr=True, out=st["d_zrgb"][f])
-        if want_seed and res is not None:              # sr:803-808: finish the normal-coloured mask on the device, per eye
-            _, st["d_rem"] = r.finish_infill_mask_sbs(res["seed"], out=st["d_infill"][:n], max_rounds=telea_rounds, want_remaining=True)
-            if basic_infill:                           # sr:809-812: march along the normals into the holes
-                from .stereo_rerender import infill_using_normals
-                for f in range(n):
-                    for eye in range(2):
-                        sl = slice(eye * W, (eye + 1) * W)
-                        normals = (st["d_infill"][f, :, sl].to(torch.float32) / 255.0) * 2 - 1
-                        st["d_sbs"][f, :, sl] = infill_using_normals(st["d_sbs"][f, :, sl], st["d_mask"][f, :, sl] > 0, normals)
-        if want_infill and green_and_black and res is not None:      # sr:787-793: the key colour at holes, black elsewhere
-            key = torch.tensor(r.key_rgb, dtype=torch.uint8, device=dev)
-            torch.mul((st["d_mask"][:n] > 0)[..., None], key, out=st["d_infill"][:n])
-        main = st["d_sbs"][:n]
-        if touchly1:
-            main = _post_touchly1(r, clip, [rec.depth_scale for rec in brecs], st["d_d"], st["d_c"], st["d_sbs"], st["d_mask"], st["d_z"], st["d_post"], n, posed)
-        elif vr180:
-            main = _post_vr180(r, clip, brecs, st["d_sbs"], st["d_z"], st["d_post"], n)
+        res, main = device_stage(st, a, n, telea_rounds, True)
         st["render_done"].record(s_cmp)
         with torch.cuda.stream(s_out):
             s_out.wait_event(st["render_done"])
@@ -405,10 +423,10 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
                 st["h_zrgb"][:n].copy_(st["d_zrgb"][:n], non_blocking=True)
             if want_infill and res is not None:
                 st["h_seed"][:n].copy_(st["d_infill"][:n], non_blocking=True)
-            if st.get("d_rem") is not None:
+            st["check_rem"] = st.get("d_rem") is not None
+            if st["check_rem"]:
                 st["h_rem"][:, :n].copy_(st["d_rem"], non_blocking=True)
                 st["d_rem"].record_stream(s_out)
-                st["check_rem"] = True
             st["out_done"].record(s_out)
         st["stored"] = pool.submit(store, st, a, n)
         stores.append(st["stored"])
@@ -422,23 +440,19 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         render_clip.last_steady_fps = float("nan")
     for a, n in redo:
         # cv2.inpaint fills every masked pixel (sr:806).  The default 256 levels did not reach the bottom of a hole of this
-        # batch: render it again and let the front travel as far as the frame is large (W + H levels always suffice).
+        # batch: run the batch's whole device stage again and let the front travel as far as the frame is large (W + H
+        # levels always suffice); every output the completion feeds is written again (the infill mask, and with
+        # --do_basic_infill the stereo frames, through the VR180 post-processing if that is on).
         st = sets[0]
-        st["d_d"][:n].copy_(torch.from_numpy(np.ascontiguousarray(depth_frames[a:a + n])))
-        st["d_c"][:n].copy_(torch.from_numpy(np.ascontiguousarray(color_frames[a:a + n])))
-        res = r.render(st["d_d"][:n], st["d_c"][:n], recs[a - lo:a - lo + n], out_sbs=st["d_sbs"][:n], out_mask=st["d_mask"][:n], want_seed=True)
-        r.finish_infill_mask_sbs(res["seed"], out=st["d_infill"][:n], max_rounds=W + H)
+        f_depth.read_into(st["h_d"][:n].numpy(), a, n)
+        f_color.read_into(st["h_c"][:n].numpy(), a, n)
+        st["d_d"][:n].copy_(st["h_d"][:n])
+        st["d_c"][:n].copy_(st["h_c"][:n])
+        _, main = device_stage(st, a, n, W + H, False)
         if basic_infill:
-            from .stereo_rerender import infill_using_normals
-            for f in range(n):
-                for eye in range(2):
-                    sl = slice(eye * W, (eye + 1) * W)
-                    normals = (st["d_infill"][f, :, sl].to(torch.float32) / 255.0) * 2 - 1
-                    st["d_sbs"][f, :, sl] = infill_using_normals(st["d_sbs"][f, :, sl], st["d_mask"][f, :, sl] > 0, normals)
-            if not post:
-                f_sbs.write_from(st["d_sbs"][:n].cpu().numpy(), a, n)
+            f_sbs.write_from(main.cpu().numpy(), a - out_base, n)
         if want_infill:
-            f_infill.write_from(st["d_infill"][:n].cpu().numpy(), a, n)
+            f_infill.write_from(st["d_infill"][:n].cpu().numpy(), a - out_base, n)
     dt = time.perf_counter() - t0
     if trace is not None:
         for ev in sorted(trace, key=lambda e: e[2]):
@@ -452,20 +466,166 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     return hi - lo, dt, holes
 
 
+def npy_shape(path: str):
+    """Shape recorded in a .npy header (no mapping: an empty segment cannot be mapped)."""
+    with open(path, "rb") as fh:
+        major, _ = np.lib.format.read_magic(fh)
+        shape, _, _ = (np.lib.format.read_array_header_1_0 if major == 1 else np.lib.format.read_array_header_2_0)(fh)
+    return shape
+
+
 def verify_and_move(tmp_path: str, expected_frames: int, final_path: str):
     """The reference's tmp -> final protocol (dfh:163-179): rename only if the frame count matches."""
-    arr = np.load(tmp_path, mmap_mode="r")
-    if arr.shape[0] != expected_frames:
-        raise RuntimeError(f"{tmp_path}: {arr.shape[0]} frames written, expected {expected_frames}; left in place")
-    del arr
+    got = npy_shape(tmp_path)[0]
+    if got != expected_frames:
+        raise RuntimeError(f"{tmp_path}: {got} frames written, expected {expected_frames}; left in place")
     os.replace(tmp_path, final_path)
 
 
+OUTPUT_KINDS = {"sbs": "", "mask": "_holemask.npy", "depth": "_depth.npy", "infill": "_infillmask.npy"}
+
+
+def segment_path(path: str, rank: int, world: int) -> str:
+    """File of rank `rank`'s output segment: `<path>` itself for a single rank, else `<path>.rank<r>of<R>.npy`."""
+    return path if world == 1 else f"{path}.rank{rank}of{world}.npy"
+
+
+def plan_outputs(depth_path: str, clip: D.ClipParameters, world: int, *, create_sbs_depth_video: bool = False,
+                 infill_mask: bool = False):
+    """Names and shapes of everything a run writes (pure host logic).  With one rank every output is one `.npy` dump, as the
+    reference writes one file per output (sr:411-444).  With R ranks every rank owns the SEGMENT of each output that holds
+    its contiguous frame range -- its own file `<output>.rank<r>of<R>.npy`, written as `<tmp>.rank<r>of<R>.npy` and renamed
+    by the rank itself once all its frames are in (dfh:163-179 per segment) -- plus one small `<output>.index.json` from
+    rank 0: like the reference's one-file-per-scene outputs (m23d:433-452), no two writers share a file (writers of one
+    file serialise on its inode lock at ~13 GB/s on the GPU box: tools/probe/io_probe.py).  open_output() / merge_output()
+    read either form.  Returns {kind: dict(final, tmp, frame_shape, segments=[(rank, lo, hi)])} ."""
+    N, W, H = clip.n_frames, clip.W, clip.H
+    kind = "Touchly1" if clip.mode_flags & 64 else ("Touchly0" if clip.mode_flags & 32 else "stereo")     # sr:411-422
+    final = depth_path + f"_{kind}.npy"
+    tmp = depth_path + f"_tmp_{kind}.npy"
+    oH, oW = output_shape(clip)
+    shapes = {"sbs": (oH, oW, 3), "mask": (H, 2 * W)}
+    if create_sbs_depth_video:
+        shapes["depth"] = (H, 2 * W, 3)
+    if infill_mask and not ((clip.mode_flags & 64) and clip.transformations is None):
+        shapes["infill"] = (H, 2 * W, 3)
+    segs = [(r,) + tuple(D.frame_range(r, world, N)) for r in range(world)]
+    return {k: dict(final=final + OUTPUT_KINDS[k], tmp=tmp + OUTPUT_KINDS[k], frame_shape=shp, segments=segs, frames=N)
+            for k, shp in shapes.items()}
+
+
+class SegmentedFrames:
+    """Read-only view of an output written as per-rank segments: indexable like the single [N, ...] array."""
+
+    def __init__(self, parts, bounds):
+        self.parts, self.bounds = parts, bounds          # bounds[k] = first frame of part k; bounds[-1] = N
+        self.shape = (bounds[-1],) + tuple(parts[0].shape[1:])
+        self.dtype = parts[0].dtype
+
+    def __len__(self):
+        return self.bounds[-1]
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            lo, hi, step = idx.indices(len(self))
+            if step != 1:
+                return np.stack([self[t] for t in range(lo, hi, step)])
+            out = [p[max(lo, b0) - b0:min(hi, b1) - b0] for p, b0, b1 in zip(self.parts, self.bounds[:-1], self.bounds[1:])
+                   if max(lo, b0) < min(hi, b1)]
+            return np.concatenate(out) if out else np.empty((0,) + self.shape[1:], self.dtype)
+        t = int(idx)
+        if t < 0:
+            t += len(self)
+        k = int(np.searchsorted(self.bounds, t, side="right")) - 1
+        return self.parts[k][t - self.bounds[k]]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self[0:len(self)]
+        return a if dtype is None else a.astype(dtype)
+
+
+def open_output(path: str, mmap_mode: Optional[str] = "r"):
+    """An output of run(): the single dump `<path>` if it exists, else the per-rank segments named by `<path>.index.json`."""
+    if os.path.exists(path):
+        return np.load(path, mmap_mode=mmap_mode)
+    with open(path + ".index.json") as fh:
+        idx = json.load(fh)
+    here = os.path.dirname(path)
+    parts = [np.load(os.path.join(here, s["file"]), mmap_mode=mmap_mode if s["hi"] > s["lo"] else None) for s in idx["segments"]]
+    bounds = [s["lo"] for s in idx["segments"]] + [idx["frames"]]
+    for p, s in zip(parts, idx["segments"]):
+        if p.shape[0] != s["hi"] - s["lo"]:
+            raise RuntimeError(f"{s['file']}: {p.shape[0]} frames, the index says {s['hi'] - s['lo']}")
+    return SegmentedFrames(parts, bounds)
+
+
+def merge_output(path: str, remove_segments: bool = True) -> str:
+    """Concatenate the segments of `<path>.index.json` into the single dump `<path>` (tmp -> final rename)."""
+    seg = open_output(path)
+    if isinstance(seg, np.ndarray):
+        return path
+    tmp = path + ".merge_tmp.npy"
+    out = np.lib.format.open_memmap(tmp, mode="w+", dtype=seg.dtype, shape=seg.shape)
+    for p, b0 in zip(seg.parts, seg.bounds[:-1]):
+        out[b0:b0 + p.shape[0]] = p
+    out.flush()
+    del out
+    os.replace(tmp, path)
+    if remove_segments:
+        with open(path + ".index.json") as fh:
+            idx = json.load(fh)
+        for s in idx["segments"]:
+            os.remove(os.path.join(os.path.dirname(path), s["file"]))
+        os.remove(path + ".index.json")
+    return path
+
+
+def _usable_cores() -> int:
+    """Cores this process may use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+def pin_to_gpu_numa_node(device_index: int) -> Optional[int]:
+    """Restrict this process (and the I/O threads it starts afterwards) to the CPUs of the NUMA node its GPU hangs off:
+    the pinned staging buffers and the page-cache copies of a rank then stay on the memory controller next to its PCIe
+    root.  Best effort: returns the node, or None when the topology cannot be read (containers often hide it)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
 def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_sbs_depth_video: bool = False,
-        max_frames: int = -1, green_and_black_infill_mask: bool = False, **clip_kwargs):
+        max_frames: int = -1, green_and_black_infill_mask: bool = False, backend: Optional[str] = None, **clip_kwargs):
     """File-level entry (what `python stereo_rerender.py --depth_video ...` is to the reference).
-    Multi-process aware: under torchrun every rank renders its own contiguous frame range."""
-    rank, world = D.init_process_group()
+    Multi-process aware: under torchrun every rank renders its own contiguous frame range into its own output segment
+    files (plan_outputs); rank 0 adds the index.  `backend`: torch.distributed backend (default: RCCL when a GPU is
+    visible; MDVT_DIST_BACKEND overrides -- the two-ranks-on-one-GPU tests use gloo)."""
+    rank, world = D.init_process_group(backend or os.environ.get("MDVT_DIST_BACKEND"))
     depth = np.load(depth_path, mmap_mode="r")
     color = depth if color_path is None else np.load(color_path, mmap_mode="r")                        # sr:508-509
     if depth.ndim != 4 or depth.shape[3] != 3 or depth.dtype != np.uint8:
@@ -479,34 +639,43 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
         N = min(N, max_frames)      # the reference processes max_frames+1 and then fails its own check: dropped
     clip = load_clip_parameters(n_total, W, H, n_use=N, **clip_kwargs) if rank == 0 else None
     clip = D.broadcast_clip_parameters(clip, src=0)
-    kind = "Touchly1" if clip.mode_flags & 64 else ("Touchly0" if clip.mode_flags & 32 else "stereo")     # sr:411-422
-    final = depth_path + f"_{kind}.npy"
-    tmp = depth_path + f"_tmp_{kind}.npy"
-    oH, oW = output_shape(clip)
-    names = {"sbs": (tmp, final, (N, oH, oW, 3)),
-             "mask": (tmp + "_holemask.npy", final + "_holemask.npy", (N, H, 2 * W))}
-    if create_sbs_depth_video:
-        names["depth"] = (tmp + "_depth.npy", final + "_depth.npy", (N, H, 2 * W, 3))
-    if clip_kwargs.get("infill_mask") and not ((clip.mode_flags & 64) and clip.transformations is None):
-        names["infill"] = (tmp + "_infillmask.npy", final + "_infillmask.npy", (N, H, 2 * W, 3))
-    if rank == 0:
-        for t, _, shape in names.values():
-            np.lib.format.open_memmap(t, mode="w+", dtype=np.uint8, shape=shape).flush()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    outs = {k: np.load(v[0], mmap_mode="r+") for k, v in names.items()}
+    plan = plan_outputs(depth_path, clip, world, create_sbs_depth_video=create_sbs_depth_video,
+                        infill_mask=bool(clip_kwargs.get("infill_mask")))
+    final = plan["sbs"]["final"]
     lo, hi = D.frame_range(rank, world, N)
+    io_threads = 12
+    if world > 1:
+        import torch
+        if torch.cuda.is_available():
+            pin_to_gpu_numa_node(torch.cuda.current_device())
+        io_threads = max(2, min(12, _usable_cores() // world))      # the ranks share the box's CPU quota
+    # every rank creates, fills, checks and renames its own segment files: no shared inode, no barrier before the loop
+    outs = {}
+    for k, pl in plan.items():
+        t = segment_path(pl["tmp"], rank, world)
+        if hi > lo:
+            outs[k] = np.lib.format.open_memmap(t, mode="w+", dtype=np.uint8, shape=(hi - lo,) + pl["frame_shape"])
+        else:                                   # more ranks than frames: an empty segment (cannot be mapped)
+            outs[k] = np.empty((0,) + pl["frame_shape"], np.uint8)
+            np.save(t, outs[k])
     frames, secs, holes = render_clip(depth, color, outs["sbs"], outs["mask"], clip, lo=lo, hi=hi, batch=batch,
-                                      out_depth_rgb=outs.get("depth"),
-                                      out_infill=outs.get("infill"), green_and_black=green_and_black_infill_mask)
+                                      out_depth_rgb=outs.get("depth"), out_infill=outs.get("infill"),
+                                      green_and_black=green_and_black_infill_mask, out_base=lo, io_threads=io_threads)
     # (no msync: the dumps were written through the page cache, which every later reader shares; forcing 6 GB of dirty pages
     #  to the disk before the rename is what the reference's writers do not do either, and costs seconds on a container fs)
-    stats = D.gather_rank_stats(frames, secs, holes)
+    del outs
+    for k, pl in plan.items():
+        verify_and_move(segment_path(pl["tmp"], rank, world), hi - lo, segment_path(pl["final"], rank, world))
+    stats = D.gather_rank_stats(frames, secs, holes)          # (a collective: every rank's segments are in place after it)
+    if world > 1 and rank == 0:
+        for k, pl in plan.items():
+            idx = {"frames": N, "world": world, "frame_shape": list(pl["frame_shape"]), "dtype": "uint8",
+                   "segments": [{"rank": r, "lo": a, "hi": b, "file": os.path.basename(segment_path(pl["final"], r, world))}
+                                for r, a, b in pl["segments"]]}
+            with open(pl["final"] + ".index.json.tmp", "w") as fh:
+                json.dump(idx, fh)
+            os.replace(pl["final"] + ".index.json.tmp", pl["final"] + ".index.json")
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
-    if rank == 0:
-        for t, f, _ in names.values():
-            verify_and_move(t, N, f)
     return stats, final

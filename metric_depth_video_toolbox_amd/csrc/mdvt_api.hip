@@ -237,8 +237,12 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         c->bigq = nullptr;
         // one segment per (frame slot, cell row), each with room for all four triangles of every cell of the row (8 bytes
         // per triangle) and its own counter: the queue cannot overflow
-        const size_t cap = nf * npx * 4;
-        c->bigq_cap = cap > 0xFFFFFFF0u ? 0xFFFFFFF0u : (uint32_t)cap;
+        // (entry indices are 32-bit: chunk_of() keeps nf * npx * 4 below 2^32, so allocation and counter offset use ONE value)
+        size_t nfq = (size_t)0xFFFFFFF0u / (4 * npx);          // a general launch set never has more slots than this (chunk_of)
+        if (nfq < 1) return fail(c, MDVT_ERR_UNSUPPORTED, "general mesh path: a %d x %d frame exceeds the 32-bit triangle queue", c->W, c->H);
+        if (nfq > nf) nfq = nf;
+        const size_t cap = nfq * npx * 4;
+        c->bigq_cap = (uint32_t)cap;
         MDVT_HIP(c, hipMalloc((void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 1) * sizeof(uint32_t)));   // entries, counters, prefix sums
         c->ws_gverts = true;
     }
@@ -462,7 +466,13 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         const int n = r.f1 - r.f0;
         if (!(r.general || plan.remove_edges)) return n;                  // no workspace: the whole run in one launch
         int ws_chunk = (r.general && plan.mode == MDVT_MODE_POINTS) ? 2 : kWorkspaceChunk;
-        if (r.general && plan.mode == MDVT_MODE_MESH) ws_chunk = 2 * kWorkspaceChunk;      // 16: measured -4 % (convergence) / -11 % (pose) vs 8
+        if (r.general && plan.mode == MDVT_MODE_MESH) {
+            ws_chunk = 2 * kWorkspaceChunk;      // 16: measured -4 % (convergence) / -11 % (pose) vs 8
+            // ~100 B/px per slot (records, z keys, colour side buffer, triangle queue): 3.3 GB at 1080p, 13 GB at 4K; the queue's
+            // entry indices are 32-bit, so very large frames get fewer slots (4 entries per pixel and slot)
+            const size_t fit = (size_t)0xFFFFFFF0u / (4 * (size_t)W * (size_t)H);
+            if ((size_t)ws_chunk > fit) ws_chunk = fit < 1 ? 1 : (int)fit;
+        }
         // pure-shift mesh rows with edge removal: a launch is (frames x 135 bands) workgroups for 512 slots -- 8 frames
         // leave the chip 30 % idle in the last wave of workgroups (476 -> see DESIGN.md); the workspace is 11 B/px per frame
         if (!r.general && plan.mode == MDVT_MODE_MESH) ws_chunk = 4 * kWorkspaceChunk;

@@ -86,3 +86,47 @@ def test_bench_line_under_torchrun_with_one_rank():
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "weak" and line["roofline"]["bound"] == "hbm"
     assert line["extra"]["clip_c3"]["frames"] == 12 and line["extra"]["clip_c3"]["scaling"] == "strong"
     assert "mesh" in line["extra"] and "product_default" in line["extra"]
+
+
+@pytest.mark.parametrize("variant", ["points", "product_default"])
+def test_two_ranks_render_one_clip_into_per_rank_segments(tmp_path, variant):
+    """BASELINE config C3's multi-rank leg end to end on the hardware at hand: `clip.run` under torchrun with TWO ranks
+    (backend gloo, both on cuda:0 -- RCCL refuses two ranks on one device), through the CLI with the reference's flag
+    names.  Every rank renders its contiguous frame range into its own segment files; read back through open_output they
+    equal the single-rank run's files byte for byte (frames are independent: sharding must not change a bit)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import numpy as np
+    from metric_depth_video_toolbox_amd import clip
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
+    W, H, N = 256, 144, 21
+    d, c = SyntheticScene(W, H, config_id=3, n_fg=6).clip(N)
+    flags = ["--xfov", "45", "--pupillary_distance", "65", "--batch", "4", "--create_sbs_depth_video"]
+    if variant == "points":
+        flags += ["--render_as_pointcloud"]
+    else:
+        (tmp_path / "conv.json").write_text(json.dumps([2.5 + 0.02 * k if k % 7 else float("nan") for k in range(N)]))
+        flags += ["--infill_mask", "--convergence_file", str(tmp_path / "conv.json")]
+    outs = {}
+    for world in (1, 2):
+        wd = tmp_path / f"w{world}"
+        wd.mkdir()
+        dp, cp = str(wd / "v_depth.npy"), str(wd / "v.npy")
+        np.save(dp, d); np.save(cp, c)
+        env = dict(os.environ, MDVT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=REPO)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), "-m", "metric_depth_video_toolbox_amd.stereo_rerender",
+               "--depth_video", dp, "--color_video", cp] + flags
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+        assert p.returncode == 0 and "Processing complete" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+        final = dp + "_stereo.npy"
+        kinds = ["", "_holemask.npy", "_depth.npy"] + (["_infillmask.npy"] if variant == "product_default" else [])
+        if world == 2:
+            assert not os.path.exists(final) and os.path.exists(final + ".rank0of2.npy") and os.path.exists(final + ".rank1of2.npy")
+            idx = json.load(open(final + ".index.json"))
+            assert [(s["lo"], s["hi"]) for s in idx["segments"]] == [(0, 10), (10, 21)]
+        outs[world] = {k: np.asarray(clip.open_output(final + k)) for k in kinds}
+        assert not [f for f in os.listdir(wd) if "_tmp_" in f]
+    for k in outs[1]:
+        assert outs[1][k].shape[0] == N and np.array_equal(outs[1][k], outs[2][k]), f"output {k!r} differs between 1 and 2 ranks"
+    assert (outs[1]["_holemask.npy"] > 0).any()

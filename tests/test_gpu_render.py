@@ -778,9 +778,10 @@ def test_touchly_depth_plane(mods, tmax, tmin):
 
 
 def test_bench_workload_is_bit_exact_and_deterministic(mods, orc):
-    """The exact workload bench.py times (32 distinct 1920x1080 frames, points mode, 65 mm, xfov 45, one
-    batched launch): every frame equals the oracle bit for bit, two launches agree (atomic order does not
-    matter), and a frame rendered inside the batch equals the same frame rendered alone."""
+    """The 32 host-generated frames of the workload bench.py times (1920x1080, points mode, 65 mm, xfov 45, one batched
+    launch; the bench's step is 128 frames -- these 32 plus device-rolled copies, see
+    test_bench_step_of_128_frames_with_rolled_copies): every frame equals the oracle bit for bit, two launches agree
+    (atomic order does not matter), and a frame rendered inside the batch equals the same frame rendered alone."""
     _lib, sr, synthetic = mods
     W, H, N = 1920, 1080, 32
     d, c = synthetic.SyntheticScene(W, H, config_id=2).clip(N)
@@ -804,6 +805,58 @@ def test_bench_workload_is_bit_exact_and_deterministic(mods, orc):
         assert (want["left_mask"] == 0).sum() <= W * H
     one = r.render(dt[17], ct[17], p)
     assert torch.equal(one["sbs"], sbs1[17]) and torch.equal(one["mask"], mask1[17])
+    r.close()
+
+
+def test_bench_step_of_128_frames_with_rolled_copies(mods, orc):
+    """bench.py's headline step literally: 128 frames of 1920x1080 in ONE launch, frames 32.. being the first 32 rolled by
+    whole pixels on the device (bench.py main()).  Frames from every quarter of the batch -- index >= 32 included -- are
+    compared with the oracle on the same (host-rolled) inputs."""
+    _lib, sr, synthetic = mods
+    W, H, N, NH = 1920, 1080, 128, 32
+    d, c = synthetic.SyntheticScene(W, H, config_id=2).clip(NH)
+    dt = torch.empty((N, H, W, 3), dtype=torch.uint8, device="cuda")
+    ct = torch.empty((N, H, W, 3), dtype=torch.uint8, device="cuda")
+    dt[:NH], ct[:NH] = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    for k in range(NH, N):
+        sh = (7 * (k // NH), 13 * (k // NH))
+        dt[k] = torch.roll(dt[k % NH], shifts=sh, dims=(0, 1))
+        ct[k] = torch.roll(ct[k % NH], shifts=sh, dims=(0, 1))
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True)
+    p = r.frame_params(xfov=45.0)
+    got = r.render(dt, ct, r.pack_params([p] * N, N))
+    op = orc.make_params(W, H, _K(p), ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_POINTS)
+    for k in (5, 37, 70, 101, 127):
+        sh = (7 * (k // NH), 13 * (k // NH))
+        dk, ck = np.roll(d[k % NH], sh, axis=(0, 1)), np.roll(c[k % NH], sh, axis=(0, 1))
+        assert np.array_equal(dt[k].cpu().numpy(), dk)
+        want = orc.render_stereo(op, np.ascontiguousarray(dk), np.ascontiguousarray(ck))
+        _compare({"sbs": got["sbs"][k], "mask": got["mask"][k]}, want, W, f"128-frame step, frame {k}")
+    r.close()
+
+
+@pytest.mark.parametrize("variant", ["mesh", "product_default"])
+def test_bench_extras_at_full_hd(mods, orc, variant):
+    """What bench.py's `extra` object times, at the size it times it (1920x1080, 65 mm, xfov 45), frames inside a batch:
+    `mesh` = plain mesh mode, pure shift (k_mesh_band<0, 512>); `product_default` = mesh + --infill_mask + convergence at
+    2.5 m (movie_2_3D.py:433-445) with the seed image.  LDS ring sizing, queue segments and launch-set chunking all depend
+    on W and H, so the small-frame tests do not stand in for this one."""
+    _lib, sr, synthetic = mods
+    W, H, N = 1920, 1080, 3
+    d, c = synthetic.SyntheticScene(W, H, config_id=2).clip(N, t0=11)
+    kw = dict(infill_mask=True) if variant == "product_default" else {}
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, **kw)
+    p = r.frame_params(xfov=45.0, convergence_distance=2.5 if variant == "product_default" else None)
+    seed = variant == "product_default"
+    got = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), [p] * N, want_depth=True, want_seed=seed)
+    for k in (0, 2):
+        op = orc.make_params(W, H, _K(p), ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_MESH,
+                             remove_edges=r.remove_edges, edge_points=int(r.edge_points), conv_angle=p.convergence_angle, key_rgb=r.key_rgb)
+        want = orc.render_stereo(op, d[k], c[k], want_depth=True, want_seed=seed)
+        _compare({key: got[key][k] for key in ("sbs", "mask", "depth")}, want, W, f"{variant} 1080p frame {k}")
+        if seed:
+            for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+                assert np.array_equal(got["seed"][k][:, sl].cpu().numpy(), want[eye + "_seed"]), f"{variant} seed {eye} frame {k}"
     r.close()
 
 

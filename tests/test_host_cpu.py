@@ -237,3 +237,31 @@ def test_every_abi_symbol_is_documented():
         base = sym.replace("_stereo", "").replace("_batch", "")
         assert sym in integ or base in integ, f"{sym} missing from INTEGRATION.md"
         assert sym in design or base in design or sym.split("mdvt_")[1].split("_")[0] in design, f"{sym} missing from DESIGN.md"
+
+
+def test_raw_frames_follow_sliced_memmaps(tmp_path):
+    """render_clip accepts memmaps; a slice of one (depth[k:]) keeps its parent's filename and `offset`, so the
+    pread / pwrite fast path has to find the slice's own file position (it read frames 0.. instead of k..)."""
+    from metric_depth_video_toolbox_amd.clip import _RawFrames
+    path = str(tmp_path / "frames.npy")
+    m = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint8, shape=(10, 4, 6, 3))
+    m[:] = np.arange(10, dtype=np.uint8)[:, None, None, None]
+    m.flush()
+    for arr, first in ((m, 0), (m[5:], 5), (m[3:][2:8], 5), (np.load(path, mmap_mode="r")[7:], 7)):
+        f = _RawFrames(arr, False)
+        assert f.fd >= 0
+        dst = np.empty((2, 4, 6, 3), np.uint8)
+        f.read_into(dst, 1, 2)
+        assert dst[0, 0, 0, 0] == first + 1 and dst[1, 0, 0, 0] == first + 2 and (dst[0] == first + 1).all()
+        f.close()
+    w = _RawFrames(m[4:], True)
+    w.write_from(np.full((2, 4, 6, 3), 200, np.uint8), 1, 2)
+    w.close()
+    back = np.load(path)
+    assert (back[5:7] == 200).all() and (back[4] == 4).all() and (back[7] == 7).all() and (back[:4, 0, 0, 0] == np.arange(4)).all()
+    # a strided view (every other frame) is not one byte range: ordinary indexing
+    s = _RawFrames(m[::2], False)
+    assert s.fd < 0
+    dst = np.empty((2, 4, 6, 3), np.uint8)
+    s.read_into(dst, 1, 2)
+    assert dst[0, 0, 0, 0] == 2 and dst[1, 0, 0, 0] == 4
