@@ -40,6 +40,24 @@ __device__ __forceinline__ void op1(float& a, float& b, float x, float y)
     if (OP == 13) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(a) : "v"(x));
     if (OP == 14) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a));
     if (OP == 15) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a), "v"(x) : "vcc");
+    if (OP == 16) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a) : "v"(x) : "s20", "s21");
+    if (OP == 17) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a) : "v"(x), "v"(y) : "vcc");    // 2 instructions
+    if (OP == 18) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]" : "+v"(a) : "v"(x), "v"(y) : "s20", "s21");   // 2 instructions
+    if (OP == 19) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a) : "v"(x));
+    if (OP == 20) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a) : "v"(x));
+    if (OP == 21) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a) : "v"(x));
+    if (OP == 22) asm volatile("v_mov_b32 %0, %1" : "+v"(a) : "v"(x));
+    if (OP == 23) asm volatile("v_rndne_f32 %0, %0" : "+v"(a));
+    if (OP == 24) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a));
+    if (OP == 25) asm volatile("v_alignbit_b32 %0, %0, %1, 8" : "+v"(a) : "v"(x));
+    if (OP == 26) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+    if (OP == 27) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+    if (OP == 28) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a) : "v"(x));
+    if (OP == 29) asm volatile("v_ashrrev_i32 %0, 8, %0" : "+v"(a));
+    // pairs on two chains: do a 4-cycle-class and a fast-class instruction share one issue pipe (times add) or not (max)?
+    if (OP == 30) asm volatile("v_mul_u32_u24 %0, %0, %2\n\tv_add_f32 %1, %1, %2" : "+v"(a), "+v"(b) : "v"(x));
+    if (OP == 31) asm volatile("v_cvt_f32_i32 %0, %0\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(a), "+v"(b) : "v"(x), "v"(y));
+    if (OP == 32) asm volatile("v_mul_u32_u24 %0, %0, %2\n\tv_perm_b32 %1, %1, %2, %2" : "+v"(a), "+v"(b) : "v"(x));
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -130,6 +148,13 @@ int main(int argc, char** argv)
         ROW("v_perm_b32", k_stream, 9), ROW("v_cndmask_b32", k_stream, 10), ROW("v_min3_i32", k_stream, 11),
         ROW("v_cmp_lt_f32", k_stream, 15), ROW("v_mov_b32_dpp wave_shl", k_stream, 12), ROW("v_cvt_pk_u8_f32", k_stream, 13),
         ROW("v_fma_f64", k_stream2, 104),
+        ROW("v_cndmask_b32_e64 (sgpr mask)", k_stream, 16), ROW("v_cmp + v_cndmask vcc (PAIRS/ns)", k_stream, 17),
+        ROW("v_cmp + v_cndmask sgpr (PAIRS/ns)", k_stream, 18), ROW("v_max_f32", k_stream, 19), ROW("v_sub_f32", k_stream, 28),
+        ROW("v_sub_u32", k_stream, 20), ROW("v_and_b32", k_stream, 21), ROW("v_mov_b32", k_stream, 22),
+        ROW("v_rndne_f32", k_stream, 23), ROW("v_cvt_i32_f32", k_stream, 24), ROW("v_alignbit_b32", k_stream, 25),
+        ROW("v_add3_u32", k_stream, 26), ROW("v_mad_i32_i24", k_stream, 27), ROW("v_ashrrev_i32", k_stream, 29),
+        ROW("v_mul_u32_u24 + v_add_f32 (PAIRS)", k_stream, 30), ROW("v_cvt_f32_i32 + v_fma_f32 (PAIRS)", k_stream, 31),
+        ROW("v_mul_u32_u24 + v_perm_b32 (PAIRS)", k_stream, 32),
     };
     printf("%-26s", "wave-instr/ns/SIMD at waves/SIMD =");
     const int wps[] = {1, 2, 4, 8};
