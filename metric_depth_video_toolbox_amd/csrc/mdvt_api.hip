@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -145,7 +146,65 @@ int fill_frame_dev(mdvt_ctx* c, const mdvt_frame_params& p, FrameDev& f)
             f.Md[eye][4 * r + 3] = ((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r];
         }
     }
+    // Convergence and nothing else (sr:707-726: rotation about the camera's y axis, shift along x): the projected row of a
+    // vertex is depth independent, v = (gy - cy) / rz(j) + cy with rz(j) = m10 + m8 (gx_j - cx) / fx, which k_mesh_conv
+    // (mdvt_mesh_conv.hip) builds on.  It takes the frame if the vertex rows stay low staircases: at most 12 rows of tilt
+    // across the frame (its row tags are 5 bits, its column pairs expect neighbouring brackets to differ by one).
+    f.conv_band = 0;
+    if (mesh && !p.has_T && conv != 0.0 && same_k) {
+        bool ok = true;
+        for (int eye = 0; eye < 2 && ok; ++eye) {
+            const float* M = f.M[eye];
+            ok = M[1] == 0.0f && M[4] == 0.0f && M[5] == 1.0f && M[6] == 0.0f && M[7] == 0.0f && M[9] == 0.0f && M[11] == 0.0f;
+            const double rz0 = (double)M[10] + (double)M[8] * ((0.0 - cx) / fx);
+            const double rz1 = (double)M[10] + (double)M[8] * (((double)(W - 1) * ((double)W + 1.0) / (double)W - cx) / fx);
+            if (!(rz0 > 0.5 && rz1 > 0.5 && rz0 < 2.0 && rz1 < 2.0)) ok = false;
+            else if (fabs(1.0 / rz0 - 1.0 / rz1) * ((double)H * 0.5 + 1.0) * (fyr / fy) > 12.0) ok = false;
+        }
+        f.conv_band = ok ? 1 : 0;
+    }
     return MDVT_OK;
+}
+
+// Pinned host staging memory is NEVER returned to the driver while the process lives.  The r03 parity soak found one frame in
+// ~20 000 context create / render / destroy cycles (14 processes sharing the GPU) rendered with the PREVIOUS context's
+// parameter block: a hipHostMalloc'ed buffer that recycles the address of one just hipHostFree'd can be read by the GPU --
+// copy engine or kernel alike, even with a stream synchronisation after the copy -- with the old allocation's content
+// (tests/dbg_param_stress.py reproduces it: 12 wrong frames in 191 000 contexts with per-context hipHostMalloc /
+// hipHostFree, 0 in 1 064 000 with this pool, and a context is created 5 x faster).  MDVT_PARAM_UPLOAD=recycle restores
+// the per-context allocation for that A/B.
+struct PoolBlock { void* host; void* dev; size_t bytes; };
+std::mutex g_pool_mutex;
+std::vector<PoolBlock>& param_pool() { static std::vector<PoolBlock> p; return p; }
+bool param_pool_off()
+{
+    const char* e = getenv("MDVT_PARAM_UPLOAD");
+    return e && strcmp(e, "recycle") == 0;
+}
+// A pinned host block of at least `bytes`, with a device block of the same size if with_dev.
+hipError_t pool_take(size_t bytes, bool with_dev, void** host, void** dev, size_t* got)
+{
+    if (!param_pool_off()) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        auto& pool = param_pool();
+        for (size_t k = 0; k < pool.size(); ++k)
+            if (pool[k].bytes >= bytes && (pool[k].dev != nullptr) == with_dev) {
+                *host = pool[k].host; *dev = pool[k].dev; *got = pool[k].bytes;
+                pool.erase(pool.begin() + (long)k);
+                return hipSuccess;
+            }
+    }
+    *host = nullptr; *dev = nullptr; *got = bytes;
+    hipError_t e = hipHostMalloc(host, bytes, hipHostMallocDefault);
+    if (e == hipSuccess && with_dev) e = hipMalloc(dev, bytes);
+    return e;
+}
+void pool_give(void* host, void* dev, size_t bytes)
+{
+    if (!host) return;
+    if (param_pool_off()) { (void)hipHostFree(host); if (dev) (void)hipFree(dev); return; }
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    param_pool().push_back({host, dev, bytes});
 }
 
 // Stage n FrameDev records to the device through the pinned ring; returns the device pointer.
@@ -162,14 +221,14 @@ int stage_params(mdvt_ctx* c, const std::vector<FrameDev>& v, hipStream_t s, con
     c->next_slot = (c->next_slot + 1) % kParamSlots;
     if (sl.used) MDVT_HIP(c, hipEventSynchronize(sl.done));     // slot is being reused: its last user must be done
     if (sl.capacity < v.size()) {
-        if (sl.host) (void)hipHostFree(sl.host);
-        if (sl.dev) (void)hipFree(sl.dev);
+        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev));
         sl.host = nullptr; sl.dev = nullptr; sl.capacity = 0;
         size_t cap = 16;
         while (cap < v.size()) cap *= 2;
-        MDVT_HIP(c, hipHostMalloc((void**)&sl.host, cap * sizeof(FrameDev), hipHostMallocDefault));
-        MDVT_HIP(c, hipMalloc((void**)&sl.dev, cap * sizeof(FrameDev)));
-        sl.capacity = cap;
+        void *h = nullptr, *d = nullptr;
+        size_t got = 0;
+        MDVT_HIP(c, pool_take(cap * sizeof(FrameDev), true, &h, &d, &got));
+        sl.host = (FrameDev*)h; sl.dev = (FrameDev*)d; sl.capacity = got / sizeof(FrameDev);
     }
     if (!sl.done) MDVT_HIP(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     memcpy(sl.host, v.data(), v.size() * sizeof(FrameDev));
@@ -338,8 +397,7 @@ int mdvt_destroy(mdvt_ctx* c)
     DeviceGuard g(c->device);
     (void)hipDeviceSynchronize();
     for (auto& sl : c->slots) {
-        if (sl.host) (void)hipHostFree(sl.host);
-        if (sl.dev) (void)hipFree(sl.dev);
+        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev));
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); if (c->gverts[e]) (void)hipFree(c->gverts[e]); if (c->cbuf[e]) (void)hipFree(c->cbuf[e]); }
@@ -349,7 +407,7 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->elist) (void)hipFree(c->elist);
     if (c->row_counts) (void)hipFree(c->row_counts);
     if (c->rowcell) (void)hipFree(c->rowcell);
-    if (c->telea_levels_host) (void)hipHostFree(c->telea_levels_host);
+    pool_give(c->telea_levels_host, nullptr, 64);
     free_telea(c);
     delete c;
     return MDVT_OK;
@@ -423,7 +481,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     }
     // The arithmetic of a frame (pure shift or general) is its own property, never its batch
     // neighbours': consecutive frames of one kind form a run, every run gets its own launches.
-    struct Run { int f0, f1, general; };        // general here = "takes the global-key kernels"
+    struct Run { int f0, f1, general, conv; };  // general = "takes the global-key kernels"; conv = k_mesh_conv (mesh, convergence only)
     std::vector<Run> runs;
 
     const FrameDev* dfp = nullptr;
@@ -449,14 +507,24 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     // stays 0), so the pixels do not depend on which kernels ran.  MDVT_FORCE_GLOBAL=1 sends every frame that way (tests).
     const bool wide = !mdvt::render_fits_lds(plan, W) || getenv("MDVT_FORCE_GLOBAL") != nullptr;
     if (wide) general = 1;
+    bool conv_kernel = false;
+    if (plan.mode == MDVT_MODE_MESH && !wide) {
+        RenderArgs probe{};
+        probe.W = W; probe.H = H;
+        conv_kernel = mdvt::mesh_conv_supported(plan, probe);
+    }
+    bool any_global = false, any_conv = false;
     for (int k = 0; k < n_frames; ++k) {
-        const int g = (wide || fd[(size_t)k].general) ? 1 : 0;
-        if (runs.empty() || runs.back().general != g) runs.push_back({k, k + 1, g});
+        const int cv = (conv_kernel && fd[(size_t)k].conv_band) ? 1 : 0;
+        const int g = (!cv && (wide || fd[(size_t)k].general)) ? 1 : 0;
+        any_global |= g != 0; any_conv |= cv != 0;
+        if (runs.empty() || runs.back().general != g || runs.back().conv != cv) runs.push_back({k, k + 1, g, cv});
         else runs.back().f1 = k + 1;
     }
-    const bool need_keys = general != 0;
+    general = (any_global || any_conv) ? 1 : 0;          // some run uses the global workspace
+    const bool need_keys = any_global;
     const bool need_ekeys = general && plan.edge_points;
-    const bool need_gverts = general && plan.mode == MDVT_MODE_MESH;
+    const bool need_gverts = any_global && plan.mode == MDVT_MODE_MESH;
     // frames per launch set.  Point splat, general: two frames keep the 64-bit key buffers (33 MB per 1080p frame)
     // inside the 256 MiB Infinity Cache between splat and resolve (measured +12 %); the mesh needs the slack of
     // eight (rows full of slivers leave a long tail), and the edge filter alone streams, so 8 as well.
@@ -464,7 +532,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     if (const char* e = getenv("MDVT_WS_CHUNK")) { const int v = atoi(e); if (v > 0) tuned_chunk = v; }   // tuning hook
     auto chunk_of = [&](const Run& r) {
         const int n = r.f1 - r.f0;
-        if (!(r.general || plan.remove_edges)) return n;                  // no workspace: the whole run in one launch
+        if (!(r.general || plan.remove_edges || (r.conv && plan.edge_points))) return n;                  // no workspace: the whole run in one launch
         int ws_chunk = (r.general && plan.mode == MDVT_MODE_POINTS) ? 2 : kWorkspaceChunk;
         if (r.general && plan.mode == MDVT_MODE_MESH) {
             ws_chunk = 2 * kWorkspaceChunk;      // 16: measured -4 % (convergence) / -11 % (pose) vs 8
@@ -483,7 +551,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     int ws_frames = 0, count_frames = 0;
     for (const Run& r : runs) {
         const int ch = chunk_of(r);
-        if ((r.general || plan.remove_edges) && ch > ws_frames) ws_frames = ch;
+        if ((r.general || r.conv || plan.remove_edges) && ch > ws_frames) ws_frames = ch;
         if (ch > count_frames) count_frames = ch;
     }
     if (ws_frames && (rc = ensure_workspace(c, ws_frames, need_keys, need_ekeys, plan.remove_edges, need_gverts, s)) != MDVT_OK) return rc;
@@ -539,6 +607,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     }
     for (const Run& r : runs) {
       plan.general = r.general;
+      plan.conv = r.conv;
       const int chunk = chunk_of(r);
       for (int f0 = r.f0; f0 < r.f1; f0 += chunk) {
         plan.n = (r.f1 - f0 < chunk) ? r.f1 - f0 : chunk;
@@ -781,7 +850,12 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
     }
     c->telea.offs = c->telea.counts + (max_rounds + 2);
     c->telea.ncounts = c->telea.offs + (max_rounds + 2);
-    if (!c->telea_levels_host) MDVT_HIP(c, hipHostMalloc((void**)&c->telea_levels_host, sizeof(uint32_t), hipHostMallocDefault));
+    if (!c->telea_levels_host) {
+        void *h = nullptr, *d = nullptr;
+        size_t got = 0;
+        MDVT_HIP(c, pool_take(64, false, &h, &d, &got));          // pinned, from the process-wide pool (see pool_take)
+        c->telea_levels_host = (uint32_t*)h;
+    }
     const uint32_t key = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);
     const mdvt::BlurKernel K = masked_blur_kernel();
     const int eyes = d_seed_right ? 2 : 1;

@@ -26,6 +26,7 @@ struct FrameDev {
     float sx, sy;        // (W+1)/W, (H+1)/H in f32 for the mesh grid, 1 for points   dmt:1117-1122
     float sW, sH;        // (W-1)/W, (H-1)/H in f32: edge points' "undo"              sr:599-600
     int32_t general;     // 0: pure +-ipd/2 shift, 1: pose / convergence / K != Krender
+    int32_t conv_band;   // general, but nothing except a toe-in about the y axis small enough for k_mesh_conv (mdvt_mesh_conv.hip)
     float M[2][12];      // per eye 3x4 = Translate(+-ipd/2) * Ry(-+a) * T, f32       sr:615-619, 724-725, 832-836
     double Kd[4];        // fx, fy, cx, cy in f64 for the 89-degree edge filter       dmt:1127-1128, 1283-1294
     double Md[2][12];    // the per-eye 3x4 maps in f64 (infill-mask seed normals)       sr:727-733
@@ -86,6 +87,7 @@ struct RenderPlan {
     int remove_edges;
     int edge_points;
     int general;         // any frame of the launch needs the general path
+    int conv;            // mesh: every frame of the launch is convergence-only (FrameDev.conv_band): k_mesh_conv instead of the global-key kernels
     int vec4;            // W%4==0 and every pointer/pitch 4-byte aligned
     int fused_bits;      // set by launch_render when the render kernel itself produced maskbits / hole_counts
     int n;               // frames in this launch
@@ -94,6 +96,12 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 // mdvt_mesh_band.hip: the pure-shift mesh rows as bands (no edge removal)
 bool mesh_band_supported(const RenderPlan& plan, const RenderArgs& a);
 hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+// mdvt_mesh_conv.hip: mesh + convergence only, z-buffer in LDS (the product default of movie_2_3D.py:433-445)
+bool mesh_conv_supported(const RenderPlan& plan, const RenderArgs& a);
+hipError_t launch_mesh_conv(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+// the general paths' edge-point splat into the global edge keys, and the pass that empties the written words again
+hipError_t launch_edge_points_splat(const RenderArgs& a, int n, hipStream_t s);
+hipError_t launch_edge_keys_reset(const RenderArgs& a, int n, hipStream_t s);
 // mdvt_mesh_general.hip: the rasteriser of the general mesh path (between the vertex pass and the resolve pass)
 hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const uint8_t* hole, size_t hole_pitch,

@@ -773,6 +773,12 @@ __global__ void __launch_bounds__(256) k_edge_points_splat4(RenderArgs a)
     }
 }
 
+hipError_t launch_edge_keys_reset(const RenderArgs& a, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_edge_keys_reset, dim3(a.H, n), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
 // Resolve of both general paths: PX pixels per thread, coalesced key reads; the z keys need no clearing pass (parity
 // scheme, mdvt_device.h: only the uncovered words are rewritten; the edge keys: k_edge_keys_reset), colour from the key (mesh) or gathered
 // from the source frame by the winning source index (points).
@@ -879,7 +885,7 @@ static hipError_t launch_resolve_general(const RenderPlan& plan, const RenderArg
         MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(4) MDVT_CASE(5) MDVT_CASE(8) MDVT_CASE(9) MDVT_CASE(12) MDVT_CASE(13)
     }
 #undef MDVT_CASE
-    if (edge) hipLaunchKernelGGL(k_edge_keys_reset, dim3(a.H, plan.n), dim3(64), 0, s, a);
+    if (edge) return launch_edge_keys_reset(a, plan.n, s);
     return hipGetLastError();
 }
 
@@ -2642,6 +2648,19 @@ static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a_i
     return launch_mesh_rows_tpb<PX, 512>(plan, a, lds, vrgb, s);
 }
 
+// mesh mode: the vertices of removed triangles into the global edge keys (sr:589-606)
+hipError_t launch_edge_points_splat(const RenderArgs& a, int n, hipStream_t s)
+{
+    if (a.W % 4 == 0) {
+        const dim3 grid_s((a.W / 4 + 255) / 256, a.H, n);
+        hipLaunchKernelGGL(k_edge_points_splat4, grid_s, dim3(256), 0, s, a);
+    } else {
+        const dim3 grid_s((a.W + 255) / 256, a.H, n);
+        hipLaunchKernelGGL((k_points_splat_general<14>), grid_s, dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
 static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
     RenderArgs a = a_in;
@@ -2658,16 +2677,7 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = launch_mesh_raster_general(plan, a, s)) != hipSuccess) return e;
-    if (edge) {
-        if (a.W % 4 == 0) {
-            const dim3 grid_s((a.W / 4 + 255) / 256, a.H, plan.n);
-            hipLaunchKernelGGL(k_edge_points_splat4, grid_s, dim3(256), 0, s, a);
-        } else {
-            const dim3 grid_s((a.W + 255) / 256, a.H, plan.n);
-            hipLaunchKernelGGL((k_points_splat_general<14>), grid_s, dim3(256), 0, s, a);
-        }
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
+    if (edge && (e = launch_edge_points_splat(a, plan.n, s)) != hipSuccess) return e;
     return launch_resolve_general<true>(plan, a, s);
 }
 
@@ -2678,6 +2688,7 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
         if (plan.general) return launch_points_general(plan, a, s);
         return plan.vec4 ? launch_points_rows_vec4(plan, a, s) : launch_points_rows_cfg<1, 256, 0>(plan, a, s);
     }
+    if (plan.conv) return launch_mesh_conv(plan, a, s);
     if (plan.general) return launch_mesh_general(plan, a, s);
     if (mesh_band_supported(plan, a) && getenv("MDVT_MESH_OLD") == nullptr) return launch_mesh_band(plan, a, s);
     return plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);

@@ -198,6 +198,78 @@ def test_mesh_general_path(mods, orc, case, infill_mask):
     r.close()
 
 
+@pytest.mark.parametrize("W,H", [(64, 48), (96, 64), (256, 144), (320, 240), (8, 2), (36, 300), (1000, 40)])
+@pytest.mark.parametrize("flags", [dict(), dict(infill_mask=True), dict(remove_edges=True, dont_place_points_in_edges=True)])
+def test_mesh_convergence_only_band_kernel(mods, orc, W, H, flags, monkeypatch):
+    """Mesh + per-frame convergence and nothing else (movie_2_3D.py:433-445): k_mesh_conv keeps the scanline's z-buffer in LDS
+    instead of the global-key kernels' round trips.  Several toe-in angles in one batch (incl. one too strong for the kernel,
+    which the host sends down the general path), depth planes and seed images; then the same batch with MDVT_MESH_CONV_OFF=1
+    (general path for every frame) must give the same bytes."""
+    _lib, sr, synthetic = mods
+    convs = [2.5, 8.0, 1.2, 0.9, 0.25]
+    frames = [_scene(synthetic, W, H, seed=500 + 13 * k + W, n_fg=3 + k % 3) for k in range(len(convs))]
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, **flags)
+    ps = [r.frame_params(xfov=45.0 + 5 * (k % 2), convergence_distance=cd) for k, cd in enumerate(convs)]
+    d = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    c = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    seed = bool(flags.get("infill_mask"))
+    got = r.render(d, c, ps, want_depth=True, want_seed=seed)
+    for k in range(len(convs)):
+        op = orc.make_params(W, H, _K(ps[k]), ipd_m=0.065, max_depth=100, depth_scale=ps[k].depth_scale, mode=orc.MODE_MESH,
+                             remove_edges=r.remove_edges, edge_points=int(r.edge_points), conv_angle=ps[k].convergence_angle, key_rgb=r.key_rgb)
+        want = orc.render_stereo(op, frames[k][0], frames[k][1], want_depth=True, want_seed=seed)
+        _compare({key: got[key][k] for key in ("sbs", "mask", "depth")}, want, W, f"conv band {W}x{H} {flags} conv={convs[k]}")
+        if seed:
+            for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+                assert np.array_equal(got["seed"][k][:, sl].cpu().numpy(), want[eye + "_seed"]), f"conv band seed {eye} conv={convs[k]}"
+    monkeypatch.setenv("MDVT_MESH_CONV_OFF", "1")
+    ref = r.render(d, c, ps, want_depth=True, want_seed=seed)
+    for key in got:
+        assert torch.equal(got[key], ref[key]), f"k_mesh_conv and the general path disagree on {key}"
+    r.close()
+
+
+def test_mesh_convergence_band_kernel_on_hard_scenes(mods, orc, monkeypatch):
+    """k_mesh_conv on what stresses its special cases: the contention band of C4 (hundreds of cells folded onto a few
+    pixels: exact depth ties, stretched cells, twisted cells), alternating near / far columns, sub-millimetre and zero depths
+    (near plane), face culling, a toe-in just inside the kernel's admission bound, and forced tie passes."""
+    from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
+    _lib, sr, synthetic = mods
+    rng = np.random.default_rng(77)
+    cases = []
+    for (W, H, t) in ((256, 96, 180), (256, 64, 299)):
+        K = compute_camera_matrix(45.0, None, W, H)
+        sc = synthetic.SyntheticScene(W, H, config_id=4)
+        z = synthetic.contention_band(sc.depth_m(t), K[0, 0], 0.065, row0=H // 3, rows=H // 3)
+        cases.append((synthetic.quantise_depth_to_rgb(z), sc.frame(t)[1]))
+    W, H = 256, 96
+    for style in range(4):
+        d = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        if style == 0:      # alternating near / far columns
+            code = np.where((np.arange(W)[None, :] // 2) % 2 == 0, 150, 30000).astype(np.uint32) + np.zeros((H, 1), np.uint32)
+        elif style == 1:    # very near content: codes 0..3 (Z = 0 rejected by the near plane)
+            code = rng.integers(0, 4, (H, W)).astype(np.uint32)
+        elif style == 2:    # one-code noise on a slope
+            code = (3000 + np.arange(W)[None, :] // 3 + rng.integers(0, 2, (H, W))).astype(np.uint32)
+        else:               # rectangles over a far plane
+            code = np.full((H, W), 40000, np.uint32); code[20:60, 40:90] = 500; code[5:90, 150:160] = 90; code[70:, :] = 2500
+        d[..., 0] = (code >> 8) & 0xFF; d[..., 2] = code & 0xFF
+        cases.append((d, rng.integers(0, 256, (H, W, 3), dtype=np.uint8)))
+    for n, (depth_rgb, color) in enumerate(cases):
+        H, W = depth_rgb.shape[:2]
+        for kw, conv in ((dict(), 2.5), (dict(infill_mask=True), 1.5), (dict(cull=1), 2.0), (dict(cull=2, remove_edges=True), 3.0), (dict(), 0.62)):
+            r = sr.StereoRerenderer(W, H, pupillary_distance=65, **kw)
+            p = r.frame_params(xfov=45.0, convergence_distance=conv)
+            want = _oracle(orc, r, p, depth_rgb, color)
+            for dbg in (None, "32"):
+                if dbg:
+                    monkeypatch.setenv("MDVT_DEBUG_SKIP", dbg)
+                got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
+                _compare(got, want, W, f"conv band hard scene {n} {kw} conv={conv} dbg={dbg}")
+                monkeypatch.delenv("MDVT_DEBUG_SKIP", raising=False)
+            r.close()
+
+
 @pytest.mark.parametrize("mode", ["mesh", "points"])
 def test_general_paths_reuse_their_key_planes_across_submissions(mods, orc, mode):
     """The z-key planes of the general paths are never cleared between submissions: a slot's uses alternate in parity
@@ -618,19 +690,18 @@ def test_render_is_hip_graph_capturable(mods, orc):
     r.close()
 
 
-def test_randomised_parity_sweep(mods, orc):
-    """Seeded random sweep over sizes (incl. tiny / odd), camera scalars, modes, flags, poses and
-    degenerate depth content; every output plane must equal the oracle bit for bit."""
-    _lib, sr, synthetic = mods
+def sweep_cases(synthetic):
+    """The seeded case generator of test_randomised_parity_sweep (also used by tests/dbg_sweep_case.py to replay one case).
+    Soak runs: MDVT_SWEEP_SEED / MDVT_SWEEP_CASES widen the sweep (e.g. 400 cases per seed) without touching the default;
+    MDVT_SWEEP_SIZES="1920x1080,1280x720" gives a full-size soak (the oracle takes seconds per case)."""
     import os
-    # soak runs: MDVT_SWEEP_SEED / MDVT_SWEEP_CASES widen the sweep (e.g. 400 cases per seed) without touching the default
     rng = np.random.default_rng(int(os.environ.get("MDVT_SWEEP_SEED", "20260927")))
     sizes = [(2, 2), (3, 2), (4, 4), (5, 3), (8, 8), (17, 9), (36, 20), (61, 33), (64, 32), (100, 31), (128, 16), (200, 12)]
     n_cases = int(os.environ.get("MDVT_SWEEP_CASES", "60"))
     soak = n_cases > 60 or "MDVT_SWEEP_SIZES" in os.environ
     if soak:
         sizes += [(320, 200), (257, 129), (96, 96), (512, 9), (40, 300)]
-    if "MDVT_SWEEP_SIZES" in os.environ:                 # e.g. "1920x1080,1280x720": full-size soak (the oracle takes seconds per case)
+    if "MDVT_SWEEP_SIZES" in os.environ:
         sizes = [tuple(int(v) for v in t.split("x")) for t in os.environ["MDVT_SWEEP_SIZES"].split(",")]
     for case in range(n_cases):
         W, H = sizes[int(rng.integers(len(sizes)))]
@@ -679,8 +750,6 @@ def test_randomised_parity_sweep(mods, orc):
         color = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         if rng.integers(2):
             color[rng.integers(H), rng.integers(W)] = (0, 255, 0) if infill else (0, 0, 0)
-        r = sr.StereoRerenderer(W, H, pupillary_distance=ipd, max_depth=max_depth, master_xfov=master,
-                                render_as_pointcloud=not mesh, infill_mask=infill, dont_place_points_in_edges=no_pts)
         T = None
         if kind >= 2:
             T = synthetic.synthetic_pose_track(64)[int(rng.integers(1, 64))]
@@ -693,10 +762,23 @@ def test_randomised_parity_sweep(mods, orc):
         conv_d = float(rng.uniform(0.3, 8.0)) if kind in (1, 3) else None
         if soak and conv_d is not None and rng.integers(5) == 0:
             conv_d = float(rng.choice([0.02, 0.05, 500.0]))
-        p = r.frame_params(xfov=xfov, convergence_distance=conv_d, transformation=T)
+        yield dict(case=case, W=W, H=H, mesh=mesh, infill=infill, no_pts=no_pts, ipd=ipd, xfov=xfov, master=master, max_depth=max_depth,
+                   kind=kind, style=style, depth_rgb=depth_rgb, color=color, T=T, conv_d=conv_d)
+
+
+def test_randomised_parity_sweep(mods, orc):
+    """Seeded random sweep over sizes (incl. tiny / odd), camera scalars, modes, flags, poses and
+    degenerate depth content; every output plane must equal the oracle bit for bit."""
+    _lib, sr, synthetic = mods
+    for cs in sweep_cases(synthetic):
+        W, H, mesh, infill, no_pts, ipd, xfov, max_depth, T = (cs[k] for k in ("W", "H", "mesh", "infill", "no_pts", "ipd", "xfov", "max_depth", "T"))
+        depth_rgb, color = cs["depth_rgb"], cs["color"]
+        r = sr.StereoRerenderer(W, H, pupillary_distance=ipd, max_depth=max_depth, master_xfov=cs["master"],
+                                render_as_pointcloud=not mesh, infill_mask=infill, dont_place_points_in_edges=no_pts)
+        p = r.frame_params(xfov=xfov, convergence_distance=cs["conv_d"], transformation=T)
         want_seed = infill and H >= 3 and W >= 3
         got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True, want_seed=want_seed)
-        tag = f"sweep#{case} {W}x{H} mesh={mesh} infill={infill} no_pts={no_pts} ipd={ipd} xfov={xfov} md={max_depth} kind={kind} style={style}"
+        tag = f"sweep#{cs['case']} {W}x{H} mesh={mesh} infill={infill} no_pts={no_pts} ipd={ipd} xfov={xfov} md={max_depth} kind={cs['kind']} style={cs['style']}"
         op = orc.make_params(W, H, _K(p), ipd_m=ipd / 1000, max_depth=max_depth, depth_scale=p.depth_scale,
                              mode=orc.MODE_MESH if mesh else orc.MODE_POINTS, remove_edges=r.remove_edges, edge_points=int(r.edge_points),
                              conv_angle=p.convergence_angle, T=T, key_rgb=r.key_rgb)
