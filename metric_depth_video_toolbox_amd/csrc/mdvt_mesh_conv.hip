@@ -24,9 +24,11 @@
 //     height h (the three edges of a tilted cell have slightly different heights); the barycentric weights are the
 //     three edge functions evaluated directly in 32 bits (24-bit multiplies: |X| < 2^19, cell height < 512).
 //   * where the bracket row changes between two neighbouring columns (a handful of places per scanline: the staircase's
-//     steps) the scanline leaves a cell through its top or bottom edge; those column pairs, like every other irregular
-//     cell (near plane, twisted, out of range), take the generic 64-bit triangle path on the whole wave, the steps
-//     with their vertices worked out on the spot from the source frame (the ring does not hold them).
+//     steps) the scanline leaves a cell through its top or bottom edge, and the ring does not hold all the vertices of the
+//     cells involved.  The waves only LIST those column pairs; the last wave to finish the scanline takes the whole list,
+//     one step per lane: vertices from the source frame, triangles through the 32-bit small-triangle set-up (a step at a
+//     depth edge -- a long triangle -- goes to the generic 64-bit path on the whole wave, like every other irregular cell:
+//     near plane, twisted, out of range).
 //   * edge points (sr:589-606) land up to a few rows away from their source row: they keep the general path's global
 //     64-bit edge keys (k_edge_points_splat4 before this kernel, read back here only where the render left a hole,
 //     k_edge_keys_reset after it).
@@ -41,6 +43,7 @@ namespace {
 constexpr int kQueueWave = 128;        // (cell, pixel) items per wave: pushes of <= 64 followed by a drain keep it < 128
 constexpr int kConvCoord = 1 << 19;    // |X| of the fast path (sub-pixels): every edge value then fits 32 bits
 constexpr int kConvMaxH = 512;         // height of a fast-path edge (sub-pixels)
+constexpr int kStepCap = 62;           // listed staircase steps per scanline pass (+ the two counters = 64 words of LDS); more: whole-wave path
 
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
@@ -52,10 +55,6 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_
 
 // A vertex record in the ring: x = snapped X, y = snapped Y, z = bits of 1/Z' (0: behind the near plane), w = rgb |
 // flags << 24 (bit 0 / 1: tri1 / tri2 of the cell whose top-left corner this vertex is were removed, dmt:1372) | (row & 31) << 27.
-struct EyeConst {
-    float rz0, rzs;       // Z'/z of column j = rz0 + rzs * ((gx - cx) / fx): depth independent
-};
-
 // Z'/z of grid column j (exact-arithmetic value m10 + m8 (gx - cx)/fx; used for ESTIMATES only)
 __device__ __forceinline__ float rz_of(const FrameDev& fp, const float* M, int j)
 {
@@ -174,6 +173,8 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
     ties.nwords = (W + 31) / 32;
     ties.mode = 0;
     ties.force = (a.debug_skip & 32) != 0;
+    uint32_t* steps = ties.bits + ties.nwords + 1;          // [kStepCap] listed staircase steps, then [0] their count, [1] waves done
+    uint32_t* steps_n = steps + kStepCap;
 
     const int eye = blockIdx.x & 1;                         // the two eyes of a band run side by side: they read the same source rows
     const int bf = blockIdx.x >> 1;
@@ -234,8 +235,129 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
         }
     };
 
+    // The common case of stage_to -- a column moves on by one row per scanline -- with the loads in flight while the scanline is
+    // rasterised: a thread owns the columns tid, tid + TPB, ...; for each one whose bracket has to move for the next scanline
+    // the next row's pixel is fetched BEFORE the raster passes (prefetch_next) and turned into a vertex record AFTER them
+    // (stage_prefetched).  Columns are independent, so the steps of the staircase (columns that stay, or move two rows) cost a
+    // masked lane, not a serial pass; a column that has to move a second row is stage_rest's work (as is the band's first scanline:
+    // stage_to).
+    // prefetch registers of column tid + q * TPB: depth pixel | 1 << 31 (valid), colour word incl. flags and the row's tag
+    uint32_t pdx[4] = {0, 0, 0, 0}, pcw[4] = {0, 0, 0, 0};
+    auto column_state = [&](int col, int ib, int& arow, int& Ybot) {
+        const int4 r0 = ring[col], r1 = ring[W + col];
+        const bool t0 = r0.y < r1.y;
+        const uint32_t tw = (uint32_t)(t0 ? r0.w : r1.w);
+        arow = ib + (int)(((tw >> 27) - (uint32_t)ib) & 31u);
+        Ybot = t0 ? r1.y : r0.y;
+    };
+    auto prefetch_next = [&](int Ycn, int ib) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {            // W <= 4 * TPB (launcher)
+            const int col = tid + q * TPB;
+            pdx[q] = 0u;
+            if (col >= W) continue;
+            int arow, Ybot;
+            column_state(col, ib, arow, Ybot);
+            if (!(Ybot <= Ycn && arow + 2 <= H - 1)) continue;
+            const int row = arow + 2;
+            pdx[q] = load_px_bytes(dbase + (size_t)row * a.depth_pitch, col) | 0x80000000u;
+            uint32_t cw = load_px_bytes(cbase + (size_t)row * a.color_pitch, col) | (((uint32_t)row & 31u) << 27);
+            if (EDGES && row <= H - 2 && col <= W - 2) {
+                const uint8_t* ti = tinv + (size_t)row * (W - 1) + col;
+                cw |= (ti[0] ? 1u << 24 : 0u) | (ti[ncell] ? 2u << 24 : 0u);
+            }
+            pcw[q] = cw;
+        }
+    };
+    // returns true if some column of this thread still does not bracket Ycn
+    auto stage_prefetched = [&](int Ycn, int ib) -> bool {
+        bool more = false;
+        // (one copy of the vertex programme, four trips: unrolled, the four independent programmes cost 60 more VGPRs than the
+        //  kernel has at four waves per SIMD)
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t dpv = q == 0 ? pdx[0] : (q == 1 ? pdx[1] : (q == 2 ? pdx[2] : pdx[3]));
+            if (!(dpv >> 31)) continue;
+            const uint32_t dpx = dpv & 0xFFFFFFu;
+            const uint32_t cw = q == 0 ? pcw[0] : (q == 1 ? pcw[1] : (q == 2 ? pcw[2] : pcw[3]));
+            const int row = ib + (int)(((cw >> 27) - (uint32_t)ib) & 31u);
+            const int col = tid + q * TPB;
+            const int4 rec = conv_vertex(dpx, cw, row, col, fp, M);
+            ring[(size_t)(row & 1) * W + col] = rec;
+            more |= rec.y <= Ycn && row + 1 <= H - 1;
+        }
+        return more;
+    };
+    auto stage_rest = [&](int Ycn, int ib) {      // stage_to for this thread's own columns
+        for (int col = tid; col < W; col += TPB) {
+            int arow, Ybot;
+            column_state(col, ib, arow, Ybot);
+            while (Ybot <= Ycn && arow + 2 <= H - 1) {
+                const int row = arow + 2;
+                const int4 rec = vertex_at(row, col);
+                ring[(size_t)(row & 1) * W + col] = rec;
+                ++arow; Ybot = rec.y;
+            }
+        }
+    };
+
+    // One listed staircase step: the cells (r, bj), r = rlo .. rhi, with their vertices from the source frame, on the whole wave.
+    auto step_whole_wave = [&](int bj, int rlo, int rhi, int k) {
+        if (rhi > rlo + 29) rhi = rlo + 29;                   // (64 lanes hold the vertices of 30 cells; the host bounds the staircase far below)
+        if (rhi > H - 2) rhi = H - 2;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (lane < 2 * (rhi - rlo + 2)) v = vertex_at(rlo + (lane >> 1), bj + (lane & 1));
+        for (int r = rlo; r <= rhi; ++r) {
+            const int q = 2 * (r - rlo);
+#define MDVT_V(field, idx) __builtin_amdgcn_readlane(v.field, (idx))
+            const uint32_t wAq = (uint32_t)MDVT_V(w, q);
+            conv_exotic_cell(MDVT_V(x, q), MDVT_V(y, q), __int_as_float(MDVT_V(z, q)), wAq & 0xFFFFFFu,
+                             MDVT_V(x, q + 2), MDVT_V(y, q + 2), __int_as_float(MDVT_V(z, q + 2)), (uint32_t)MDVT_V(w, q + 2) & 0xFFFFFFu,
+                             MDVT_V(x, q + 3), MDVT_V(y, q + 3), __int_as_float(MDVT_V(z, q + 3)), (uint32_t)MDVT_V(w, q + 3) & 0xFFFFFFu,
+                             MDVT_V(x, q + 1), MDVT_V(y, q + 1), __int_as_float(MDVT_V(z, q + 1)), (uint32_t)MDVT_V(w, q + 1) & 0xFFFFFFu,
+                             EDGES ? (wAq >> 24) & 3u : 0u, (int)cull, k, W, lane, ((uint32_t)r << 16) | (uint32_t)bj, zb, ties);
+#undef MDVT_V
+        }
+    };
+    // One cell of a listed step on ONE lane, its four vertices given: the 32-bit small-triangle set-up, this scanline's pixels
+    // walked by the lane.  Returns false -- nothing drawn -- for a cell that is not small (a depth edge: long triangles) or has a
+    // vertex out of the 24-bit range or behind the near plane: those go to step_whole_wave.
+    auto cell_on_lane = [&](const int4& vA, const int4& vB, const int4& vC, const int4& vD, int r, int bj, int k) -> bool {
+        const int Yc = k * kSubpix + kSubpix / 2;
+        const int mnX = min(min(vA.x, vB.x), min(vC.x, vD.x)), mxX = max(max(vA.x, vB.x), max(vC.x, vD.x));
+        const int mnY = min(vA.y, vD.y), mxY = max(vB.y, vC.y);
+        const bool small = mxX - mnX < kSmallTriExtent / 2 && mxY - mnY < kSmallTriExtent / 2 && mnX > -kConvCoord && mxX < kConvCoord &&
+                           vA.z != 0 && vB.z != 0 && vC.z != 0 && vD.z != 0;
+        if (!small) return false;
+        const uint32_t skip = EDGES ? ((uint32_t)vA.w >> 24) & 3u : 0u;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (skip & (1u << pass)) continue;
+            const int4 v1 = pass == 0 ? vB : vC, v2 = pass == 0 ? vC : vD;
+            if (Yc < min3i(vA.y, v1.y, v2.y) || Yc > max3i(vA.y, v1.y, v2.y)) continue;
+            TriSmall ts;
+            if (!tri_small_setup(ts, vA.x, vA.y, __int_as_float(vA.z), v1.x, v1.y, __int_as_float(v1.z), v2.x, v2.y, __int_as_float(v2.z), (int)cull)) continue;
+            int bx0 = floordiv_subpix(min3i(vA.x, v1.x, v2.x) - kSubpix / 2 + kSubpix - 1), bx1 = floordiv_subpix(max3i(vA.x, v1.x, v2.x) - kSubpix / 2);
+            bx0 = max(bx0, 0); bx1 = min(bx1, W - 1);
+            if (bx1 < bx0) continue;
+            TriWalk32 w = tri_small_start(ts, bx0, k);
+            for (int px = bx0; px <= bx1; ++px) {
+                if (tri_small_inside(ts, w)) {
+                    float q0, q1, q2;
+                    tri_small_weights(ts, w, q0, q1, q2);
+                    const float iz = (q0 + q1) + q2;
+                    post_row_fragment(zb, px, iz, shade_px(q0, q1, q2, rcp_exact(iz), (uint32_t)vA.w & 0xFFFFFFu, (uint32_t)v1.w & 0xFFFFFFu, (uint32_t)v2.w & 0xFFFFFFu),
+                                      ((uint32_t)pass << 31) | ((uint32_t)r << 16) | (uint32_t)bj, ties);
+                }
+                tri_small_right(ts, w);
+            }
+        }
+        return true;
+    };
+
     for (int x = tid; x < W; x += TPB) zb[x] = kEmpty64;
     for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
+    if (tid < 2) steps_n[tid] = 0u;
     stage_to(k0 * kSubpix + kSubpix / 2, 0, true);
     __syncthreads();
 
@@ -245,6 +367,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
         const int ib = ibase_of(Yc);
         const int4* r0p = ring;
         const int4* r1p = ring + W;
+        if (k + 1 < k1 && !(a.debug_skip & 128)) prefetch_next(Yc + kSubpix, ib);          // in flight while the scanline is rasterised
         // (passes 1 and 2 only for a row with exact depth ties between different colours: RowTies in mdvt_device.h)
 #pragma unroll 1
         for (ties.mode = 0; ties.mode < 3; ++ties.mode) {
@@ -358,34 +481,70 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
                                          MDVT_BI(XC), MDVT_BI(YC), MDVT_BF(izC), MDVT_BU(cC), MDVT_BI(XD), MDVT_BI(YD), MDVT_BF(izD), MDVT_BU(cD),
                                          MDVT_BU(skip), (int)cull, k, W, lane, MDVT_BU(rowcol), zb, ties);
                     }
-                    // steps of the staircase: the cells of every row between the two brackets, vertices from the source frame
-                    u64 sm = (a.debug_skip & 8) ? 0ull : __ballot(step);
-                    while (sm) {
-                        const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)sm) - 1);
-                        sm &= sm - 1;
-                        const int bj = MDVT_BI(j);
-                        const int ra = ib + (int)(((uint32_t)MDVT_BI(rowA) - (uint32_t)ib) & 31u), rd = ib + (int)(((uint32_t)MDVT_BI(rowD) - (uint32_t)ib) & 31u);
-                        const int rlo = min(ra, rd);
-                        int rhi = max(ra, rd);
-                        if (rhi > rlo + 29) rhi = rlo + 29;                   // (64 lanes hold the vertices of 30 cells; the host bounds the staircase far below)
-                        if (rhi > H - 2) rhi = H - 2;
-                        int4 v = make_int4(0, 0, 0, 0);
-                        if (lane < 2 * (rhi - rlo + 2)) v = vertex_at(rlo + (lane >> 1), bj + (lane & 1));
-                        for (int r = rlo; r <= rhi; ++r) {
-                            const int q = 2 * (r - rlo);
-#define MDVT_V(field, idx) __builtin_amdgcn_readlane(v.field, (idx))
-                            const uint32_t wAq = (uint32_t)MDVT_V(w, q);
-                            conv_exotic_cell(MDVT_V(x, q), MDVT_V(y, q), __int_as_float(MDVT_V(z, q)), wAq & 0xFFFFFFu,
-                                             MDVT_V(x, q + 2), MDVT_V(y, q + 2), __int_as_float(MDVT_V(z, q + 2)), (uint32_t)MDVT_V(w, q + 2) & 0xFFFFFFu,
-                                             MDVT_V(x, q + 3), MDVT_V(y, q + 3), __int_as_float(MDVT_V(z, q + 3)), (uint32_t)MDVT_V(w, q + 3) & 0xFFFFFFu,
-                                             MDVT_V(x, q + 1), MDVT_V(y, q + 1), __int_as_float(MDVT_V(z, q + 1)), (uint32_t)MDVT_V(w, q + 1) & 0xFFFFFFu,
-                                             EDGES ? (wAq >> 24) & 3u : 0u, (int)cull, k, W, lane, ((uint32_t)r << 16) | (uint32_t)bj, zb, ties);
-#undef MDVT_V
+                    // steps of the staircase: listed for the last wave out (below); a full list: here and now, on this wave
+                    if (__ballot(step) != 0ull && !(a.debug_skip & 8)) {
+                        uint32_t slot = kStepCap;
+                        if (step) {
+                            const int ra = ib + (int)(((uint32_t)rowA - (uint32_t)ib) & 31u), rd = ib + (int)(((uint32_t)rowD - (uint32_t)ib) & 31u);
+                            const int rlo = min(ra, rd), rhi = min(max(ra, rd), rlo + 29);
+                            slot = atomicAdd(&steps_n[0], 1u);
+                            if (slot < (uint32_t)kStepCap) steps[slot] = (uint32_t)j | ((uint32_t)rlo << 12) | ((uint32_t)(rhi - rlo) << 27);
+                        }
+                        u64 sm = __ballot(step && slot >= (uint32_t)kStepCap);
+                        while (sm) {
+                            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)sm) - 1);
+                            sm &= sm - 1;
+                            const int ra = ib + (int)(((uint32_t)MDVT_BI(rowA) - (uint32_t)ib) & 31u), rd = ib + (int)(((uint32_t)MDVT_BI(rowD) - (uint32_t)ib) & 31u);
+                            step_whole_wave(MDVT_BI(j), min(ra, rd), max(ra, rd), k);
                         }
                     }
 #undef MDVT_BI
 #undef MDVT_BF
 #undef MDVT_BU
+                }
+                // ---- the listed steps: the last wave to get here takes them all, one step per lane ----
+                uint32_t arrived = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // this wave's list entries before its arrival
+                if (lane == 0) arrived = atomicAdd(&steps_n[1], 1u);
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)arrived) == (uint32_t)(TPB / 64 - 1)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const uint32_t ns = min(steps_n[0], (uint32_t)kStepCap);
+                    // eight steps per round, eight lanes per step: lane `sub` works out vertex (rlo + sub / 2, bj + (sub & 1)) -- one copy
+                    // of the vertex programme --, the lane holding a cell's top-left vertex collects the other three and draws
+                    // the cell (steps of more than three cell rows do not exist within the host's admission bound: whole wave)
+                    for (uint32_t base = 0; base < ns; base += 8) {
+                        const uint32_t si = base + (uint32_t)(lane >> 3);
+                        const int sub = lane & 7;
+                        const uint32_t e = si < ns ? steps[si] : 0u;
+                        const int bj = (int)(e & 0xFFFu), rlo = (int)((e >> 12) & 0x7FFFu);
+                        int nr = si < ns ? (int)(e >> 27) + 1 : 0;              // cell rows of the step
+                        if (rlo + nr - 1 > H - 2) nr = H - 1 - rlo;
+                        const bool wide_step = nr > 3;
+                        int4 v = make_int4(0, 0, 0, 0);
+                        if (!wide_step && sub < 2 * (nr + 1)) v = vertex_at(rlo + (sub >> 1), bj + (sub & 1));
+                        int4 vD, vB, vC;
+                        vD.x = __shfl_down(v.x, 1); vD.y = __shfl_down(v.y, 1); vD.z = __shfl_down(v.z, 1); vD.w = __shfl_down(v.w, 1);
+                        vB.x = __shfl_down(v.x, 2); vB.y = __shfl_down(v.y, 2); vB.z = __shfl_down(v.z, 2); vB.w = __shfl_down(v.w, 2);
+                        vC.x = __shfl_down(v.x, 3); vC.y = __shfl_down(v.y, 3); vC.z = __shfl_down(v.z, 3); vC.w = __shfl_down(v.w, 3);
+                        bool left = false;
+                        const int r = rlo + (sub >> 1);
+                        if (!wide_step && !(sub & 1) && (sub >> 1) < nr) left = !cell_on_lane(v, vB, vC, vD, r, bj, k);
+                        u64 lm = __ballot(left);                            // cells at a depth edge / near plane / out of range: generic path
+                        while (lm) {
+                            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
+                            lm &= lm - 1;
+                            const int rr = __builtin_amdgcn_readlane(r, l);
+                            step_whole_wave(__builtin_amdgcn_readlane(bj, l), rr, rr, k);
+                        }
+                        u64 wm = __ballot(wide_step && sub == 0);
+                        while (wm) {
+                            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1);
+                            wm &= wm - 1;
+                            const int rl = __builtin_amdgcn_readlane(rlo, l);
+                            step_whole_wave(__builtin_amdgcn_readlane(bj, l), rl, rl + __builtin_amdgcn_readlane(nr, l) - 1, k);
+                        }
+                    }
+                    if (lane < 2) steps_n[lane] = 0u;
                 }
             }
             __syncthreads();
@@ -399,7 +558,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
         ties.mode = 0;
 
         // the brackets of the next scanline (the ring's last readers were the raster passes above)
-        if (k + 1 < k1) stage_to(Yc + kSubpix, ib, false);
+        if (k + 1 < k1 && stage_prefetched(Yc + kSubpix, ib) && !(a.debug_skip & 4)) stage_rest(Yc + kSubpix, ib);
 
         // ---- resolve: LDS keys -> colour-key hole test -> coalesced stores; the keys are reset on the way ----
         if (act4 && !(a.debug_skip & 2)) {
@@ -454,7 +613,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
 size_t mesh_conv_lds_bytes(int W, int tpb)
 {
     return (size_t)W * sizeof(u64) + 2 * (size_t)W * 16 + (size_t)(tpb / 64) * kQueueWave * sizeof(uint32_t) +
-           (((size_t)W + 31) / 32 + 1) * sizeof(uint32_t);
+           (((size_t)W + 31) / 32 + 1) * sizeof(uint32_t) + (kStepCap + 2) * sizeof(uint32_t);
 }
 
 static int mesh_conv_tpb(int W)
@@ -467,7 +626,12 @@ static int mesh_conv_tpb(int W)
 bool mesh_conv_supported(const RenderPlan& plan, const RenderArgs& a)
 {
     if (!plan.vec4 || plan.mode != MDVT_MODE_MESH) return false;
-    if (getenv("MDVT_MESH_CONV_OFF") != nullptr) return false;                 // A/B and test hook: the general path instead
+    // Opt-in (MDVT_MESH_CONV=1): measured at 1080p, 32 frames per launch (profiles/r03_conv_band.md), the kernel moves 44 MB per
+    // frame where the general path moves 438, but it is VALU bound like the general rasteriser and only draws level with it
+    // without edge removal (89.7 against 91.7 us per frame) and loses with it (the product default: 123 against 91 us per
+    // frame): the general vertex programme runs once per eye AND per band here.  The general path stays the default.
+    const char* on = getenv("MDVT_MESH_CONV");
+    if (!(on && on[0] == '1')) return false;
     if (a.W < 8 || a.W > 4096 || a.H < 2) return false;
     return mesh_conv_lds_bytes(a.W, mesh_conv_tpb(a.W)) <= 160 * 1024;
 }

@@ -41,7 +41,7 @@ for cs in sweep_cases(synthetic):
         for (y, x) in dm[:3]:
             print("  at", y, x, "got mask", m[y, sl][x], "want", want[eye + "_mask"][y, x], "got rgb", c[y, sl][x], "want rgb", want[eye + "_rgb"][y, x],
                   "got z", z[y, sl][x], "want z", want[eye + "_depth"][y, x])
-    for env in ("MDVT_FORCE_GLOBAL", "MDVT_MESH_CONV_OFF"):
+    for env in ("MDVT_FORCE_GLOBAL", "MDVT_MESH_CONV"):
         os.environ[env] = "1"
         alt = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
         print(env, "changes the device result:", not (torch.equal(alt["mask"], got["mask"]) and torch.equal(alt["sbs"], got["sbs"])))

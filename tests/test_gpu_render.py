@@ -203,9 +203,10 @@ def test_mesh_general_path(mods, orc, case, infill_mask):
 def test_mesh_convergence_only_band_kernel(mods, orc, W, H, flags, monkeypatch):
     """Mesh + per-frame convergence and nothing else (movie_2_3D.py:433-445): k_mesh_conv keeps the scanline's z-buffer in LDS
     instead of the global-key kernels' round trips.  Several toe-in angles in one batch (incl. one too strong for the kernel,
-    which the host sends down the general path), depth planes and seed images; then the same batch with MDVT_MESH_CONV_OFF=1
+    which the host sends down the general path), depth planes and seed images; then the same batch without MDVT_MESH_CONV=1
     (general path for every frame) must give the same bytes."""
     _lib, sr, synthetic = mods
+    monkeypatch.setenv("MDVT_MESH_CONV", "1")                # the kernel is opt-in (it does not beat the general path: profiles/r03_conv_band.md)
     convs = [2.5, 8.0, 1.2, 0.9, 0.25]
     frames = [_scene(synthetic, W, H, seed=500 + 13 * k + W, n_fg=3 + k % 3) for k in range(len(convs))]
     r = sr.StereoRerenderer(W, H, pupillary_distance=65, **flags)
@@ -222,7 +223,7 @@ def test_mesh_convergence_only_band_kernel(mods, orc, W, H, flags, monkeypatch):
         if seed:
             for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
                 assert np.array_equal(got["seed"][k][:, sl].cpu().numpy(), want[eye + "_seed"]), f"conv band seed {eye} conv={convs[k]}"
-    monkeypatch.setenv("MDVT_MESH_CONV_OFF", "1")
+    monkeypatch.delenv("MDVT_MESH_CONV")
     ref = r.render(d, c, ps, want_depth=True, want_seed=seed)
     for key in got:
         assert torch.equal(got[key], ref[key]), f"k_mesh_conv and the general path disagree on {key}"
@@ -235,6 +236,7 @@ def test_mesh_convergence_band_kernel_on_hard_scenes(mods, orc, monkeypatch):
     (near plane), face culling, a toe-in just inside the kernel's admission bound, and forced tie passes."""
     from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
     _lib, sr, synthetic = mods
+    monkeypatch.setenv("MDVT_MESH_CONV", "1")
     rng = np.random.default_rng(77)
     cases = []
     for (W, H, t) in ((256, 96, 180), (256, 64, 299)):
