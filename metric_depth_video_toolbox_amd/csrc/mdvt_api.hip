@@ -481,7 +481,8 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     }
     // The arithmetic of a frame (pure shift or general) is its own property, never its batch
     // neighbours': consecutive frames of one kind form a run, every run gets its own launches.
-    struct Run { int f0, f1, general, conv; };  // general = "takes the global-key kernels"; conv = k_mesh_conv (mesh, convergence only)
+    struct Run { int f0, f1, general, conv, craster; };  // general = "takes the global-key kernels"; conv = k_mesh_conv (mesh, convergence only);
+                                                         // craster = general, but every frame convergence-only: k_mesh_raster_conv
     std::vector<Run> runs;
 
     const FrameDev* dfp = nullptr;
@@ -517,8 +518,9 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     for (int k = 0; k < n_frames; ++k) {
         const int cv = (conv_kernel && fd[(size_t)k].conv_band) ? 1 : 0;
         const int g = (!cv && (wide || fd[(size_t)k].general)) ? 1 : 0;
+        const int cr = (g && !wide && plan.mode == MDVT_MODE_MESH && fd[(size_t)k].conv_band) ? 1 : 0;
         any_global |= g != 0; any_conv |= cv != 0;
-        if (runs.empty() || runs.back().general != g || runs.back().conv != cv) runs.push_back({k, k + 1, g, cv});
+        if (runs.empty() || runs.back().general != g || runs.back().conv != cv || runs.back().craster != cr) runs.push_back({k, k + 1, g, cv, cr});
         else runs.back().f1 = k + 1;
     }
     general = (any_global || any_conv) ? 1 : 0;          // some run uses the global workspace
@@ -608,6 +610,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     for (const Run& r : runs) {
       plan.general = r.general;
       plan.conv = r.conv;
+      plan.conv_raster = r.craster;
       const int chunk = chunk_of(r);
       for (int f0 = r.f0; f0 < r.f1; f0 += chunk) {
         plan.n = (r.f1 - f0 < chunk) ? r.f1 - f0 : chunk;

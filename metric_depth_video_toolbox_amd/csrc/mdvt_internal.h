@@ -88,6 +88,7 @@ struct RenderPlan {
     int edge_points;
     int general;         // any frame of the launch needs the general path
     int conv;            // mesh: every frame of the launch is convergence-only (FrameDev.conv_band): k_mesh_conv instead of the global-key kernels
+    int conv_raster;     // general mesh path, every frame of the launch convergence-only: k_mesh_raster_conv instead of k_mesh_raster_small
     int vec4;            // W%4==0 and every pointer/pitch 4-byte aligned
     int fused_bits;      // set by launch_render when the render kernel itself produced maskbits / hole_counts
     int n;               // frames in this launch

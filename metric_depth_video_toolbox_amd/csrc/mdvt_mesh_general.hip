@@ -130,6 +130,188 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
     }
 }
 
+// ---- The same stage for frames whose vertex rows stay (almost) horizontal on screen: convergence only ---------------------
+// With nothing but a toe-in (FrameDev.conv_band: sr:707-726, no pose, K == Krender) the projected row of a vertex does not
+// depend on its depth: a cell is still a slightly sheared box, at most a sub-pixel taller on one side than on the other, and
+// nearly every scanline that meets it enters through its left column edge and leaves through its right one, crossing the
+// diagonal in between -- never its top or bottom edge.  On such a scanline the covered pixels are
+//     [P(left crossing), P(right crossing))  split at P(diagonal crossing),   P(k, h) = ceil((k - 128 h) / (256 h))
+// (the top-left rule of the generic edge functions written out for edges that start above the scanline and end below it; h =
+// the edge's own height), and a fragment's three edge functions are 32-bit values from 24-bit multiplies.  That is ~150
+// instructions per cell and eye where the triangle-by-triangle set-up and walk of k_mesh_raster_small needs 2 x 211.  Whatever
+// does not fit -- a scanline through a cell's top or bottom edge (a few per thousand cells), twisted or folded cells, cells
+// behind the near plane or beyond +-2^19 sub-pixels, stretched cells -- is listed per workgroup and goes through the generic
+// small-triangle / queue code afterwards, every lane a listed triangle.  Fragments are the same words either way (a fragment
+// posted twice changes nothing: the key is a minimum, the side buffer word is identical).
+__device__ __forceinline__ int conv_first_pixel(int k, int h, int W)
+{
+    const int D = h * kSubpix;
+    int n = k + h * (kSubpix / 2) - 1;
+    n = n < 0 ? 0 : n;
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)D));
+    const int rem = n - __mul24(q, D);
+    q += rem < 0 ? -1 : (rem >= D ? 1 : 0);
+    return q > W ? W : q;
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
+{
+    constexpr bool EDGES = FLAGS & 2;
+    constexpr int kCoord = 1 << 19, kMaxH = 512, kMaxSpan = 12;
+    const int W = a.W, H = a.H;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    const int fr = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const bool act = j < W - 1;
+    const uint32_t parity = (a.key_parity >> fr) & 1u;
+    const size_t ncell = (size_t)(W - 1) * (H - 1);
+    __shared__ uint4 sv[2][2][129];
+    __shared__ uint32_t glist[256];           // cells (thread | eye << 8) for the generic code
+    __shared__ uint32_t gcount;
+    uint32_t inv0 = 0, inv1 = 0;
+    {
+        const int t = threadIdx.x;
+        const int j0 = blockIdx.x * blockDim.x;
+        const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
+        const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);
+        uint4 rx = make_uint4(0, 0, 0, 0);
+        if (t < 4) rx = (t & 2 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t & 1) * W + jx];
+        const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
+        const uint4 r2 = a.gverts[1][base + jc], r3 = a.gverts[1][base + W + jc];
+        if (EDGES && act) {
+            const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
+            inv0 = tinv[0]; inv1 = tinv[ncell];
+        }
+        if (t < 4) sv[t >> 1][t & 1][128] = rx;
+        sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
+        if (t == 0) gcount = 0u;
+    }
+    __syncthreads();
+    const uint32_t cull = (uint32_t)a.cull;
+#pragma unroll 1
+    for (int eye = 0; eye < 2; ++eye) {
+        if (!act || (inv0 && inv1)) continue;
+        u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
+        u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
+        const int t = threadIdx.x;
+        const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
+        const int XA = (int)A.x, YA = (int)A.y, XB = (int)B.x, YB = (int)B.y, XC = (int)Cv.x, YC = (int)Cv.y, XD = (int)D.x, YD = (int)D.y;
+        const float izA = __uint_as_float(A.z), izB = __uint_as_float(B.z), izC = __uint_as_float(Cv.z), izD = __uint_as_float(D.z);
+        if (!(izA > 0.0f)) continue;                                   // A is a vertex of both triangles: near plane, both dropped
+        bool generic = !(izB > 0.0f && izC > 0.0f && izD > 0.0f);
+        const int hAB = YB - YA, hAC = YC - YA, hDC = YC - YD;
+        const uint32_t inr = (uint32_t)(XA + kCoord) | (uint32_t)(XB + kCoord) | (uint32_t)(XC + kCoord) | (uint32_t)(XD + kCoord);
+        generic |= (inr >> 20) != 0u || hAB <= 0 || hAB >= kMaxH || hAC <= 0 || hAC >= kMaxH || hDC <= 0 || hDC >= kMaxH;
+        if (!generic) {
+            int k_lo = floordiv_subpix(min(YA, YD) - kSubpix / 2 + kSubpix - 1), k_hi = floordiv_subpix(max(YB, YC) - kSubpix / 2 - 1);
+            k_lo = max(k_lo, 0); k_hi = min(k_hi, H - 1);
+            if (k_hi - k_lo > 2) generic = true;
+            else {
+                for (int k = k_lo; k <= k_hi; ++k) {
+                    const int Yc = k * kSubpix + kSubpix / 2;
+                    if (!(YA <= Yc && YD <= Yc && Yc < YB && Yc < YC)) {
+                        // the scanline passes through the cell's top or bottom edge -- unless it misses the cell altogether
+                        if (!((Yc < YA && Yc < YD) || (YB <= Yc && YC <= Yc))) generic = true;
+                        continue;
+                    }
+                    const int tA = Yc - YA, tD = Yc - YD;
+                    const int kAB = __mul24(XB - XA, tA) + __mul24(hAB, XA), kAC = __mul24(XC - XA, tA) + __mul24(hAC, XA);
+                    const int kDC = __mul24(XC - XD, tD) + __mul24(hDC, XD);
+                    const int pAB = conv_first_pixel(kAB, hAB, W), pAC = conv_first_pixel(kAC, hAC, W), pDC = conv_first_pixel(kDC, hDC, W);
+                    const bool regular = pAB <= pDC;
+                    const bool mono = regular ? (pAB <= pAC && pAC <= pDC) : (pAC <= pAB && pDC <= pAC);
+                    const int plo = regular ? pAB : pDC, n = regular ? pDC - pAB : pAB - pDC;
+                    if (!mono || n > kMaxSpan) { generic = true; continue; }
+                    for (int px = plo; px < plo + n; ++px) {
+                        const bool in1 = (px < pAC) == regular;              // tri1 = (A, B, C) on the B side of the diagonal, tri2 = (A, C, D)
+                        if (in1 ? inv0 : inv1) continue;                     // removed by the 89-degree filter (dmt:1372)
+                        const int X1 = in1 ? XB : XC, Y1 = in1 ? YB : YC, X2 = in1 ? XC : XD, Y2 = in1 ? YC : YD;
+                        const int Xc = px * kSubpix + kSubpix / 2;
+                        // the raw edge functions of tri_setup_snapped; inside the triangle all three carry the sign of the doubled area
+                        const int w0 = __mul24(X2 - X1, Yc - Y1) - __mul24(Y2 - Y1, Xc - X1);
+                        const int w1 = __mul24(XA - X2, Yc - Y2) - __mul24(YA - Y2, Xc - X2);
+                        const int w2 = __mul24(X1 - XA, Yc - YA) - __mul24(Y1 - YA, Xc - XA);
+                        const int a2 = (w0 + w1) + w2;
+                        if (a2 == 0) continue;
+                        if (cull && (cull == 1u) != (a2 < 0)) continue;
+                        const float ra = rcp_exact((float)(a2 < 0 ? -a2 : a2));
+                        const float q0 = ((float)(w0 < 0 ? -w0 : w0) * ra) * izA;
+                        const float q1 = ((float)(w1 < 0 ? -w1 : w1) * ra) * (in1 ? izB : izC);
+                        const float q2 = ((float)(w2 < 0 ? -w2 : w2) * ra) * (in1 ? izC : izD);
+                        mesh_global_fragment(keys, cbuf, parity, (size_t)k * W + (size_t)px, q0, q1, q2, A.w, in1 ? B.w : Cv.w, in1 ? Cv.w : D.w,
+                                             draw_id_global(in1 ? 0 : 1, i, j));
+                    }
+                }
+            }
+        }
+        if (generic) glist[atomicAdd(&gcount, 1u)] = (uint32_t)t | ((uint32_t)eye << 8);
+    }
+    __syncthreads();
+    // ---- the listed cells: k_mesh_raster_small's code, a listed TRIANGLE per lane ----
+    const uint32_t ng = 2u * gcount;
+    for (uint32_t base = 0; base < ng; base += 128u) {                   // (workgroup uniform)
+        const uint32_t idx = base + threadIdx.x;
+        const bool on = idx < ng;
+        const uint32_t ent = glist[on ? idx >> 1 : 0];
+        const int t = (int)(ent & 0xFFu), eye = (int)(ent >> 8), pass = (int)(idx & 1u);
+        const int cj = blockIdx.x * blockDim.x + t;
+        u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
+        u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
+        const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
+        const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
+        const uint32_t did = draw_id_global(pass, i, cj);
+        bool removed = false;
+        if (EDGES && on) removed = a.tri_invalid[(size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + cj + (pass ? ncell : 0)] != 0;
+        bool toq = false;
+        if (on && !removed) {
+            const int X0 = (int)A.x, Y0 = (int)A.y, X1 = (int)v1.x, Y1 = (int)v1.y, X2 = (int)v2.x, Y2 = (int)v2.y;
+            const float iz0 = __uint_as_float(A.z), iz1 = __uint_as_float(v1.z), iz2 = __uint_as_float(v2.z);
+            if (iz0 > 0.0f && iz1 > 0.0f && iz2 > 0.0f) {
+                const int mnX = min3i(X0, X1, X2), mxX = max3i(X0, X1, X2), mnY = min3i(Y0, Y1, Y2), mxY = max3i(Y0, Y1, Y2);
+                int bx0 = floordiv_subpix(mnX - kSubpix / 2 + kSubpix - 1), bx1 = floordiv_subpix(mxX - kSubpix / 2);
+                int by0 = floordiv_subpix(mnY - kSubpix / 2 + kSubpix - 1), by1 = floordiv_subpix(mxY - kSubpix / 2);
+                bx0 = max(bx0, 0); by0 = max(by0, 0); bx1 = min(bx1, W - 1); by1 = min(by1, H - 1);
+                if (bx1 >= bx0 && by1 >= by0) {
+                    if (max(mxX - mnX, mxY - mnY) >= kSmallTriExtent || (bx1 - bx0 + 1) * (by1 - by0 + 1) > kSmallBox) {
+                        toq = true;
+                    } else {
+                        TriSmall ts;
+                        if (tri_small_setup(ts, X0, Y0, iz0, X1, Y1, iz1, X2, Y2, iz2, a.cull)) {
+                            TriWalk32 row = tri_small_start(ts, bx0, by0);
+                            for (int py = by0; py <= by1; ++py) {
+                                TriWalk32 w = row;
+                                for (int px = bx0; px <= bx1; ++px) {
+                                    if (tri_small_inside(ts, w)) {
+                                        float q0, q1, q2;
+                                        tri_small_weights(ts, w, q0, q1, q2);
+                                        mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
+                                    }
+                                    tri_small_right(ts, w);
+                                }
+                                tri_small_down(ts, row);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const u64 mq = __ballot(toq);
+        if (mq) {
+            const size_t seg = (size_t)fr * H + i;
+            uint32_t qb = 0;
+            const int first = __ffsll((long long)mq) - 1;
+            if (lane == first) qb = atomicAdd(&a.bigq_count[seg], (uint32_t)__popcll(mq));
+            qb = __shfl(qb, first);
+            if (toq) {
+                uint2* q = (uint2*)a.bigq + seg * (size_t)(4 * W);
+                q[qb + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = make_uint2(did, (uint32_t)fr * 2u + (uint32_t)eye);
+            }
+        }
+    }
+}
+
 // Exclusive prefix sums of the segment counters (n <= a few 10^4): one workgroup.  prefix[n] = number of queued triangles.
 __global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ prefix, int n)
 {
@@ -203,7 +385,11 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
     hipError_t e = hipMemsetAsync(a.bigq_count, 0, (size_t)plan.n * a.H * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
-    if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2>), grid_c, dim3(128), 0, s, a);
+    // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
+    if (plan.conv_raster && getenv("MDVT_RASTER_CONV_OFF") == nullptr) {
+        if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_c, dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_c, dim3(128), 0, s, a);
+    } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2>), grid_c, dim3(128), 0, s, a);
     else hipLaunchKernelGGL((k_mesh_raster_small<0>), grid_c, dim3(128), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const int nseg = plan.n * a.H;

@@ -224,19 +224,25 @@ def test_mesh_convergence_only_band_kernel(mods, orc, W, H, flags, monkeypatch):
             for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
                 assert np.array_equal(got["seed"][k][:, sl].cpu().numpy(), want[eye + "_seed"]), f"conv band seed {eye} conv={convs[k]}"
     monkeypatch.delenv("MDVT_MESH_CONV")
-    ref = r.render(d, c, ps, want_depth=True, want_seed=seed)
+    ref = r.render(d, c, ps, want_depth=True, want_seed=seed)           # the general path, its rasteriser = k_mesh_raster_conv (default)
+    monkeypatch.setenv("MDVT_RASTER_CONV_OFF", "1")
+    ref2 = r.render(d, c, ps, want_depth=True, want_seed=seed)          # ... = k_mesh_raster_small (what poses take)
     for key in got:
         assert torch.equal(got[key], ref[key]), f"k_mesh_conv and the general path disagree on {key}"
+        assert torch.equal(got[key], ref2[key]), f"the two rasterisers of the general path disagree on {key}"
     r.close()
 
 
-def test_mesh_convergence_band_kernel_on_hard_scenes(mods, orc, monkeypatch):
-    """k_mesh_conv on what stresses its special cases: the contention band of C4 (hundreds of cells folded onto a few
+@pytest.mark.parametrize("kernel", ["k_mesh_conv", "k_mesh_raster_conv"])
+def test_mesh_convergence_band_kernel_on_hard_scenes(mods, orc, monkeypatch, kernel):
+    """The two convergence-only kernels (k_mesh_conv: opt-in, z-buffer in LDS; k_mesh_raster_conv: the general path's default
+    rasteriser for such frames) on what stresses their special cases: the contention band of C4 (hundreds of cells folded onto a few
     pixels: exact depth ties, stretched cells, twisted cells), alternating near / far columns, sub-millimetre and zero depths
     (near plane), face culling, a toe-in just inside the kernel's admission bound, and forced tie passes."""
     from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
     _lib, sr, synthetic = mods
-    monkeypatch.setenv("MDVT_MESH_CONV", "1")
+    if kernel == "k_mesh_conv":
+        monkeypatch.setenv("MDVT_MESH_CONV", "1")
     rng = np.random.default_rng(77)
     cases = []
     for (W, H, t) in ((256, 96, 180), (256, 64, 299)):
