@@ -57,7 +57,8 @@ typedef struct mdvt_config {
     int32_t cull;                /* mesh mode: 0 = draw both faces (default), 1 = cull back faces, 2 = cull front faces.
                                     The grid's own winding (dmt:1243-1254: counter-clockwise on screen) is the front face.
                                     dmt:1507-1556 never sets Open3D's mesh_show_back_face, whose legacy default (off) most
-                                    likely means GL_CULL_FACE: either behaviour can be matched once it has been observed */
+                                    likely means GL_CULL_FACE: either behaviour can be matched once it has been observed
+                                    (an OPEN parity risk for posed / converged mesh renders without edge removal: DESIGN.md section 3) */
     double ipd_m;                /* --pupillary_distance / 1000 (sr:458-459)                         */
     double max_depth;            /* --max_depth (dfh:22)                                             */
     uint8_t key_rgb[4];          /* bg_color*255: (0,0,0), or (0,255,0) with --infill_mask (sr:555-558) */
@@ -197,7 +198,9 @@ int mdvt_masked_blur(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, uint
  * seed; the rounds stop at the level of the deepest key-coloured pixel, and d_remaining (optional, n_images x uint32)
  * receives the number of key-coloured pixels beyond max_rounds.  Up to 32 images share one pass (14 B/px of workspace
  * each).  Unlike the other entry points this one WAITS on the stream once per pass: the levels come from a distance
- * transform, and the host reads the deepest level back so that exactly that many level launches follow.
+ * transform, and the host reads the deepest level back so that exactly that many level launches follow -- a caller that
+ * pipelines batches should issue it from the thread / stream that can afford the wait (the read-back word is per-ctx state:
+ * like every entry point, not to be called on one ctx from two threads at once).
  * The key colour is the ctx's cfg.key_rgb.  d_out may not alias d_seed. */
 int mdvt_finish_infill_mask(mdvt_ctx* ctx, const uint8_t* d_seed, size_t seed_pitch, size_t seed_stride, uint8_t* d_out,
                             size_t out_pitch, size_t out_stride, int n_images, int max_rounds, uint32_t* d_remaining,

@@ -4,13 +4,13 @@ u = ex +- dl / Z, row i) differ from the reference's f64 chain for the pure ster
 Open3D / OpenCV in f64 end to end (dmt:1117-1128 unprojection, sr:599-600 undo of the off-by-one scale, Open3D translate,
 cv2.projectPoints with the camera matrix cast to f32, np.round: sr:592-600, 733-746); for the pure shift it is closed form and is
 restated here in NumPy f64 (cv2.projectPoints by its published arithmetic: x' = X * (1 / Z), u = x' * fx + cx).
-CPU only.  usage: python tools/edge_point_f64_rate.py [W H frames]"""
+CPU only.  usage: python tests/report_edge_points_f64.py [W H frames]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
 from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
-from oracle import c_oracle as orc            # (a measurement tool for DESIGN.md, not product code: lives beside the tests' tooling)
+from oracle import c_oracle as orc
 
 W, H, N = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080, 8)
 K = compute_camera_matrix(45.0, None, W, H)
