@@ -16,8 +16,6 @@
 // segment holds all four triangles of every cell of its row, so nothing can overflow.
 #include "mdvt_device.h"
 
-#include <stdlib.h>
-
 namespace mdvt {
 
 namespace {
@@ -46,7 +44,6 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
     const int fr = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
-    if ((int)(blockIdx.x * blockDim.x) >= W - 1) return;          // (padding workgroup of the XCD-aware grid)
     const uint32_t parity = (a.key_parity >> fr) & 1u;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     // the 2 x 129 vertex records of both eyes, fetched once per workgroup with all loads in flight together
@@ -168,7 +165,6 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
     const int fr = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
-    if ((int)(blockIdx.x * blockDim.x) >= W - 1) return;          // (padding workgroup of the XCD-aware grid)
     const uint32_t parity = (a.key_parity >> fr) & 1u;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     __shared__ uint4 sv[2][2][129];
@@ -388,12 +384,7 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
 {
     hipError_t e = hipMemsetAsync(a.bigq_count, 0, (size_t)plan.n * a.H * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    // XCD-aware grid: workgroup b runs on XCD b % 8, each XCD has its own L2, and the cell rows i and i + 1 share a vertex
-    // row.  With the column blocks padded to a multiple of 8 (idle workgroups leave at once) the block below a block lands
-    // on the SAME XCD a moment later and finds the shared row's records in that L2 (MDVT_RASTER_XCD=0: unpadded, for A/B runs)
-    unsigned gx = (unsigned)((a.W - 1 + 127) / 128);
-    { const char* ev = getenv("MDVT_RASTER_XCD"); if (!(ev && ev[0] == '0')) gx = (gx + 7u) & ~7u; }
-    const dim3 grid_c(gx, a.H - 1, plan.n);
+    const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
     // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
     if (plan.conv_raster && getenv("MDVT_RASTER_CONV_OFF") == nullptr) {
         if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_c, dim3(128), 0, s, a);
