@@ -266,13 +266,18 @@ def main():
     from metric_depth_video_toolbox_amd.stereo_rerender import StereoRerenderer
     from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
 
-    rank, world = D.init_process_group()
+    # (MDVT_DIST_BACKEND=gloo + MDVT_BENCH_SHARE_GPU=1: the N > 1 code path on a one-GPU box, for tests/ only -- RCCL refuses
+    # two ranks on one device; the driver's launch line leaves both unset and gets RCCL, one rank per GPU)
+    share_gpu = os.environ.get("MDVT_BENCH_SHARE_GPU") == "1"
+    rank, world = D.init_process_group(os.environ.get("MDVT_DIST_BACKEND"))
     if torch.distributed.is_initialized():
         world = torch.distributed.get_world_size()          # what RCCL actually spans, not what the env claims
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the job has {world} rank(s)\n")
         sys.exit(3)
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if share_gpu:
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     W, H, N = args.width, args.height, args.frames

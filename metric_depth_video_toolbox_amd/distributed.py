@@ -89,6 +89,16 @@ def init_process_group(backend: Optional[str] = None):
     return rank, world
 
 
+def _collective_device(device):
+    """Where a collective's tensors live: the caller's device under RCCL (default: the current one), host memory under
+    gloo (whose device-tensor support covers only some collectives: the tests that put two ranks on one GPU use it)."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() != "nccl":
+        return torch.device("cpu")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else device
+
+
 def broadcast_clip_parameters(params: Optional[ClipParameters], src: int = 0, device=None) -> ClipParameters:
     """One broadcast of the packed parameter block from `src` (two tiny collectives: length, payload).
     With a single process this is the identity."""
@@ -97,8 +107,7 @@ def broadcast_clip_parameters(params: Optional[ClipParameters], src: int = 0, de
     if not (dist.is_available() and dist.is_initialized()):
         assert params is not None
         return params
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    device = _collective_device(device)
     rank = dist.get_rank()
     blk = params.pack() if rank == src else None
     n = torch.tensor([0 if blk is None else blk.size], dtype=torch.int64, device=device)
@@ -115,8 +124,7 @@ def gather_rank_stats(frames: float, seconds: float, hole_px: float, device=None
     mine = np.array([frames, seconds, hole_px], np.float64)
     if not (dist.is_available() and dist.is_initialized()):
         return mine[None]
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    device = _collective_device(device)
     t = torch.from_numpy(mine).to(device)
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
@@ -128,8 +136,7 @@ def max_over_ranks(value: float, device=None) -> float:
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    device = _collective_device(device)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -88,6 +88,35 @@ def test_bench_line_under_torchrun_with_one_rank():
     assert "mesh" in line["extra"] and "product_default" in line["extra"]
 
 
+def test_bench_line_with_two_ranks_sharing_the_gpu():
+    """bench.py's N > 1 code path end to end on the hardware at hand (the driver's SCALE run is otherwise the first time it
+    executes): the driver's launch line with two ranks, backend gloo, both on cuda:0 (RCCL refuses two ranks on one
+    device; MDVT_BENCH_SHARE_GPU is read by bench.py for this test only).  The parameter block is broadcast, every rank
+    renders its own frames, rank 0 prints ONE line that counts both ranks' frames, and the strong-scaling clips split
+    their frames over the ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MDVT_DIST_BACKEND="gloo", MDVT_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--frames", "8", "--prewarm-ms", "0", "--clip-frames", "30", "--clip-repeats", "3"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                      # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and len(line["config"]["devices"]) == 2 and line["scaling"] == "weak"
+    assert line["config"]["frames_per_step_per_gpu"] == 8
+    # whole-job value: both ranks' frames over the slower rank's wall clock
+    assert abs(line["value"] - 2 * 8 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
+    assert line["cpu_baseline"] is None and line["roofline"]["bound"] == "hbm"
+    ex = line["extra"]
+    assert ex["clip_c3"]["frames"] == 30 and ex["clip_c3"]["n_gpus"] == 2 and ex["clip_c3"]["scaling"] == "strong"
+    assert ex["clip_c3_long"]["frames"] == 90 and ex["clip_c3_long"]["repeats"] == 3 and ex["clip_c3_long"]["n_gpus"] == 2
+    assert "mesh" not in ex                               # the N = 1 extras stay at N = 1
+
+
 @pytest.mark.parametrize("variant", ["points", "product_default"])
 def test_two_ranks_render_one_clip_into_per_rank_segments(tmp_path, variant):
     """BASELINE config C3's multi-rank leg end to end on the hardware at hand: `clip.run` under torchrun with TWO ranks
