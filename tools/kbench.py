@@ -28,6 +28,8 @@ ap.add_argument("--pose", action="store_true")
 ap.add_argument("--bits", action="store_true")
 ap.add_argument("--counts", action="store_true")
 ap.add_argument("--edges", action="store_true", help="remove_edges without --infill_mask (edge points painted, no seed image)")
+ap.add_argument("--split", type=int, default=1, help="the batch as this many sub-batches, each with its own context on its own stream")
+ap.add_argument("--stagger-us", type=float, default=0.0, help="with --split: sub-batch k starts k x this late and the streams free-run (joined once per timing)")
 ap.add_argument("--noedgepts", action="store_true", help="with --edges / --infill: dont_place_points_in_edges")
 a = ap.parse_args()
 W, H, N = a.width, a.height, a.frames
@@ -47,7 +49,22 @@ mask = torch.empty((N, H, 2 * W), dtype=torch.uint8, device="cuda")
 zo = torch.empty((N, H, 2 * W), dtype=torch.float32, device="cuda") if a.zout else None
 job = r.prepare(d, c, p, out_sbs=sbs, out_mask=mask, want_depth=a.zout, out_depth=zo, want_maskbits=a.bits, want_hole_counts=a.counts)
 stream = torch.cuda.current_stream()
+if a.split > 1:
+    per = (N + a.split - 1) // a.split
+    rs = [StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not a.mesh, infill_mask=a.infill, remove_edges=a.edges or a.infill,
+                           dont_place_points_in_edges=a.noedgepts) for _ in range(a.split)]
+    streams = [torch.cuda.Stream() for _ in range(a.split)]
+    jobs = [rs[k].prepare(d[k * per:(k + 1) * per], c[k * per:(k + 1) * per], p[k * per:(k + 1) * per], out_sbs=sbs[k * per:(k + 1) * per],
+                          out_mask=mask[k * per:(k + 1) * per], want_depth=a.zout, out_depth=None if zo is None else zo[k * per:(k + 1) * per],
+                          want_maskbits=a.bits, want_hole_counts=a.counts) for k in range(a.split)]
 def run():
+    if a.split > 1:
+        for k in range(a.split):
+            streams[k].wait_stream(stream)
+            jobs[k].launch(streams[k])
+        for k in range(a.split):
+            stream.wait_stream(streams[k])
+        return
     job.launch(stream)
 res = {k: [] for k in a.cfgs}
 for k in a.cfgs:
@@ -58,7 +75,15 @@ for _ in range(a.rounds):
         os.environ[a.env] = '' if k == 'default' else k
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(a.calls): run()
+        if a.split > 1 and a.stagger_us > 0:
+            for j in range(a.split):
+                streams[j].wait_stream(stream)
+                with torch.cuda.stream(streams[j]):
+                    if j: torch.cuda._sleep(int(j * a.stagger_us * 2400))
+                for _ in range(a.calls): jobs[j].launch(streams[j])
+            for j in range(a.split): stream.wait_stream(streams[j])
+        else:
+            for _ in range(a.calls): run()
         e1.record(); torch.cuda.synchronize()
         res[k].append(e0.elapsed_time(e1) / a.calls * 1e3)
 bpp = 14 + (8 if a.zout else 0)
