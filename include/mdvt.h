@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 9
+#define MDVT_VERSION_MINOR 10
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -212,6 +212,20 @@ int mdvt_finish_infill_mask(mdvt_ctx* ctx, const uint8_t* d_seed, size_t seed_pi
 int mdvt_finish_infill_mask_stereo(mdvt_ctx* ctx, const uint8_t* d_left_seed, const uint8_t* d_right_seed, size_t seed_pitch,
                                    size_t seed_stride, uint8_t* d_left_out, uint8_t* d_right_out, size_t out_pitch,
                                    size_t out_stride, int n_frames, int max_rounds, uint32_t* d_remaining, void* stream);
+
+/* basic_nomal_infill.normal_infill (basic_nomal_infill.py:87-119, called per eye at :186 and :226): the stereo image
+ * d_img and its finished infill-mask image d_infill_mask (the output of mdvt_finish_infill_mask; both u8 RGB, the mask's
+ * r, g = the direction to march in, black = not a hole) -> the image with its holes filled.  In the reference's order:
+ * the pixels whose mask has no zero channel go black (:88-91), masked_blur (:98), infill_using_normals along
+ * ((mask/255)*2-1) with max_steps 400 (:101), cv2.blur 4x4 of the result written to those pixels (:104-107),
+ * mark_lower_side(mask) with max_steps 30, grown by scipy's binary_dilation(iterations=6) (:111-115), and
+ * blur_under_mask inside that band (:118, 46-85).  cv2.blur is restated from OpenCV's published box filter (anchor (2,2),
+ * BORDER_REFLECT_101, cvRound), cv2.filter2D as in mdvt_masked_blur.  The reference also blackens the caller's img in
+ * place (:91) and writes the blurred infill into it (:107); here d_img is read only and d_out receives the returned
+ * image.  n_images images share the launches (9 B/px of workspace each, kept by the ctx).  d_out may not alias an input. */
+int mdvt_normal_infill(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, size_t img_stride, const uint8_t* d_infill_mask,
+                       size_t mask_pitch, size_t mask_stride, uint8_t* d_out, size_t out_pitch, size_t out_stride,
+                       int n_images, void* stream);
 
 #ifdef __cplusplus
 }

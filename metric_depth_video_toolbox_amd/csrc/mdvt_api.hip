@@ -67,6 +67,9 @@ struct mdvt_ctx {
     int telea_images = 0, telea_rounds = 0;
     mdvt::TeleaWorkspace telea{};
     uint32_t* telea_levels_host = nullptr;      // pinned: the deepest level of a pass, read back once per pass
+    // normal_infill: 9 B/px per image in flight
+    uint8_t* ni_ws = nullptr;
+    int ni_images = 0;
 };
 
 namespace {
@@ -409,6 +412,7 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->rowcell) (void)hipFree(c->rowcell);
     pool_give(c->telea_levels_host, nullptr, 64);
     free_telea(c);
+    if (c->ni_ws) (void)hipFree(c->ni_ws);
     delete c;
     return MDVT_OK;
 }
@@ -812,6 +816,39 @@ int mdvt_masked_blur(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, uint8_
     DeviceGuard g(c->device);
     const mdvt::ImageSet in{const_cast<uint8_t*>(d_img), img_pitch, 0, 0, 1}, out{d_out, out_pitch, 0, 0, 1};
     MDVT_HIP(c, launch_masked_blur(in, nullptr, out, 1, c->W, c->H, masked_blur_kernel(), 0u, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
+constexpr int kNormalInfillChunk = 16;       // images per launch set
+
+int mdvt_normal_infill(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, size_t img_stride, const uint8_t* d_infill_mask,
+                       size_t mask_pitch, size_t mask_stride, uint8_t* d_out, size_t out_pitch, size_t out_stride, int n_images,
+                       void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_img || !d_infill_mask || !d_out) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (n_images < 1) return fail(c, MDVT_ERR_INVALID_ARG, "n_images must be >= 1");
+    if (img_pitch < (size_t)3 * c->W || mask_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W)
+        return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (d_out == d_img || d_out == d_infill_mask) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias an input");
+    DeviceGuard g(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int chunk = n_images < kNormalInfillChunk ? n_images : kNormalInfillChunk;
+    if (c->ni_images < chunk) {
+        MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
+        if (c->ni_ws) (void)hipFree(c->ni_ws);
+        c->ni_ws = nullptr; c->ni_images = 0;
+        MDVT_HIP(c, hipMalloc((void**)&c->ni_ws, mdvt::normal_infill_workspace_bytes(chunk, c->W, c->H)));
+        c->ni_images = chunk;
+    }
+    const mdvt::BlurKernel K = masked_blur_kernel();
+    for (int i0 = 0; i0 < n_images; i0 += chunk) {
+        const int n = n_images - i0 < chunk ? n_images - i0 : chunk;
+        const mdvt::ImageSet img{const_cast<uint8_t*>(d_img) + (size_t)i0 * img_stride, img_pitch, img_stride, 0, n};
+        const mdvt::ImageSet mask{const_cast<uint8_t*>(d_infill_mask) + (size_t)i0 * mask_stride, mask_pitch, mask_stride, 0, n};
+        const mdvt::ImageSet out{d_out + (size_t)i0 * out_stride, out_pitch, out_stride, 0, n};
+        MDVT_HIP(c, launch_normal_infill(img, mask, out, c->ni_ws, n, c->W, c->H, K, s));
+    }
     return MDVT_OK;
 }
 

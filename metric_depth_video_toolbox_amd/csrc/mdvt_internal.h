@@ -136,6 +136,10 @@ hipError_t launch_swap_rb(const ImageSet& src, const ImageSet& dst, int n, int W
 struct BlurKernel { float k[36]; };      // masked_blur's 6x6 Gaussian, f32, row major (built on the host in f64)
 hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const ImageSet& out, int n, int W, int H,
                               const BlurKernel& K, uint32_t key_rgb, hipStream_t s, uint32_t* list = nullptr, uint32_t* count = nullptr);
+// mdvt_normal_infill.hip: basic_nomal_infill.normal_infill for n images (workspace: normal_infill_workspace_bytes)
+size_t normal_infill_workspace_bytes(int n, int W, int H);
+hipError_t launch_normal_infill(const ImageSet& img, const ImageSet& mask, const ImageSet& out, uint8_t* workspace, int n, int W, int H,
+                                const BlurKernel& K, hipStream_t s);
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_selftest(int which, unsigned long long seed, unsigned long long* d_mism, hipStream_t s);

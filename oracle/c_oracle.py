@@ -84,6 +84,14 @@ def lib():
         L.orc_telea_fmm.restype = None
         L.orc_finish_infill_mask.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, u8p, u8p]
         L.orc_finish_infill_mask.restype = C.c_int
+        L.orc_box_blur4.argtypes = [u8p, C.c_int, C.c_int, u8p]
+        L.orc_box_blur4.restype = None
+        L.orc_dilate_cross.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_dilate_cross.restype = None
+        L.orc_blur_under_mask.argtypes = [u8p, u8p, C.c_int, C.c_int, u8p]
+        L.orc_blur_under_mask.restype = None
+        L.orc_normal_infill.argtypes = [u8p, u8p, C.c_int, C.c_int, u8p, u8p]
+        L.orc_normal_infill.restype = None
         _lib = L
     return _lib
 
@@ -316,3 +324,47 @@ def telea_fmm(img: np.ndarray, mask: np.ndarray, radius: int = 3) -> np.ndarray:
     out = np.empty_like(img)
     lib().orc_telea_fmm(_p(img, C.c_uint8), _p(mask, C.c_uint8), W, H, int(radius), _p(out, C.c_uint8))
     return out
+
+
+def box_blur4(img: np.ndarray) -> np.ndarray:
+    """cv2.blur(img, (4, 4)) on uint8 [H,W,3] (basic_nomal_infill.py:103)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape[:2]
+    out = np.empty_like(img)
+    lib().orc_box_blur4(_p(img, C.c_uint8), W, H, _p(out, C.c_uint8))
+    return out
+
+
+def dilate_cross(mask: np.ndarray, iterations: int = 6) -> np.ndarray:
+    """scipy.ndimage.binary_dilation(mask, iterations=iterations) (basic_nomal_infill.py:112) -> bool [H,W]."""
+    m = np.ascontiguousarray(mask, np.uint8)
+    H, W = m.shape
+    out = np.empty_like(m)
+    lib().orc_dilate_cross(_p(m, C.c_uint8), W, H, int(iterations), _p(out, C.c_uint8))
+    return out.astype(bool)
+
+
+def blur_under_mask(img: np.ndarray, bool_mask: np.ndarray) -> np.ndarray:
+    """basic_nomal_infill.blur_under_mask (basic_nomal_infill.py:46-85) with its default ksize / sigma."""
+    img = np.ascontiguousarray(img, np.uint8)
+    m = np.ascontiguousarray(bool_mask, np.uint8)
+    H, W = m.shape
+    out = np.empty_like(img)
+    lib().orc_blur_under_mask(_p(img, C.c_uint8), _p(m, C.c_uint8), W, H, _p(out, C.c_uint8))
+    return out
+
+
+def normal_infill(img: np.ndarray, infill_mask: np.ndarray, want_stages: bool = False):
+    """basic_nomal_infill.normal_infill (basic_nomal_infill.py:87-119).  -> out, or (out, dict of the stages)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    mask = np.ascontiguousarray(infill_mask, np.uint8)
+    H, W = img.shape[:2]
+    n = H * W
+    out = np.empty_like(img)
+    st = np.empty(11 * n, np.uint8) if want_stages else None
+    lib().orc_normal_infill(_p(img, C.c_uint8), _p(mask, C.c_uint8), W, H, _p(out, C.c_uint8), None if st is None else _p(st, C.c_uint8))
+    if not want_stages:
+        return out
+    return out, {"blur": st[:3 * n].reshape(H, W, 3), "filled": st[3 * n:6 * n].reshape(H, W, 3),
+                 "merged": st[6 * n:9 * n].reshape(H, W, 3), "bg": st[9 * n:10 * n].reshape(H, W).astype(bool),
+                 "grown": st[10 * n:11 * n].reshape(H, W).astype(bool)}

@@ -945,3 +945,110 @@ void orc_telea_fmm(const uint8_t* img, const uint8_t* mask, int W, int H, int ra
     }
     free(stamp); free(T); free(heap);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* basic_nomal_infill.normal_infill (bni:87-119) and the helpers it is made of                 */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline int orc_reflect101(int p, int len)        /* cv::borderInterpolate(p, len, BORDER_REFLECT_101) */
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+void orc_box_blur4(const uint8_t* img, int W, int H, uint8_t* out)
+{
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int c = 0; c < 3; ++c) {
+                int sum = 0;
+                for (int dy = -2; dy <= 1; ++dy)
+                    for (int dx = -2; dx <= 1; ++dx)
+                        sum += img[3 * ((size_t)orc_reflect101(y + dy, H) * W + orc_reflect101(x + dx, W)) + c];
+                int q = sum >> 4;                                 /* cvRound(sum * (1/16)): half to even */
+                const int rem = sum & 15;
+                if (rem > 8 || (rem == 8 && (q & 1))) ++q;
+                out[3 * ((size_t)y * W + x) + c] = (uint8_t)q;
+            }
+}
+
+void orc_dilate_cross(const uint8_t* mask, int W, int H, int iterations, uint8_t* out)
+{
+    const size_t n = (size_t)W * H;
+    uint8_t* cur = (uint8_t*)malloc(n + 1);
+    for (size_t k = 0; k < n; ++k) out[k] = mask[k] ? 1 : 0;
+    for (int it = 0; it < iterations; ++it) {
+        memcpy(cur, out, n);
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const size_t k = (size_t)y * W + x;
+                if (cur[k]) continue;
+                if ((x > 0 && cur[k - 1]) || (x + 1 < W && cur[k + 1]) || (y > 0 && cur[k - W]) || (y + 1 < H && cur[k + W])) out[k] = 1;
+            }
+    }
+    free(cur);
+}
+
+void orc_blur_under_mask(const uint8_t* img, const uint8_t* mask, int W, int H, uint8_t* out)
+{
+    float K[36];
+    orc_masked_blur_kernel(K);                                  /* bni:58-59: the same 6 x 6 kernel as masked_blur */
+    memcpy(out, img, (size_t)W * H * 3);                        /* bni:82: outside the mask the image stays */
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (!mask[(size_t)y * W + x]) continue;
+            float acc[3] = { 0.0f, 0.0f, 0.0f }, wsum = 0.0f;
+            for (int ky = 0; ky < 6; ++ky)
+                for (int kx = 0; kx < 6; ++kx) {                /* correlation, anchor (3,3), zero border (bni:68-71) */
+                    const int sx = x + kx - 3, sy = y + ky - 3;
+                    if (sx < 0 || sx >= W || sy < 0 || sy >= H) continue;
+                    if (!mask[(size_t)sy * W + sx]) continue;   /* img_f * m: an unmasked tap adds k * 0 */
+                    const uint8_t* s = img + 3 * ((size_t)sy * W + sx);
+                    const float k = K[6 * ky + kx];
+                    for (int c = 0; c < 3; ++c) acc[c] = acc[c] + k * (float)s[c];
+                    wsum = wsum + k;
+                }
+            uint8_t* o = out + 3 * ((size_t)y * W + x);
+            for (int c = 0; c < 3; ++c) {
+                float v = acc[c] / wsum;                        /* the pixel itself is masked: wsum > 0 (bni:74-77) */
+                if (v < 0.0f) v = 0.0f;
+                if (v > 255.0f) v = 255.0f;
+                o[c] = (uint8_t)v;                              /* np.clip(...).astype(np.uint8) (bni:85) */
+            }
+        }
+}
+
+void orc_normal_infill(const uint8_t* img, const uint8_t* infill_mask, int W, int H, uint8_t* out, uint8_t* stages)
+{
+    const size_t n = (size_t)W * H;
+    uint8_t* bg = (uint8_t*)malloc(n + 1);
+    uint8_t* work = (uint8_t*)malloc(3 * n + 1);
+    uint8_t* blur = (uint8_t*)malloc(3 * n + 1);
+    uint8_t* filled = (uint8_t*)malloc(3 * n + 1);
+    uint8_t* box = (uint8_t*)malloc(3 * n + 1);
+    uint8_t* blue = (uint8_t*)malloc(3 * n + 1);
+    uint8_t* marks = (uint8_t*)malloc(n + 1);
+    uint8_t* grown = (uint8_t*)malloc(n + 1);
+    float* normal = (float*)malloc(3 * n * sizeof(float) + 4);
+    memcpy(work, img, 3 * n);
+    for (size_t k = 0; k < n; ++k) {
+        const uint8_t* m = infill_mask + 3 * k;
+        bg[k] = (m[0] != 0 && m[1] != 0 && m[2] != 0) ? 1 : 0;                  /* bni:88: np.all(mask != black, axis=-1) */
+        if (bg[k]) { work[3 * k] = 0; work[3 * k + 1] = 0; work[3 * k + 2] = 0; }   /* bni:91 */
+        for (int c = 0; c < 3; ++c) normal[3 * k + c] = (((float)m[c] / 255.0f) * 2.0f) - 1.0f;   /* bni:94 (f32) */
+    }
+    orc_masked_blur(work, W, H, blur);                                           /* bni:98 */
+    orc_infill_using_normals(blur, bg, normal, W, H, 400, filled);               /* bni:101 */
+    orc_box_blur4(filled, W, H, box);                                            /* bni:104 */
+    for (size_t k = 0; k < n; ++k) if (bg[k]) memcpy(work + 3 * k, box + 3 * k, 3);   /* bni:107 */
+    orc_mark_lower_side(infill_mask, W, H, 30, blue);                            /* bni:111 */
+    for (size_t k = 0; k < n; ++k) marks[k] = (blue[3 * k] == 0 && blue[3 * k + 1] == 0 && blue[3 * k + 2] == 255) ? 1 : 0;   /* bni:112 */
+    orc_dilate_cross(marks, W, H, 6, grown);                                     /* bni:115 */
+    orc_blur_under_mask(work, grown, W, H, out);                                 /* bni:118 */
+    if (stages) {
+        memcpy(stages, blur, 3 * n); memcpy(stages + 3 * n, filled, 3 * n); memcpy(stages + 6 * n, work, 3 * n);
+        memcpy(stages + 9 * n, bg, n); memcpy(stages + 10 * n, grown, n);
+    }
+    free(bg); free(work); free(blur); free(filled); free(box); free(blue); free(marks); free(grown); free(normal);
+}

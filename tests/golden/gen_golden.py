@@ -252,7 +252,49 @@ def main():
     mb["b_img"], mb["b_out"] = img2, sr.masked_blur(img2.copy())
     np.savez_compressed(os.path.join(HERE, "masked_blur.npz"), meta=json.dumps(meta), **mb)
 
-    for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz", "equirect.npz", "masked_blur.npz"):
+    # ------------------------------------------------------------------ normal_infill (basic_nomal_infill.py:46-119)
+    # The reference's own normal_infill / blur_under_mask (with its masked_blur, infill_using_normals, mark_lower_side and
+    # SciPy's binary_dilation) around the same two cv2 stand-ins as above plus cv2.blur, restated exactly (integer box
+    # sums over a BORDER_REFLECT_101 frame, cvRound(sum / 16)).  Pinned exactly: which pixels each step touches
+    # (bni:88-91, 107, 111-118); within a few LSB: the values that went through the stand-in filter2D's summation order.
+    def _blur(src, ksize, **kw):
+        assert tuple(ksize) == (4, 4) and src.dtype == np.uint8
+        p_ = np.pad(src.astype(np.int64), ((2, 1), (2, 1), (0, 0)), mode="reflect")
+        H_, W_ = src.shape[:2]
+        s_ = sum(p_[dy:dy + H_, dx:dx + W_] for dy in range(4) for dx in range(4))
+        return np.rint(s_ / 16.0).astype(np.uint8)
+    cv2_stub.blur = _blur
+    import basic_nomal_infill as bni
+    ni = {}
+    for name, (W, H, seed) in {"n1": (96, 64, 11), "n2": (160, 90, 12)}.items():
+        r4 = np.random.default_rng(5000 + seed)
+        yy, xx = np.mgrid[0:H, 0:W]
+        img = np.clip(np.stack([xx * 255 // W, yy * 255 // H, (xx + yy) * 255 // (W + H)], -1) + r4.integers(-40, 41, (H, W, 3)), 1, 255).astype(np.uint8)
+        mask = np.zeros((H, W, 3), np.uint8)
+        for k in range(7):                       # holes: rectangles and discs coloured by a direction, some touching the border
+            ang = r4.uniform(0, 2 * np.pi)
+            base = np.array([(np.cos(ang) + 1) / 2 * 255, (np.sin(ang) + 1) / 2 * 255, r4.uniform(40, 255)])
+            if k % 2:
+                x0, y0 = int(r4.integers(-4, W - 6)), int(r4.integers(-4, H - 6))
+                sel = (xx >= x0) & (xx < x0 + int(r4.integers(4, W // 4))) & (yy >= y0) & (yy < y0 + int(r4.integers(4, H // 3)))
+            else:
+                cx_, cy_, rad = r4.uniform(0, W), r4.uniform(0, H), r4.uniform(3, H / 4)
+                sel = (xx - cx_) ** 2 + (yy - cy_) ** 2 < rad * rad
+            col = np.clip(base[None, :] + r4.normal(0, 10, (int(sel.sum()), 3)), 0, 255).astype(np.uint8)
+            mask[sel] = col
+        mask[5:9, 10:14] = (200, 0, 90)          # non-black but one channel zero: not "bg" at bni:88, still marches in mark_lower_side
+        mask[20, 30] = (128, 127, 200)           # a direction of ~zero length
+        img[np.all(mask != 0, axis=-1)] = 0      # (the renderer leaves holes black)
+        img[40:44, 50:60] = 0                    # black pixels outside the holes (masked_blur ignores them)
+        ni[f"{name}_img"], ni[f"{name}_mask"] = img.copy(), mask.copy()
+        ni[f"{name}_out"] = bni.normal_infill(img.copy(), mask.copy())
+        m = r4.uniform(size=(H, W)) < 0.3
+        m[10:30, 20:50] = True
+        ni[f"{name}_bum_mask"] = m
+        ni[f"{name}_bum_out"] = bni.blur_under_mask(img.copy(), m.copy())
+    np.savez_compressed(os.path.join(HERE, "normal_infill.npz"), meta=json.dumps(meta), **ni)
+
+    for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz", "equirect.npz", "masked_blur.npz", "normal_infill.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

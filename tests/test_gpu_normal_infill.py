@@ -1,0 +1,153 @@
+"""GPU parity of basic_nomal_infill.normal_infill (basic_nomal_infill.py:87-119) through the C ABI: bit-exact against the
+oracle's seven plain passes (orc_normal_infill, itself pinned on the reference's function by tests/golden/normal_infill.npz),
+on the golden scenes, on random scenes of many shapes, on 1080p frames, on batches and strided side-by-side halves, on the
+masks the product default really produces (render -> finish_infill_mask -> normal_infill), and through the file driver."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def bni():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from metric_depth_video_toolbox_amd import basic_nomal_infill
+    return basic_nomal_infill
+
+
+def ni_scene(rng, W, H, holes=7):
+    """An image and a normal-coloured infill mask: discs and rectangles coloured by a direction (some off the border),
+    a patch with a zero channel (not `bg` at bni:88 but marching in mark_lower_side), black pixels outside the holes."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.clip(np.stack([xx * 255 // max(W, 1), yy * 255 // max(H, 1), (xx + yy) * 255 // (W + H)], -1)
+                  + rng.integers(-40, 41, (H, W, 3)), 1, 255).astype(np.uint8)
+    mask = np.zeros((H, W, 3), np.uint8)
+    for k in range(holes):
+        ang = rng.uniform(0, 2 * np.pi)
+        base = np.array([(np.cos(ang) + 1) / 2 * 255, (np.sin(ang) + 1) / 2 * 255, rng.uniform(40, 255)])
+        if k % 2:
+            x0, y0 = int(rng.integers(-4, max(W - 6, 1))), int(rng.integers(-4, max(H - 6, 1)))
+            sel = (xx >= x0) & (xx < x0 + int(rng.integers(2, max(W // 4, 3)))) & (yy >= y0) & (yy < y0 + int(rng.integers(2, max(H // 3, 3))))
+        else:
+            cx, cy, rad = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(2, max(H / 4, 3))
+            sel = (xx - cx) ** 2 + (yy - cy) ** 2 < rad * rad
+        mask[sel] = np.clip(base[None, :] + rng.normal(0, 10, (int(sel.sum()), 3)), 0, 255).astype(np.uint8)
+    if H > 12 and W > 16:
+        mask[5:9, 10:14] = (200, 0, 90)
+        mask[H // 2, W // 3] = (128, 127, 200)
+    img[np.all(mask != 0, axis=-1)] = 0
+    if H > 8 and W > 12:
+        img[H // 2:H // 2 + 3, W // 2:W // 2 + 7] = 0
+    return img, mask
+
+
+def _run(bni, img, mask):
+    return bni.normal_infill(torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda()).cpu().numpy()
+
+
+def test_golden_scenes(bni, orc, golden):
+    g = golden("normal_infill")
+    for scene in ("n1", "n2"):
+        got = _run(bni, g[f"{scene}_img"], g[f"{scene}_mask"])
+        assert np.array_equal(got, orc.normal_infill(g[f"{scene}_img"], g[f"{scene}_mask"])), scene
+        assert np.array_equal(got, g[f"{scene}_out"]), scene           # = the reference's normal_infill over restated cv2 calls
+
+
+@pytest.mark.parametrize("W,H", [(64, 48), (250, 37), (33, 17), (9, 5), (2, 2), (1, 7), (641, 33), (640, 480)])
+def test_random_scenes(bni, orc, W, H):
+    rng = np.random.default_rng(W * 1000 + H)
+    for rep in range(3):
+        img, mask = ni_scene(rng, W, H, holes=3 + 4 * rep)
+        if rep == 2:
+            mask[:] = np.where(mask.any(-1, keepdims=True), mask, 0)
+            mask[0, :] = (255, 127, 127); mask[:, 0] = (127, 255, 127)          # holes along two borders: REFLECT_101 and dead rays
+            img[0, :] = 0; img[:, 0] = 0
+        got = _run(bni, img, mask)
+        want, st = orc.normal_infill(img, mask, want_stages=True)
+        bad = np.any(got != want, axis=-1)
+        assert not bad.any(), f"{W}x{H} rep {rep}: {int(bad.sum())} px differ (bg {int((bad & st['bg']).sum())}, grown {int((bad & st['grown']).sum())})"
+
+
+def test_full_hd_batch_and_sbs_halves(bni, orc):
+    """Four 1080p eyes as two side-by-side frames: strided halves, a batch per half (what process_pair launches)."""
+    W, H = 1920, 1080
+    rng = np.random.default_rng(77)
+    sbs = np.zeros((2, H, 2 * W, 3), np.uint8)
+    msk = np.zeros((2, H, 2 * W, 3), np.uint8)
+    for f in range(2):
+        for e in range(2):
+            img, mask = ni_scene(rng, W, H, holes=40)
+            sbs[f, :, e * W:(e + 1) * W], msk[f, :, e * W:(e + 1) * W] = img, mask
+    got = bni.normal_infill_sbs(torch.from_numpy(sbs).cuda(), torch.from_numpy(msk).cuda()).cpu().numpy()
+    for f in range(2):
+        for e in range(2):
+            sl = slice(e * W, (e + 1) * W)
+            want = orc.normal_infill(np.ascontiguousarray(sbs[f, :, sl]), np.ascontiguousarray(msk[f, :, sl]))
+            assert np.array_equal(got[f, :, sl], want), (f, e)
+    # more images than one launch set holds (16): a batch of 18 small ones
+    imgs, masks = zip(*(ni_scene(rng, 96, 64) for _ in range(18)))
+    got = bni.normal_infill(torch.from_numpy(np.stack(imgs)).cuda(), torch.from_numpy(np.stack(masks)).cuda()).cpu().numpy()
+    for k in range(18):
+        assert np.array_equal(got[k], orc.normal_infill(imgs[k], masks[k])), k
+
+
+def test_product_default_masks(bni, orc):
+    """The masks the path really hands over: mesh + --infill_mask + convergence render, finished infill mask, then the
+    normal infill of both eyes, every stage against the oracle's."""
+    from metric_depth_video_toolbox_amd import stereo_rerender as sr, synthetic
+    W, H = 480, 270
+    depth_rgb, color = synthetic.SyntheticScene(W, H, seed=5, n_fg=6).frame(0, 100)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
+    p = r.frame_params(xfov=45.0, convergence_distance=2.5)
+    res = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_seed=True)
+    fin = r.finish_infill_mask_sbs(res["seed"])
+    out = bni.normal_infill_sbs(res["sbs"], fin).cpu().numpy()
+    sbs, fin = res["sbs"].cpu().numpy(), fin.cpu().numpy()
+    for e in range(2):
+        sl = slice(e * W, (e + 1) * W)
+        img, mask = np.ascontiguousarray(sbs[:, sl]), np.ascontiguousarray(fin[:, sl])
+        want, st = orc.normal_infill(img, mask, want_stages=True)
+        assert st["bg"].sum() > 1000
+        assert np.array_equal(out[:, sl], want), e
+        holes = np.all(img == 0, -1) & st["bg"]
+        assert (out[:, sl][holes].max(-1) > 0).mean() > 0.9          # the holes are filled
+    r.close()
+
+
+def test_argument_checks(bni):
+    from metric_depth_video_toolbox_amd import _lib
+    img = torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(_lib.MdvtError):
+        bni.normal_infill(img, img.clone(), out=img)                 # d_out may not alias an input
+    with pytest.raises(AssertionError):
+        bni.normal_infill(img, torch.zeros((8, 9, 3), dtype=torch.uint8, device="cuda"))
+
+
+def test_process_pair_on_frame_dumps(bni, orc, tmp_path):
+    W, H, N = 80, 48, 5
+    rng = np.random.default_rng(9)
+    sbs = np.zeros((N, H, 2 * W, 3), np.uint8); msk = np.zeros((N - 1, H, 2 * W, 3), np.uint8)   # the mask clip ends one frame early
+    for f in range(N):
+        for e in range(2):
+            img, mask = ni_scene(rng, W, H)
+            sbs[f, :, e * W:(e + 1) * W] = img
+            if f < N - 1:
+                msk[f, :, e * W:(e + 1) * W] = mask
+    cpath, mpath = str(tmp_path / "clip_stereo.npy"), str(tmp_path / "clip_stereo.npy_infillmask.npy")
+    np.save(cpath, sbs); np.save(mpath, msk)
+    final = bni.process_pair(cpath, mpath, batch=2)
+    assert final == str(tmp_path / "clip_stereo_infilled.npy") and not os.path.exists(str(tmp_path / "clip_stereo_tmp_infilled.npy"))
+    got = np.load(final)
+    assert got.shape == sbs.shape
+    for f in range(N):
+        for e in range(2):
+            sl = slice(e * W, (e + 1) * W)
+            m = msk[f, :, sl] if f < N - 1 else np.zeros((H, W, 3), np.uint8)
+            assert np.array_equal(got[f, :, sl], orc.normal_infill(np.ascontiguousarray(sbs[f, :, sl]), np.ascontiguousarray(m))), (f, e)
+    assert np.array_equal(got[N - 1], sbs[N - 1])                     # no mask: nothing changes
+    assert np.load(bni.process_pair(cpath, mpath, max_frames=2)).shape[0] == 2

@@ -396,3 +396,48 @@ def test_rasteriser_against_reference_renders(orc):
             keep = g[eye + "_mask"] == 0
             d = np.abs(got[eye + "_rgb"].astype(int) - g[eye + "_rgb"].astype(int))[keep]
             assert d.max(initial=0) <= 1, f"{f} {eye}: RGB differs by up to {d.max()} LSB from the reference render"
+
+
+# ------------------------------------------------------------------------------- normal_infill (basic_nomal_infill.py)
+def test_dilate_cross_is_scipys_binary_dilation(orc):
+    """orc_dilate_cross against scipy.ndimage.binary_dilation itself (basic_nomal_infill.py:112 calls it with iterations=6)."""
+    from scipy import ndimage
+    rng = np.random.default_rng(21)
+    for H, W in ((1, 1), (3, 5), (7, 1), (1, 9), (40, 56), (64, 64), (33, 130)):
+        m = rng.uniform(size=(H, W)) < 0.03
+        m[0, 0] = True; m[H - 1, W - 1] = True
+        for it in (1, 2, 6):
+            assert np.array_equal(orc.dilate_cross(m, it), ndimage.binary_dilation(m, iterations=it)), (H, W, it)
+
+
+def test_box_blur4_is_the_published_box_filter(orc):
+    """orc_box_blur4 against a NumPy statement of cv2.blur(img, (4,4)): integer sums over a REFLECT_101 frame, anchor (2,2),
+    cvRound(sum / 16) (np.rint rounds half to even like cvRound)."""
+    rng = np.random.default_rng(22)
+    for H, W in ((3, 3), (5, 4), (40, 56), (17, 250)):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        img[0] = 8; img[-1] = 24                       # rows whose sums end in .5 after the division
+        p = np.pad(img.astype(np.int64), ((2, 1), (2, 1), (0, 0)), mode="reflect")
+        s = sum(p[dy:dy + H, dx:dx + W] for dy in range(4) for dx in range(4))
+        assert np.array_equal(orc.box_blur4(img), np.rint(s / 16.0).astype(np.uint8)), (H, W)
+
+
+@pytest.mark.parametrize("scene", ["n1", "n2"])
+def test_normal_infill_golden(orc, golden, scene):
+    """orc_normal_infill / orc_blur_under_mask against the reference's own normal_infill and blur_under_mask
+    (basic_nomal_infill.py:46-119: its masked_blur, infill_using_normals, mark_lower_side, SciPy's binary_dilation) run over
+    restated cv2.getGaussianKernel / filter2D / blur (tests/golden/gen_golden.py).  The stand-in filter2D sums its taps in
+    another order than the oracle, which could move a value by an LSB; on these scenes nothing moves."""
+    g = golden("normal_infill")
+    img, mask = g[f"{scene}_img"], g[f"{scene}_mask"]
+    out, st = orc.normal_infill(img, mask, want_stages=True)
+    ref = g[f"{scene}_out"]
+    assert np.abs(out.astype(int) - ref.astype(int)).max() <= 1
+    assert np.array_equal(out, ref)
+    assert np.array_equal(st["bg"], np.all(mask != 0, axis=-1))                       # bni:88
+    untouched = ~st["bg"] & ~st["grown"]
+    assert np.array_equal(out[untouched], img[untouched])
+    assert st["bg"].sum() > 500 and st["grown"].sum() > 500 and (st["bg"] & (out.max(-1) > 0)).sum() > 0.8 * st["bg"].sum()
+    got = orc.blur_under_mask(img, g[f"{scene}_bum_mask"])
+    assert np.abs(got.astype(int) - g[f"{scene}_bum_out"].astype(int)).max() <= 1
+    assert np.array_equal(got[~g[f"{scene}_bum_mask"]], img[~g[f"{scene}_bum_mask"]])
