@@ -496,6 +496,25 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
     out["product_default_with_finished_infill_mask"] = {
         "fps": 1.0 / (1.0 / out["product_default"]["fps"] + ms[2] * 1e-3 / nf),
         "what": "render + completion, per-frame times added"}
+    # the step after it in movie_2_3D.py: basic_nomal_infill.normal_infill of both eyes with that mask
+    from metric_depth_video_toolbox_amd import basic_nomal_infill as bni
+    filled = torch.empty_like(res["sbs"])
+    bni.normal_infill_sbs(res["sbs"], fin, out=filled)
+    ms2 = []
+    for _ in range(5):
+        torch.cuda.synchronize(dev)
+        ev[0].record()
+        bni.normal_infill_sbs(res["sbs"], fin, out=filled)
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+        ms2.append(ev[0].elapsed_time(ev[1]))
+    ms2.sort()
+    out["normal_infill"] = {"frames_per_call": nf, "ms_per_call_median_of_5": ms2[2], "ms_per_frame": ms2[2] / nf,
+                            "what": "mdvt_normal_infill (basic_nomal_infill.py:87-119) of both eyes of the product-default frames with their "
+                                    "finished infill masks: masked_blur, normal march, 4x4 box blur, lower-side marks, dilation, blur_under_mask"}
+    out["product_default_through_normal_infill"] = {
+        "fps": 1.0 / (1.0 / out["product_default"]["fps"] + ms[2] * 1e-3 / nf + ms2[2] * 1e-3 / nf),
+        "what": "render + infill-mask completion + normal infill, per-frame times added"}
     rp.close()
     rme = StereoRerenderer(W, H, device=dev.index, pupillary_distance=65, infill_mask=True)
     nf = min(32, n_have)
