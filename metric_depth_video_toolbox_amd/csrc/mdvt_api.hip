@@ -883,7 +883,7 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
         MDVT_HIP(c, hipMalloc((void**)&w.img, (size_t)images * npx * 3 + 4));      // + 4: pixels are fetched as unaligned dwords
         MDVT_HIP(c, hipMalloc((void**)&w.need, (size_t)images * npx));
         MDVT_HIP(c, hipMalloc((void**)&w.nlist, (size_t)images * npx * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.counts, 3 * ((size_t)rounds + 2) * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&w.counts, mdvt::telea_counter_words(rounds) * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.remaining, (size_t)kTeleaChunk * sizeof(uint32_t)));
         MDVT_HIP(c, hipMalloc((void**)&w.last_round, (size_t)kTeleaChunk * sizeof(uint32_t)));
         c->telea_images = images; c->telea_rounds = rounds;

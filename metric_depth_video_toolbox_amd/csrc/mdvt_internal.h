@@ -124,11 +124,12 @@ struct TeleaWorkspace {              // per image pixel: stamp u16, T f32, work 
     uint16_t* stamp; float* T; uint8_t* img; uint8_t* need; uint32_t* nlist;
     uint32_t* counts;                // [max_rounds + 2], followed by
     uint32_t* offs;                  // [max_rounds + 2] and
-    uint32_t* ncounts;               // [max_rounds + 2] (one allocation of 3 x (max_rounds + 2) words)
+    uint32_t* ncounts;               // [max_rounds + 2] x kNcStride words, one counter per cache line (one allocation: telea_counter_words)
     uint32_t* remaining;             // [images]
     uint32_t* last_round;            // [images]
 };
 constexpr int kTeleaMaxImages = 32;  // images per pass
+size_t telea_counter_words(int max_rounds);      // counts + offs + the strided ncounts
 hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int n, int W, int H, int max_rounds, uint32_t key_rgb,
                              uint32_t* h_levels, hipStream_t s);
 hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int levels, uint32_t key_rgb, hipStream_t s);

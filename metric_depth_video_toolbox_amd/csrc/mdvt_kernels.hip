@@ -1558,6 +1558,12 @@ hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t sr
 constexpr uint16_t kTeleaUnknown = 0xFFFFu;
 constexpr uint32_t kTeleaNeedBit = 0x8000u;        // from the list scatter on: top bit of a level word = "this pixel's estimate is needed"
 constexpr uint32_t kTeleaLevelMask = 0x7FFFu;      // (levels stay below 32767: max_rounds <= 32766)
+#ifndef MDVT_NC_STRIDE
+#define MDVT_NC_STRIDE 32
+#endif
+// The per-level counters of needed pixels take the appends of every workgroup of a launch: atomics on one address serialise at
+// ~4 ns each, and neighbouring levels' counters in one cache line queue behind each other -- one counter per 128-byte line.
+constexpr uint32_t kNcStride = MDVT_NC_STRIDE;
 
 // The level of a pixel -- the round in which the level-synchronous front reaches it -- is its 4-connected distance to the
 // nearest known pixel: an L1 distance transform, two separable passes (A) instead of one dependent launch per level.
@@ -1932,7 +1938,7 @@ __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
     for (int b = threadIdx.x; b < kLevelBins; b += 256) {
         const uint32_t c = hist[b];
         if (!c) continue;
-        slot[b] = atomicAdd(&a.ncounts[b], c); hist[b] = 0u;
+        slot[b] = atomicAdd(&a.ncounts[(uint32_t)b * kNcStride], c); hist[b] = 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -1942,7 +1948,7 @@ __global__ void __launch_bounds__(256) k_telea_sort(TeleaArgs a)
             const uint32_t l = lv[k][q];
             if (!l) continue;
             const uint32_t e = (uint32_t)im * npx + (uint32_t)(ty0 + ly0 + 16 * k) * (uint32_t)a.W + (uint32_t)(tx0 + lx + q);
-            const uint32_t pos = l < (uint32_t)kLevelBins ? slot[l] + atomicAdd(&hist[l], 1u) : atomicAdd(&a.ncounts[l], 1u);
+            const uint32_t pos = l < (uint32_t)kLevelBins ? slot[l] + atomicAdd(&hist[l], 1u) : atomicAdd(&a.ncounts[l * kNcStride], 1u);
             a.nlist[a.offs[l] + pos] = e;
         }
 }
@@ -2006,7 +2012,7 @@ __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
 {
     __shared__ uint32_t stage[5][kNeedStage];
     __shared__ uint32_t cnt[5], base[5];
-    const uint32_t count = a.ncounts[r], off = a.offs[r];
+    const uint32_t count = a.ncounts[r * kNcStride], off = a.offs[r];
     constexpr uint32_t per_block = 256 / kNeedLanes;
     // XCD-aware dealing (workgroup b runs on XCD b % 8, each XCD has its own L2): every XCD walks one contiguous eighth of the
     // level's list -- neighbouring entries are neighbouring pixels, whose 9 x 9 windows share their cache lines
@@ -2055,14 +2061,14 @@ __global__ void __launch_bounds__(256) k_telea_need(TeleaArgs a, uint32_t r)
             const uint32_t d = r - 1u - su[k];
             const uint32_t pos = d < 5u ? atomicAdd(&cnt[d], 1u) : (uint32_t)kNeedStage;
             if (pos < (uint32_t)kNeedStage) stage[d][pos] = uu[k];
-            else a.nlist[a.offs[su[k]] + atomicAdd(&a.ncounts[su[k]], 1u)] = uu[k];
+            else a.nlist[a.offs[su[k]] + atomicAdd(&a.ncounts[su[k] * kNcStride], 1u)] = uu[k];
         }
     }
     __syncthreads();
     if (threadIdx.x < 5) {
         const uint32_t n = min(cnt[threadIdx.x], (uint32_t)kNeedStage);
         cnt[threadIdx.x] = n;
-        base[threadIdx.x] = n ? a.offs[r - 1u - threadIdx.x] + atomicAdd(&a.ncounts[r - 1u - threadIdx.x], n) : 0u;
+        base[threadIdx.x] = n ? a.offs[r - 1u - threadIdx.x] + atomicAdd(&a.ncounts[(r - 1u - threadIdx.x) * kNcStride], n) : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -2108,7 +2114,7 @@ __global__ void __launch_bounds__(256) k_telea_fill(TeleaArgs a, uint32_t r)
     __shared__ float wt[8][81];
     __shared__ uint8_t wkn[8][84];
     const int lane32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
-    const uint32_t nneed = a.ncounts[r];
+    const uint32_t nneed = a.ncounts[r * kNcStride];
     const DiscPixel dp = kDisc[lane32];
     const int qv = 4 + ((lane32 & 1) ? 9 : -9), qh = 4 * 9 + 4 + ((lane32 & 2) ? 1 : -1);     // this lane's quadrant: cells (0, +-1) and (+-1, 0)
     // every entry of nlist is a pixel to estimate: they are dealt round-robin to all half-waves of the grid
@@ -2362,6 +2368,8 @@ __global__ void __launch_bounds__(64) k_masked_blur_list(ImageSet imgs, ImageSet
     }
 }
 
+size_t telea_counter_words(int max_rounds) { return (2 + (size_t)kNcStride) * ((size_t)max_rounds + 2); }
+
 static TeleaArgs telea_args(const TeleaWorkspace& ws, int n, int W, int H, uint32_t key_rgb)
 {
     return TeleaArgs{ws.stamp, ws.T, ws.img, ws.need, ws.nlist, ws.counts, ws.offs, ws.ncounts, ws.remaining, ws.last_round, W, H, n, key_rgb};
@@ -2377,7 +2385,7 @@ hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int
     hipError_t e = hipMemsetAsync(ws.remaining, 0, (size_t)kTeleaMaxImages * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(ws.last_round, 0, (size_t)kTeleaMaxImages * sizeof(uint32_t), s)) != hipSuccess) return e;
-    e = hipMemsetAsync(ws.counts, 0, 3 * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts, offs and ncounts (adjacent)
+    e = hipMemsetAsync(ws.counts, 0, (2 + (size_t)kNcStride) * ((size_t)max_rounds + 2) * sizeof(uint32_t), s);      // counts, offs and ncounts (adjacent)
     if (e != hipSuccess) return e;
     if (W % 4 == 0 && (((uintptr_t)seed.base | seed.pitch | seed.stride | (size_t)seed.eye_offset) & 3) == 0)
         hipLaunchKernelGGL(k_telea_init<4>, dim3((W / 4 + 127) / 128, H, n), dim3(128), 0, s, seed, a);
@@ -2414,12 +2422,12 @@ hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int level
     for (int r = levels; r >= 2; --r) hipLaunchKernelGGL(k_telea_need, grid, block, 0, s, a, (uint32_t)r);
     for (int r = 1; r <= levels; ++r) hipLaunchKernelGGL(k_telea_fill, dim3(4 * nb), block, 0, s, a, (uint32_t)r);
     if (getenv("MDVT_TELEA_DUMP")) {         // tuning hook: level sizes / needed pixels of this pass on stderr
-        std::vector<uint32_t> c(levels + 2), nc(levels + 2);
+        std::vector<uint32_t> c(levels + 2), nc((size_t)(levels + 2) * kNcStride);
         hipError_t e = hipStreamSynchronize(s);
         if (e == hipSuccess) e = hipMemcpy(c.data(), ws.counts, c.size() * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(nc.data(), ws.ncounts, nc.size() * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) return e;
-        for (int r = 1; r <= levels; ++r) fprintf(stderr, "level %d count %u need %u\n", r, c[r], nc[r]);
+        for (int r = 1; r <= levels; ++r) fprintf(stderr, "level %d count %u need %u\n", r, c[r], nc[(size_t)r * kNcStride]);
     }
     return hipGetLastError();
 }

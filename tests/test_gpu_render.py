@@ -1177,10 +1177,10 @@ def test_edge_filter_on_sub_millimetre_depths(mods, orc):
 
 def test_randomised_aux_sweep(mods, orc):
     """Seeded random sweep over the stand-alone entry points (codec, Touchly plane, equirect remap, masked blur,
-    normal-marching infill, mark_lower_side) against the oracle; MDVT_SWEEP_SEED / MDVT_SWEEP_CASES widen it."""
+    normal-marching infill, mark_lower_side, normal_infill) against the oracle; MDVT_SWEEP_SEED / MDVT_SWEEP_CASES widen it."""
     import os
     _lib, sr, synthetic = mods
-    from metric_depth_video_toolbox_amd import depth_frames_helper as dfh, infill_common
+    from metric_depth_video_toolbox_amd import depth_frames_helper as dfh, infill_common, basic_nomal_infill
     rng = np.random.default_rng(int(os.environ.get("MDVT_SWEEP_SEED", "20260928")))
     n_cases = int(os.environ.get("MDVT_SWEEP_CASES", "12"))
     sizes = [(2, 2), (5, 3), (17, 9), (33, 17), (64, 48), (100, 31), (130, 70), (257, 129)]
@@ -1223,6 +1223,24 @@ def test_randomised_aux_sweep(mods, orc):
         steps = int(rng.choice([2, 8, 30]))
         got = infill_common.mark_lower_side(torch.from_numpy(msk).cuda(), steps)
         assert np.array_equal(got.cpu().numpy(), orc.mark_lower_side(msk, steps)), tag
+        # normal_infill (basic_nomal_infill.py:87-119): a random noise mask (every pixel its own direction, zero channels at
+        # random) and a mask of a few blobs with coherent directions
+        for kind in range(2):
+            nmask = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            if kind == 0:
+                nmask[rng.uniform(size=(H, W)) < rng.uniform(0.2, 0.95)] = 0
+                nmask[rng.uniform(size=(H, W)) < 0.05, int(rng.integers(3))] = 0
+            else:
+                yy, xx = np.mgrid[0:H, 0:W]
+                keep = np.zeros((H, W), bool)
+                for _ in range(3):
+                    keep |= (xx - rng.uniform(0, W)) ** 2 + (yy - rng.uniform(0, H)) ** 2 < rng.uniform(1, max(2.0, max(W, H) / 3)) ** 2
+                base = rng.integers(1, 256, 3)
+                nmask = np.clip(base[None, None, :] + rng.integers(-6, 7, (H, W, 3)), 1, 255).astype(np.uint8)
+                nmask[~keep] = 0
+            nimg = img.copy(); nimg[rng.uniform(size=(H, W)) < 0.1] = 0
+            got = basic_nomal_infill.normal_infill(torch.from_numpy(nimg).cuda(), torch.from_numpy(nmask).cuda()).cpu().numpy()
+            assert np.array_equal(got, orc.normal_infill(nimg, nmask)), tag + f" normal_infill kind {kind}"
 
 
 def test_swap_rb_is_cvtcolor_bgr_rgb(mods):
