@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Time the --do_basic_infill stage of the clip driver (sr:809-812) as clip.device_stage runs it: per frame and eye,
+normals = (finished mask / 255) * 2 - 1 and mdvt_infill_using_normals into the stereo frame.  1080p product-default frames.
+usage: python tools/basic_infill_bench.py [--frames 16] [--conv 2.5]"""
+import argparse, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from metric_depth_video_toolbox_amd import stereo_rerender as sr, synthetic
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=16)
+ap.add_argument("--conv", type=float, default=0.0)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+W, H, n = 1920, 1080, a.frames
+sc = synthetic.SyntheticScene(W, H, config_id=2)
+d, c = zip(*(sc.frame(t) for t in range(n)))
+d, c = torch.from_numpy(np.stack(d)).cuda(), torch.from_numpy(np.stack(c)).cuda()
+r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True, do_basic_infill=True) if "do_basic_infill" in sr.StereoRerenderer.__init__.__code__.co_varnames \
+    else sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
+recs = [r.frame_params(xfov=45.0, convergence_distance=a.conv if a.conv > 0 else None) for _ in range(n)]
+res = r.render(d, c, recs, want_seed=True)
+fin = r.finish_infill_mask_sbs(res["seed"])
+sbs, mask = res["sbs"].clone(), res["mask"]
+
+
+def stage(dst):
+    for f in range(n):
+        for eye in range(2):
+            sl = slice(eye * W, (eye + 1) * W)
+            normals = (fin[f, :, sl].to(torch.float32) / 255.0) * 2 - 1
+            dst[f, :, sl] = sr.infill_using_normals(sbs[f, :, sl], mask[f, :, sl] > 0, normals)
+
+
+out = torch.empty_like(sbs)
+stage(out); torch.cuda.synchronize()
+ts = []
+for _ in range(a.reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); stage(out); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+ms = float(np.median(ts))
+print(f"--do_basic_infill stage as clip.py runs it, {n} frames: {ms:.2f} ms = {ms / n:.3f} ms per stereo frame")
+if hasattr(sr, "infill_using_mask_normals"):
+    out2 = torch.empty_like(sbs)
+    sr.infill_using_mask_normals(sbs, mask, fin, out=out2); torch.cuda.synchronize()
+    assert torch.equal(out, out2), "batched entry point differs from the per-eye loop"
+    ts = []
+    for _ in range(a.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); sr.infill_using_mask_normals(sbs, mask, fin, out=out2); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = float(np.median(ts))
+    print(f"batched mdvt_infill_using_mask_normals, {n} frames: {ms:.2f} ms = {ms / n:.3f} ms per stereo frame (same bytes)")
