@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 10
+#define MDVT_VERSION_MINOR 11
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -226,6 +226,14 @@ int mdvt_finish_infill_mask_stereo(mdvt_ctx* ctx, const uint8_t* d_left_seed, co
 int mdvt_normal_infill(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, size_t img_stride, const uint8_t* d_infill_mask,
                        size_t mask_pitch, size_t mask_stride, uint8_t* d_out, size_t out_pitch, size_t out_stride,
                        int n_images, void* stream);
+
+/* sr:809-812 (--do_basic_infill) for n_images images at once: infill_using_normals(image, bg_mask, mask * 2 - 1) with the
+ * normals taken straight from the finished infill-mask image d_mask_img (u8 RGB; ((v / 255) * 2) - 1 in f32, as sr:808 + 810
+ * evaluate it), d_hole the u8 hole plane (non-zero = hole, e.g. the mask output of mdvt_render_stereo).  d_img is filled IN
+ * PLACE: a source pixel is never a hole pixel (sr:226), so the march reads what the reference's unmodified input holds. */
+int mdvt_infill_using_mask_normals(mdvt_ctx* ctx, uint8_t* d_img, size_t img_pitch, size_t img_stride, const uint8_t* d_hole,
+                                   size_t hole_pitch, size_t hole_stride, const uint8_t* d_mask_img, size_t mask_pitch,
+                                   size_t mask_stride, int n_images, int max_steps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -368,13 +368,11 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         st["d_rem"] = None
         if want_seed and res is not None:              # sr:803-808: finish the normal-coloured mask on the device, per eye
             _, st["d_rem"] = r.finish_infill_mask_sbs(res["seed"], out=st["d_infill"][:n], max_rounds=rounds, want_remaining=True)
-            if basic_infill:                           # sr:809-812: march along the normals into the holes
-                from .stereo_rerender import infill_using_normals
-                for f in range(n):
-                    for eye in range(2):
-                        sl = slice(eye * W, (eye + 1) * W)
-                        normals = (st["d_infill"][f, :, sl].to(torch.float32) / 255.0) * 2 - 1
-                        st["d_sbs"][f, :, sl] = infill_using_normals(st["d_sbs"][f, :, sl], st["d_mask"][f, :, sl] > 0, normals)
+            if basic_infill:                           # sr:809-812: march along the normals into the holes, all frames of an eye at once
+                from .stereo_rerender import infill_using_mask_normals
+                for eye in range(2):
+                    sl = slice(eye * W, (eye + 1) * W)
+                    infill_using_mask_normals(st["d_sbs"][:n, :, sl], st["d_mask"][:n, :, sl], st["d_infill"][:n, :, sl], out=st["d_sbs"][:n, :, sl])
         if want_infill and green_and_black and res is not None:      # sr:787-793: the key colour at holes, black elsewhere
             key = torch.tensor(r.key_rgb, dtype=torch.uint8, device=dev)
             torch.mul((st["d_mask"][:n] > 0)[..., None], key, out=st["d_infill"][:n])

@@ -821,6 +821,18 @@ int mdvt_masked_blur(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, uint8_
 
 constexpr int kNormalInfillChunk = 16;       // images per launch set
 
+static int ensure_ni_workspace(mdvt_ctx* c, int chunk)
+{
+    if (c->ni_images >= chunk) return MDVT_OK;
+    MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
+    if (c->ni_ws) (void)hipFree(c->ni_ws);
+    c->ni_ws = nullptr; c->ni_images = 0;
+    MDVT_HIP(c, hipMalloc((void**)&c->ni_ws, mdvt::normal_infill_workspace_bytes(chunk, c->W, c->H)));
+    c->ni_images = chunk;
+    return MDVT_OK;
+}
+
+
 int mdvt_normal_infill(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, size_t img_stride, const uint8_t* d_infill_mask,
                        size_t mask_pitch, size_t mask_stride, uint8_t* d_out, size_t out_pitch, size_t out_stride, int n_images,
                        void* stream)
@@ -834,13 +846,7 @@ int mdvt_normal_infill(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, size
     DeviceGuard g(c->device);
     hipStream_t s = (hipStream_t)stream;
     const int chunk = n_images < kNormalInfillChunk ? n_images : kNormalInfillChunk;
-    if (c->ni_images < chunk) {
-        MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
-        if (c->ni_ws) (void)hipFree(c->ni_ws);
-        c->ni_ws = nullptr; c->ni_images = 0;
-        MDVT_HIP(c, hipMalloc((void**)&c->ni_ws, mdvt::normal_infill_workspace_bytes(chunk, c->W, c->H)));
-        c->ni_images = chunk;
-    }
+    if (int rc = ensure_ni_workspace(c, chunk)) return rc;
     const mdvt::BlurKernel K = masked_blur_kernel();
     for (int i0 = 0; i0 < n_images; i0 += chunk) {
         const int n = n_images - i0 < chunk ? n_images - i0 : chunk;
@@ -848,6 +854,30 @@ int mdvt_normal_infill(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, size
         const mdvt::ImageSet mask{const_cast<uint8_t*>(d_infill_mask) + (size_t)i0 * mask_stride, mask_pitch, mask_stride, 0, n};
         const mdvt::ImageSet out{d_out + (size_t)i0 * out_stride, out_pitch, out_stride, 0, n};
         MDVT_HIP(c, launch_normal_infill(img, mask, out, c->ni_ws, n, c->W, c->H, K, s));
+    }
+    return MDVT_OK;
+}
+
+int mdvt_infill_using_mask_normals(mdvt_ctx* c, uint8_t* d_img, size_t img_pitch, size_t img_stride, const uint8_t* d_hole,
+                                   size_t hole_pitch, size_t hole_stride, const uint8_t* d_mask_img, size_t mask_pitch,
+                                   size_t mask_stride, int n_images, int max_steps, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!d_img || !d_hole || !d_mask_img) return fail(c, MDVT_ERR_INVALID_ARG, "NULL buffer");
+    if (n_images < 1) return fail(c, MDVT_ERR_INVALID_ARG, "n_images must be >= 1");
+    if (img_pitch < (size_t)3 * c->W || mask_pitch < (size_t)3 * c->W || hole_pitch < (size_t)c->W)
+        return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (max_steps < 0) return fail(c, MDVT_ERR_INVALID_ARG, "max_steps must be >= 0");
+    if (d_img == d_mask_img) return fail(c, MDVT_ERR_INVALID_ARG, "d_img may not alias d_mask_img");
+    DeviceGuard g(c->device);
+    const int chunk = n_images < kNormalInfillChunk ? n_images : kNormalInfillChunk;
+    if (int rc = ensure_ni_workspace(c, chunk)) return rc;
+    for (int i0 = 0; i0 < n_images; i0 += chunk) {
+        const int n = n_images - i0 < chunk ? n_images - i0 : chunk;
+        const mdvt::ImageSet img{d_img + (size_t)i0 * img_stride, img_pitch, img_stride, 0, n};
+        const mdvt::ImageSet hole{const_cast<uint8_t*>(d_hole) + (size_t)i0 * hole_stride, hole_pitch, hole_stride, 0, n};
+        const mdvt::ImageSet mask{const_cast<uint8_t*>(d_mask_img) + (size_t)i0 * mask_stride, mask_pitch, mask_stride, 0, n};
+        MDVT_HIP(c, launch_infill_mask_normals(img, hole, mask, c->ni_ws, n, c->W, c->H, max_steps, (hipStream_t)stream));
     }
     return MDVT_OK;
 }

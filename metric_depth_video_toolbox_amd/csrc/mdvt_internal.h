@@ -141,6 +141,8 @@ hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const I
 size_t normal_infill_workspace_bytes(int n, int W, int H);
 hipError_t launch_normal_infill(const ImageSet& img, const ImageSet& mask, const ImageSet& out, uint8_t* workspace, int n, int W, int H,
                                 const BlurKernel& K, hipStream_t s);
+hipError_t launch_infill_mask_normals(const ImageSet& img, const ImageSet& hole, const ImageSet& mask, uint8_t* workspace, int n, int W, int H,
+                                      int max_steps, hipStream_t s);
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_selftest(int which, unsigned long long seed, unsigned long long* d_mism, hipStream_t s);

@@ -470,6 +470,89 @@ __global__ void __launch_bounds__(256) k_ni_collect(NiArgs a)
     ni_emit(a.list_b + ((size_t)im * kNSub + sub) * a.cap_b, a.count + (size_t)(4 * im + 1 + WHICH) * kNSub + sub, lds_list, &lds_cnt, &lds_base);
 }
 
+// ---- sr:809-812 (--do_basic_infill) for whole batches: the holes of the stereo frames filled along the finished infill mask ----
+// The reference calls infill_using_normals(image, bg_mask, mask * 2 - 1) per eye; its sources are never hole pixels, so the
+// image can be filled in place, and the normal of a hole pixel is needed by that pixel alone: ((u8 / 255) * 2) - 1 on the spot
+// instead of a float image.  Same scheme as above: a dense pass lists the hole pixels, then one lane per listed pixel.
+struct HfArgs {
+    ImageSet img, hole, mask;         // img: filled in place; hole: u8 plane, non-zero = hole; mask: the finished infill-mask image
+    uint32_t* count;                  // [n][kNSub]
+    uint32_t* list;                   // [n][kNSub][cap]
+    uint32_t cap;
+    int W, H, max_steps;
+};
+
+__global__ void __launch_bounds__(256) k_hf_collect(HfArgs a)
+{
+    __shared__ uint32_t lds_list[kTileW * kTileH];
+    __shared__ uint32_t lds_cnt, lds_base;
+    const int W = a.W, H = a.H, im = blockIdx.z;
+    const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint8_t* plane = a.hole.image(im);
+    if (threadIdx.x == 0) lds_cnt = 0u;
+    __syncthreads();
+    const int x = blockIdx.x * kTileW + (threadIdx.x & 127);
+#pragma unroll
+    for (int k = 0; k < kTileH / 2; ++k) {
+        const int y = blockIdx.y * kTileH + (threadIdx.x >> 7) + 2 * k;
+        const bool f = y < H && x < W && plane[(size_t)y * a.hole.pitch + x] != 0;
+        ni_wave_put(lds_list, &lds_cnt, f, (uint32_t)y * (uint32_t)W + (uint32_t)x);
+    }
+    const uint32_t sub = tile % kNSub;
+    ni_emit(a.list + ((size_t)im * kNSub + sub) * a.cap, a.count + (size_t)im * kNSub + sub, lds_list, &lds_cnt, &lds_base);
+}
+
+__global__ void __launch_bounds__(256) k_hf_run(HfArgs a)
+{
+    const int im = blockIdx.z, sub = blockIdx.y, W = a.W, H = a.H;
+    const uint32_t* list = a.list + ((size_t)im * kNSub + sub) * a.cap;
+    const uint32_t n = a.count[(size_t)im * kNSub + sub];
+    const uint8_t* hole = a.hole.image(im);
+    const size_t hp = a.hole.pitch;
+    uint8_t* img = a.img.image(im);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t idx = list[i];
+        const int y = (int)(idx / (uint32_t)W), x = (int)(idx - (uint32_t)y * (uint32_t)W);
+        const uint32_t m = load_px_bytes(a.mask.image(im) + (size_t)y * a.mask.pitch, x);
+        const float nx = (((float)(m & 0xFFu) / 255.0f) * 2.0f) - 1.0f;           // sr:808 (.../255.0) and sr:810 (*2 - 1), f32
+        const float ny = (((float)((m >> 8) & 0xFFu) / 255.0f) * 2.0f) - 1.0f;
+        const float nz = (((float)((m >> 16) & 0xFFu) / 255.0f) * 2.0f) - 1.0f;
+        const float len = sqrtf(nx * nx + ny * ny);                               // sr:177
+        const bool green = nx == 0.0f && ny == 1.0f && nz == 0.0f;               // sr:182
+        if (!(len > 1e-6f) || green) continue;
+        const float dx = nx / len, dy = ny / len;
+        const float fx = (float)x, fy = (float)y;
+        bool done = false;
+        for (int t0 = 1; t0 <= a.max_steps && !done; t0 += kHoleBatch) {
+            uint8_t hb[kHoleBatch];
+            bool in[kHoleBatch];
+#pragma unroll
+            for (int k = 0; k < kHoleBatch; ++k) {
+                const float ft = (float)(t0 + k);
+                const float rx = rintf(fx + dx * ft), ry = rintf(fy + dy * ft);  // sr:205-207
+                in[k] = ni_in_image(rx, ry, W, H);
+                hb[k] = hole[in[k] ? (size_t)(int)ry * hp + (int)rx : (size_t)y * hp + x];
+            }
+#pragma unroll
+            for (int k = 0; k < kHoleBatch; ++k) {
+                if (done) break;
+                const int t = t0 + k;
+                if (t > a.max_steps || !in[k]) { done = true; break; }               // sr:231: the ray left the image
+                if (hb[k]) continue;
+                for (int dt = 2; dt >= 0; --dt) {                                 // sr:220-228
+                    const float fo = (float)(t + dt);
+                    const float qx = rintf(fx + dx * fo), qy = rintf(fy + dy * fo);
+                    if (!ni_in_image(qx, qy, W, H)) continue;
+                    if (hole[(size_t)(int)qy * hp + (int)qx]) continue;
+                    store_px_bytes(img + (size_t)y * a.img.pitch, x, load_px_bytes(img + (size_t)(int)qy * a.img.pitch, (int)qx));
+                    break;
+                }
+                done = true;
+            }
+        }
+    }
+}
+
 struct NiLayout { uint32_t cap_a, cap_b; int tiles_x, tiles_y; size_t ncoarse, bytes_lists, bytes_zero, bytes_total; };
 
 // cap_a covers both shapes of k_ni_prep (128 threads x 4 px or x 1 px per workgroup)
@@ -493,6 +576,27 @@ NiLayout ni_layout(int n, int W, int H)
 
 // sub-lists (~4 + 4 B/px), filled 3, bg / need / marks / grown 1 each + counters, coarse maps
 size_t normal_infill_workspace_bytes(int n, int W, int H) { return ni_layout(n, W, H).bytes_total; }
+
+// workspace: the same allocation as launch_normal_infill's (its list B and counters)
+hipError_t launch_infill_mask_normals(const ImageSet& img, const ImageSet& hole, const ImageSet& mask, uint8_t* workspace, int n, int W, int H,
+                                      int max_steps, hipStream_t s)
+{
+    const size_t npx = (size_t)W * H;
+    const NiLayout l = ni_layout(n, W, H);
+    HfArgs a;
+    a.img = img; a.hole = hole; a.mask = mask;
+    a.W = W; a.H = H; a.max_steps = max_steps;
+    a.cap = l.cap_b;
+    a.list = (uint32_t*)workspace + (size_t)n * kNSub * l.cap_a;
+    a.count = a.list + (size_t)n * kNSub * l.cap_b;
+    hipError_t e = hipMemsetAsync(a.count, 0, (size_t)n * kNSub * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    unsigned per_sub = (unsigned)((npx / kNSub / 16 + 255) / 256);
+    per_sub = per_sub < 1 ? 1 : (per_sub > 16 ? 16 : per_sub);
+    hipLaunchKernelGGL(k_hf_collect, dim3(l.tiles_x, l.tiles_y, n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_hf_run, dim3(per_sub, kNSub, n), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_normal_infill(const ImageSet& img, const ImageSet& mask, const ImageSet& out, uint8_t* workspace, int n, int W, int H,
                                 const BlurKernel& K, hipStream_t s)

@@ -84,6 +84,38 @@ def infill_using_normals(color_img, hole_mask, normal_map, max_steps=400, out=No
     return out
 
 
+def infill_using_mask_normals(img, hole_mask, infill_mask, max_steps=400, out=None):
+    """sr:809-812 (--do_basic_infill) for whole batches: `infill_using_normals(image, bg_mask, infill_mask * 2 - 1)` with the
+    normals taken straight from the finished infill-mask image ((u8 / 255) * 2 - 1 in f32, sr:808 + 810).  img, infill_mask: uint8
+    CUDA [H,W,3] or [N,H,W,3]; hole_mask: uint8 / bool CUDA [H,W] or [N,H,W] (non-zero = hole); rows and images may be strided
+    (one half of side-by-side frames).  out None: a filled copy of img is returned; out given (may be img itself): filled in
+    place after img has been copied into it."""
+    import torch
+    from .depth_frames_helper import _ctx
+    assert img.is_cuda and img.dtype == torch.uint8 and img.dim() in (3, 4) and img.shape[-1] == 3
+    assert infill_mask.shape == img.shape and infill_mask.dtype == torch.uint8 and tuple(hole_mask.shape) == tuple(img.shape[:-1])
+    if hole_mask.dtype == torch.bool:
+        hole_mask = hole_mask.to(torch.uint8)
+    if out is None:
+        out = img.clone()
+    elif out.data_ptr() != img.data_ptr():
+        out.copy_(img)
+    for t in (out, infill_mask):
+        assert t.stride(-1) == 1 and t.stride(-2) == 3, "pixels must be packed RGB"
+    assert hole_mask.stride(-1) == 1
+    batched = img.dim() == 4
+    N = int(img.shape[0]) if batched else 1
+    H, W = int(img.shape[-3]), int(img.shape[-2])
+    ctx = _ctx(img.device.index or 0, W, H)
+    s = torch.cuda.current_stream(img.device)
+    stride = (lambda t: t.stride(0) if batched else 0)
+    ctx.check(_lib.load().mdvt_infill_using_mask_normals(ctx.handle, out.data_ptr(), out.stride(-3), stride(out),
+                                                         hole_mask.data_ptr(), hole_mask.stride(-2), stride(hole_mask),
+                                                         infill_mask.data_ptr(), infill_mask.stride(-3), stride(infill_mask),
+                                                         N, int(max_steps), C.c_void_p(s.cuda_stream)))
+    return out
+
+
 def touchly_depth(depth, touchly_max_depth=5, touchly_min_depth=0, zero_is_far=False, out=None):
     """float32 CUDA depth [H,W] -> uint8 [H,W,3] Touchly reverse-depth plane (sr:549-551; with zero_is_far the
     variant used after a render, sr:689-691 / 825-829).  --touchly1 without a pose file is

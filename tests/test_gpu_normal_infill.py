@@ -151,3 +151,45 @@ def test_process_pair_on_frame_dumps(bni, orc, tmp_path):
             assert np.array_equal(got[f, :, sl], orc.normal_infill(np.ascontiguousarray(sbs[f, :, sl]), np.ascontiguousarray(m))), (f, e)
     assert np.array_equal(got[N - 1], sbs[N - 1])                     # no mask: nothing changes
     assert np.load(bni.process_pair(cpath, mpath, max_frames=2)).shape[0] == 2
+
+
+def test_batched_basic_infill_is_the_per_eye_loop(bni, orc):
+    """mdvt_infill_using_mask_normals (sr:809-812 for a batch, normals read from the u8 mask, filled in place) against the
+    oracle's infill_using_normals fed with NumPy's ((mask / 255) * 2 - 1) in f32 -- on strided side-by-side halves."""
+    from metric_depth_video_toolbox_amd import stereo_rerender as sr
+    rng = np.random.default_rng(31)
+    for W, H, N in ((96, 64, 3), (250, 37, 2), (33, 17, 1), (640, 360, 2)):
+        sbs = np.zeros((N, H, 2 * W, 3), np.uint8); msk = np.zeros_like(sbs); hole = np.zeros((N, H, 2 * W), np.uint8)
+        for f in range(N):
+            for e in range(2):
+                img, mask = ni_scene(rng, W, H)
+                h = np.any(mask != 0, -1)                                   # the hole plane of the render: mask != black <=> hole
+                img[h] = 0
+                sbs[f, :, e * W:(e + 1) * W], msk[f, :, e * W:(e + 1) * W], hole[f, :, e * W:(e + 1) * W] = img, mask, h * 255
+        d_sbs, d_msk, d_hole = torch.from_numpy(sbs).cuda(), torch.from_numpy(msk).cuda(), torch.from_numpy(hole).cuda()
+        for e in range(2):
+            sl = slice(e * W, (e + 1) * W)
+            sr.infill_using_mask_normals(d_sbs[:, :, sl], d_hole[:, :, sl], d_msk[:, :, sl], out=d_sbs[:, :, sl])     # in place
+        got = d_sbs.cpu().numpy()
+        for f in range(N):
+            for e in range(2):
+                sl = slice(e * W, (e + 1) * W)
+                wn = ((msk[f, :, sl].astype(np.float32) / np.float32(255.0)) * 2 - 1).astype(np.float32)              # sr:808, 810
+                want = orc.infill_using_normals(np.ascontiguousarray(sbs[f, :, sl]), hole[f, :, sl] > 0, wn)
+                assert np.array_equal(got[f, :, sl], want), (W, H, f, e)
+        # a copy instead of in place, and fewer steps
+        out = sr.infill_using_mask_normals(torch.from_numpy(sbs[0, :, :W].copy()).cuda(), torch.from_numpy(hole[0, :, :W].copy()).cuda() > 0,
+                                           torch.from_numpy(msk[0, :, :W].copy()).cuda(), max_steps=5).cpu().numpy()
+        wn = ((msk[0, :, :W].astype(np.float32) / np.float32(255.0)) * 2 - 1).astype(np.float32)
+        assert np.array_equal(out, orc.infill_using_normals(np.ascontiguousarray(sbs[0, :, :W]), hole[0, :, :W] > 0, wn, 5))
+
+
+def test_torch_division_by_255_is_the_reference_division():
+    """The reference's normals are `u8.astype(float32) / 255.0` in NumPy (sr:808): a correctly rounded f32 division.  Torch on
+    the device may multiply by a reciprocal instead; the batched kernel divides.  All 256 inputs."""
+    v = torch.arange(256, dtype=torch.uint8, device="cuda")
+    t = ((v.to(torch.float32) / 255.0) * 2 - 1).cpu().numpy()
+    n = ((np.arange(256, dtype=np.uint8).astype(np.float32) / np.float32(255.0)) * 2 - 1).astype(np.float32)
+    diff = int((t.view(np.uint32) != n.view(np.uint32)).sum())
+    print(f"torch (x / 255.0) * 2 - 1 differs from NumPy's on {diff} of 256 inputs")
+    # (informational: the clip driver no longer computes normals with torch)
