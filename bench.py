@@ -512,6 +512,23 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
     out["normal_infill"] = {"frames_per_call": nf, "ms_per_call_median_of_5": ms2[2], "ms_per_frame": ms2[2] / nf,
                             "what": "mdvt_normal_infill (basic_nomal_infill.py:87-119) of both eyes of the product-default frames with their "
                                     "finished infill masks: masked_blur, normal march, 4x4 box blur, lower-side marks, dilation, blur_under_mask"}
+    # --do_basic_infill's own stage (sr:809-812): the holes of both eyes filled along the finished mask, in place on a copy
+    from metric_depth_video_toolbox_amd.stereo_rerender import infill_using_mask_normals
+    basic = res["sbs"].clone()
+    ms3 = []
+    for _ in range(5):
+        basic.copy_(res["sbs"])
+        torch.cuda.synchronize(dev)
+        ev[0].record()
+        for eye in range(2):
+            sl = slice(eye * W, (eye + 1) * W)
+            infill_using_mask_normals(basic[:, :, sl], res["mask"][:, :, sl], fin[:, :, sl], out=basic[:, :, sl])
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+        ms3.append(ev[0].elapsed_time(ev[1]))
+    ms3.sort()
+    out["basic_infill"] = {"frames_per_call": nf, "ms_per_call_median_of_5": ms3[2], "ms_per_frame": ms3[2] / nf,
+                           "what": "mdvt_infill_using_mask_normals (--do_basic_infill, sr:809-812) on both eyes of the same frames"}
     out["product_default_through_normal_infill"] = {
         "fps": 1.0 / (1.0 / out["product_default"]["fps"] + ms[2] * 1e-3 / nf + ms2[2] * 1e-3 / nf),
         "what": "render + infill-mask completion + normal infill, per-frame times added"}
