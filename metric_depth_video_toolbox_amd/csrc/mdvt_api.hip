@@ -843,6 +843,8 @@ int mdvt_normal_infill(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, size
     if (img_pitch < (size_t)3 * c->W || mask_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W)
         return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
     if (d_out == d_img || d_out == d_infill_mask) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias an input");
+    if (mask_pitch >= (1u << 24) || (unsigned long long)mask_pitch * c->H > 0xFFFFFFFFull || (unsigned long long)c->W * c->H > 0xFFFFFFFFull)
+        return fail(c, MDVT_ERR_UNSUPPORTED, "image too large for the marches' 32-bit offsets (pitch %zu, %d x %d)", mask_pitch, c->W, c->H);
     DeviceGuard g(c->device);
     hipStream_t s = (hipStream_t)stream;
     const int chunk = n_images < kNormalInfillChunk ? n_images : kNormalInfillChunk;
@@ -869,6 +871,8 @@ int mdvt_infill_using_mask_normals(mdvt_ctx* c, uint8_t* d_img, size_t img_pitch
         return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
     if (max_steps < 0) return fail(c, MDVT_ERR_INVALID_ARG, "max_steps must be >= 0");
     if (d_img == d_mask_img) return fail(c, MDVT_ERR_INVALID_ARG, "d_img may not alias d_mask_img");
+    if (hole_pitch >= (1u << 24) || (unsigned long long)hole_pitch * c->H > 0xFFFFFFFFull)
+        return fail(c, MDVT_ERR_UNSUPPORTED, "hole plane too large for the march's 32-bit offsets (pitch %zu, %d rows)", hole_pitch, c->H);
     DeviceGuard g(c->device);
     const int chunk = n_images < kNormalInfillChunk ? n_images : kNormalInfillChunk;
     if (int rc = ensure_ni_workspace(c, chunk)) return rc;

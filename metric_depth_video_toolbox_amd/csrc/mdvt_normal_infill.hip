@@ -82,6 +82,19 @@ __device__ __forceinline__ bool ni_in_image(float x, float y, int W, int H)
     return x >= 0.0f && x < (float)W && y >= 0.0f && y < (float)H;
 }
 
+// Sample t of a march from (x, y) along (dx, dy): np.rint(p + d * t) in f32 (sr:205-207, ic:25-27), as integers -- the march is
+// instruction bound, and "in the image?" on integers plus a 32-bit offset (rows x pitch and pixel strides stay below 2^24:
+// checked by the launchers) is half the instructions of float compares and 64-bit addresses.  A sample outside the image
+// gives `self` (never used).
+__device__ __forceinline__ bool ni_sample(int x, int y, float dx, float dy, float t, int W, int H, uint32_t pitch, uint32_t px_bytes,
+                                          uint32_t self, uint32_t& off)
+{
+    const int xi = (int)rintf((float)x + dx * t), yi = (int)rintf((float)y + dy * t);
+    const bool in = (uint32_t)xi < (uint32_t)W && (uint32_t)yi < (uint32_t)H;
+    off = in ? __umul24((uint32_t)yi, pitch) + __umul24((uint32_t)xi, px_bytes) : self;
+    return in;
+}
+
 // A wave puts its flagged pixels into the workgroup's LDS list IN LANE ORDER (one LDS atomic per wave): listed neighbours
 // stay neighbours, so that the lanes which later work on 64 consecutive entries read the same cache lines (with entries in
 // the order the lanes' own atomics happened to land, every lane of a load had its own line: 54 line accesses per instruction).
@@ -188,14 +201,15 @@ __device__ __forceinline__ int ni_march_lower_side(const uint8_t* mimg, size_t p
     if (!(len > 1e-6f)) return -1;                                     // ic:12
     const float dx = dx0 / len, dy = dy0 / len;
     const float fx = (float)x, fy = (float)y;
+    const uint32_t self = __umul24((uint32_t)y, (uint32_t)pitch) + 3u * (uint32_t)x;
     for (int t0 = 1; t0 < 30; t0 += kMarchBatch) {
         uint32_t v[kMarchBatch];
         bool in[kMarchBatch];
 #pragma unroll
         for (int k = 0; k < kMarchBatch; ++k) {
-            const float rx = rintf(fx + dx * (float)(t0 + k)), ry = rintf(fy + dy * (float)(t0 + k));
-            in[k] = ni_in_image(rx, ry, W, H);
-            v[k] = load_px_bytes(mimg + (size_t)(in[k] ? (int)ry : y) * pitch, in[k] ? (int)rx : x);
+            uint32_t off;
+            in[k] = ni_sample(x, y, dx, dy, (float)(t0 + k), W, H, (uint32_t)pitch, 3u, self, off);
+            v[k] = load_px_bytes(mimg + off, 0);
         }
 #pragma unroll
         for (int k = 0; k < kMarchBatch; ++k) {
@@ -328,10 +342,9 @@ __device__ __forceinline__ void ni_stage_filled(const NiArgs& a, int im, int x, 
                 bool in[kHoleBatch];
 #pragma unroll
                 for (int k = 0; k < kHoleBatch; ++k) {
-                    const float ft = (float)(t0 + k);
-                    const float rx = rintf(fx + dx * ft), ry = rintf(fy + dy * ft);  // sr:205-207
-                    in[k] = ni_in_image(rx, ry, W, H);
-                    hb[k] = bg[in[k] ? (size_t)(int)ry * W + (int)rx : (size_t)y * W + x];
+                    uint32_t off;
+                    in[k] = ni_sample(x, y, dx, dy, (float)(t0 + k), W, H, (uint32_t)W, 1u, (uint32_t)y * (uint32_t)W + (uint32_t)x, off);   // sr:205-207
+                    hb[k] = bg[off];
                 }
 #pragma unroll
                 for (int k = 0; k < kHoleBatch; ++k) {
@@ -528,10 +541,9 @@ __global__ void __launch_bounds__(256) k_hf_run(HfArgs a)
             bool in[kHoleBatch];
 #pragma unroll
             for (int k = 0; k < kHoleBatch; ++k) {
-                const float ft = (float)(t0 + k);
-                const float rx = rintf(fx + dx * ft), ry = rintf(fy + dy * ft);  // sr:205-207
-                in[k] = ni_in_image(rx, ry, W, H);
-                hb[k] = hole[in[k] ? (size_t)(int)ry * hp + (int)rx : (size_t)y * hp + x];
+                uint32_t off;
+                in[k] = ni_sample(x, y, dx, dy, (float)(t0 + k), W, H, (uint32_t)hp, 1u, (uint32_t)y * (uint32_t)hp + (uint32_t)x, off);   // sr:205-207
+                hb[k] = hole[off];
             }
 #pragma unroll
             for (int k = 0; k < kHoleBatch; ++k) {
