@@ -67,7 +67,7 @@ struct mdvt_ctx {
     int telea_images = 0, telea_rounds = 0;
     mdvt::TeleaWorkspace telea{};
     uint32_t* telea_levels_host = nullptr;      // pinned: the deepest level of a pass, read back once per pass
-    // normal_infill: 14 B/px per image in flight
+    // normal_infill / infill_using_mask_normals: about 16 B/px per image in flight
     uint8_t* ni_ws = nullptr;
     int ni_images = 0;
 };

@@ -17,7 +17,7 @@
 // pixels themselves) and at the hit of a marching bg pixel.  The tests hold it, bit for bit, to the seven passes written out
 // in plain C (and those to the reference's own function, tests/golden/normal_infill.npz).
 //
-// Launches per set of images (14 B/px of workspace).  The expensive parts -- the two marches and the Gaussians -- belong to
+// Launches per set of images (about 16 B/px of workspace: two lists, four planes, the filled image).  The expensive parts -- the two marches and the Gaussians -- belong to
 // a few per cent of the pixels, which sit together (holes are compact): done where they lie, a few workgroups would carry all
 // of it (measured: 830 us per 8 images, 560 of them the marches on a handful of compute units).  So the dense passes only
 // LIST pixels, and the work is dealt one listed pixel per lane over the whole chip:
