@@ -696,6 +696,8 @@ int mdvt_edge_filter(mdvt_ctx* c, const uint8_t* d_depth_rgb, size_t depth_pitch
     return MDVT_OK;
 }
 
+static int ensure_ni_workspace(mdvt_ctx* c, int chunk);      // (the listed-pixel stages' workspace, below)
+
 int mdvt_infill_using_normals(mdvt_ctx* c, const uint8_t* d_color, size_t color_pitch, const uint8_t* d_hole,
                               size_t hole_pitch, const float* d_normal, size_t normal_pitch, uint8_t* d_out,
                               size_t out_pitch, int max_steps, void* stream)
@@ -707,9 +709,12 @@ int mdvt_infill_using_normals(mdvt_ctx* c, const uint8_t* d_color, size_t color_
         normal_pitch < (size_t)12 * c->W || normal_pitch % 4 != 0)
         return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
     if (max_steps < 0) return fail(c, MDVT_ERR_INVALID_ARG, "max_steps must be >= 0");
+    if (hole_pitch >= (1u << 24) || (unsigned long long)hole_pitch * c->H > 0xFFFFFFFFull)
+        return fail(c, MDVT_ERR_UNSUPPORTED, "hole plane too large for the march's 32-bit offsets (pitch %zu, %d rows)", hole_pitch, c->H);
     DeviceGuard g(c->device);
+    if (int rc = ensure_ni_workspace(c, 1)) return rc;
     MDVT_HIP(c, launch_infill_normals(d_color, color_pitch, d_hole, hole_pitch, d_normal, normal_pitch, d_out, out_pitch,
-                                      c->W, c->H, max_steps, (hipStream_t)stream));
+                                      c->W, c->H, max_steps, c->ni_ws, (hipStream_t)stream));
     return MDVT_OK;
 }
 
@@ -721,8 +726,11 @@ int mdvt_mark_lower_side(mdvt_ctx* c, const uint8_t* d_normals_img, size_t img_p
     if (d_out == d_normals_img) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias the input image");
     if (img_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
     if (max_steps < 0) return fail(c, MDVT_ERR_INVALID_ARG, "max_steps must be >= 0");
+    if (img_pitch >= (1u << 24) || (unsigned long long)img_pitch * c->H > 0xFFFFFFFFull)
+        return fail(c, MDVT_ERR_UNSUPPORTED, "image too large for the march's 32-bit offsets (pitch %zu, %d rows)", img_pitch, c->H);
     DeviceGuard g(c->device);
-    MDVT_HIP(c, launch_mark_lower_side(d_normals_img, img_pitch, d_out, out_pitch, c->W, c->H, max_steps, (hipStream_t)stream));
+    if (int rc = ensure_ni_workspace(c, 1)) return rc;
+    MDVT_HIP(c, launch_mark_lower_side(d_normals_img, img_pitch, d_out, out_pitch, c->W, c->H, max_steps, c->ni_ws, (hipStream_t)stream));
     return MDVT_OK;
 }
 

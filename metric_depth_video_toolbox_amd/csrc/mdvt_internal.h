@@ -105,11 +105,12 @@ hipError_t launch_edge_points_splat(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_edge_keys_reset(const RenderArgs& a, int n, hipStream_t s);
 // mdvt_mesh_general.hip: the rasteriser of the general mesh path (between the vertex pass and the resolve pass)
 hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+// (mdvt_normal_infill.hip; workspace: normal_infill_workspace_bytes(1, W, H))
 hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const uint8_t* hole, size_t hole_pitch,
                                  const float* normal, size_t normal_pitch, uint8_t* out, size_t out_pitch, int W, int H,
-                                 int max_steps, hipStream_t s);
+                                 int max_steps, uint8_t* workspace, hipStream_t s);
 hipError_t launch_mark_lower_side(const uint8_t* img, size_t img_pitch, uint8_t* out, size_t out_pitch, int W, int H,
-                                  int max_steps, hipStream_t s);
+                                  int max_steps, uint8_t* workspace, hipStream_t s);
 hipError_t launch_touchly_depth(const float* depth, size_t depth_pitch, uint8_t* rgb, size_t rgb_pitch, int W, int H,
                                 float tmax, float tmin, float k, int zero_is_far, hipStream_t s);
 hipError_t launch_equirect_remap(const uint8_t* src, size_t src_pitch, size_t src_stride, uint8_t* dst, size_t dst_pitch,

@@ -1360,100 +1360,7 @@ __global__ void __launch_bounds__(256) k_mesh_vertices_general(RenderArgs a)
     }
 }
 
-// =================================================================================================
-// infill_using_normals (sr:155-240): one thread per pixel, lock-step free ray march
-// =================================================================================================
-// The reference marches all rays in lock step (one NumPy pass per step t); rays are independent and
-// sources are read from the unmodified input image, so a per-pixel loop gives the same result.
-
-__device__ __forceinline__ bool in_image(float x, float y, int W, int H)
-{
-    return x >= 0.0f && x < (float)W && y >= 0.0f && y < (float)H;
-}
-
-__global__ void __launch_bounds__(256) k_infill_normals(const uint8_t* __restrict__ color, size_t color_pitch,
-                                                        const uint8_t* __restrict__ hole, size_t hole_pitch,
-                                                        const float* __restrict__ normal, size_t normal_pitch,
-                                                        uint8_t* __restrict__ out, size_t out_pitch, int W, int H, int max_steps)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= W) return;
-    uint32_t px = load_px_bytes(color + (size_t)y * color_pitch, x);
-    if (hole[(size_t)y * hole_pitch + x]) {
-        const float* n = (const float*)((const uint8_t*)normal + (size_t)y * normal_pitch) + 3 * (size_t)x;
-        const float nx = n[0], ny = n[1], nz = n[2];
-        const float len = sqrtf(nx * nx + ny * ny);                       // np.linalg.norm of the f32 XY pair
-        const bool green = nx == 0.0f && ny == 1.0f && nz == 0.0f;       // sr:182
-        if (len > 1e-6f && !green) {
-            const float dx = nx / len, dy = ny / len;
-            const float fx = (float)x, fy = (float)y;
-            for (int t = 1; t <= max_steps; ++t) {
-                const float ft = (float)t;
-                const float rx = rintf(fx + dx * ft), ry = rintf(fy + dy * ft);      // sr:205-207
-                if (!in_image(rx, ry, W, H)) break;                                 // sr:231: the ray left the image
-                if (hole[(size_t)(int)ry * hole_pitch + (int)rx]) continue;
-                // first non-hole sample: take t+2, else t+1, else t (sr:220-228)
-                for (int dt = 2; dt >= 0; --dt) {
-                    const float fo = (float)(t + dt);
-                    const float qx = rintf(fx + dx * fo), qy = rintf(fy + dy * fo);
-                    if (!in_image(qx, qy, W, H)) continue;
-                    if (hole[(size_t)(int)qy * hole_pitch + (int)qx]) continue;
-                    px = load_px_bytes(color + (size_t)(int)qy * color_pitch, (int)qx);
-                    break;
-                }
-                break;
-            }
-        }
-    }
-    store_px_bytes(out + (size_t)y * out_pitch, x, px);
-}
-
-hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const uint8_t* hole, size_t hole_pitch,
-                                 const float* normal, size_t normal_pitch, uint8_t* out, size_t out_pitch, int W, int H,
-                                 int max_steps, hipStream_t s)
-{
-    dim3 grid((W + 255) / 256, H);
-    hipLaunchKernelGGL(k_infill_normals, grid, dim3(256), 0, s, color, color_pitch, hole, hole_pitch, normal, normal_pitch,
-                       out, out_pitch, W, H, max_steps);
-    return hipGetLastError();
-}
-
-// mark_lower_side (infill_common.py:4-49): one thread per pixel of the normal-coloured mask image.
-// `out` is zeroed beforehand; every hit writes the same (0,0,255), so concurrent writers agree.
-__global__ void __launch_bounds__(256) k_mark_lower_side(const uint8_t* __restrict__ img, size_t img_pitch,
-                                                         uint8_t* __restrict__ out, size_t out_pitch, int W, int H, int max_steps)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= W) return;
-    const uint32_t px = load_px_bytes(img + (size_t)y * img_pitch, x);
-    if (px == 0) return;                                               // ic:7: only non-black pixels march
-    const float dx0 = ((float)(px & 0xFF) / 255.0f) * 2.0f - 1.0f;     // ic:10
-    const float dy0 = ((float)((px >> 8) & 0xFF) / 255.0f) * 2.0f - 1.0f;
-    const float len = sqrtf(dx0 * dx0 + dy0 * dy0);
-    if (!(len > 1e-6f)) return;                                        // ic:12
-    const float dx = dx0 / len, dy = dy0 / len;
-    const float fx = (float)x, fy = (float)y;
-    for (int t = 1; t < max_steps; ++t) {
-        const float rx = rintf(fx + dx * (float)t), ry = rintf(fy + dy * (float)t);
-        if (!in_image(rx, ry, W, H)) return;                           // ic:41-42
-        if (load_px_bytes(img + (size_t)(int)ry * img_pitch, (int)rx) != 0) continue;
-        const float bx = rintf(fx + dx * (float)(t - 1)), by = rintf(fy + dy * (float)(t - 1));   // ic:35-39
-        if (bx >= 0.0f && by >= 0.0f) store_px_bytes(out + (size_t)(int)by * out_pitch, (int)bx, 0xFF0000u);
-        return;
-    }
-}
-
-hipError_t launch_mark_lower_side(const uint8_t* img, size_t img_pitch, uint8_t* out, size_t out_pitch, int W, int H,
-                                  int max_steps, hipStream_t s)
-{
-    hipError_t e = hipMemset2DAsync(out, out_pitch, 0, (size_t)3 * W, (size_t)H, s);
-    if (e != hipSuccess) return e;
-    dim3 grid((W + 255) / 256, H);
-    hipLaunchKernelGGL(k_mark_lower_side, grid, dim3(256), 0, s, img, img_pitch, out, out_pitch, W, H, max_steps);
-    return hipGetLastError();
-}
+// (infill_using_normals and mark_lower_side: mdvt_normal_infill.hip)
 
 // Touchly inverse-depth plane (sr:549-551, 689-691, 825-829).
 __global__ void __launch_bounds__(256) k_touchly_depth(const float* __restrict__ depth, size_t depth_pitch,

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(128) k_ni_prep(NiArgs a)
 // mark_lower_side (ic:4-49) for one non-black pixel of the mask image.  The samples of kMarchBatch steps are fetched
 // together and then looked at in order -- a sample beyond the step that ends the march is simply not used.  Returns the
 // marked pixel, or -1.
-__device__ __forceinline__ int ni_march_lower_side(const uint8_t* mimg, size_t pitch, uint32_t px, int x, int y, int W, int H)
+__device__ __forceinline__ int ni_march_lower_side(const uint8_t* mimg, size_t pitch, uint32_t px, int x, int y, int W, int H, int max_steps = 30)
 {
     const float dx0 = ((float)(px & 0xFFu) / 255.0f) * 2.0f - 1.0f;    // ic:10
     const float dy0 = ((float)((px >> 8) & 0xFFu) / 255.0f) * 2.0f - 1.0f;
@@ -202,7 +202,7 @@ __device__ __forceinline__ int ni_march_lower_side(const uint8_t* mimg, size_t p
     const float dx = dx0 / len, dy = dy0 / len;
     const float fx = (float)x, fy = (float)y;
     const uint32_t self = __umul24((uint32_t)y, (uint32_t)pitch) + 3u * (uint32_t)x;
-    for (int t0 = 1; t0 < 30; t0 += kMarchBatch) {
+    for (int t0 = 1; t0 < max_steps; t0 += kMarchBatch) {
         uint32_t v[kMarchBatch];
         bool in[kMarchBatch];
 #pragma unroll
@@ -214,7 +214,7 @@ __device__ __forceinline__ int ni_march_lower_side(const uint8_t* mimg, size_t p
 #pragma unroll
         for (int k = 0; k < kMarchBatch; ++k) {
             const int t = t0 + k;
-            if (t >= 30 || !in[k]) return -1;                          // ic:20, 41-42
+            if (t >= max_steps || !in[k]) return -1;                   // ic:20, 41-42
             if (v[k] != 0u) continue;
             const float bx = rintf(fx + dx * (float)(t - 1)), by = rintf(fy + dy * (float)(t - 1));   // ic:35-39
             return (bx >= 0.0f && by >= 0.0f) ? (int)by * W + (int)bx : -1;
@@ -565,6 +565,94 @@ __global__ void __launch_bounds__(256) k_hf_run(HfArgs a)
     }
 }
 
+// ---- the two stand-alone entry points on the same scheme: mdvt_infill_using_normals (float normals, sr:155-240) and
+//      mdvt_mark_lower_side (ic:4-49), one image per call ----
+struct SoloArgs {
+    const uint8_t* src; size_t src_pitch;        // infill: the colour image; lower side: the normal-coloured mask image
+    const uint8_t* hole; size_t hole_pitch;      // infill only
+    const float* normal; size_t normal_pitch;    // infill only (bytes)
+    uint8_t* out; size_t out_pitch;
+    uint32_t* count;                             // [kNSub]
+    uint32_t* list;                              // [kNSub][cap]
+    uint32_t cap;
+    int W, H, max_steps;
+};
+
+// WHICH 0: the hole pixels; 1: the non-black pixels of the mask image
+template <int WHICH>
+__global__ void __launch_bounds__(256) k_solo_collect(SoloArgs a)
+{
+    __shared__ uint32_t lds_list[kTileW * kTileH];
+    __shared__ uint32_t lds_cnt, lds_base;
+    const int W = a.W, H = a.H;
+    const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) lds_cnt = 0u;
+    __syncthreads();
+    const int x = blockIdx.x * kTileW + (threadIdx.x & 127);
+#pragma unroll
+    for (int k = 0; k < kTileH / 2; ++k) {
+        const int y = blockIdx.y * kTileH + (threadIdx.x >> 7) + 2 * k;
+        bool f = false;
+        if (y < H && x < W) f = WHICH == 0 ? a.hole[(size_t)y * a.hole_pitch + x] != 0 : load_px_bytes(a.src + (size_t)y * a.src_pitch, x) != 0u;
+        ni_wave_put(lds_list, &lds_cnt, f, (uint32_t)y * (uint32_t)W + (uint32_t)x);
+    }
+    const uint32_t sub = tile % kNSub;
+    ni_emit(a.list + (size_t)sub * a.cap, a.count + sub, lds_list, &lds_cnt, &lds_base);
+}
+
+template <int WHICH>
+__global__ void __launch_bounds__(256) k_solo_run(SoloArgs a)
+{
+    const int sub = blockIdx.y, W = a.W, H = a.H;
+    const uint32_t* list = a.list + (size_t)sub * a.cap;
+    const uint32_t n = a.count[sub];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t idx = list[i];
+        const int y = (int)(idx / (uint32_t)W), x = (int)(idx - (uint32_t)y * (uint32_t)W);
+        if (WHICH == 1) {
+            const int mark = ni_march_lower_side(a.src, a.src_pitch, load_px_bytes(a.src + (size_t)y * a.src_pitch, x), x, y, W, H, a.max_steps);
+            if (mark >= 0) store_px_bytes(a.out + (size_t)(mark / W) * a.out_pitch, mark % W, 0xFF0000u);      // (0, 0, 255), ic:46
+            continue;
+        }
+        const float* nrm = (const float*)((const uint8_t*)a.normal + (size_t)y * a.normal_pitch) + 3 * (size_t)x;
+        const float nx = nrm[0], ny = nrm[1], nz = nrm[2];
+        const float len = sqrtf(nx * nx + ny * ny);                               // sr:177
+        const bool green = nx == 0.0f && ny == 1.0f && nz == 0.0f;               // sr:182
+        if (!(len > 1e-6f) || green) continue;
+        const float dx = nx / len, dy = ny / len;
+        const float fx = (float)x, fy = (float)y;
+        const uint8_t* hole = a.hole;
+        const size_t hp = a.hole_pitch;
+        bool done = false;
+        for (int t0 = 1; t0 <= a.max_steps && !done; t0 += kHoleBatch) {
+            uint8_t hb[kHoleBatch];
+            bool in[kHoleBatch];
+#pragma unroll
+            for (int k = 0; k < kHoleBatch; ++k) {
+                uint32_t off;
+                in[k] = ni_sample(x, y, dx, dy, (float)(t0 + k), W, H, (uint32_t)hp, 1u, (uint32_t)y * (uint32_t)hp + (uint32_t)x, off);   // sr:205-207
+                hb[k] = hole[off];
+            }
+#pragma unroll
+            for (int k = 0; k < kHoleBatch; ++k) {
+                if (done) break;
+                const int t = t0 + k;
+                if (t > a.max_steps || !in[k]) { done = true; break; }               // sr:231: the ray left the image
+                if (hb[k]) continue;
+                for (int dt = 2; dt >= 0; --dt) {                                 // sr:220-228
+                    const float fo = (float)(t + dt);
+                    const float qx = rintf(fx + dx * fo), qy = rintf(fy + dy * fo);
+                    if (!ni_in_image(qx, qy, W, H)) continue;
+                    if (hole[(size_t)(int)qy * hp + (int)qx]) continue;
+                    store_px_bytes(a.out + (size_t)y * a.out_pitch, x, load_px_bytes(a.src + (size_t)(int)qy * a.src_pitch, (int)qx));
+                    break;
+                }
+                done = true;
+            }
+        }
+    }
+}
+
 struct NiLayout { uint32_t cap_a, cap_b; int tiles_x, tiles_y; size_t ncoarse, bytes_lists, bytes_zero, bytes_total; };
 
 // cap_a covers both shapes of k_ni_prep (128 threads x 4 px or x 1 px per workgroup)
@@ -608,6 +696,51 @@ hipError_t launch_infill_mask_normals(const ImageSet& img, const ImageSet& hole,
     hipLaunchKernelGGL(k_hf_collect, dim3(l.tiles_x, l.tiles_y, n), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_hf_run, dim3(per_sub, kNSub, n), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+static hipError_t solo_launch(int which, SoloArgs a, uint8_t* workspace, hipStream_t s)
+{
+    const NiLayout l = ni_layout(1, a.W, a.H);
+    a.cap = l.cap_b;
+    a.list = (uint32_t*)workspace + (size_t)kNSub * l.cap_a;
+    a.count = a.list + (size_t)kNSub * l.cap_b;
+    hipError_t e = hipMemsetAsync(a.count, 0, (size_t)kNSub * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    unsigned per_sub = (unsigned)(((size_t)a.W * a.H / kNSub / 16 + 255) / 256);
+    per_sub = per_sub < 1 ? 1 : (per_sub > 16 ? 16 : per_sub);
+    const dim3 tiles(l.tiles_x, l.tiles_y), lanes(per_sub, kNSub);
+    if (which == 0) {
+        hipLaunchKernelGGL(k_solo_collect<0>, tiles, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_solo_run<0>, lanes, dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_solo_collect<1>, tiles, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_solo_run<1>, lanes, dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+// mdvt_infill_using_normals: out = the colour image with its holes filled (workspace: normal_infill_workspace_bytes(1, W, H))
+hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const uint8_t* hole, size_t hole_pitch,
+                                 const float* normal, size_t normal_pitch, uint8_t* out, size_t out_pitch, int W, int H,
+                                 int max_steps, uint8_t* workspace, hipStream_t s)
+{
+    hipError_t e = hipMemcpy2DAsync(out, out_pitch, color, color_pitch, (size_t)3 * W, (size_t)H, hipMemcpyDeviceToDevice, s);     // sr:172
+    if (e != hipSuccess) return e;
+    SoloArgs a{};
+    a.src = color; a.src_pitch = color_pitch; a.hole = hole; a.hole_pitch = hole_pitch; a.normal = normal; a.normal_pitch = normal_pitch;
+    a.out = out; a.out_pitch = out_pitch; a.W = W; a.H = H; a.max_steps = max_steps;
+    return solo_launch(0, a, workspace, s);
+}
+
+// mdvt_mark_lower_side: out = (0,0,255) at the marks, black elsewhere
+hipError_t launch_mark_lower_side(const uint8_t* img, size_t img_pitch, uint8_t* out, size_t out_pitch, int W, int H,
+                                  int max_steps, uint8_t* workspace, hipStream_t s)
+{
+    hipError_t e = hipMemset2DAsync(out, out_pitch, 0, (size_t)3 * W, (size_t)H, s);
+    if (e != hipSuccess) return e;
+    SoloArgs a{};
+    a.src = img; a.src_pitch = img_pitch; a.out = out; a.out_pitch = out_pitch; a.W = W; a.H = H; a.max_steps = max_steps;
+    return solo_launch(1, a, workspace, s);
 }
 
 hipError_t launch_normal_infill(const ImageSet& img, const ImageSet& mask, const ImageSet& out, uint8_t* workspace, int n, int W, int H,
