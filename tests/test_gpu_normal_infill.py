@@ -193,3 +193,33 @@ def test_torch_division_by_255_is_the_reference_division():
     diff = int((t.view(np.uint32) != n.view(np.uint32)).sum())
     print(f"torch (x / 255.0) * 2 - 1 differs from NumPy's on {diff} of 256 inputs")
     # (informational: the clip driver no longer computes normals with torch)
+
+
+def test_more_images_than_a_launch_set_and_argument_checks_of_the_batched_infill(bni, orc):
+    from metric_depth_video_toolbox_amd import stereo_rerender as sr, _lib
+    rng = np.random.default_rng(41)
+    W, H, N = 80, 48, 19                                                       # 19 > 16 images per launch set
+    imgs, masks = zip(*(ni_scene(rng, W, H) for _ in range(N)))
+    imgs, masks = np.stack(imgs), np.stack(masks)
+    hole = np.any(masks != 0, -1)
+    imgs[hole] = 0
+    got = sr.infill_using_mask_normals(torch.from_numpy(imgs).cuda(), torch.from_numpy(hole).cuda(), torch.from_numpy(masks).cuda()).cpu().numpy()
+    for k in range(N):
+        wn = ((masks[k].astype(np.float32) / np.float32(255.0)) * 2 - 1).astype(np.float32)
+        assert np.array_equal(got[k], orc.infill_using_normals(imgs[k], hole[k], wn)), k
+    img = torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(_lib.MdvtError):
+        sr.infill_using_mask_normals(img, torch.zeros((8, 8), dtype=torch.uint8, device="cuda"), img, out=img)     # d_img may not alias the mask image
+    with pytest.raises(AssertionError):
+        sr.infill_using_mask_normals(img, torch.zeros((8, 9), dtype=torch.uint8, device="cuda"), img.clone())
+
+
+def test_ultra_hd_frame(bni, orc):
+    """3840 x 2160 (BASELINE config 4's size): 30 x 135 tiles, sub-list capacities, 32-bit offsets."""
+    W, H = 3840, 2160
+    rng = np.random.default_rng(2160)
+    img, mask = ni_scene(rng, W, H, holes=60)
+    got = _run(bni, img, mask)
+    want, st = orc.normal_infill(img, mask, want_stages=True)
+    assert st["bg"].sum() > 100000 and st["grown"].sum() > 10000
+    assert np.array_equal(got, want)
