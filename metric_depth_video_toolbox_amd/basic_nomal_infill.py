@@ -7,7 +7,8 @@ same names and argument meaning, on PyTorch-ROCm tensors through libmdvt_hip.so.
 
 The reference reads and writes FFV1 videos through OpenCV; here the inputs are the `.npy` dumps the clip driver writes
 (`<depth>_stereo.npy`, `<depth>_stereo.npy_infillmask.npy`: uint8 [N, H, 2W, 3], RGB order) and the output is
-`<sbs_color>_infilled.npy`, written as `<sbs_color>_tmp_infilled.npy` and renamed once every frame is in
+`<sbs_color>_infilled.npy` (the reference appends `_infilled.mkv` to the colour video's full name, bni:141), written as
+`<sbs_color>_tmp_infilled.npy` and renamed once every frame is in
 (depth_frames_helper.verify_and_move, dfh:163-179).
 """
 from __future__ import annotations
@@ -77,8 +78,7 @@ def process_pair(sbs_color_video_path: str, sbs_mask_video_path: str, max_frames
     assert color.ndim == 4 and color.shape[-1] == 3 and color.dtype == np.uint8, "uint8 [N, H, 2W, 3] expected"
     assert color.shape[1:] == mask.shape[1:], "mask and color video not same resolution"
     n = color.shape[0] if max_frames == -1 else min(color.shape[0], max_frames)
-    stem = sbs_color_video_path[:-4] if sbs_color_video_path.endswith(".npy") else sbs_color_video_path
-    tmp, final = stem + "_tmp_infilled.npy", stem + "_infilled.npy"
+    tmp, final = sbs_color_video_path + "_tmp_infilled.npy", sbs_color_video_path + "_infilled.npy"      # bni:140-141
     out = np.lib.format.open_memmap(tmp, mode="w+", dtype=np.uint8, shape=(n,) + tuple(color.shape[1:]))
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
     for a in range(0, n, batch):

@@ -242,10 +242,12 @@ class _RawFrames:
 
 def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParameters, *, lo: int = 0,
                 hi: Optional[int] = None, batch: int = 16, out_depth_rgb=None, out_infill=None, green_and_black: bool = False,
-                device: Optional[int] = None, out_base: int = 0, io_threads: int = 12):
+                device: Optional[int] = None, out_base: int = 0, io_threads: int = 12, out_infilled=None):
     """Render frames [lo, hi) of a clip.  depth_frames / color_frames / out_*: array-likes indexed
     [frame] (NumPy arrays or memmaps, uint8); frame t is written to out_*[t - out_base] (a rank that owns the output
-    segment [lo, hi) passes out_base = lo).  Returns (frames, seconds, hole_pixels)."""
+    segment [lo, hi) passes out_base = lo).  out_infilled (optional, [frames, H, 2W, 3]): the stereo frames after
+    basic_nomal_infill.normal_infill of both eyes with the finished infill mask -- movie_2_3D.py's next step, run here
+    while frame and mask are still on the device instead of through two more video files.  Returns (frames, seconds, hole_pixels)."""
     import time
     import torch
     from . import depth_frames_helper as dfh
@@ -263,10 +265,16 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     want_z = want_zrgb or touchly0 or (touchly1 and posed)
     basic_infill = bool(clip.mode_flags & 128) and not touchly1
     want_infill = out_infill is not None and not skip_render   # (the reference writes no infill-mask frame on its fast path)
+    want_infilled = out_infilled is not None
+    if want_infilled and (not (clip.mode_flags & 2) or not (clip.mode_flags & 8) or vr180 or touchly1 or basic_infill):
+        raise ValueError("normal_infill needs --infill_mask with edge removal and the plain stereo output "
+                         "(basic_nomal_infill.py consumes <depth>_stereo and its infill mask)")
     if not (clip.mode_flags & 2):
         green_and_black = True       # --infill_mask --dont_remove_edges: no normals to show, the mask is the key colour at holes
         basic_infill = False
-    want_seed = ((want_infill and not green_and_black) or basic_infill) and bool(clip.mode_flags & 2)
+    if want_infilled and green_and_black:
+        raise ValueError("normal_infill marches along the normal-coloured mask: not with --green_and_black_infill_mask")
+    want_seed = ((want_infill and not green_and_black) or basic_infill or want_infilled) and bool(clip.mode_flags & 2)
     # without --infill_mask the key colour is black and every black pixel counts as "to fill" (sr:803-805): the front
     # then has to cross the whole frame, as the reference's own cv2.inpaint call does
     telea_rounds = 0 if (clip.mode_flags & 8) else W + H
@@ -285,6 +293,8 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             "h_counts": pinned((B, 2), torch.int32), "h_rem": pinned((2, B), torch.int32),
             "h_zrgb": pinned((B, H, 2 * W, 3), torch.uint8) if want_zrgb else None,
             "h_seed": pinned((B, H, 2 * W, 3), torch.uint8) if want_infill else None,
+            "h_infilled": pinned((B, H, 2 * W, 3), torch.uint8) if want_infilled else None,
+            "d_infilled": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if want_infilled else None,
             "d_infill": torch.empty((B, H, 2 * W, 3), dtype=torch.uint8, device=dev) if (want_seed or want_infill) else None,
             "d_d": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
             "d_c": torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev),
@@ -317,6 +327,7 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
     f_sbs, f_mask = _RawFrames(out_sbs, True), _RawFrames(out_mask, True)
     f_zrgb = _RawFrames(out_depth_rgb, True) if out_depth_rgb is not None else None
     f_infill = _RawFrames(out_infill, True) if out_infill is not None else None
+    f_infilled = _RawFrames(out_infilled, True) if out_infilled is not None else None
 
     trace = [] if os.environ.get("MDVT_CLIP_TRACE") else None
 
@@ -343,6 +354,8 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             jobs += fan(f_zrgb.write_from, st["h_zrgb"][:n].numpy(), o, n, 3)
         if want_infill:
             jobs += fan(f_infill.write_from, st["h_seed"][:n].numpy(), o, n, 3)
+        if want_infilled:
+            jobs += fan(f_infilled.write_from, st["h_infilled"][:n].numpy(), o, n, 3)
         for j in jobs:
             j.result()
         store_done.append(time.perf_counter())
@@ -373,6 +386,9 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
                 for eye in range(2):
                     sl = slice(eye * W, (eye + 1) * W)
                     infill_using_mask_normals(st["d_sbs"][:n, :, sl], st["d_mask"][:n, :, sl], st["d_infill"][:n, :, sl], out=st["d_sbs"][:n, :, sl])
+        if want_infilled and res is not None:          # basic_nomal_infill.py:172-228: both eyes of every frame
+            from .basic_nomal_infill import normal_infill_sbs
+            normal_infill_sbs(st["d_sbs"][:n], st["d_infill"][:n], out=st["d_infilled"][:n])
         if want_infill and green_and_black and res is not None:      # sr:787-793: the key colour at holes, black elsewhere
             key = torch.tensor(r.key_rgb, dtype=torch.uint8, device=dev)
             torch.mul((st["d_mask"][:n] > 0)[..., None], key, out=st["d_infill"][:n])
@@ -421,6 +437,8 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
                 st["h_zrgb"][:n].copy_(st["d_zrgb"][:n], non_blocking=True)
             if want_infill and res is not None:
                 st["h_seed"][:n].copy_(st["d_infill"][:n], non_blocking=True)
+            if want_infilled:
+                st["h_infilled"][:n].copy_(st["d_infilled"][:n], non_blocking=True)
             st["check_rem"] = st.get("d_rem") is not None
             if st["check_rem"]:
                 st["h_rem"][:, :n].copy_(st["d_rem"], non_blocking=True)
@@ -451,13 +469,15 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
             f_sbs.write_from(main.cpu().numpy(), a - out_base, n)
         if want_infill:
             f_infill.write_from(st["d_infill"][:n].cpu().numpy(), a - out_base, n)
+        if want_infilled:
+            f_infilled.write_from(st["d_infilled"][:n].cpu().numpy(), a - out_base, n)
     dt = time.perf_counter() - t0
     if trace is not None:
         for ev in sorted(trace, key=lambda e: e[2]):
             print("clip trace: %-5s frame %4d  t=%7.1f ms  wait %6.1f ms  copy %6.1f ms" % (ev[0], ev[1], ev[2] * 1e3, ev[3] * 1e3, ev[4] * 1e3))
     pool.shutdown()
     io_pool.shutdown()
-    for f in (f_depth, f_color, f_sbs, f_mask, f_zrgb, f_infill):
+    for f in (f_depth, f_color, f_sbs, f_mask, f_zrgb, f_infill, f_infilled):
         if f is not None:
             f.close()
     r.close()
@@ -480,7 +500,7 @@ def verify_and_move(tmp_path: str, expected_frames: int, final_path: str):
     os.replace(tmp_path, final_path)
 
 
-OUTPUT_KINDS = {"sbs": "", "mask": "_holemask.npy", "depth": "_depth.npy", "infill": "_infillmask.npy"}
+OUTPUT_KINDS = {"sbs": "", "mask": "_holemask.npy", "depth": "_depth.npy", "infill": "_infillmask.npy", "infilled": "_infilled.npy"}
 
 
 def segment_path(path: str, rank: int, world: int) -> str:
@@ -489,7 +509,7 @@ def segment_path(path: str, rank: int, world: int) -> str:
 
 
 def plan_outputs(depth_path: str, clip: D.ClipParameters, world: int, *, create_sbs_depth_video: bool = False,
-                 infill_mask: bool = False):
+                 infill_mask: bool = False, normal_infill: bool = False):
     """Names and shapes of everything a run writes (pure host logic).  With one rank every output is one `.npy` dump, as the
     reference writes one file per output (sr:411-444).  With R ranks every rank owns the SEGMENT of each output that holds
     its contiguous frame range -- its own file `<output>.rank<r>of<R>.npy`, written as `<tmp>.rank<r>of<R>.npy` and renamed
@@ -507,6 +527,8 @@ def plan_outputs(depth_path: str, clip: D.ClipParameters, world: int, *, create_
         shapes["depth"] = (H, 2 * W, 3)
     if infill_mask and not ((clip.mode_flags & 64) and clip.transformations is None):
         shapes["infill"] = (H, 2 * W, 3)
+    if normal_infill:
+        shapes["infilled"] = (H, 2 * W, 3)
     segs = [(r,) + tuple(D.frame_range(r, world, N)) for r in range(world)]
     return {k: dict(final=final + OUTPUT_KINDS[k], tmp=tmp + OUTPUT_KINDS[k], frame_shape=shp, segments=segs, frames=N)
             for k, shp in shapes.items()}
@@ -618,7 +640,8 @@ def pin_to_gpu_numa_node(device_index: int) -> Optional[int]:
 
 
 def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_sbs_depth_video: bool = False,
-        max_frames: int = -1, green_and_black_infill_mask: bool = False, backend: Optional[str] = None, **clip_kwargs):
+        max_frames: int = -1, green_and_black_infill_mask: bool = False, backend: Optional[str] = None,
+        normal_infill: bool = False, **clip_kwargs):
     """File-level entry (what `python stereo_rerender.py --depth_video ...` is to the reference).
     Multi-process aware: under torchrun every rank renders its own contiguous frame range into its own output segment
     files (plan_outputs); rank 0 adds the index.  `backend`: torch.distributed backend (default: RCCL when a GPU is
@@ -638,7 +661,7 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     clip = load_clip_parameters(n_total, W, H, n_use=N, **clip_kwargs) if rank == 0 else None
     clip = D.broadcast_clip_parameters(clip, src=0)
     plan = plan_outputs(depth_path, clip, world, create_sbs_depth_video=create_sbs_depth_video,
-                        infill_mask=bool(clip_kwargs.get("infill_mask")))
+                        infill_mask=bool(clip_kwargs.get("infill_mask")), normal_infill=normal_infill)
     final = plan["sbs"]["final"]
     lo, hi = D.frame_range(rank, world, N)
     io_threads = 12
@@ -658,7 +681,8 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
             np.save(t, outs[k])
     frames, secs, holes = render_clip(depth, color, outs["sbs"], outs["mask"], clip, lo=lo, hi=hi, batch=batch,
                                       out_depth_rgb=outs.get("depth"), out_infill=outs.get("infill"),
-                                      green_and_black=green_and_black_infill_mask, out_base=lo, io_threads=io_threads)
+                                      green_and_black=green_and_black_infill_mask, out_base=lo, io_threads=io_threads,
+                                      out_infilled=outs.get("infilled"))
     # (no msync: the dumps were written through the page cache, which every later reader shares; forcing 6 GB of dirty pages
     #  to the disk before the rename is what the reference's writers do not do either, and costs seconds on a container fs)
     del outs

@@ -514,6 +514,9 @@ def build_arg_parser():
     ap.add_argument("--touchly_max_depth", default=5, type=float)
     ap.add_argument("--touchly_min_depth", default=0, type=float)
     ap.add_argument("--do_basic_infill", action="store_true", help="fill the holes by marching along the infill-mask normals")
+    ap.add_argument("--normal_infill", action="store_true",
+                    help="not a reference flag: also run basic_nomal_infill.py's normal_infill on every frame while it is on the device "
+                         "and write <output>_infilled.npy (needs --infill_mask)")
     for flag in ("--compressed", "--mask_video", "--save_background", "--load_background"):
         ap.add_argument(flag, nargs="?", const=True, default=None, help="reference flag outside the built hot path")
     return ap
@@ -545,7 +548,7 @@ def main(argv=None):
                             infill_mask=args.infill_mask,
                             dont_place_points_in_edges=args.dont_place_points_in_edges,
                             vr180=args.vr180, touchly0=args.touchly0, touchly1=args.touchly1,
-                            do_basic_infill=args.do_basic_infill,
+                            do_basic_infill=args.do_basic_infill, normal_infill=args.normal_infill,
                             touchly_max_depth=args.touchly_max_depth, touchly_min_depth=args.touchly_min_depth)
     if int(os.environ.get("RANK", "0")) == 0:
         frames, secs = float(stats[:, 0].sum()), float(stats[:, 1].max())

@@ -266,6 +266,36 @@ def test_infill_mask_clip(mods, orc, tmp_path, basic):
     r.close()
 
 
+def test_normal_infill_in_the_same_run(mods, orc, tmp_path, capsys):
+    """--normal_infill (not a reference flag): movie_2_3D.py's next step, basic_nomal_infill.normal_infill of both eyes, run while
+    frame and finished mask are on the device.  Its file = what process_pair makes of the run's two other outputs, and both =
+    the oracle's normal_infill of the oracle's frames and masks."""
+    clip, sr, synthetic = mods
+    from metric_depth_video_toolbox_amd import basic_nomal_infill as bni
+    W, H, N = 192, 108, 5
+    d, c = synthetic.SyntheticScene(W, H, config_id=3, n_fg=6).clip(N)
+    dp, cp = str(tmp_path / "d.npy"), str(tmp_path / "c.npy")
+    np.save(dp, d); np.save(cp, c)
+    (tmp_path / "conv.json").write_text(json.dumps([2.0, float("nan"), 2.2, 2.3, 0.0]))
+    rc = sr.main(["--depth_video", dp, "--color_video", cp, "--xfov", "45", "--pupillary_distance", "65", "--infill_mask", "--normal_infill",
+                  "--convergence_file", str(tmp_path / "conv.json"), "--batch", "2"])
+    assert rc == 0
+    final = dp + "_stereo.npy"
+    filled = np.load(final + "_infilled.npy")
+    sbs, im = np.load(final), np.load(final + "_infillmask.npy")
+    assert filled.shape == sbs.shape and not os.path.exists(dp + "_tmp_stereo.npy_infilled.npy")
+    os.rename(final + "_infilled.npy", str(tmp_path / "fused.npy"))
+    again = np.load(bni.process_pair(final, final + "_infillmask.npy", batch=3))
+    assert np.array_equal(again, filled)
+    for t in range(N):
+        for sl in (slice(0, W), slice(W, 2 * W)):
+            assert np.array_equal(filled[t][:, sl], orc.normal_infill(np.ascontiguousarray(sbs[t][:, sl]), np.ascontiguousarray(im[t][:, sl]))), t
+    holes = np.all(sbs == 0, -1)
+    assert (filled[holes].max(-1) > 0).mean() > 0.8
+    with pytest.raises(ValueError):
+        clip.run(dp, cp, xfov=45.0, normal_infill=True)                       # no --infill_mask: no normals to march along
+
+
 def test_max_frames_with_full_length_side_cars_and_unremoved_edges(mods, orc, tmp_path):
     """(a) --max_frames with side-cars that cover the whole clip: the reference checks the xfov list against the video's
     frame count (sr:403) and indexes the convergence list by frame, so this combination works upstream and must here.

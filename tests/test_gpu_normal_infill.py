@@ -141,7 +141,7 @@ def test_process_pair_on_frame_dumps(bni, orc, tmp_path):
     cpath, mpath = str(tmp_path / "clip_stereo.npy"), str(tmp_path / "clip_stereo.npy_infillmask.npy")
     np.save(cpath, sbs); np.save(mpath, msk)
     final = bni.process_pair(cpath, mpath, batch=2)
-    assert final == str(tmp_path / "clip_stereo_infilled.npy") and not os.path.exists(str(tmp_path / "clip_stereo_tmp_infilled.npy"))
+    assert final == str(tmp_path / "clip_stereo.npy_infilled.npy") and not os.path.exists(str(tmp_path / "clip_stereo.npy_tmp_infilled.npy"))
     got = np.load(final)
     assert got.shape == sbs.shape
     for f in range(N):
