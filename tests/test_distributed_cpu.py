@@ -62,7 +62,7 @@ def test_single_process_is_identity():
 # clip.run with more than one rank: per-rank output segments ("each rank owns its output segment")
 # ---------------------------------------------------------------------------------------------------------------------
 def _fake_render_clip(depth_frames, color_frames, out_sbs, out_mask, clip, *, lo=0, hi=None, batch=16, out_depth_rgb=None,
-                      out_infill=None, green_and_black=False, device=None, out_base=0, io_threads=12):
+                      out_infill=None, green_and_black=False, device=None, out_base=0, io_threads=12, out_infilled=None):
     """Stand-in for the GPU stage (CPU tests cannot render): every output frame is a pure function of its input frame, and
     goes through the driver's own file writer (_RawFrames: pwrite at the segment's offset)."""
     from metric_depth_video_toolbox_amd.clip import _RawFrames
