@@ -96,14 +96,49 @@ def process_pair(sbs_color_video_path: str, sbs_mask_video_path: str, max_frames
     return final
 
 
+def _is_txt(path) -> bool:
+    return isinstance(path, str) and path.lower().endswith(".txt")                      # bni:29-30
+
+
+def _read_list_file(path: str):
+    """Stripped lines of a list file, blank lines and lines starting with '#' ignored (bni:32-43)."""
+    with open(path, "r", encoding="utf-8") as f:
+        return [ln.strip() for ln in f if ln.strip() and not ln.strip().startswith("#")]
+
+
+def pairs_from_arguments(sbs_color_video: str, sbs_mask_video: str):
+    """bni:246-260: one pair, or -- if the colour argument is a .txt list -- the pairs of two lists of equal length."""
+    if not _is_txt(sbs_color_video):
+        return [(sbs_color_video, sbs_mask_video)]
+    if not _is_txt(sbs_mask_video):
+        raise ValueError("If --sbs_color_video is a .txt file, then --sbs_mask_video must also be a .txt file.")
+    colors, masks = _read_list_file(sbs_color_video), _read_list_file(sbs_mask_video)
+    if len(colors) != len(masks):
+        raise ValueError(f"List length mismatch: {sbs_color_video} has {len(colors)} entries, {sbs_mask_video} has {len(masks)} entries.")
+    return list(zip(colors, masks))
+
+
 def main(argv=None):
     p = argparse.ArgumentParser(description="Normal infill script (frame dumps)")
-    p.add_argument("--sbs_color_video", type=str, required=True, help="side by side stereo frames (.npy) rendered with point clouds in the masked area")
-    p.add_argument("--sbs_mask_video", type=str, required=True, help="side by side infill mask frames (.npy)")
+    p.add_argument("--sbs_color_video", type=str, required=True, help="side by side stereo frames (.npy) rendered with point clouds in the masked area, or a .txt list of them")
+    p.add_argument("--sbs_mask_video", type=str, required=True, help="side by side infill mask frames (.npy), or the matching .txt list")
     p.add_argument("--max_frames", default=-1, type=int, help="quit after max_frames nr of frames", required=False)
     args = p.parse_args(argv)
-    print("Done. Wrote:", process_pair(args.sbs_color_video, args.sbs_mask_video, args.max_frames))
+    pairs = pairs_from_arguments(args.sbs_color_video, args.sbs_mask_video)
+    if _is_txt(args.sbs_color_video):
+        # (the reference runs two clips at a time with the GPU sections serialised, bni:262-274; here a clip is I/O and one
+        #  launch set per batch, so the clips simply follow each other)
+        print(f"Batch mode: {len(pairs)} pairs")
+        for c_path, m_path in pairs:
+            try:
+                print("Done. Wrote:", process_pair(c_path, m_path, args.max_frames))
+            except Exception as e:                                    # bni:270-274: surface the error, keep the other clips going
+                print(f"[ERROR] A clip failed: {e}")
+        return 0
+    print("Done. Wrote:", process_pair(*pairs[0], args.max_frames))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    sys.exit(main())

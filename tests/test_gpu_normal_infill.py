@@ -223,3 +223,29 @@ def test_ultra_hd_frame(bni, orc):
     want, st = orc.normal_infill(img, mask, want_stages=True)
     assert st["bg"].sum() > 100000 and st["grown"].sum() > 10000
     assert np.array_equal(got, want)
+
+
+def test_cli_batch_mode_keeps_going_after_a_failed_clip(bni, orc, tmp_path, capsys):
+    """basic_nomal_infill.py:246-276: .txt lists of clips; a clip that fails is reported, the others are processed."""
+    W, H = 64, 40
+    rng = np.random.default_rng(12)
+    paths = []
+    for k in range(2):
+        sbs = np.zeros((2, H, 2 * W, 3), np.uint8); msk = np.zeros_like(sbs)
+        for f in range(2):
+            for e in range(2):
+                sbs[f, :, e * W:(e + 1) * W], msk[f, :, e * W:(e + 1) * W] = ni_scene(rng, W, H)
+        c, m = str(tmp_path / f"clip{k}_stereo.npy"), str(tmp_path / f"clip{k}_stereo.npy_infillmask.npy")
+        np.save(c, sbs); np.save(m, msk)
+        paths.append((c, m, sbs, msk))
+    (tmp_path / "colors.txt").write_text(f"{paths[0][0]}\n{tmp_path / 'nope.npy'}\n# comment\n{paths[1][0]}\n")
+    (tmp_path / "masks.txt").write_text(f"{paths[0][1]}\n{tmp_path / 'nope_mask.npy'}\n{paths[1][1]}\n")
+    assert bni.main(["--sbs_color_video", str(tmp_path / "colors.txt"), "--sbs_mask_video", str(tmp_path / "masks.txt")]) == 0
+    out = capsys.readouterr().out
+    assert "Batch mode: 3 pairs" in out and "[ERROR] A clip failed" in out and out.count("Done. Wrote:") == 2
+    for c, m, sbs, msk in paths:
+        got = np.load(c + "_infilled.npy")
+        for f in range(2):
+            for e in range(2):
+                sl = slice(e * W, (e + 1) * W)
+                assert np.array_equal(got[f, :, sl], orc.normal_infill(np.ascontiguousarray(sbs[f, :, sl]), np.ascontiguousarray(msk[f, :, sl])))

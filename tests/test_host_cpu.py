@@ -265,3 +265,19 @@ def test_raw_frames_follow_sliced_memmaps(tmp_path):
     dst = np.empty((2, 4, 6, 3), np.uint8)
     s.read_into(dst, 1, 2)
     assert dst[0, 0, 0, 0] == 2 and dst[1, 0, 0, 0] == 4
+
+
+def test_basic_nomal_infill_list_files(tmp_path):
+    """The batch-mode argument logic of basic_nomal_infill.py:29-43, 246-260 (no GPU needed: it fails before any frame is read)."""
+    from metric_depth_video_toolbox_amd import basic_nomal_infill as bni
+    (tmp_path / "c.txt").write_text("# clips\n a_stereo.npy \n\nb_stereo.npy\n")
+    (tmp_path / "m.txt").write_text("a_mask.npy\n#skipped\nb_mask.npy\n")
+    (tmp_path / "m1.txt").write_text("a_mask.npy\n")
+    assert bni.pairs_from_arguments(str(tmp_path / "c.txt"), str(tmp_path / "m.txt")) == [("a_stereo.npy", "a_mask.npy"), ("b_stereo.npy", "b_mask.npy")]
+    assert bni.pairs_from_arguments("x.npy", "y.npy") == [("x.npy", "y.npy")]
+    with pytest.raises(ValueError, match="must also be a .txt"):
+        bni.pairs_from_arguments(str(tmp_path / "c.txt"), "y.npy")
+    with pytest.raises(ValueError, match="List length mismatch"):
+        bni.pairs_from_arguments(str(tmp_path / "c.txt"), str(tmp_path / "m1.txt"))
+    with pytest.raises(Exception, match="does not exist"):
+        bni.process_pair(str(tmp_path / "missing.npy"), str(tmp_path / "m.txt"))
