@@ -222,7 +222,9 @@ int mdvt_finish_infill_mask_stereo(mdvt_ctx* ctx, const uint8_t* d_left_seed, co
  * blur_under_mask inside that band (:118, 46-85).  cv2.blur is restated from OpenCV's published box filter (anchor (2,2),
  * BORDER_REFLECT_101, cvRound), cv2.filter2D as in mdvt_masked_blur.  The reference also blackens the caller's img in
  * place (:91) and writes the blurred infill into it (:107); here d_img is read only and d_out receives the returned
- * image.  n_images images share the launches (about 16 B/px of workspace each, kept by the ctx); d_out is also the work image of the passes.  d_out may not alias an input. */
+ * image.  n_images images share the launches (about 16 B/px of workspace each, kept by the ctx); d_out is also the work image of the passes.  d_out may not alias an input.
+ * The marches address a plane with 32-bit offsets: pitches below 2^24 bytes and pitch x height below 2^32 (MDVT_ERR_UNSUPPORTED otherwise;
+ * the same holds for mdvt_infill_using_normals, mdvt_infill_using_mask_normals and mdvt_mark_lower_side). */
 int mdvt_normal_infill(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, size_t img_stride, const uint8_t* d_infill_mask,
                        size_t mask_pitch, size_t mask_stride, uint8_t* d_out, size_t out_pitch, size_t out_stride,
                        int n_images, void* stream);
