@@ -66,6 +66,8 @@ def lib():
         L.orc_render_stereo.restype = C.c_int
         L.orc_render_stereo_seed.argtypes = [C.POINTER(OrcParams), u8p, u8p, u8p, u8p, u8p, u8p, f32p, f32p, u8p, u8p]
         L.orc_render_stereo_seed.restype = C.c_int
+        L.orc_edge_point_chain.argtypes = [C.POINTER(OrcParams), f32p, f64p, C.POINTER(C.c_int32), f64p, f64p]
+        L.orc_edge_point_chain.restype = None
         L.orc_infill_using_normals.argtypes = [u8p, u8p, f32p, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_infill_using_normals.restype = None
         L.orc_mark_lower_side.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p]
@@ -226,6 +228,23 @@ def render_stereo(p: OrcParams, depth_rgb: np.ndarray, color_rgb: np.ndarray, wa
     if rc != 0:
         raise ValueError(f"orc_render_stereo failed: {rc}")
     return out
+
+
+def edge_point_chain(p: OrcParams, depth: np.ndarray, normals: np.ndarray | None = None):
+    """The edge points' f64 chain for EVERY vertex of a decoded, scaled depth map -> (px i32[H*W, 2 eyes, 2 (x, y)] with
+    INT32_MIN outside the frame / for depth code 0, z f64[H*W, 2], unprojected normals f64[H*W, 2, 3] | None)."""
+    depth = np.ascontiguousarray(depth, np.float32)
+    n = p.W * p.H
+    assert depth.shape == (p.H, p.W)
+    px = np.empty((n, 2, 2), np.int32)
+    z = np.empty((n, 2), np.float64)
+    nrm = None
+    if normals is not None:
+        normals = np.ascontiguousarray(normals, np.float64)
+        nrm = np.empty((n, 2, 3), np.float64)
+    lib().orc_edge_point_chain(C.byref(p), _p(depth, C.c_float), None if normals is None else _p(normals, C.c_double),
+                               _p(px, C.c_int32), _p(z, C.c_double), None if nrm is None else _p(nrm, C.c_double))
+    return px, z, nrm
 
 
 def infill_using_normals(color: np.ndarray, hole_mask: np.ndarray, normal_map: np.ndarray, max_steps: int = 400) -> np.ndarray:

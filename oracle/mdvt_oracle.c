@@ -183,11 +183,9 @@ typedef struct {
     float fx, fy, cx, cy;       /* input camera, f32 */
     float fxr, fyr, cxr, cyr;   /* render camera, f32 */
     float sx, sy;               /* (W+1)/W, (H+1)/H in f32 (or 1) */
-    float sW, sH;               /* (W-1)/W, (H-1)/H in f32: the edge points' "undo" (sr:599-600) */
     float dl;                   /* fxr * ipd/2 in f32: pure-shift disparity numerator */
     float sign;                 /* +1 left eye, -1 right eye (pure shift) */
     float M[12];                /* general: 3x4 eye*pose matrix, f32 */
-    double Md[12];              /* the same map in f64 (pure shift: identity + the +-ipd/2 translation) */
 } orc_eye;
 
 static void orc_eye_setup(const orc_params* p, int eye /*0 left, 1 right*/, orc_eye* e)
@@ -202,8 +200,6 @@ static void orc_eye_setup(const orc_params* p, int eye /*0 left, 1 right*/, orc_
     e->fxr = (float)p->Kr[0]; e->fyr = (float)p->Kr[1]; e->cxr = (float)p->Kr[2]; e->cyr = (float)p->Kr[3];
     e->sx = e->of_by_one ? (float)(((double)p->W + 1.0) / (double)p->W) : 1.0f;
     e->sy = e->of_by_one ? (float)(((double)p->H + 1.0) / (double)p->H) : 1.0f;
-    e->sW = (float)(((double)p->W - 1.0) / (double)p->W);
-    e->sH = (float)(((double)p->H - 1.0) / (double)p->H);
     const double half = p->ipd_m / 2.0;
     e->dl = (float)(p->Kr[0] * half);
     e->sign = eye == 0 ? 1.0f : -1.0f;
@@ -219,9 +215,6 @@ static void orc_eye_setup(const orc_params* p, int eye /*0 left, 1 right*/, orc_
         for (int col = 0; col < 3; ++col)
             e->M[4 * r + col] = (float)((R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col]);
         e->M[4 * r + 3] = (float)(((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r]);
-        for (int col = 0; col < 3; ++col)
-            e->Md[4 * r + col] = (R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col];
-        e->Md[4 * r + 3] = ((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r];
     }
 }
 
@@ -256,35 +249,109 @@ static inline orc_vert orc_vertex(const orc_eye* e, int i, int j, float zsrc)
     return o;
 }
 
-/* Edge point (vertex of a removed triangle) -> integer pixel by round-half-even (sr:746, 858),
- * after the "undo off by one" scaling of X and Y (sr:599-600). */
-static inline int orc_edge_point(const orc_eye* e, int i, int j, float zsrc, int* px, int* py, float* zout)
+/* ------------------------------------------------------------------------------------------ */
+/* edge points: the reference's own f64 chain (sr:589-606, 615-619, 727-735, 745-752, 838-858)  */
+/* ------------------------------------------------------------------------------------------ */
+/* A vertex of a removed triangle is splatted where THIS sequence of f64 operations puts it -- NumPy's unprojection
+ * (dmt:1117-1128, f64 under NumPy >= 2), the "undo" of the off-by-one scale (sr:599-600), Open3D's in-place
+ * transform / rotate / translate of the point cloud (Geometry3D::TransformPoints, RotatePoints, TranslatePoints:
+ * 4x4 times (x,y,z,1) divided by w; R (p - 0) + 0; p += t), the right eye's operations applied ON TOP of the left
+ * eye's (sr:838-847), cv2.projectPoints with the camera matrix cast to f32 (dmt:1058; cvProjectPoints2 converts
+ * everything to double: z = z ? 1/z : 1, x *= z, u = x fx + cx), np.round (sr:746, 858).  One IEEE operation per
+ * node, sums left to right, no contraction.  Pinned by tests/golden/edge_points.npz (the loop body's statements run
+ * on the reference's own functions).  Exact simplifications used below: a product with an exact 0 or 1 entry of
+ * Ry / of an affine pose's last row, and the additions of 0.0 in y and z of a translate, change no finite value. */
+typedef struct {
+    int W, H, of_by_one;
+    float sx, sy;
+    double fx, fy, cx, cy;          /* input camera (f64) */
+    double fxr, fyr, cxr, cyr;      /* render camera, each rounded to f32 first (dmt:1058) */
+    double sW, sH, h;
+    int has_T, has_conv;
+    double T[16], c, s;
+} orc_echain;
+
+static void orc_echain_setup(const orc_params* p, orc_echain* e)
 {
-    const float gx = (float)j * e->sx;
-    const float gy = (float)i * e->sy;
-    float u, v, z;
-    if (!(zsrc > ORC_NEAR)) return 0;
-    if (!e->general) {
-        const float ex = ((gx - e->cx) * e->sW) + e->cx;
-        const float d = e->dl / zsrc;
-        u = e->sign > 0.0f ? ex + d : ex - d;
-        v = (float)i;                 /* exact-arithmetic row: i*(1-1/H^2)+1/2 rounds to i (decree) */
-        z = zsrc;
-    } else {
-        const float xc = (((gx - e->cx) * zsrc) / e->fx) * e->sW;
-        const float yc = (((gy - e->cy) * zsrc) / e->fy) * e->sH;
-        const float* M = e->M;
-        const float X = ((M[0] * xc + M[1] * yc) + M[2] * zsrc) + M[3];
-        const float Y = ((M[4] * xc + M[5] * yc) + M[6] * zsrc) + M[7];
-        z = ((M[8] * xc + M[9] * yc) + M[10] * zsrc) + M[11];
-        if (!(z > ORC_NEAR)) return 0;
-        u = (e->fxr * X) / z + e->cxr;
-        v = (e->fyr * Y) / z + e->cyr;
+    memset(e, 0, sizeof *e);
+    e->W = p->W; e->H = p->H;
+    e->of_by_one = (p->mode == ORC_MODE_MESH);
+    e->sx = e->of_by_one ? (float)(((double)p->W + 1.0) / (double)p->W) : 1.0f;
+    e->sy = e->of_by_one ? (float)(((double)p->H + 1.0) / (double)p->H) : 1.0f;
+    e->fx = p->K[0]; e->fy = p->K[1]; e->cx = p->K[2]; e->cy = p->K[3];
+    e->fxr = (double)(float)p->Kr[0]; e->fyr = (double)(float)p->Kr[1];
+    e->cxr = (double)(float)p->Kr[2]; e->cyr = (double)(float)p->Kr[3];
+    e->sW = ((double)p->W - 1.0) / (double)p->W;
+    e->sH = ((double)p->H - 1.0) / (double)p->H;
+    e->h = p->ipd_m / 2.0;
+    e->has_T = p->has_T;
+    if (p->has_T) memcpy(e->T, p->T, sizeof e->T);
+    e->has_conv = (p->conv_angle == p->conv_angle) && p->conv_angle != 0.0;
+    e->c = cos(p->conv_angle); e->s = sin(p->conv_angle);
+}
+
+/* dmt:1117-1128: the vertex as NumPy leaves it in mesh.vertices */
+static inline void orc_echain_vertex(const orc_echain* e, int i, int j, float zsrc, double* P)
+{
+    const double gx = e->of_by_one ? (double)((float)j * e->sx) : (double)j;
+    const double gy = e->of_by_one ? (double)((float)i * e->sy) : (double)i;
+    P[0] = ((gx - e->cx) * (double)zsrc) / e->fx;
+    P[1] = ((gy - e->cy) * (double)zsrc) / e->fy;
+    P[2] = (double)zsrc;
+}
+
+static inline void orc_echain_roty(double c, double s, double* q)     /* Ry = [[c,0,s],[0,1,0],[-s,0,c]] */
+{
+    const double x = c * q[0] + s * q[2];
+    const double z = (-s) * q[0] + c * q[2];
+    q[0] = x; q[2] = z;
+}
+
+/* a point of the cloud (already scaled / offset as the caller needs) -> where it stands for the left and the right eye */
+static void orc_echain_eyes(const orc_echain* e, const double* q0, double* L, double* R)
+{
+    double q[3] = { q0[0], q0[1], q0[2] };
+    if (e->has_T) {                                                  /* sr:615-619 */
+        const double* T = e->T;
+        double hh[4];
+        for (int r = 0; r < 4; ++r) hh[r] = ((T[4 * r] * q[0] + T[4 * r + 1] * q[1]) + T[4 * r + 2] * q[2]) + T[4 * r + 3] * 1.0;
+        q[0] = hh[0] / hh[3]; q[1] = hh[1] / hh[3]; q[2] = hh[2] / hh[3];
     }
-    if (!(u > -1.0f && u < (float)e->W + 1.0f && v > -1.0f && v < (float)e->H + 1.0f)) return 0;
-    const int x = (int)rintf(u), y = (int)rintf(v);
-    if (x < 0 || x >= e->W || y < 0 || y >= e->H) return 0;
-    *px = x; *py = y; *zout = z;
+    if (e->has_conv) orc_echain_roty(e->c, -e->s, q);                /* sr:729 */
+    q[0] += e->h;                                                    /* sr:731: translate([-left_shift, 0, 0]) */
+    L[0] = q[0]; L[1] = q[1]; L[2] = q[2];
+    q[0] += -e->h;                                                   /* sr:839 */
+    if (e->has_conv) { orc_echain_roty(e->c, e->s, q); orc_echain_roty(e->c, e->s, q); }   /* sr:842-843 */
+    q[0] += -e->h;                                                   /* sr:846 */
+    R[0] = q[0]; R[1] = q[1]; R[2] = q[2];
+}
+
+/* cv2.projectPoints + np.round; returns 0 if the rounded pixel lies outside the frame (sr:747-750) */
+static inline int orc_echain_pixel(const orc_echain* e, const double* q, int* px, int* py)
+{
+    const double iz = q[2] != 0.0 ? 1.0 / q[2] : 1.0;
+    const double u = (q[0] * iz) * e->fxr + e->cxr;
+    const double v = (q[1] * iz) * e->fyr + e->cyr;
+    const double ru = rint(u), rv = rint(v);
+    if (!(ru >= 0.0 && ru < (double)e->W && rv >= 0.0 && rv < (double)e->H)) return 0;     /* (NaN fails) */
+    *px = (int)ru; *py = (int)rv;
+    return 1;
+}
+
+/* Edge point of vertex (i, j) for one eye: pixel, and the depth the painter's order sorts by (sr:752) rounded to f32
+ * (decree: the nearest point wins, an exact tie in that f32 goes to the lower source index -- the reference's
+ * unstable argsort leaves ties undefined).  Vertices of depth code 0 (Z = 0: the reference would splat them all onto
+ * the one pixel round(+-ipd/2 fx + cx, cy)) are not splatted (decree, unchanged). */
+static inline int orc_edge_point(const orc_echain* e, int eye, int i, int j, float zsrc, int* px, int* py, float* zout)
+{
+    double P[3], L[3], R[3];
+    if (!(zsrc > ORC_NEAR)) return 0;
+    orc_echain_vertex(e, i, j, zsrc, P);
+    P[0] *= e->sW; P[1] *= e->sH;                                    /* sr:599-600 */
+    orc_echain_eyes(e, P, L, R);
+    const double* q = eye == 0 ? L : R;
+    if (!orc_echain_pixel(e, q, px, py)) return 0;
+    *zout = (float)q[2];
     return 1;
 }
 
@@ -401,20 +468,16 @@ static void orc_raster_tri(orc_target* t, const orc_vert* a, const orc_vert* b, 
 /* ------------------------------------------------------------------------------------------ */
 
 /* Normal colour of an edge point for the infill-mask seed image (sr:596-606, 727-733, 777-802): the removed
- * vertex normal n is carried as the point n + p, both it and the (undo-scaled, sr:599-600) edge point go
- * through the eye / pose map, their difference is normalised and stored as (n'+1)/2 * 255, truncated. */
-static void orc_edge_normal_colour(const orc_eye* e, const double* p, const double* n, uint8_t* rgb)
+ * vertex normal n is carried as the point n + p (p BEFORE the undo scale, sr:596), both it and the undo-scaled edge
+ * point go through the same chain of operations, their difference is normalised and stored as (n'+1)/2 * 255, truncated. */
+static void orc_edge_normal_colour(const orc_echain* e, int eye, const double* p, const double* n, uint8_t* rgb)
 {
-    const double sW = ((double)e->W - 1.0) / (double)e->W, sH = ((double)e->H - 1.0) / (double)e->H;
     const double a[3] = { n[0] + p[0], n[1] + p[1], n[2] + p[2] };
-    const double q[3] = { p[0] * sW, p[1] * sH, p[2] };
-    double d[3];
-    for (int r = 0; r < 3; ++r) {
-        const double* M = e->Md + 4 * r;
-        const double ar = ((M[0] * a[0] + M[1] * a[1]) + M[2] * a[2]) + M[3];
-        const double qr = ((M[0] * q[0] + M[1] * q[1]) + M[2] * q[2]) + M[3];
-        d[r] = ar - qr;
-    }
+    const double q[3] = { p[0] * e->sW, p[1] * e->sH, p[2] };
+    double aL[3], aR[3], qL[3], qR[3], d[3];
+    orc_echain_eyes(e, a, aL, aR);
+    orc_echain_eyes(e, q, qL, qR);
+    for (int r = 0; r < 3; ++r) d[r] = eye == 0 ? aL[r] - qL[r] : aR[r] - qR[r];
     const double len = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
     for (int r = 0; r < 3; ++r) {
         const double c = ((d[r] / len) + 1.0) / 2.0 * 255.0;
@@ -507,6 +570,8 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
 
     /* edge points (sr:745-781, 813-814): far-to-near overwrite == nearest wins, only into holes. */
     if (p->edge_points && unused) {
+        orc_echain ec;
+        orc_echain_setup(p, &ec);
         float* ez = (float*)malloc(n * sizeof(float));
         for (size_t k = 0; k < n; ++k) ez[k] = INFINITY;
         for (int i = 0; i < H; ++i)
@@ -514,13 +579,13 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
                 const size_t k = (size_t)i * W + j;
                 int px, py; float z;
                 if (!unused[k]) continue;
-                if (!orc_edge_point(&e, i, j, depth[k], &px, &py, &z)) continue;
+                if (!orc_edge_point(&ec, eye, i, j, depth[k], &px, &py, &z)) continue;
                 const size_t o = (size_t)py * W + px;
                 if (!out_mask[o]) continue;                  /* sr:776: only where still background */
                 if (!(z < ez[o])) continue;                  /* ties: lower source index wins (decree) */
                 ez[o] = z;
                 if (p->edge_points != 2) memcpy(out_rgb + 3 * o, color + 3 * k, 3);      /* 2: seed only (sr:809-812) */
-                if (out_seed) orc_edge_normal_colour(&e, P + 3 * k, vnormals + 3 * k, out_seed + 3 * o);   /* sr:802 */
+                if (out_seed) orc_edge_normal_colour(&ec, eye, P + 3 * k, vnormals + 3 * k, out_seed + 3 * o);   /* sr:802 */
             }
         free(ez);
     }
@@ -564,6 +629,40 @@ int orc_render_stereo(const orc_params* p, const uint8_t* depth_rgb, const uint8
 {
     return orc_render_stereo_seed(p, depth_rgb, color_rgb, left_rgb, right_rgb, left_mask, right_mask,
                                   left_depth, right_depth, NULL, NULL);
+}
+
+/* The edge-point chain on its own (tests): for every vertex k = i*W + j of a decoded, scaled depth map the rounded
+ * pixel of both eyes -- px[k][eye][0..1] = (x, y), INT32_MIN twice where the rounded pixel lies outside the frame or the
+ * vertex has depth code 0 --, the f64 depth z[k][eye] the painter's order sorts by and, if `normals` (H*W*3, the removed
+ * vertex normals of orc_edge_filter) is given, the un-normalised unprojected normal nrm[k][eye][0..2] (sr:733, 849).
+ * Any of px / z / nrm may be NULL. */
+void orc_edge_point_chain(const orc_params* p, const float* depth, const double* normals, int32_t* px, double* z, double* nrm)
+{
+    orc_echain e;
+    orc_echain_setup(p, &e);
+    const int W = p->W, H = p->H;
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            const size_t k = (size_t)i * W + j;
+            double P[3], Q[3], A[3], qe[2][3], ae[2][3];
+            orc_echain_vertex(&e, i, j, depth[k], P);
+            Q[0] = P[0] * e.sW; Q[1] = P[1] * e.sH; Q[2] = P[2];
+            orc_echain_eyes(&e, Q, qe[0], qe[1]);
+            if (normals && nrm) {
+                for (int r = 0; r < 3; ++r) A[r] = normals[3 * k + r] + P[r];
+                orc_echain_eyes(&e, A, ae[0], ae[1]);
+            }
+            for (int eye = 0; eye < 2; ++eye) {
+                if (px) {
+                    int x, y;
+                    int32_t* o = px + 4 * k + 2 * eye;
+                    if (depth[k] > ORC_NEAR && orc_echain_pixel(&e, qe[eye], &x, &y)) { o[0] = x; o[1] = y; }
+                    else { o[0] = o[1] = INT32_MIN; }
+                }
+                if (z) z[2 * k + eye] = qe[eye][2];
+                if (normals && nrm) for (int r = 0; r < 3; ++r) nrm[6 * k + 3 * eye + r] = ae[eye][r] - qe[eye][r];
+            }
+        }
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -165,3 +165,64 @@ def curve_fit(values):
         win -= 1
     sm = savgol_filter(ext, window_length=win, polyorder=2)
     return sm[:-n_tail] if n_tail > 0 else sm
+
+
+# ----------------------------------------------------------------------------- edge points (sr)
+def edge_point_chain(depth, K, Kr, W, H, of_by_one, ipd_m, conv_angle=0.0, T=None, normals=None):
+    """Where the reference splats the vertices of removed triangles, for EVERY vertex of the (decoded, scaled, f32)
+    depth map: the f64 operations of dmt:1117-1128, sr:596-600, Open3D's transform / rotate / translate on the cloud
+    (sr:615-619, 727-732 and, on top of the left eye's state, 838-847), cv2.projectPoints with the f32-cast camera matrix
+    (dmt:1058) and np.round (sr:746, 858), one NumPy operation per node.
+    -> (px int64[H*W, 2 eyes, 2 (x, y)] = np.round(points_2d), z f64[H*W, 2], unprojected normals f64[H*W, 2, 3] | None)."""
+    depth = np.asarray(depth, np.float32)
+    K, Kr = np.asarray(K, np.float64), np.asarray(Kr, np.float64).astype(np.float32).astype(np.float64)
+    x, y = np.meshgrid(np.arange(W), np.arange(H))
+    if of_by_one:
+        x = x.astype(np.float32); y = y.astype(np.float32)
+        x *= (W + 1) / W
+        y *= (H + 1) / H
+    z = depth
+    X = (x - K[0, 2]) * z / K[0, 0]
+    Y = (y - K[1, 2]) * z / K[1, 1]
+    P = np.stack((X, Y, z), axis=-1).reshape(-1, 3).astype(np.float64)
+    clouds = [P * np.array([(W - 1) / W, (H - 1) / H, 1.0])]
+    if normals is not None:
+        clouds.append(np.asarray(normals, np.float64).reshape(-1, 3) + P)
+    h = ipd_m / 2.0
+    has_conv = conv_angle == conv_angle and conv_angle != 0.0
+    c, s = math.cos(conv_angle), math.sin(conv_angle)
+
+    def roty(q, sn):
+        return np.stack([c * q[:, 0] + sn * q[:, 2], q[:, 1], (-sn) * q[:, 0] + c * q[:, 2]], axis=1)
+
+    eyes = []
+    for q in clouds:
+        if T is not None:
+            Tm = np.asarray(T, np.float64).reshape(4, 4)
+            hh = [((Tm[r, 0] * q[:, 0] + Tm[r, 1] * q[:, 1]) + Tm[r, 2] * q[:, 2]) + Tm[r, 3] * 1.0 for r in range(4)]
+            q = np.stack([hh[0] / hh[3], hh[1] / hh[3], hh[2] / hh[3]], axis=1)
+        if has_conv:
+            q = roty(q, -s)
+        left = q + np.array([h, 0.0, 0.0])
+        q = left + np.array([-h, 0.0, 0.0])
+        if has_conv:
+            q = roty(roty(q, s), s)
+        right = q + np.array([-h, 0.0, 0.0])
+        eyes.append((left, right))
+    px = np.empty((H * W, 2, 2), np.int64)
+    zz = np.empty((H * W, 2), np.float64)
+    for e in range(2):
+        q = eyes[0][e]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iz = np.where(q[:, 2] != 0.0, 1.0 / q[:, 2], 1.0)
+            u = (q[:, 0] * iz) * Kr[0, 0] + Kr[0, 2]
+            v = (q[:, 1] * iz) * Kr[1, 1] + Kr[1, 2]
+            ru, rv = np.round(u), np.round(v)
+        ok = np.isfinite(ru) & np.isfinite(rv) & (np.abs(ru) < 2.0 ** 30) & (np.abs(rv) < 2.0 ** 30)
+        px[:, e, 0] = np.where(ok, ru, -(2.0 ** 30)).astype(np.int64)
+        px[:, e, 1] = np.where(ok, rv, -(2.0 ** 30)).astype(np.int64)
+        zz[:, e] = q[:, 2]
+    nrm = None
+    if normals is not None:
+        nrm = np.stack([eyes[1][0] - eyes[0][0], eyes[1][1] - eyes[0][1]], axis=1)
+    return px, zz, nrm

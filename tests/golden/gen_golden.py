@@ -12,6 +12,7 @@ Recorded with every fixture: numpy / scipy versions (the unprojection dtype is N
 dependent).
 """
 import json
+import math
 import os
 import sys
 import types
@@ -53,6 +54,193 @@ def import_reference():
     return dfh, dmt, sr, ic
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# edge points (sr:589-606, 615-619, 707-735, 745-756, 831-858): where the vertices of removed triangles are splatted
+# ---------------------------------------------------------------------------------------------------------------------
+class _O3dPoints:
+    """Stand-in for o3d.geometry.PointCloud with the three in-place operations the loop body uses, restated from
+    Open3D's published Geometry3D::TransformPoints / RotatePoints / TranslatePoints in f64: a 4x4 times (x, y, z, 1)
+    divided by its w; R (p - centre) + centre; p += t.  Sums run left to right (Eigen's own order inside a 3- or
+    4-term dot product is not observable here: it moves a coordinate by an ulp of f64, i.e. the pixel of a point
+    that sits within ~1e-13 px of a rounding tie)."""
+
+    def __init__(s):
+        s.points = np.zeros((0, 3))
+
+    def transform(s, T):
+        T = np.asarray(T, np.float64)
+        p = np.asarray(s.points)
+        h = [((T[r, 0] * p[:, 0] + T[r, 1] * p[:, 1]) + T[r, 2] * p[:, 2]) + T[r, 3] * 1.0 for r in range(4)]
+        s.points = np.stack([h[0] / h[3], h[1] / h[3], h[2] / h[3]], axis=1)
+        return s
+
+    def rotate(s, R, center=(0, 0, 0)):
+        R, c = np.asarray(R, np.float64), np.asarray(center, np.float64)
+        d = np.asarray(s.points) - c
+        s.points = np.stack([((R[r, 0] * d[:, 0] + R[r, 1] * d[:, 1]) + R[r, 2] * d[:, 2]) + c[r] for r in range(3)], axis=1)
+        return s
+
+    def translate(s, t, relative=True):
+        assert relative
+        s.points = np.asarray(s.points) + np.asarray(t, np.float64)
+        return s
+
+
+def _rotation_matrix_from_xyz(rot):
+    """open3d get_rotation_matrix_from_xyz = Rx(a) Ry(b) Rz(c) with the textbook matrices (for (0, b, 0): Ry(b) itself,
+    the products with the identity being exact)."""
+    a, b, c = (float(v) for v in rot)
+    Rx = np.array([[1, 0, 0], [0, math.cos(a), -math.sin(a)], [0, math.sin(a), math.cos(a)]])
+    Ry = np.array([[math.cos(b), 0, math.sin(b)], [0, 1, 0], [-math.sin(b), 0, math.cos(b)]])
+    Rz = np.array([[math.cos(c), -math.sin(c), 0], [math.sin(c), math.cos(c), 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+def _project_points(obj, rvec, tvec, K, dist):
+    """cv2.projectPoints by its published arithmetic (cvProjectPoints2): everything is converted to double first (so a
+    float32 camera matrix contributes f64(f32(fx)) ...), R = Rodrigues(0) = I and t = 0 leave the point as it is,
+    z = z ? 1/z : 1, x *= z, y *= z, zero distortion coefficients leave x and y as they are, u = x fx + cx."""
+    assert not np.any(np.asarray(rvec)) and not np.any(np.asarray(tvec)) and not np.any(np.asarray(dist))
+    K = np.asarray(K).astype(np.float64)
+    P = np.asarray(obj, np.float64).reshape(-1, 3)
+    z = P[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iz = np.where(z != 0.0, 1.0 / z, 1.0)
+    x, y = P[:, 0] * iz, P[:, 1] * iz
+    return np.stack([x * K[0, 0] + K[0, 2], y * K[1, 1] + K[1, 2]], axis=1).reshape(-1, 1, 2), None
+
+
+def edge_point_goldens(dfh, dmt, sr, meta):
+    """The loop body's own statements for the edge points, run on the reference's functions (get_mesh_from_depth_map,
+    pts_2_pcd, project_3d_points_to_2d, convergence_angle) with Open3D's point cloud and cv2.projectPoints standing in
+    as above.  Recorded per case and eye, for EVERY vertex of a removed triangle in the order of `unused_indices`:
+    np.round(points_2d) (sr:746, 858), the depth the painter's order sorts by (sr:752), and the un-normalised
+    `unprojected_normals` (sr:733, 849)."""
+    import cv2 as cv2_stub
+    import open3d as o3d_stub
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene, synthetic_pose_track
+    cv2_stub.projectPoints = _project_points
+    o3d_stub.geometry.PointCloud = _O3dPoints
+
+    def run_case(W, H, depth_rgb, color, xfov, K, master_xfov, ipd_mm, pointcloud, conv_dist, T, max_depth=100):
+        frame_width, frame_height = W, H
+        cam_matrix = dmt.compute_camera_matrix(xfov, None, W, H) if K is None else np.array(K, np.float64)
+        render_cam_matrix = cam_matrix
+        depth = dfh.decode_rgb_depth_frame(depth_rgb, max_depth, True)
+        scale = 1.0
+        if master_xfov is not None:                                           # sr:537-541
+            scale = 1.0 / (math.tan(math.radians(master_xfov / 2)) / math.tan(math.radians(xfov / 2)))
+            depth *= scale
+        left_shift = -(ipd_mm / 1000) / 2                                      # sr:458-459
+        right_shift = +(ipd_mm / 1000) / 2
+        mesh, unused_indices, removed_normals = dmt.get_mesh_from_depth_map(
+            depth, cam_matrix, color, None, remove_edges=True, of_by_one=not pointcloud, return_normals_of_removed=True)
+        in_edge = np.zeros(len(mesh.vertices), dtype=bool)
+        in_edge[unused_indices] = True
+        edge_points = np.asarray(mesh.vertices)[in_edge]                       # (a copy: boolean indexing)
+        world_normals = removed_normals + edge_points                          # sr:596, before the undo
+        edge_points[:, 0] *= (frame_width - 1) / frame_width                   # sr:599-600
+        edge_points[:, 1] *= (frame_height - 1) / frame_height
+        edge_pcd, normal_pcd = dmt.pts_2_pcd(edge_points), dmt.pts_2_pcd(world_normals)
+        if T is not None:                                                      # sr:615-619
+            edge_pcd.transform(np.array(T)); normal_pcd.transform(np.array(T))
+        rot_plus = rot_minus = None
+        if conv_dist is not None:                                              # sr:707-722
+            cd = float(conv_dist) * scale
+            ang = sr.convergence_angle(cd, ipd_mm / 1000)
+            rot_plus, rot_minus = _rotation_matrix_from_xyz((0, ang, 0)), _rotation_matrix_from_xyz((0, -ang, 0))
+        out = {}
+        # left eye, sr:727-735, 745-752
+        if rot_minus is not None:
+            edge_pcd.rotate(rot_minus, center=(0, 0, 0)); normal_pcd.rotate(rot_minus, center=(0, 0, 0))
+        edge_pcd.translate([-left_shift, 0.0, 0.0]); normal_pcd.translate([-left_shift, 0.0, 0.0])
+        for eye in ("L", "R"):
+            if eye == "R":                                                     # sr:838-850: on top of the left eye's state
+                edge_pcd.translate([left_shift, 0.0, 0.0]); normal_pcd.translate([left_shift, 0.0, 0.0])
+                if rot_plus is not None:
+                    for _ in range(2):
+                        edge_pcd.rotate(rot_plus, center=(0, 0, 0)); normal_pcd.rotate(rot_plus, center=(0, 0, 0))
+                edge_pcd.translate([-right_shift, 0.0, 0.0]); normal_pcd.translate([-right_shift, 0.0, 0.0])
+            unprojected_normals = np.asarray(normal_pcd.points) - np.asarray(edge_pcd.points)
+            points_3d = np.asarray(edge_pcd.points)
+            points_2d = dmt.project_3d_points_to_2d(points_3d, render_cam_matrix)
+            with np.errstate(invalid="ignore"):
+                pr = np.round(points_2d)
+            # (astype(int) of a non-finite or huge value is undefined: such points fail the reference's bounds test anyway)
+            ok = np.all(np.isfinite(pr) & (np.abs(pr) < 2.0 ** 30), axis=1)
+            out[eye + "_px"] = np.where(ok[:, None], pr, -(2.0 ** 30)).astype(np.int64)
+            out[eye + "_z"] = points_3d[:, 2].copy()
+            out[eye + "_n"] = unprojected_normals.copy()
+        out["unused"] = np.flatnonzero(in_edge).astype(np.int64)
+        out["K"] = cam_matrix
+        out["scale"] = np.array([scale], np.float64)
+        return out
+
+    def scene(W, H, seed, zero_patch=False):
+        d, c = SyntheticScene(W, H, seed=seed, n_fg=6).frame(0)
+        d = d.copy()
+        d[:, W // 3] = d[:, W // 3 + 1] = (3, 3, 0)          # a near pole over the full height: edges in rows 0 and H-1
+        d[H // 2, :] = (5, 5, 128)                            # and a wire over the full width: edges in columns 0 and W-1
+        if zero_patch:
+            d[4:7, 9:12] = 0
+        return d, c
+
+    # a focal length whose f32 rounding is BELOW / ABOVE it by most of half an ulp (the rows that flip depend on the sign), found by search
+    def xfov_with_delta(W, H, want_negative):
+        best = None
+        for k in range(4000):
+            xf = 40.0 + k * 0.01
+            Kc = dmt.compute_camera_matrix(xf, None, W, H)
+            rel = (float(np.float32(Kc[1, 1])) - Kc[1, 1]) / Kc[1, 1]
+            if (rel < 0) == want_negative and (best is None or abs(rel) > abs(best[1])):
+                best = (xf, rel)
+        return best[0]
+
+    cases = {}
+    pose = synthetic_pose_track(60)[59]
+    big_pose = np.eye(4); a = math.radians(4.0)
+    big_pose[:3, :3] = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]]) @ \
+        np.array([[1, 0, 0], [0, math.cos(a / 2), -math.sin(a / 2)], [0, math.sin(a / 2), math.cos(a / 2)]])
+    big_pose[:3, 3] = (0.03, -0.02, 0.05)
+    spec = {
+        # name: W, H, seed, xfov, K, master_xfov, ipd_mm, pointcloud, convergence distance, pose, zero patch
+        "mesh_shift": (64, 48, 21, 45.0, None, None, 65, False, None, None, False),
+        "points_shift": (64, 48, 22, 45.0, None, None, 65, True, None, None, True),
+        "mesh_master": (48, 32, 23, 60.0, None, 45.0, 63, False, None, None, False),
+        "mesh_conv": (64, 48, 24, 45.0, None, None, 65, False, 2.0, None, False),
+        "points_conv_master": (64, 48, 25, 50.0, None, 45.0, 65, True, 1.5, None, False),
+        "mesh_pose": (64, 48, 26, 45.0, None, None, 65, False, None, pose, False),
+        "mesh_pose_conv": (48, 32, 27, 45.0, None, None, 65, False, 3.0, big_pose, True),
+        "points_pose": (48, 32, 28, 70.0, None, None, 65, True, None, big_pose, False),
+        # fy exactly representable in f32: in exact arithmetic source row 0 sits ON the tie 0.5, the f64 roundings of each point decide
+        "mesh_k_pow2": (64, 48, 29, None, [[512.0, 0, 32.0], [0, 512.0, 24.0], [0, 0, 1]], None, 65, False, None, None, False),
+        "points_k_pow2": (64, 48, 30, None, [[512.0, 0, 32.0], [0, 512.0, 24.0], [0, 0, 1]], None, 65, True, None, None, False),
+        "mesh_fy_below": (96, 64, 31, xfov_with_delta(96, 64, True), None, None, 65, False, None, None, False),
+        "mesh_fy_above": (96, 64, 32, xfov_with_delta(96, 64, False), None, None, 65, False, None, None, False),
+        "mesh_tall": (16, 400, 33, xfov_with_delta(16, 400, True), None, None, 65, False, None, None, False),
+    }
+    for name, (W, H, seed, xfov, K, master, ipd, pc, conv, T, zp) in spec.items():
+        d, c = scene(W, H, seed, zp)
+        r = run_case(W, H, d, c, xfov, K, master, ipd, pc, conv, T)
+        cases[name + "_depth_rgb"] = d
+        cases[name + "_par"] = np.array([W, H, np.nan if xfov is None else xfov, np.nan if master is None else master, ipd,
+                                         1.0 if pc else 0.0, np.nan if conv is None else conv], np.float64)
+        cases[name + "_T"] = np.zeros((0, 4)) if T is None else np.array(T, np.float64)
+        for k, v in r.items():
+            cases[f"{name}_{k}"] = v
+    # full HD, the camera of the benchmark: pixels only, for every removed vertex (int16) -- rows 0, 1, H-1, columns 0, W-1 included
+    W, H = 1920, 1080
+    d, c = SyntheticScene(W, H, config_id=2).frame(3)
+    d = d.copy(); d[:, 700] = d[:, 701] = (3, 3, 0); d[600, :] = (5, 5, 128)
+    r = run_case(W, H, d, c, 45.0, None, None, 65, False, None, None)
+    cases["hd_frame"] = np.array([2, 3], np.int64)          # SyntheticScene(1920, 1080, config_id=2).frame(3) + the pole and the wire above
+    cases["hd_unused"] = r["unused"].astype(np.int32)
+    for eye in "LR":
+        cases[f"hd_{eye}_px"] = np.clip(r[eye + "_px"], -32768, 32767).astype(np.int16)
+    np.savez_compressed(os.path.join(HERE, "edge_points.npz"), meta=json.dumps(meta), names=np.array(sorted(spec)), **cases)
+
+
 def main():
     import scipy
     dfh, dmt, sr, ic = import_reference()
@@ -61,6 +249,10 @@ def main():
 
     meta = {"numpy": np.__version__, "scipy": scipy.__version__, "reference_snapshot": "2026-05-15"}
     rng = np.random.default_rng(20260927)
+    if "--only-edge-points" in sys.argv:
+        edge_point_goldens(dfh, dmt, sr, meta)
+        print("edge_points.npz", os.path.getsize(os.path.join(HERE, "edge_points.npz")), "bytes")
+        return
 
     # ------------------------------------------------------------------ codec
     kat_rgb = np.array([[0, 0, 0], [0, 0, 1], [0, 9, 1], [1, 1, 0], [2, 2, 133], [252, 252, 5],
@@ -294,7 +486,9 @@ def main():
         ni[f"{name}_bum_out"] = bni.blur_under_mask(img.copy(), m.copy())
     np.savez_compressed(os.path.join(HERE, "normal_infill.npz"), meta=json.dumps(meta), **ni)
 
-    for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz", "equirect.npz", "masked_blur.npz", "normal_infill.npz"):
+    edge_point_goldens(dfh, dmt, sr, meta)
+
+    for f in ("codec.npz", "camera.npz", "geometry.npz", "infill.npz", "equirect.npz", "masked_blur.npz", "normal_infill.npz", "edge_points.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -167,6 +167,119 @@ def test_master_scale_golden(orc, golden):
     assert np.array_equal(bits(onp.decode_rgb_depth_frame(g["a_depth_rgb"], 100, scale)), bits(g["a_depth_scaled_60_to_45"]))
 
 
+# ------------------------------------------------------------------------------- edge points (sr:589-606, 727-752, 838-858)
+def _edge_case(g, name):
+    W, H, xfov, master, ipd_mm, pc, conv = g[name + "_par"]
+    W, H = int(W), int(H)
+    T = g[name + "_T"]
+    T = None if T.shape[0] == 0 else T
+    K, scale = g[name + "_K"], float(g[name + "_scale"][0])
+    ipd_m = ipd_mm / 1000
+    ang = 0.0 if math.isnan(conv) else onp.convergence_angle(float(conv) * scale, ipd_m)
+    return W, H, K, scale, ipd_m, bool(pc), ang, T
+
+
+def _edge_case_names(golden):
+    return [str(n) for n in golden("edge_points")["names"]]
+
+
+EDGE_CASES = ["mesh_shift", "points_shift", "mesh_master", "mesh_conv", "points_conv_master", "mesh_pose", "mesh_pose_conv",
+              "points_pose", "mesh_k_pow2", "points_k_pow2", "mesh_fy_below", "mesh_fy_above", "mesh_tall"]
+
+
+def test_edge_point_golden_cases_are_all_used(golden):
+    assert sorted(EDGE_CASES) == sorted(_edge_case_names(golden))
+
+
+@pytest.mark.parametrize("name", EDGE_CASES)
+def test_edge_points_land_where_the_reference_puts_them(orc, golden, name):
+    """The oracle's edge-point chain (C and NumPy) against the loop body's own statements run on the reference's functions:
+    the rounded pixel of every vertex of a removed triangle, both eyes -- rows 0, 1, H-1 and columns 0, W-1 included --,
+    the depth of the painter's order and the unprojected normal, bit for bit."""
+    g = golden("edge_points")
+    W, H, K, scale, ipd_m, pc, ang, T = _edge_case(g, name)
+    depth = orc.decode_depth(g[name + "_depth_rgb"], 100.0, scale)
+    _, unused, normals = orc.edge_filter(depth, K, not pc, want_normals=True)
+    idx = g[name + "_unused"]
+    assert np.array_equal(np.flatnonzero(unused), idx)
+    p = orc.make_params(W, H, K, ipd_m=ipd_m, depth_scale=scale, mode=orc.MODE_POINTS if pc else orc.MODE_MESH,
+                        remove_edges=True, edge_points=True, conv_angle=ang, T=T)
+    px, z, nrm = orc.edge_point_chain(p, depth, normals)
+    px_np, z_np, nrm_np = onp.edge_point_chain(depth, K, K, W, H, not pc, ipd_m, ang, T, normals)
+    rows = idx // W
+    seen_rows, seen_cols = set(), set()
+    for e, eye in enumerate("LR"):
+        want = g[f"{name}_{eye}_px"]
+        inside = (want[:, 0] >= 0) & (want[:, 0] < W) & (want[:, 1] >= 0) & (want[:, 1] < H)
+        assert inside.sum() > 100
+        # NumPy restatement: every vertex, inside the frame or not
+        assert np.array_equal(px_np[idx, e], want)
+        assert np.array_equal(z_np[idx, e], g[f"{name}_{eye}_z"])
+        assert np.array_equal(nrm_np[idx, e], g[f"{name}_{eye}_n"])
+        # C oracle: pixels inside the frame (INT32_MIN outside), except the decree's one deviation -- depth code 0 is not splatted
+        live = depth.reshape(-1)[idx] > 1e-4
+        got = px[idx, e].astype(np.int64)
+        assert np.array_equal(got[inside & live], want[inside & live])
+        assert np.all(got[~(inside & live)] == np.iinfo(np.int32).min)
+        assert np.array_equal(z[idx, e], g[f"{name}_{eye}_z"])
+        assert np.array_equal(nrm[idx, e], g[f"{name}_{eye}_n"])
+        seen_rows |= set(rows[inside].tolist()); seen_cols |= set((idx % W)[inside].tolist())
+    if T is None:
+        assert {0, 1, H - 1} <= seen_rows and {0, W - 1} <= seen_cols, "fixture must cover the border rows and columns"
+
+
+def test_edge_points_rows_that_flip_in_the_goldens(golden):
+    """What the fixtures hold about the row: without pose / convergence an edge point of source row i lands on row i or
+    i + 1, and which of the two depends on the camera matrix (the f32-rounded fy of dmt:1058 against the f64 one of
+    dmt:1128) -- not only for row 0."""
+    g = golden("edge_points")
+    flips = {}
+    for name in ("mesh_shift", "points_shift", "mesh_master", "mesh_k_pow2", "points_k_pow2", "mesh_fy_below", "mesh_fy_above", "mesh_tall"):
+        W, H = int(g[name + "_par"][0]), int(g[name + "_par"][1])
+        idx = g[name + "_unused"]
+        live = orc_depth_live(g, name)
+        for eye in "LR":
+            px = g[f"{name}_{eye}_px"]
+            inside = (px[:, 0] >= 0) & (px[:, 0] < W) & (px[:, 1] >= 0) & (px[:, 1] < H) & live
+            d = px[inside, 1] - idx[inside] // W
+            assert set(np.unique(d).tolist()) <= {0, 1}, name
+            flips.setdefault(name, set()).update((idx[inside] // W)[d == 1].tolist())
+    assert flips["mesh_fy_below"] == {0} and flips["mesh_master"] == {0} and flips["mesh_tall"] == {0, 1}
+    assert flips["mesh_fy_above"] == set() and flips["mesh_shift"] == set()
+
+
+def orc_depth_live(g, name):
+    d = g[name + "_depth_rgb"].reshape(-1, 3)[g[name + "_unused"]]
+    return (d[:, 0] != 0) | (d[:, 2] != 0)
+
+
+def test_edge_points_full_hd_golden(orc, golden):
+    """1920x1080, the benchmark's camera: every removed vertex of the frame, both eyes (25 951 points), against the chain."""
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
+    g = golden("edge_points")
+    W, H = 1920, 1080
+    cfg, t = (int(v) for v in g["hd_frame"])
+    d, _ = SyntheticScene(W, H, config_id=cfg).frame(t)
+    d = d.copy(); d[:, 700] = d[:, 701] = (3, 3, 0); d[600, :] = (5, 5, 128)
+    K = onp.compute_camera_matrix(45.0, None, W, H)
+    depth = orc.decode_depth(d, 100.0)
+    _, unused, _ = orc.edge_filter(depth, K, True)
+    idx = g["hd_unused"].astype(np.int64)
+    assert np.array_equal(np.flatnonzero(unused), idx)
+    p = orc.make_params(W, H, K, mode=orc.MODE_MESH, remove_edges=True, edge_points=True)
+    px, _, _ = orc.edge_point_chain(p, depth)
+    px_np, _, _ = onp.edge_point_chain(depth, K, K, W, H, True, 0.065)
+    n_row1 = 0
+    for e, eye in enumerate("LR"):
+        want = g[f"hd_{eye}_px"].astype(np.int64)
+        inside = (want[:, 0] >= 0) & (want[:, 0] < W) & (want[:, 1] >= 0) & (want[:, 1] < H)
+        assert np.array_equal(px[idx, e].astype(np.int64)[inside], want[inside])
+        assert np.all(px[idx, e][~inside] == np.iinfo(np.int32).min)
+        assert np.array_equal(np.clip(px_np[idx, e], -32768, 32767), want)
+        n_row1 += int(((want[:, 1] == 1) & (idx // W == 0) & inside).sum())
+    assert n_row1 == 16, "source row 0 lands on row 1 with this camera (0.5 + 8e-8 rounds up)"
+
+
 # ------------------------------------------------------------------------------- infill_using_normals
 @pytest.mark.parametrize("scene", ["a", "b"])
 def test_infill_using_normals_golden(orc, golden, scene):
