@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 11
+#define MDVT_VERSION_MINOR 12
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -137,6 +137,17 @@ int mdvt_encode_depth(mdvt_ctx* ctx, const float* d_depth, size_t depth_pitch, u
  * all tri2), d_unused[H*W] u8 (1 = vertex of a removed triangle).  Either output may be NULL. */
 int mdvt_edge_filter(mdvt_ctx* ctx, const uint8_t* d_depth_rgb, size_t depth_pitch, const double K[9],
                      double depth_scale, int of_by_one, uint8_t* d_tri_invalid, uint8_t* d_unused, void* stream);
+
+/* Diagnostic: where the edge point of EVERY vertex of one frame lands (sr:589-606, 615-619, 727-735, 745-750, 838-858: the
+ * vertices of removed triangles, undo-scaled, taken through pose / convergence / +-ipd/2, cv2.projectPoints with the f32-cast
+ * camera matrix (dmt:1057-1060), np.round).  d_px: int32 [H*W][2 eyes][2] = (x, y), INT32_MIN twice where the rounded pixel
+ * lies outside the frame or the vertex has depth code 0 (not splatted).  how = 0: the f64 chain of the reference's
+ * operations, evaluated per vertex as the general kernels do; how = 1 (pure-shift frames only): as the LDS row kernels
+ * take it -- column from an f32 estimate wherever that is provably the chain's, the chain otherwise; row = the source row
+ * except on the scanlines the frame's camera matrix sends elsewhere.  Both must give the same numbers.  Uses mode, ipd_m
+ * and max_depth of the config. */
+int mdvt_edge_point_pixels(mdvt_ctx* ctx, const mdvt_frame_params* params, const uint8_t* d_depth_rgb, size_t depth_pitch,
+                           int how, int32_t* d_px, void* stream);
 
 /* stereo_rerender.infill_using_normals (sr:155-240; --do_basic_infill at sr:810-812, and
  * basic_nomal_infill.py:103): every hole pixel marches from its position along the XY direction of its

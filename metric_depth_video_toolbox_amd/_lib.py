@@ -24,7 +24,8 @@ SYMBOLS = ("mdvt_version", "mdvt_create", "mdvt_destroy", "mdvt_last_error", "md
            "mdvt_render_stereo", "mdvt_render_stereo_batch", "mdvt_decode_depth", "mdvt_encode_depth",
            "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side", "mdvt_touchly_depth",
            "mdvt_equirect_tables", "mdvt_equirect_remap", "mdvt_masked_blur", "mdvt_finish_infill_mask",
-           "mdvt_finish_infill_mask_stereo", "mdvt_swap_rb", "mdvt_selftest", "mdvt_normal_infill", "mdvt_infill_using_mask_normals")
+           "mdvt_finish_infill_mask_stereo", "mdvt_swap_rb", "mdvt_selftest", "mdvt_normal_infill", "mdvt_infill_using_mask_normals",
+           "mdvt_edge_point_pixels")
 
 
 class MdvtError(RuntimeError):
@@ -114,6 +115,8 @@ def load():
     L.mdvt_infill_using_mask_normals.restype = C.c_int
     L.mdvt_infill_using_mask_normals.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t,
                                                  C.c_int, C.c_int, vp]
+    L.mdvt_edge_point_pixels.restype = C.c_int
+    L.mdvt_edge_point_pixels.argtypes = [vp, C.POINTER(MdvtFrameParams), vp, C.c_size_t, C.c_int, vp, vp]
     _lib = L
     return L
 

@@ -11,6 +11,7 @@
 
 #include <mutex>
 #include <new>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,10 @@ struct mdvt_ctx {
     // normal_infill / infill_using_mask_normals: about 16 B/px per image in flight
     uint8_t* ni_ws = nullptr;
     int ni_images = 0;
+    // edge_row_range() of the most recent camera matrix (a clip's frames mostly share it)
+    double erow_key[5] = {0, 0, 0, 0, 0};
+    int erow_val[3] = {0, 0, 0};
+    bool erow_cached = false;
 };
 
 namespace {
@@ -98,6 +103,36 @@ struct DeviceGuard {
 };
 
 // Everything the kernels need about one frame, derived in f64 and rounded once to f32.
+// Pure-shift frames: on which row does the chain (mdvt_device.h "edge points") put an edge point of source row i?  Without
+// pose and convergence the row is round( ((gy - cy) z / fy sH) (1/z) fyr + cyr ): in exact arithmetic independent of z,
+//   v*(i) = (gy_i - cy) sH (fyr / fy) + cyr  ~  i + 1/2 - i / H^2   (mesh grid, cy = H/2),
+// a hair below the tie i + 1/2 -- by less than the f32 rounding of fy (dmt:1058) moves it for the first rows, which then land
+// on i + 1 -- and the eight f64 roundings of the chain move v by at most 8 H 2^-53.  Rows whose v* keeps a margin of four
+// times that from a tie have their row decided here, once per camera matrix; the others (a tie in exact arithmetic: the
+// roundings of each point decide) and the rows that land on i + 1 form [erow_lo, erow_hi), left to k_edge_rows_exact.
+static void edge_row_range(FrameDev& f, int H)
+{
+    const long double fy = f.Kd[1], cy = f.Kd[3], sH = f.sHd, fyr = (long double)f.fyr, cyr = (long double)f.cyr;
+    const long double margin = 32.0L * 1.1102230246251565e-16L * ((long double)H + fabsl(cyr) + 1.0L);
+    int lo = H, hi = 0;
+    bool wild = false;
+    for (int i = 0; i < H; ++i) {
+        const long double gy = f.sy == 1.0f ? (long double)i : (long double)((float)i * f.sy);
+        const long double v = (gy - cy) * sH * (fyr / fy) + cyr;
+        const long double fl = floorl(v);
+        const bool undecided = fabsl(v - (fl + 0.5L)) <= margin;
+        const long double row = undecided ? fl : floorl(v + 0.5L);           // undecided: fl or fl + 1
+        const bool plain = !undecided && row == (long double)i;
+        if (plain) continue;
+        if (row != (long double)i && !(!undecided && row == (long double)i + 1.0L)) { wild = true; break; }
+        if (i < lo) lo = i;
+        if (i + 1 > hi) hi = i + 1;
+    }
+    f.erow_wild = wild ? 1 : 0;
+    f.erow_lo = (wild || lo >= hi) ? 0 : lo;
+    f.erow_hi = (wild || lo >= hi) ? 0 : hi;
+}
+
 int fill_frame_dev(mdvt_ctx* c, const mdvt_frame_params& p, FrameDev& f)
 {
     const mdvt_config& cfg = c->cfg;
@@ -144,10 +179,25 @@ int fill_frame_dev(mdvt_ctx* c, const mdvt_frame_params& p, FrameDev& f)
             for (int col = 0; col < 3; ++col)
                 f.M[eye][4 * r + col] = (float)((R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col]);
             f.M[eye][4 * r + 3] = (float)(((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r]);
-            for (int col = 0; col < 3; ++col)
-                f.Md[eye][4 * r + col] = (R[r][0] * T[0 + col] + R[r][1] * T[4 + col]) + R[r][2] * T[8 + col];
-            f.Md[eye][4 * r + 3] = ((R[r][0] * T[3] + R[r][1] * T[7]) + R[r][2] * T[11]) + shift[r];
         }
+    }
+    // The edge points' chain takes the reference's operands as they are (mdvt_device.h "edge points")
+    f.sWd = ((double)W - 1.0) / (double)W;
+    f.sHd = ((double)H - 1.0) / (double)H;
+    f.hd = half;
+    f.has_T = p.has_T ? 1 : 0;
+    memcpy(f.Td, T, sizeof T);
+    f.has_conv = conv != 0.0 ? 1 : 0;
+    f.cs[0] = cos(conv); f.cs[1] = sin(conv);
+    if (!f.general && cfg.remove_edges && cfg.edge_points) {
+        const double key[5] = {f.Kd[1], f.Kd[3], (double)f.fyr, (double)f.cyr, (double)f.sy};
+        if (!(c->erow_cached && memcmp(key, c->erow_key, sizeof key) == 0)) {
+            edge_row_range(f, H);
+            memcpy(c->erow_key, key, sizeof key);
+            c->erow_val[0] = f.erow_lo; c->erow_val[1] = f.erow_hi; c->erow_val[2] = f.erow_wild;
+            c->erow_cached = true;
+        }
+        f.erow_lo = c->erow_val[0]; f.erow_hi = c->erow_val[1]; f.erow_wild = c->erow_val[2];
     }
     // Convergence and nothing else (sr:707-726: rotation about the camera's y axis, shift along x): the projected row of a
     // vertex is depth independent, v = (gy - cy) / rz(j) + cy with rz(j) = m10 + m8 (gx_j - cx) / fx, which k_mesh_conv
@@ -521,7 +571,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     bool any_global = false, any_conv = false;
     for (int k = 0; k < n_frames; ++k) {
         const int cv = (conv_kernel && fd[(size_t)k].conv_band) ? 1 : 0;
-        const int g = (!cv && (wide || fd[(size_t)k].general)) ? 1 : 0;
+        const int g = (!cv && (wide || fd[(size_t)k].general || fd[(size_t)k].erow_wild)) ? 1 : 0;
         const int cr = (g && !wide && plan.mode == MDVT_MODE_MESH && fd[(size_t)k].conv_band) ? 1 : 0;
         any_global |= g != 0; any_conv |= cv != 0;
         if (runs.empty() || runs.back().general != g || runs.back().conv != cv || runs.back().craster != cr) runs.push_back({k, k + 1, g, cv, cr});
@@ -626,6 +676,11 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                                            c->unused, a.ws_stride_px, s));
         }
         a.key_parity = c->key_parity;
+        plan.edge_rows_max = 0;
+        if (!r.general && !r.conv && plan.edge_points)
+            for (int k = f0; k < f0 + plan.n; ++k)
+                if (fd[(size_t)k].erow_lo < fd[(size_t)k].erow_hi)
+                    plan.edge_rows_max = std::max(plan.edge_rows_max, fd[(size_t)k].erow_hi - fd[(size_t)k].erow_lo + 1);
         hipError_t e = launch_render(plan, a, s);
         if (r.general && e == hipSuccess) c->key_parity ^= plan.n >= 32 ? 0xFFFFFFFFu : ((1u << plan.n) - 1u);   // these slots' next use has the other parity
         if (e == hipErrorNotSupported) return fail(c, MDVT_ERR_UNSUPPORTED, "render mode %d is not built yet", plan.mode);
@@ -666,6 +721,34 @@ int mdvt_encode_depth(mdvt_ctx* c, const float* d_depth, size_t depth_pitch, uin
     if (!(max_depth > 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "max_depth must be > 0");
     DeviceGuard g(c->device);
     MDVT_HIP(c, launch_encode_depth(d_depth, depth_pitch, d_rgb, rgb_pitch, c->W, c->H, max_depth, bgr, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
+int mdvt_edge_point_pixels(mdvt_ctx* c, const mdvt_frame_params* params, const uint8_t* d_depth_rgb, size_t depth_pitch,
+                           int how, int32_t* d_px, void* stream)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!c->cfg_set) return fail(c, MDVT_ERR_INVALID_ARG, "mdvt_set_config has not been called");
+    if (!params || !d_depth_rgb || !d_px) return fail(c, MDVT_ERR_INVALID_ARG, "NULL argument");
+    if (depth_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
+    if (how != 0 && how != 1) return fail(c, MDVT_ERR_INVALID_ARG, "how must be 0 (the chain) or 1 (as the row kernels take it)");
+    DeviceGuard g(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<FrameDev> fd(1);
+    // (the row range is only worked out for configurations that splat edge points; this entry point always wants it)
+    mdvt_config saved = c->cfg;
+    c->cfg.remove_edges = 1; c->cfg.edge_points = 1;
+    const int rc0 = fill_frame_dev(c, *params, fd[0]);
+    c->cfg = saved;
+    if (rc0 != MDVT_OK) return rc0;
+    if (how == 1 && (fd[0].general || fd[0].erow_wild))
+        return fail(c, MDVT_ERR_INVALID_ARG, "how = 1 needs a pure-shift frame whose rows the row kernels take");
+    const FrameDev* dfp = nullptr;
+    ParamSlot* slot = nullptr;
+    const int rc = stage_params(c, fd, s, &dfp, &slot);
+    if (rc != MDVT_OK) return rc;
+    MDVT_HIP(c, launch_edge_point_pixels(d_depth_rgb, depth_pitch, dfp, c->W, c->H, c->cfg.mode == MDVT_MODE_MESH ? 1 : 0, how, d_px, s));
+    MDVT_HIP(c, hipEventRecord(slot->done, s));
     return MDVT_OK;
 }
 

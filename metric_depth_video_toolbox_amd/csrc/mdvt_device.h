@@ -141,20 +141,6 @@ __device__ __forceinline__ Vert vertex_for_eye(const FrameDev& f, int eye, float
     return o;
 }
 
-// Edge point (sr:599-600, 746) of vertex (i, j): screen position before rounding.
-__device__ __forceinline__ Vert edge_point_for_eye(const FrameDev& f, int eye, int i, float gx, float z, float xc, float yc)
-{
-    if (f.general) return vertex_general(f, f.M[eye], xc * f.sW, yc * f.sH, z);
-    Vert o;
-    const float ex = ((gx - f.cx) * f.sW) + f.cx;
-    const float d = f.dl / z;
-    o.u = eye == 0 ? ex + d : ex - d;
-    o.v = (float)i;                      // the exact-arithmetic row i*(1-1/H^2)+1/2 rounds to i (decree)
-    o.z = z;
-    o.ok = z > kNear;
-    return o;
-}
-
 // ---- rasteriser pieces --------------------------------------------------------------------
 // Snapped coordinates are int32 (|x| <= 2^21 px * 256 = 2^29), so every coordinate difference fits
 // int32 and every product below is one 32x32->64 multiply (v_mad_i64_i32).
@@ -476,6 +462,115 @@ __device__ __forceinline__ void vertex_f64(const FrameDev& f, int i, int j, int 
 
 
 // =================================================================================================
+// edge points: the reference's own f64 chain (sr:589-606, 615-619, 727-735, 745-752, 838-858)
+// =================================================================================================
+// A vertex of a removed triangle is splatted where THIS sequence of f64 operations puts it: NumPy's unprojection
+// (vertex_f64 above), the "undo" of the off-by-one scale (sr:599-600), Open3D's in-place transform / rotate / translate of
+// the point cloud (4x4 times (x,y,z,1) divided by w; R (p - 0) + 0; p += t), the right eye's operations applied on top of
+// the left eye's (sr:838-847), cv2.projectPoints with the camera matrix cast to f32 (dmt:1058: z = z ? 1/z : 1, x *= z,
+// u = x fx + cx in double) and np.round.  One IEEE operation per node, sums left to right, no contraction (the oracle's
+// orc_echain_* and the golden tests/golden/edge_points.npz hold the same sequence).  Exact simplifications: a product
+// with an exact 0 or 1 entry of Ry and the additions of 0.0 in y and z of a translate change no finite value.
+__device__ __forceinline__ void echain_roty(double c, double s, double (&q)[3])      // Ry = [[c,0,s],[0,1,0],[-s,0,c]]
+{
+    const double x = c * q[0] + s * q[2];
+    const double z = (-s) * q[0] + c * q[2];
+    q[0] = x; q[2] = z;
+}
+
+// a point of the cloud -> where it stands when the left / the right eye is rendered
+static __device__ void echain_eyes(const FrameDev& f, const double (&q0)[3], double (&L)[3], double (&R)[3])
+{
+    double q[3] = {q0[0], q0[1], q0[2]};
+    if (f.has_T) {                                                   // sr:615-619
+        const double* T = f.Td;
+        double hh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hh[r] = ((T[4 * r] * q[0] + T[4 * r + 1] * q[1]) + T[4 * r + 2] * q[2]) + T[4 * r + 3] * 1.0;
+        if (hh[3] != 1.0) { hh[0] = hh[0] / hh[3]; hh[1] = hh[1] / hh[3]; hh[2] = hh[2] / hh[3]; }     // (x / 1.0 == x)
+        q[0] = hh[0]; q[1] = hh[1]; q[2] = hh[2];
+    }
+    if (f.has_conv) echain_roty(f.cs[0], -f.cs[1], q);               // sr:729
+    q[0] += f.hd;                                                    // sr:731
+    L[0] = q[0]; L[1] = q[1]; L[2] = q[2];
+    q[0] += -f.hd;                                                   // sr:839
+    if (f.has_conv) { echain_roty(f.cs[0], f.cs[1], q); echain_roty(f.cs[0], f.cs[1], q); }       // sr:842-843
+    q[0] += -f.hd;                                                   // sr:846
+    R[0] = q[0]; R[1] = q[1]; R[2] = q[2];
+}
+
+// cv2.projectPoints + np.round; false if the rounded pixel lies outside the frame (sr:747-750)
+__device__ __forceinline__ bool echain_pixel(const FrameDev& f, int W, int H, const double (&q)[3], int& px, int& py)
+{
+    const double iz = q[2] != 0.0 ? 1.0 / q[2] : 1.0;
+    const double u = (q[0] * iz) * (double)f.fxr + (double)f.cxr;
+    const double v = (q[1] * iz) * (double)f.fyr + (double)f.cyr;
+    const double ru = rint(u), rv = rint(v);
+    if (!(ru >= 0.0 && ru < (double)W && rv >= 0.0 && rv < (double)H)) return false;      // (NaN fails)
+    px = (int)ru; py = (int)rv;
+    return true;
+}
+
+// The painter's order of the edge points (sr:752: far to near, i.e. the nearest one keeps the pixel) as an unsigned key:
+// the chain's depth rounded to f32, mapped so that a smaller key is a smaller (nearer, or more negative) depth.
+__device__ __forceinline__ uint32_t echain_order_key(double z)
+{
+    const uint32_t b = __float_as_uint((float)z);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+struct EdgePx { int x[2], y[2]; uint32_t zkey[2]; bool ok[2]; };
+
+// Edge point of vertex (i, j), both eyes.  Depth code 0 (Z = 0) is not splatted (decree).
+__device__ inline void edge_point_pixels(const FrameDev& f, int W, int H, int i, int j, int of_by_one, float z, EdgePx& o)
+{
+    o.ok[0] = o.ok[1] = false;
+    if (!(z > kNear)) return;
+    double p[3], L[3], R[3];
+    vertex_f64(f, i, j, of_by_one, z, p);
+    p[0] *= f.sWd; p[1] *= f.sHd;                                    // sr:599-600
+    echain_eyes(f, p, L, R);
+    o.ok[0] = echain_pixel(f, W, H, L, o.x[0], o.y[0]);
+    o.ok[1] = echain_pixel(f, W, H, R, o.x[1], o.y[1]);
+    o.zkey[0] = echain_order_key(L[2]); o.zkey[1] = echain_order_key(R[2]);
+}
+
+// ---- pure-shift frames in the LDS row kernels: the column from an f32 estimate, the chain only near a rounding tie ----
+// Without pose and convergence the chain's column is  round( ((gx - cx) z / fx sW + h [- h - h]) (1/z) fxr + cxr ), which
+// the f32 expression ex +- dl/z, ex = (gx - cx) sW + cx, misses by at most ~5 W 2^-23 px (three roundings of values <= W,
+// the f32 sW, dl and fx against their f64 counterparts, |dl/z| <= W + 1 for a point near the frame): wherever that estimate
+// is further than `guard` = W 2^-19 from a tie its rounding IS the chain's, and only the other points (~1 %) run the chain.
+static __device__ int edge_col_chain(const FrameDev& f, int eye, float gx, float z, int W)
+{
+    double X = (((double)gx - f.Kd[2]) * (double)z) / f.Kd[0];
+    X *= f.sWd;
+    X += f.hd;
+    if (eye) { X += -f.hd; X += -f.hd; }
+    const double iz = 1.0 / (double)z;                               // (z > kNear)
+    const double u = (X * iz) * (double)f.fxr + (double)f.cxr;
+    const double r = rint(u);
+    return (r >= 0.0 && r < (double)W) ? (int)r : -1;
+}
+
+__device__ __forceinline__ float edge_col_guard(int W) { return (float)(W < 1024 ? 1024 : W) * 1.9073486328125e-06f; }    // W 2^-19
+
+// column of the edge point, or -1 if it falls outside the frame.  d = dl / z.
+__device__ __forceinline__ int edge_col_pure(const FrameDev& f, int eye, float gx, float z, float d, int W, float guard)
+{
+    const float ex = ((gx - f.cx) * f.sW) + f.cx;
+    const float u = eye == 0 ? ex + d : ex - d;
+    if (!(u > -1.0f && u < (float)W + 1.0f)) return -1;
+    const float r = rintf(u);
+    int x = (int)r;
+    if (__builtin_expect(fabsf(u - r) > 0.5f - guard, 0)) { asm volatile("; edge column by the chain" ::: "memory"); x = edge_col_chain(f, eye, gx, z, W); }
+    return (x >= 0 && x < W) ? x : -1;
+}
+
+// scanlines whose edge points the LDS row kernels leave to k_edge_rows_exact
+__device__ __forceinline__ bool edge_row_deferred(const FrameDev& f, int k) { return k >= f.erow_lo && k <= f.erow_hi && f.erow_lo < f.erow_hi; }
+
+
+// =================================================================================================
 // infill-mask seed image (sr:787-803): colour of one hole pixel
 // =================================================================================================
 
@@ -509,22 +604,19 @@ static __device__ void removed_vertex_normal(const RenderArgs& a, const FrameDev
     vertex_f64(fp, i, j, of_by_one, zp, p);
 }
 
-// (n'+1)/2*255 truncated, n' = M(n + p) - M(S p) normalised (sr:596-600, 727-733, 777-802).
+// (n'+1)/2*255 truncated; n' = the point n + p (p before the undo scale, sr:596) and the undo-scaled edge point, both taken
+// through the chain, their difference normalised (sr:596-600, 727-733, 777-802).
 static __device__ uint32_t edge_normal_colour(const RenderArgs& a, const FrameDev& fp, int f, int eye, int i, int j, int of_by_one)
 {
     double n[3], p[3];
     removed_vertex_normal(a, fp, f, i, j, of_by_one, n, p);
-    const double sW = ((double)a.W - 1.0) / (double)a.W, sH = ((double)a.H - 1.0) / (double)a.H;
     const double pa[3] = {n[0] + p[0], n[1] + p[1], n[2] + p[2]};
-    const double q[3] = {p[0] * sW, p[1] * sH, p[2]};
-    double d[3];
+    const double q[3] = {p[0] * fp.sWd, p[1] * fp.sHd, p[2]};
+    double aL[3], aR[3], qL[3], qR[3], d[3];
+    echain_eyes(fp, pa, aL, aR);
+    echain_eyes(fp, q, qL, qR);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const double* M = fp.Md[eye] + 4 * r;
-        const double ar = ((M[0] * pa[0] + M[1] * pa[1]) + M[2] * pa[2]) + M[3];
-        const double qr = ((M[0] * q[0] + M[1] * q[1]) + M[2] * q[2]) + M[3];
-        d[r] = ar - qr;
-    }
+    for (int r = 0; r < 3; ++r) d[r] = eye == 0 ? aL[r] - qL[r] : aR[r] - qR[r];
     const double len = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
     uint32_t rgb = 0;
 #pragma unroll

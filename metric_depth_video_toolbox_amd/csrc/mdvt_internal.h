@@ -24,13 +24,24 @@ struct FrameDev {
     float fx, fy, cx, cy;        // input camera (f32)
     float fxr, fyr, cxr, cyr;    // render camera (f32)
     float sx, sy;        // (W+1)/W, (H+1)/H in f32 for the mesh grid, 1 for points   dmt:1117-1122
-    float sW, sH;        // (W-1)/W, (H-1)/H in f32: edge points' "undo"              sr:599-600
+    float sW, sH;        // (W-1)/W, (H-1)/H in f32: the pure-shift column estimate of an edge point (edge_col_pure)
     int32_t general;     // 0: pure +-ipd/2 shift, 1: pose / convergence / K != Krender
     int32_t conv_band;   // general, but nothing except a toe-in about the y axis small enough for k_mesh_conv (mdvt_mesh_conv.hip)
     float M[2][12];      // per eye 3x4 = Translate(+-ipd/2) * Ry(-+a) * T, f32       sr:615-619, 724-725, 832-836
     double Kd[4];        // fx, fy, cx, cy in f64 for the 89-degree edge filter       dmt:1127-1128, 1283-1294
-    double Md[2][12];    // the per-eye 3x4 maps in f64 (infill-mask seed normals)       sr:727-733
     double rKd[2];       // 1/fx, 1/fy in f64: the edge filter's screening pass only (never the exact path)
+    // The edge points' f64 chain (mdvt_device.h "edge points"): the operands of the reference's own operations
+    // (sr:599-600, 615-619, 727-732, 838-847; dmt:1058) -- nothing composed, nothing pre-multiplied.
+    double sWd, sHd;     // (W-1)/W, (H-1)/H                                          sr:599-600
+    double hd;           // ipd/2 (the translate of sr:731, 839, 846)
+    double Td[16];       // the pose, row major (has_T)                               sr:615-619
+    double cs[2];        // cos, sin of the convergence angle (has_conv)             sr:719-722
+    int32_t has_T, has_conv;
+    // pure-shift frames: an edge point of source row i lands on row i except for i in [erow_lo, erow_hi), where it lands on
+    // i or i + 1 (which of the two the chain decides per point); the LDS row kernels leave the edge points of scanlines
+    // erow_lo .. erow_hi to k_edge_rows_exact.  erow_wild: some row's offset is neither (a camera matrix with cy far
+    // from H/2): the frame is rendered by the global-key kernels, whose edge points take the whole chain.
+    int32_t erow_lo, erow_hi, erow_wild, pad_;
 };
 
 // Which row of grid cells covers output scanline k of a pure-shift mesh frame, and that row's snapped extent (depends on
@@ -92,6 +103,7 @@ struct RenderPlan {
     int vec4;            // W%4==0 and every pointer/pitch 4-byte aligned
     int fused_bits;      // set by launch_render when the render kernel itself produced maskbits / hole_counts
     int n;               // frames in this launch
+    int edge_rows_max;   // pure-shift launches with edge points: the most scanlines any frame leaves to k_edge_rows_exact (0: none)
 };
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 // mdvt_mesh_band.hip: the pure-shift mesh rows as bands (no edge removal)
@@ -103,6 +115,8 @@ hipError_t launch_mesh_conv(const RenderPlan& plan, const RenderArgs& a, hipStre
 // the general paths' edge-point splat into the global edge keys, and the pass that empties the written words again
 hipError_t launch_edge_points_splat(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_edge_keys_reset(const RenderArgs& a, int n, hipStream_t s);
+hipError_t launch_edge_point_pixels(const uint8_t* depth, size_t pitch, const FrameDev* fp, int W, int H, int of_by_one, int how,
+                                    int32_t* out, hipStream_t s);
 // mdvt_mesh_general.hip: the rasteriser of the general mesh path (between the vertex pass and the resolve pass)
 hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 // (mdvt_normal_infill.hip; workspace: normal_infill_workspace_bytes(1, W, H))

@@ -297,7 +297,7 @@ struct RowIO<1> {
 template <int PX, int FLAGS>
 __device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[PX], const uint32_t (&cpx)[PX],
                                                    const uint32_t (&un)[PX], u64* zb, uint32_t* eb, int W,
-                                                   float mult, float scale, float dl, float ecx, float esW)
+                                                   float mult, float scale, float dl, const FrameDev& fp, bool edge_on, float guard)
 {
     constexpr bool UNUSED = FLAGS & 2, EDGE = FLAGS & 4;
     const float fW = (float)W;
@@ -314,19 +314,12 @@ __device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[
             const float uL = fj + d, uR = fj - d;
             if (uL >= 0.0f && uL < fW) atomicMin(&zb[(int)floorf(uL)], key);
             if (uR >= 0.0f && uR < fW) atomicMin(&zb[W + (int)floorf(uR)], key);
-        } else if (EDGE) {
-            // sr:599-600, 746: undo the off-by-one scale on X, project, round half-even.
-            const float ex = ((fj - ecx) * esW) + ecx;
+        } else if (EDGE && edge_on) {
+            // sr:599-600, 746: the column the reference's f64 chain rounds to (mdvt_device.h "edge points")
             const uint32_t ekey = (code << 16) | (uint32_t)j;
-            const float uL = ex + d, uR = ex - d;
-            if (uL > -1.0f && uL < fW + 1.0f) {
-                const int x = (int)rintf(uL);
-                if (x >= 0 && x < W) atomicMin(&eb[x], ekey);
-            }
-            if (uR > -1.0f && uR < fW + 1.0f) {
-                const int x = (int)rintf(uR);
-                if (x >= 0 && x < W) atomicMin(&eb[W + x], ekey);
-            }
+            const int xL = edge_col_pure(fp, 0, fj, z, d, W, guard), xR = edge_col_pure(fp, 1, fj, z, d, W, guard);
+            if (xL >= 0) atomicMin(&eb[xL], ekey);
+            if (xR >= 0) atomicMin(&eb[W + xR], ekey);
         }
     }
 }
@@ -354,7 +347,9 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
     const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
     const uint8_t* crow = a.color + (size_t)f * a.color_stride + (size_t)i * a.color_pitch;
     const uint8_t* urow = UNUSED ? a.unused + (size_t)fr * a.ws_stride_px + (size_t)i * W : nullptr;
-    const float ecx = fp.cx, esW = fp.sW;
+    // (the edge points of scanlines erow_lo .. erow_hi are k_edge_rows_exact's: their row is not the source row)
+    const bool edge_on = EDGE && !edge_row_deferred(fp, i);
+    const float guard = edge_col_guard(W);
 
     constexpr int NIT = ITERS > 0 ? ITERS : 1;
     uint32_t dpx[NIT][PX], cpx[NIT][PX], un[NIT][PX];
@@ -384,14 +379,14 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
         for (int it = 0; it < NIT; ++it) {
             const int g = tid + it * TPB;
             if (g < ngroups)
-                points_splat_group<PX, FLAGS>(g, dpx[it], cpx[it], un[it], zb, eb, W, mult, scale, dl, ecx, esW);
+                points_splat_group<PX, FLAGS>(g, dpx[it], cpx[it], un[it], zb, eb, W, mult, scale, dl, fp, edge_on, guard);
         }
     } else {
         for (int g = tid; g < ngroups; g += TPB) {
             RowIO<PX>::load_nt(drow, g, dpx[0]);
             RowIO<PX>::load_nt(crow, g, cpx[0]);
             if (UNUSED) RowIO<PX>::load_u8(urow, g, un[0]);
-            points_splat_group<PX, FLAGS>(g, dpx[0], cpx[0], un[0], zb, eb, W, mult, scale, dl, ecx, esW);
+            points_splat_group<PX, FLAGS>(g, dpx[0], cpx[0], un[0], zb, eb, W, mult, scale, dl, fp, edge_on, guard);
         }
     }
     __syncthreads();
@@ -415,7 +410,7 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
                 const bool covered = key != kEmpty64;
                 const bool hole = !covered || rgb == a.key_rgb;       // sr:740 colour-key compare
                 uint32_t out = hole ? 0u : rgb;                       // sr:793
-                if (EDGE && hole) {
+                if (EDGE && hole && edge_on) {
                     const uint32_t ek = eb[(size_t)eye * W + x];
                     if (ek != kEmpty32 && a.edge_paint) {
                         // colour of source column (ek & 0xFFFF) of this row (sr:813-814)
@@ -427,7 +422,7 @@ __global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
                 if (ZOUT) oz[q] = covered ? decode_z((uint32_t)(key >> 40), mult, scale) : 0.0f;
                 if (SEED && a.seed[eye]) {
                     uint32_t esrc = ~0u;
-                    if (EDGE && hole) { const uint32_t ek = eb[(size_t)eye * W + x]; if (ek != kEmpty32) esrc = ((uint32_t)i << 16) | (ek & 0xFFFFu); }
+                    if (EDGE && hole && edge_on) { const uint32_t ek = eb[(size_t)eye * W + x]; if (ek != kEmpty32) esrc = ((uint32_t)i << 16) | (ek & 0xFFFFu); }
                     spx[q] = seed_pixel(a, fp, f, eye, x, i, hole, esrc, 0);
                 }
             }
@@ -712,15 +707,12 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
             zkey_post<false>(&a.keys[eye][(size_t)fr * a.ws_stride_px + (size_t)py * W + px], (a.key_parity >> fr) & 1u, __float_as_uint(v.z), src);   // v.z > 0
         }
     } else if (EDGE) {
+        EdgePx ep;
+        edge_point_pixels(fp, W, H, i, j, fp.sx != 1.0f, z, ep);          // the reference's f64 chain (mdvt_device.h)
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
-            const Vert v = edge_point_for_eye(fp, eye, i, gx, z, xc, yc);        // sr:599-600
-            if (!v.ok) continue;
-            if (!(v.u > -1.0f && v.u < (float)W + 1.0f && v.v > -1.0f && v.v < (float)H + 1.0f)) continue;
-            const int px = (int)rintf(v.u), py = (int)rintf(v.v);   // np.round (sr:746)
-            if (px < 0 || px >= W || py < 0 || py >= H) continue;
-            const u64 key = ((u64)__float_as_uint(v.z) << 32) | src;
-            post_edge_key(a, eye, fr, i, (size_t)py * W + px, key);
+            if (!ep.ok[eye]) continue;
+            post_edge_key(a, eye, fr, i, (size_t)ep.y[eye] * W + ep.x[eye], ((u64)ep.zkey[eye] << 32) | src);
         }
     }
 }
@@ -756,21 +748,53 @@ __global__ void __launch_bounds__(256) k_edge_points_splat4(RenderArgs a)
         const int j = cols[wave][k];
         const float z = decode_z(code16_of(load_px_bytes(drow, j)), fp.mult, fp.scale);
         if (!(z > kNear)) continue;
-        const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
-        float xc, yc;
-        camera_point(fp, gx, gy, z, xc, yc);
         const uint32_t src = ((uint32_t)i << 16) | (uint32_t)j;
+        EdgePx ep;
+        edge_point_pixels(fp, W, H, i, j, 1, z, ep);                      // the reference's f64 chain (mdvt_device.h)
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
-            const Vert v = edge_point_for_eye(fp, eye, i, gx, z, xc, yc);        // sr:599-600
-            if (!v.ok) continue;
-            if (!(v.u > -1.0f && v.u < (float)W + 1.0f && v.v > -1.0f && v.v < (float)H + 1.0f)) continue;
-            const int px = (int)rintf(v.u), py = (int)rintf(v.v);   // np.round (sr:746)
-            if (px < 0 || px >= W || py < 0 || py >= H) continue;
-            const u64 key = ((u64)__float_as_uint(v.z) << 32) | src;
-            post_edge_key(a, eye, fr, i, (size_t)py * W + px, key);
+            if (!ep.ok[eye]) continue;
+            post_edge_key(a, eye, fr, i, (size_t)ep.y[eye] * W + ep.x[eye], ((u64)ep.zkey[eye] << 32) | src);
         }
     }
+}
+
+// mdvt_edge_point_pixels: the pixel the edge point of EVERY vertex of one frame lands on, both eyes (INT32_MIN twice: outside
+// the frame, or depth code 0).  how = 0: the chain, as the global-key kernels and k_edge_rows_exact take it; how = 1: as the
+// LDS row kernels of a pure-shift frame take it -- column from the f32 estimate unless it lies within the guard of a tie
+// (edge_col_pure), row = the source row, the scanlines of edge_row_deferred by the chain.
+__global__ void __launch_bounds__(256) k_edge_point_pixels(const uint8_t* depth, size_t pitch, const FrameDev* fpp, int W, int H,
+                                                           int of_by_one, int how, int32_t* out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= W) return;
+    const FrameDev& fp = fpp[0];
+    const float z = decode_z(code16_of(load_px_bytes(depth + (size_t)i * pitch, j)), fp.mult, fp.scale);
+    int32_t* o = out + 4 * ((size_t)i * W + j);
+    EdgePx ep;
+    ep.ok[0] = ep.ok[1] = false;
+    if (how == 0 || edge_row_deferred(fp, i)) edge_point_pixels(fp, W, H, i, j, of_by_one, z, ep);
+    else if (z > kNear) {
+        const float guard = edge_col_guard(W), gx = (float)j * fp.sx, d = fp.dl / z;
+#pragma unroll
+        for (int eye = 0; eye < 2; ++eye) {
+            ep.x[eye] = edge_col_pure(fp, eye, gx, z, d, W, guard);
+            ep.y[eye] = i;
+            ep.ok[eye] = ep.x[eye] >= 0;
+        }
+    }
+#pragma unroll
+    for (int eye = 0; eye < 2; ++eye) {
+        o[2 * eye] = ep.ok[eye] ? ep.x[eye] : INT32_MIN;
+        o[2 * eye + 1] = ep.ok[eye] ? ep.y[eye] : INT32_MIN;
+    }
+}
+
+hipError_t launch_edge_point_pixels(const uint8_t* depth, size_t pitch, const FrameDev* fp, int W, int H, int of_by_one, int how,
+                                    int32_t* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_edge_point_pixels, dim3((W + 255) / 256, H), dim3(256), 0, s, depth, pitch, fp, W, H, of_by_one, how, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_edge_keys_reset(const RenderArgs& a, int n, hipStream_t s)
@@ -1222,23 +1246,17 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
         }
         if (ties.mode == 0) {
         // ---- edge points of source row k (sr:589-606, 745-781): vertices of removed triangles ----
-        if (EDGEPTS) {
+        if (EDGEPTS && !edge_row_deferred(fp, k)) {        // (scanlines erow_lo .. erow_hi: k_edge_rows_exact)
             const uint8_t* drow_k = a.depth + (size_t)f * a.depth_stride + (size_t)k * a.depth_pitch;
             const bool k_staged = c >= 0 && (k == c || k == c + 1) && !(a.debug_skip & 4);
-            const float fW = (float)W;
+            const float guard = edge_col_guard(W);
             for (int j = tid; j < W; j += TPB) {
                 if (!(cfl[j] & 4u)) continue;
                 const uint32_t code = k_staged ? (uint32_t)kcode[j] : code16_of(load_px_bytes(drow_k, j));
                 const float z = decode_z(code, fp.mult, fp.scale);
                 if (!(z > kNear)) continue;
-                const float d = fp.dl / z;
-                const float gx = (float)j * fp.sx;
-                const float ex = ((gx - fp.cx) * fp.sW) + fp.cx;
-                const float u = eye == 0 ? ex + d : ex - d;
-                if (u > -1.0f && u < fW + 1.0f) {
-                    const int x = (int)rintf(u);
-                    if (x >= 0 && x < W) atomicMin(&eb[x], (code << 16) | (uint32_t)j);
-                }
+                const int x = edge_col_pure(fp, eye, (float)j * fp.sx, z, fp.dl / z, W, guard);     // sr:599-600, 746
+                if (x >= 0) atomicMin(&eb[x], (code << 16) | (uint32_t)j);
             }
         }
         }
@@ -2596,17 +2614,78 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
     return launch_resolve_general<true>(plan, a, s);
 }
 
+// Edge points of the scanlines the LDS row kernels leave out (pure-shift frames, scanlines erow_lo .. erow_hi of the frame's
+// FrameDev): there the chain puts a point of source row i on row i or i + 1, so scanline y collects the vertices of removed
+// triangles of source rows y - 1 and y whose chain row is y -- nearest first (depth code; then the lower source index) --
+// and paints them where the render left a hole (sr:776, 813-814), after the row kernel wrote the scanline.  One workgroup
+// per (frame, scanline of the range, eye); W x 8 B of LDS.
+template <bool MESH>
+__global__ void __launch_bounds__(256) k_edge_rows_exact(RenderArgs a, int rows_max)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* ek = (u64*)smem;
+    const int W = a.W, H = a.H, tid = threadIdx.x;
+    const int fr = blockIdx.x / rows_max, r = blockIdx.x - fr * rows_max;
+    const int eye = blockIdx.y;
+    const int f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    if (fp.erow_lo >= fp.erow_hi) return;
+    const int y = fp.erow_lo + r;
+    if (y > fp.erow_hi || y >= H) return;
+    for (int x = tid; x < W; x += 256) ek[x] = kEmpty64;
+    __syncthreads();
+    const uint8_t* dbase = a.depth + (size_t)f * a.depth_stride;
+    for (int si = y - 1; si <= y; ++si) {
+        if (si < 0) continue;
+        const uint8_t* urow = a.unused + (size_t)fr * a.ws_stride_px + (size_t)si * W;
+        const uint8_t* drow = dbase + (size_t)si * a.depth_pitch;
+        for (int j = tid; j < W; j += 256) {
+            if (!urow[j]) continue;
+            const uint32_t code = code16_of(load_px_bytes(drow, j));
+            const float z = decode_z(code, fp.mult, fp.scale);
+            EdgePx ep;
+            edge_point_pixels(fp, W, H, si, j, MESH ? 1 : 0, z, ep);
+            if (ep.ok[eye] && ep.y[eye] == y)
+                atomicMin(&ek[ep.x[eye]], ((u64)code << 17) | ((u64)(uint32_t)(si - (y - 1)) << 16) | (u64)(uint32_t)j);
+        }
+    }
+    __syncthreads();
+    const uint8_t* mrow = a.mask[eye] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch;
+    uint8_t* orow = a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)y * a.rgb_pitch;
+    for (int x = tid; x < W; x += 256) {
+        const u64 k = ek[x];
+        if (k == kEmpty64 || !mrow[x]) continue;
+        const int sj = (int)(k & 0xFFFFu), si = y - 1 + (int)((k >> 16) & 1u);
+        if (a.edge_paint) store_px_bytes(orow, x, load_px_bytes(a.color + (size_t)f * a.color_stride + (size_t)si * a.color_pitch, sj));
+        if (a.seed[eye])
+            store_px_bytes(a.seed[eye] + (size_t)f * a.seed_stride + (size_t)y * a.seed_pitch, x, edge_normal_colour(a, fp, f, eye, si, sj, MESH ? 1 : 0));
+    }
+}
+
+static hipError_t launch_edge_rows_exact(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+{
+    if (!(plan.remove_edges && plan.edge_points) || plan.edge_rows_max <= 0) return hipSuccess;
+    const dim3 grid((unsigned)(plan.n * plan.edge_rows_max), 2u), block(256);
+    const size_t lds = (size_t)a.W * sizeof(u64);
+    if (plan.mode == MDVT_MODE_MESH) hipLaunchKernelGGL(k_edge_rows_exact<true>, grid, block, lds, s, a, plan.edge_rows_max);
+    else hipLaunchKernelGGL(k_edge_rows_exact<false>, grid, block, lds, s, a, plan.edge_rows_max);
+    return hipGetLastError();
+}
+
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     plan.fused_bits = 0;
     if (plan.mode == MDVT_MODE_POINTS) {
         if (plan.general) return launch_points_general(plan, a, s);
-        return plan.vec4 ? launch_points_rows_vec4(plan, a, s) : launch_points_rows_cfg<1, 256, 0>(plan, a, s);
+        const hipError_t e = plan.vec4 ? launch_points_rows_vec4(plan, a, s) : launch_points_rows_cfg<1, 256, 0>(plan, a, s);
+        return e != hipSuccess ? e : launch_edge_rows_exact(plan, a, s);
     }
     if (plan.conv) return launch_mesh_conv(plan, a, s);
     if (plan.general) return launch_mesh_general(plan, a, s);
-    if (mesh_band_supported(plan, a) && getenv("MDVT_MESH_OLD") == nullptr) return launch_mesh_band(plan, a, s);
-    return plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);
+    hipError_t e;
+    if (mesh_band_supported(plan, a) && getenv("MDVT_MESH_OLD") == nullptr) e = launch_mesh_band(plan, a, s);
+    else e = plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);
+    return e != hipSuccess ? e : launch_edge_rows_exact(plan, a, s);
 }
 
 }  // namespace mdvt

@@ -371,9 +371,10 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
             // ---- edge points of source row k (sr:589-606, 745-781): the vertices of removed triangles, nearest wins.  They land
             //      on scanline k itself, the scanline this workgroup is rendering: their keys go into the z-buffer row's own
             //      memory once its words have been read out (below); here only position and key are worked out ----
-            if (EDGEPTS && ties.mode == 0 && k >= k0) {
+            // (the edge points of scanlines erow_lo .. erow_hi are k_edge_rows_exact's: their row is not the source row)
+            if (EDGEPTS && ties.mode == 0 && k >= k0 && !edge_row_deferred(fp, k)) {
                 const uint8_t* drow_k = dbase + (size_t)k * a.depth_pitch;
-                const float fW = (float)W;
+                const float guard = edge_col_guard(W);
                 // (source row k is one of the two staged vertex rows: c(k) is k or k - 1)
                 const int4* vk = ((k & 1) ? have1 : have0) == k ? verts + (size_t)(k & 1) * W : nullptr;
 #pragma unroll
@@ -387,15 +388,12 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                     const uint32_t code = code16_of(load_px_bytes(drow_k, jj));
                     const float z = decode_z(code, fp.mult, fp.scale);
                     if (!(z > kNear)) continue;
-                    const float d = fp.dl / z;
-                    const float gx = (float)jj * fp.sx;
-                    const float ex = ((gx - fp.cx) * fp.sW) + fp.cx;                      // sr:599-600
-                    const float u = eye == 0 ? ex + d : ex - d;
-                    if (u > -1.0f && u < fW + 1.0f) {
-                        const int x = (int)rintf(u);                                      // np.round (sr:746)
-                        if (x >= 0 && x < W) { etx[q] = x; ekey[q] = (code << 16) | (uint32_t)jj; }
-                    }
+                    const int x = edge_col_pure(fp, eye, (float)jj * fp.sx, z, fp.dl / z, W, guard);      // sr:599-600, 746
+                    if (x >= 0) { etx[q] = x; ekey[q] = (code << 16) | (uint32_t)jj; }
                 }
+            } else if (EDGEPTS && ties.mode == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) etx[q] = -1;
             }
             __syncthreads();
             if (ties.mode == 0) {

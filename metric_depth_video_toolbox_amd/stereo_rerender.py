@@ -477,6 +477,19 @@ class StereoRerenderer:
                                                 C.c_void_p(s.cuda_stream)))
         return tri, unused
 
+    def edge_point_pixels(self, depth_rgb, params, how: int = 0, stream=None):
+        """Where the edge point of every vertex of a frame lands (sr:589-606, 727-735, 745-750, 838-858) ->
+        int32[H*W, 2 eyes, 2 (x, y)], INT32_MIN outside the frame.  how = 0: the reference's f64 chain per vertex; 1: as the
+        row kernels of a pure-shift frame take it (mdvt.h)."""
+        torch = self.torch
+        H, W = self.H, self.W
+        assert tuple(depth_rgb.shape) == (H, W, 3) and depth_rgb.is_cuda and depth_rgb.is_contiguous()
+        px = torch.empty((H * W, 2, 2), dtype=torch.int32, device=depth_rgb.device)
+        s = stream if stream is not None else torch.cuda.current_stream(depth_rgb.device)
+        self.ctx.check(self._L.mdvt_edge_point_pixels(self.ctx.handle, C.byref(params), depth_rgb.data_ptr(), 3 * W, int(how),
+                                                      px.data_ptr(), C.c_void_p(s.cuda_stream)))
+        return px
+
     def close(self):
         self.ctx.close()
 
