@@ -62,7 +62,8 @@ typedef struct mdvt_config {
     double ipd_m;                /* --pupillary_distance / 1000 (sr:458-459)                         */
     double max_depth;            /* --max_depth (dfh:22)                                             */
     uint8_t key_rgb[4];          /* bg_color*255: (0,0,0), or (0,255,0) with --infill_mask (sr:555-558) */
-    uint32_t reserved1;
+    uint32_t workspace_mib;      /* budget, in MiB, for the library-owned workspace of the posed / converged mesh path (about 100 B per
+                                    pixel and frame in flight: it sets how many frames one launch set takes, 1 ... 16); 0 = 4096 */
 } mdvt_config;
 
 /* Per-frame parameters: what sr:515-541, 563-566 and 707-721 compute before the render calls. */
@@ -137,6 +138,11 @@ int mdvt_encode_depth(mdvt_ctx* ctx, const float* d_depth, size_t depth_pitch, u
  * all tri2), d_unused[H*W] u8 (1 = vertex of a removed triangle).  Either output may be NULL. */
 int mdvt_edge_filter(mdvt_ctx* ctx, const uint8_t* d_depth_rgb, size_t depth_pitch, const double K[9],
                      double depth_scale, int of_by_one, uint8_t* d_tri_invalid, uint8_t* d_unused, void* stream);
+
+/* Device memory the context currently owns (workspaces of the general paths, the edge filter, the infill-mask completion,
+ * normal_infill; allocated on first use, kept until mdvt_destroy or until a larger request replaces them).  The render
+ * calls themselves allocate nothing else: every image buffer is the caller's. */
+int mdvt_workspace_bytes(mdvt_ctx* ctx, uint64_t* bytes);
 
 /* Diagnostic: where the edge point of EVERY vertex of one frame lands (sr:589-606, 615-619, 727-735, 745-750, 838-858: the
  * vertices of removed triangles, undo-scaled, taken through pose / convergence / +-ipd/2, cv2.projectPoints with the f32-cast

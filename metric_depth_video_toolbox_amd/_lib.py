@@ -25,7 +25,7 @@ SYMBOLS = ("mdvt_version", "mdvt_create", "mdvt_destroy", "mdvt_last_error", "md
            "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side", "mdvt_touchly_depth",
            "mdvt_equirect_tables", "mdvt_equirect_remap", "mdvt_masked_blur", "mdvt_finish_infill_mask",
            "mdvt_finish_infill_mask_stereo", "mdvt_swap_rb", "mdvt_selftest", "mdvt_normal_infill", "mdvt_infill_using_mask_normals",
-           "mdvt_edge_point_pixels")
+           "mdvt_edge_point_pixels", "mdvt_workspace_bytes")
 
 
 class MdvtError(RuntimeError):
@@ -36,7 +36,7 @@ class MdvtError(RuntimeError):
 
 class MdvtConfig(C.Structure):
     _fields_ = [("mode", C.c_int32), ("remove_edges", C.c_int32), ("edge_points", C.c_int32), ("cull", C.c_int32),
-                ("ipd_m", C.c_double), ("max_depth", C.c_double), ("key_rgb", C.c_uint8 * 4), ("reserved1", C.c_uint32)]
+                ("ipd_m", C.c_double), ("max_depth", C.c_double), ("key_rgb", C.c_uint8 * 4), ("workspace_mib", C.c_uint32)]
 
 
 class MdvtFrameParams(C.Structure):
@@ -55,20 +55,29 @@ class MdvtIO(C.Structure):
                 ("left_seed", C.c_void_p), ("right_seed", C.c_void_p), ("seed_pitch", C.c_size_t), ("seed_stride", C.c_size_t)]
 
 
-_lib = None
+_libs = {}
+
+
+def lib_path(variant: str = "") -> str:
+    return LIB_PATH if not variant else os.path.join(_PKG, f"libmdvt_hip_{variant}.so")
 
 
 def load():
-    """dlopen libmdvt_hip.so and declare prototypes.  Raises if the library has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    """dlopen libmdvt_hip.so and declare prototypes.  Raises if the library has not been built.
+
+    The product library has no tuning / ablation hooks.  With MDVT_LIB_VARIANT=tuning in the environment (read at every
+    call, so a test can set it for its own duration) the MDVT_TUNING build of the same objects is loaded instead --
+    libmdvt_hip_tuning.so, whose launchers re-read the MDVT_* hooks of csrc/mdvt_internal.h: tools/ and hook-driven tests only."""
+    variant = os.environ.get("MDVT_LIB_VARIANT", "")
+    if variant in _libs:
+        return _libs[variant]
+    path = lib_path(variant)
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: the HIP extension has not been built and there is no CPU fallback. "
+            f"{path} is missing: the HIP extension has not been built and there is no CPU fallback. "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C metric_depth_video_toolbox_amd/csrc`).")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.mdvt_version.restype = C.c_int
     L.mdvt_version.argtypes = []
@@ -117,7 +126,9 @@ def load():
                                                  C.c_int, C.c_int, vp]
     L.mdvt_edge_point_pixels.restype = C.c_int
     L.mdvt_edge_point_pixels.argtypes = [vp, C.POINTER(MdvtFrameParams), vp, C.c_size_t, C.c_int, vp, vp]
-    _lib = L
+    L.mdvt_workspace_bytes.restype = C.c_int
+    L.mdvt_workspace_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    _libs[variant] = L
     return L
 
 
@@ -145,6 +156,12 @@ class Context:
     def check(self, rc: int):
         if rc != MDVT_OK:
             raise MdvtError(rc, (self._L.mdvt_last_error(self._h) or b"").decode())
+
+    def workspace_bytes(self) -> int:
+        """Device memory the context owns right now (mdvt_workspace_bytes)."""
+        n = C.c_uint64()
+        self.check(self._L.mdvt_workspace_bytes(self._h, C.byref(n)))
+        return int(n.value)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

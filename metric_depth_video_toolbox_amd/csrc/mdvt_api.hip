@@ -13,6 +13,7 @@
 #include <new>
 #include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace mdvt;
@@ -75,6 +76,10 @@ struct mdvt_ctx {
     double erow_key[5] = {0, 0, 0, 0, 0};
     int erow_val[3] = {0, 0, 0};
     bool erow_cached = false;
+    // every device allocation the context owns, by size (mdvt_workspace_bytes)
+    std::unordered_map<void*, size_t> allocs;
+    size_t ws_bytes = 0;
+    bool opt_mesh_conv = false;       // MDVT_MESH_CONV=1 in the environment of mdvt_create (the opt-in kernel of mdvt_mesh_conv.hip)
 };
 
 namespace {
@@ -95,6 +100,21 @@ int fail(mdvt_ctx* c, int code, const char* fmt, ...)
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess) return fail((c), MDVT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+// device memory owned by a context, accounted for mdvt_workspace_bytes
+hipError_t ws_malloc(mdvt_ctx* c, void** p, size_t bytes)
+{
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && *p) { c->allocs[*p] = bytes; c->ws_bytes += bytes; }
+    return e;
+}
+void ws_free(mdvt_ctx* c, void* p)
+{
+    if (!p) return;
+    auto it = c->allocs.find(p);
+    if (it != c->allocs.end()) { c->ws_bytes -= it->second; c->allocs.erase(it); }
+    (void)hipFree(p);
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -226,22 +246,23 @@ int fill_frame_dev(mdvt_ctx* c, const mdvt_frame_params& p, FrameDev& f)
 // (tests/dbg_param_stress.py reproduces it: 12 wrong frames in 191 000 contexts with per-context hipHostMalloc /
 // hipHostFree, 0 in 1 064 000 with this pool, and a context is created 5 x faster).  MDVT_PARAM_UPLOAD=recycle restores
 // the per-context allocation for that A/B.
-struct PoolBlock { void* host; void* dev; size_t bytes; };
+struct PoolBlock { void* host; void* dev; size_t bytes; int device; };     // device: the GPU `dev` was allocated on (-1: no device block)
 std::mutex g_pool_mutex;
 std::vector<PoolBlock>& param_pool() { static std::vector<PoolBlock> p; return p; }
 bool param_pool_off()
 {
-    const char* e = getenv("MDVT_PARAM_UPLOAD");
+    const char* e = tuning_env(TUNE_PARAM_UPLOAD);
     return e && strcmp(e, "recycle") == 0;
 }
-// A pinned host block of at least `bytes`, with a device block of the same size if with_dev.
-hipError_t pool_take(size_t bytes, bool with_dev, void** host, void** dev, size_t* got)
+// A pinned host block of at least `bytes`, with a device block of the same size on GPU `device` if with_dev (a block that
+// carries device memory only ever goes back to a context on the GPU it was allocated on: contexts of two GPUs share the pool).
+hipError_t pool_take(size_t bytes, bool with_dev, int device, void** host, void** dev, size_t* got)
 {
     if (!param_pool_off()) {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         auto& pool = param_pool();
         for (size_t k = 0; k < pool.size(); ++k)
-            if (pool[k].bytes >= bytes && (pool[k].dev != nullptr) == with_dev) {
+            if (pool[k].bytes >= bytes && pool[k].device == (with_dev ? device : -1)) {
                 *host = pool[k].host; *dev = pool[k].dev; *got = pool[k].bytes;
                 pool.erase(pool.begin() + (long)k);
                 return hipSuccess;
@@ -249,15 +270,18 @@ hipError_t pool_take(size_t bytes, bool with_dev, void** host, void** dev, size_
     }
     *host = nullptr; *dev = nullptr; *got = bytes;
     hipError_t e = hipHostMalloc(host, bytes, hipHostMallocDefault);
-    if (e == hipSuccess && with_dev) e = hipMalloc(dev, bytes);
+    if (e == hipSuccess && with_dev) {
+        e = hipMalloc(dev, bytes);                       // (the caller's DeviceGuard has made `device` current)
+        if (e != hipSuccess) { (void)hipHostFree(*host); *host = nullptr; *dev = nullptr; }
+    }
     return e;
 }
-void pool_give(void* host, void* dev, size_t bytes)
+void pool_give(void* host, void* dev, size_t bytes, int device)
 {
     if (!host) return;
     if (param_pool_off()) { (void)hipHostFree(host); if (dev) (void)hipFree(dev); return; }
     std::lock_guard<std::mutex> lock(g_pool_mutex);
-    param_pool().push_back({host, dev, bytes});
+    param_pool().push_back({host, dev, bytes, dev ? device : -1});
 }
 
 // Stage n FrameDev records to the device through the pinned ring; returns the device pointer.
@@ -274,13 +298,13 @@ int stage_params(mdvt_ctx* c, const std::vector<FrameDev>& v, hipStream_t s, con
     c->next_slot = (c->next_slot + 1) % kParamSlots;
     if (sl.used) MDVT_HIP(c, hipEventSynchronize(sl.done));     // slot is being reused: its last user must be done
     if (sl.capacity < v.size()) {
-        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev));
+        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev), c->device);
         sl.host = nullptr; sl.dev = nullptr; sl.capacity = 0;
         size_t cap = 16;
         while (cap < v.size()) cap *= 2;
         void *h = nullptr, *d = nullptr;
         size_t got = 0;
-        MDVT_HIP(c, pool_take(cap * sizeof(FrameDev), true, &h, &d, &got));
+        MDVT_HIP(c, pool_take(cap * sizeof(FrameDev), true, c->device, &h, &d, &got));
         sl.host = (FrameDev*)h; sl.dev = (FrameDev*)d; sl.capacity = got / sizeof(FrameDev);
     }
     if (!sl.done) MDVT_HIP(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
@@ -303,29 +327,29 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     const size_t ntri = 2 * (size_t)(c->W - 1) * (c->H - 1);
     const bool grow = frames > c->ws_frames;
     if (grow || (need_keys && !c->ws_keys)) {
-        for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); c->keys[e] = nullptr; }
+        for (int e = 0; e < 2; ++e) { if (c->keys[e]) ws_free(c, c->keys[e]); c->keys[e] = nullptr; }
         c->ws_keys = false;
     }
     if (grow || (need_ekeys && !c->ws_ekeys)) {
-        for (int e = 0; e < 2; ++e) { if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); c->ekeys[e] = nullptr; }
-        if (c->elist) (void)hipFree(c->elist);
+        for (int e = 0; e < 2; ++e) { if (c->ekeys[e]) ws_free(c, c->ekeys[e]); c->ekeys[e] = nullptr; }
+        if (c->elist) ws_free(c, c->elist);
         c->elist = nullptr;
         c->ws_ekeys = false;
     }
     if (grow || (need_edges && !c->ws_edges)) {
-        if (c->tri_invalid) (void)hipFree(c->tri_invalid);
-        if (c->unused) (void)hipFree(c->unused);
+        if (c->tri_invalid) ws_free(c, c->tri_invalid);
+        if (c->unused) ws_free(c, c->unused);
         c->tri_invalid = nullptr; c->unused = nullptr; c->ws_edges = false;
     }
     if (grow || (need_gverts && !c->ws_gverts)) {
-        for (int e = 0; e < 2; ++e) { if (c->gverts[e]) (void)hipFree(c->gverts[e]); c->gverts[e] = nullptr; if (c->cbuf[e]) (void)hipFree(c->cbuf[e]); c->cbuf[e] = nullptr; }
+        for (int e = 0; e < 2; ++e) { if (c->gverts[e]) ws_free(c, c->gverts[e]); c->gverts[e] = nullptr; if (c->cbuf[e]) ws_free(c, c->cbuf[e]); c->cbuf[e] = nullptr; }
         c->ws_gverts = false;
     }
     if (grow) c->ws_frames = frames;
     const size_t nf = (size_t)c->ws_frames;
     if (need_keys && !c->ws_keys) {
         for (int e = 0; e < 2; ++e) {
-            MDVT_HIP(c, hipMalloc((void**)&c->keys[e], nf * npx * sizeof(unsigned long long)));
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->keys[e], nf * npx * sizeof(unsigned long long)));
             MDVT_HIP(c, hipMemsetAsync(c->keys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));     // parity 0's empty value
         }
         c->key_parity = 0;
@@ -333,19 +357,19 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     }
     if (need_ekeys && !c->ws_ekeys) {
         for (int e = 0; e < 2; ++e) {
-            MDVT_HIP(c, hipMalloc((void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long)));
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long)));
             MDVT_HIP(c, hipMemsetAsync(c->ekeys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));
         }
-        MDVT_HIP(c, hipMalloc((void**)&c->elist, (nf * 2 * npx + nf * (size_t)c->H) * sizeof(uint32_t)));
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->elist, (nf * 2 * npx + nf * (size_t)c->H) * sizeof(uint32_t)));
         MDVT_HIP(c, hipMemsetAsync(c->elist + nf * 2 * npx, 0, nf * (size_t)c->H * sizeof(uint32_t), s));   // counters; the reset pass keeps them 0
         c->ws_ekeys = true;
     }
     if (need_gverts && !c->ws_gverts) {
         for (int e = 0; e < 2; ++e) {
-            MDVT_HIP(c, hipMalloc((void**)&c->gverts[e], nf * npx * sizeof(uint4)));
-            MDVT_HIP(c, hipMalloc((void**)&c->cbuf[e], nf * npx * sizeof(unsigned long long)));   // validated by draw id: needs no clearing
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->gverts[e], nf * npx * sizeof(uint4)));
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->cbuf[e], nf * npx * sizeof(unsigned long long)));   // validated by draw id: needs no clearing
         }
-        if (c->bigq) (void)hipFree(c->bigq);
+        if (c->bigq) ws_free(c, c->bigq);
         c->bigq = nullptr;
         // one segment per (frame slot, cell row), each with room for all four triangles of every cell of the row (8 bytes
         // per triangle) and its own counter: the queue cannot overflow
@@ -355,12 +379,12 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         if (nfq > nf) nfq = nf;
         const size_t cap = nfq * npx * 4;
         c->bigq_cap = (uint32_t)cap;
-        MDVT_HIP(c, hipMalloc((void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 1) * sizeof(uint32_t)));   // entries, counters, prefix sums
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 1) * sizeof(uint32_t)));   // entries, counters, prefix sums
         c->ws_gverts = true;
     }
     if (need_edges && !c->ws_edges) {
-        MDVT_HIP(c, hipMalloc((void**)&c->tri_invalid, nf * ntri));
-        MDVT_HIP(c, hipMalloc((void**)&c->unused, nf * npx));
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->tri_invalid, nf * ntri));
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->unused, nf * npx));
         c->ws_edges = true;
     }
     return MDVT_OK;
@@ -395,7 +419,7 @@ int ensure_rowcell(mdvt_ctx* c, hipStream_t s)
         r.Yb = r.c >= 0 ? host_snap((float)(r.c + 1) * sy) : 1;
         t[(size_t)k] = r;
     }
-    MDVT_HIP(c, hipMalloc((void**)&c->rowcell, (size_t)H * sizeof(mdvt::RowCell)));
+    MDVT_HIP(c, ws_malloc(c, (void**)&c->rowcell, (size_t)H * sizeof(mdvt::RowCell)));
     MDVT_HIP(c, hipMemcpyAsync(c->rowcell, t.data(), (size_t)H * sizeof(mdvt::RowCell), hipMemcpyHostToDevice, s));
     MDVT_HIP(c, hipStreamSynchronize(s));      // `t` is pageable host memory
     return MDVT_OK;
@@ -430,6 +454,7 @@ int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flag
     mdvt_ctx* c = new (std::nothrow) mdvt_ctx();
     if (!c) return fail(nullptr, MDVT_ERR_OOM, "out of host memory");
     c->device = device; c->W = width; c->H = height;
+    { const char* e = getenv("MDVT_MESH_CONV"); c->opt_mesh_conv = e && e[0] == '1'; }     // the library's one switch, read here and nowhere else
     c->cfg.mode = MDVT_MODE_POINTS; c->cfg.ipd_m = 0.063; c->cfg.max_depth = 100.0;   // argparse defaults (sr:284, 288)
     *out = c;
     return MDVT_OK;
@@ -439,7 +464,7 @@ static void free_telea(mdvt_ctx* c)
 {
     mdvt::TeleaWorkspace& w = c->telea;
     void* ptrs[] = {w.stamp, w.T, w.img, w.need, w.nlist, w.counts, w.remaining, w.last_round};   // offs / ncounts live inside counts
-    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (void* p : ptrs) if (p) ws_free(c, p);
     w = mdvt::TeleaWorkspace{};
     c->telea_images = 0; c->telea_rounds = 0;
 }
@@ -450,19 +475,19 @@ int mdvt_destroy(mdvt_ctx* c)
     DeviceGuard g(c->device);
     (void)hipDeviceSynchronize();
     for (auto& sl : c->slots) {
-        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev));
+        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev), c->device);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
-    for (int e = 0; e < 2; ++e) { if (c->keys[e]) (void)hipFree(c->keys[e]); if (c->ekeys[e]) (void)hipFree(c->ekeys[e]); if (c->gverts[e]) (void)hipFree(c->gverts[e]); if (c->cbuf[e]) (void)hipFree(c->cbuf[e]); }
-    if (c->bigq) (void)hipFree(c->bigq);
-    if (c->tri_invalid) (void)hipFree(c->tri_invalid);
-    if (c->unused) (void)hipFree(c->unused);
-    if (c->elist) (void)hipFree(c->elist);
-    if (c->row_counts) (void)hipFree(c->row_counts);
-    if (c->rowcell) (void)hipFree(c->rowcell);
-    pool_give(c->telea_levels_host, nullptr, 64);
+    for (int e = 0; e < 2; ++e) { if (c->keys[e]) ws_free(c, c->keys[e]); if (c->ekeys[e]) ws_free(c, c->ekeys[e]); if (c->gverts[e]) ws_free(c, c->gverts[e]); if (c->cbuf[e]) ws_free(c, c->cbuf[e]); }
+    if (c->bigq) ws_free(c, c->bigq);
+    if (c->tri_invalid) ws_free(c, c->tri_invalid);
+    if (c->unused) ws_free(c, c->unused);
+    if (c->elist) ws_free(c, c->elist);
+    if (c->row_counts) ws_free(c, c->row_counts);
+    if (c->rowcell) ws_free(c, c->rowcell);
+    pool_give(c->telea_levels_host, nullptr, 64, -1);
     free_telea(c);
-    if (c->ni_ws) (void)hipFree(c->ni_ws);
+    if (c->ni_ws) ws_free(c, c->ni_ws);
     delete c;
     return MDVT_OK;
 }
@@ -549,6 +574,8 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     plan.remove_edges = c->cfg.remove_edges;
     plan.edge_points = c->cfg.remove_edges && c->cfg.edge_points;
     plan.general = general;
+    plan.allow_conv = c->opt_mesh_conv ? 1 : 0;
+    if (tuning_build()) { const char* e = tuning_env(TUNE_MESH_CONV); plan.allow_conv = (e && e[0] == '1') ? 1 : 0; }   // (tests toggle it per call)
     plan.vec4 = (W % 4 == 0) && aligned(io->depth_rgb, 4) && aligned(io->color_rgb, 4) && aligned(io->left_rgb, 4) &&
                 aligned(io->right_rgb, 4) && aligned(io->left_mask, 4) && aligned(io->right_mask, 4) &&
                 io->depth_pitch % 4 == 0 && io->color_pitch % 4 == 0 && io->rgb_pitch % 4 == 0 && io->mask_pitch % 4 == 0 &&
@@ -560,7 +587,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     // A pure-shift frame wider than the LDS row kernels can hold (10 240 px for points, ~4 300 for the mesh with edge
     // points) is rendered by the global-key kernels instead -- with its own pure-shift arithmetic (FrameDev.general
     // stays 0), so the pixels do not depend on which kernels ran.  MDVT_FORCE_GLOBAL=1 sends every frame that way (tests).
-    const bool wide = !mdvt::render_fits_lds(plan, W) || getenv("MDVT_FORCE_GLOBAL") != nullptr;
+    const bool wide = !mdvt::render_fits_lds(plan, W) || tuning_env(TUNE_FORCE_GLOBAL) != nullptr;
     if (wide) general = 1;
     bool conv_kernel = false;
     if (plan.mode == MDVT_MODE_MESH && !wide) {
@@ -585,7 +612,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     // inside the 256 MiB Infinity Cache between splat and resolve (measured +12 %); the mesh needs the slack of
     // eight (rows full of slivers leave a long tail), and the edge filter alone streams, so 8 as well.
     int tuned_chunk = 0;
-    if (const char* e = getenv("MDVT_WS_CHUNK")) { const int v = atoi(e); if (v > 0) tuned_chunk = v; }   // tuning hook
+    if (const char* e = tuning_env(TUNE_WS_CHUNK)) { const int v = atoi(e); if (v > 0) tuned_chunk = v; }   // tuning hook
     auto chunk_of = [&](const Run& r) {
         const int n = r.f1 - r.f0;
         if (!(r.general || plan.remove_edges || (r.conv && plan.edge_points))) return n;                  // no workspace: the whole run in one launch
@@ -596,10 +623,19 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
             // entry indices are 32-bit, so very large frames get fewer slots (4 entries per pixel and slot)
             const size_t fit = (size_t)0xFFFFFFF0u / (4 * (size_t)W * (size_t)H);
             if ((size_t)ws_chunk > fit) ws_chunk = fit < 1 ? 1 : (int)fit;
+            // ... and the slots have to fit the context's workspace budget (mdvt_config.workspace_mib, default 4 GiB: 16 slots at
+            // 1080p, 4 at 3840 x 2160 -- where 16 would be 16 GB): per slot and pixel 16 B of z keys, 48 B of vertex records and
+            // colour side buffer, 32 B of triangle queue, with edge points 24 B of edge keys and their list, 3 B of filter flags
+            const size_t per_slot = (size_t)W * (size_t)H * (16 + 48 + 32 + (plan.edge_points ? 24 : 0) + (plan.remove_edges ? 3 : 0));
+            const size_t budget = (size_t)(c->cfg.workspace_mib ? c->cfg.workspace_mib : 4096u) << 20;
+            const size_t afford = budget / per_slot;
+            if ((size_t)ws_chunk > afford) ws_chunk = afford < 1 ? 1 : (int)afford;
         }
         // pure-shift mesh rows with edge removal: a launch is (frames x 135 bands) workgroups for 512 slots -- 8 frames
         // leave the chip 30 % idle in the last wave of workgroups (476 -> see DESIGN.md); the workspace is 11 B/px per frame
-        if (!r.general && plan.mode == MDVT_MODE_MESH) ws_chunk = 4 * kWorkspaceChunk;
+        // (points with edge removal likewise since r04: every launch set ends with k_edge_rows_exact, a handful of workgroups the
+        //  stream waits for -- once per 32 frames instead of once per 8)
+        if (!r.general) ws_chunk = 4 * kWorkspaceChunk;
         if (tuned_chunk) ws_chunk = tuned_chunk;
         if (r.general && ws_chunk > 32) ws_chunk = 32;        // one parity bit per z-key slot (uint32_t key_parity)
         return n < ws_chunk ? n : ws_chunk;
@@ -624,9 +660,9 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.seed[0] = io->left_seed; a.seed[1] = io->right_seed; a.seed_pitch = io->seed_pitch; a.seed_stride = io->seed_stride;
     if (io->hole_counts) {
         if (c->row_counts_frames < count_frames) {
-            if (c->row_counts) (void)hipFree(c->row_counts);
+            if (c->row_counts) ws_free(c, c->row_counts);
             c->row_counts = nullptr; c->row_counts_frames = 0;
-            MDVT_HIP(c, hipMalloc((void**)&c->row_counts, (size_t)count_frames * 2 * H * sizeof(uint32_t)));
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->row_counts, (size_t)count_frames * 2 * H * sizeof(uint32_t)));
             c->row_counts_frames = count_frames;
         }
         a.row_counts = c->row_counts;
@@ -721,6 +757,14 @@ int mdvt_encode_depth(mdvt_ctx* c, const float* d_depth, size_t depth_pitch, uin
     if (!(max_depth > 0.0)) return fail(c, MDVT_ERR_INVALID_ARG, "max_depth must be > 0");
     DeviceGuard g(c->device);
     MDVT_HIP(c, launch_encode_depth(d_depth, depth_pitch, d_rgb, rgb_pitch, c->W, c->H, max_depth, bgr, (hipStream_t)stream));
+    return MDVT_OK;
+}
+
+int mdvt_workspace_bytes(mdvt_ctx* c, uint64_t* bytes)
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!bytes) return fail(c, MDVT_ERR_INVALID_ARG, "NULL argument");
+    *bytes = (uint64_t)c->ws_bytes;
     return MDVT_OK;
 }
 
@@ -916,9 +960,9 @@ static int ensure_ni_workspace(mdvt_ctx* c, int chunk)
 {
     if (c->ni_images >= chunk) return MDVT_OK;
     MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
-    if (c->ni_ws) (void)hipFree(c->ni_ws);
+    if (c->ni_ws) ws_free(c, c->ni_ws);
     c->ni_ws = nullptr; c->ni_images = 0;
-    MDVT_HIP(c, hipMalloc((void**)&c->ni_ws, mdvt::normal_infill_workspace_bytes(chunk, c->W, c->H)));
+    MDVT_HIP(c, ws_malloc(c, (void**)&c->ni_ws, mdvt::normal_infill_workspace_bytes(chunk, c->W, c->H)));
     c->ni_images = chunk;
     return MDVT_OK;
 }
@@ -1003,14 +1047,14 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
         const int rounds = max_rounds > c->telea_rounds ? max_rounds : c->telea_rounds;
         free_telea(c);
         mdvt::TeleaWorkspace& w = c->telea;
-        MDVT_HIP(c, hipMalloc((void**)&w.stamp, (size_t)images * npx * sizeof(uint16_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.T, (size_t)images * npx * sizeof(float)));
-        MDVT_HIP(c, hipMalloc((void**)&w.img, (size_t)images * npx * 3 + 4));      // + 4: pixels are fetched as unaligned dwords
-        MDVT_HIP(c, hipMalloc((void**)&w.need, (size_t)images * npx));
-        MDVT_HIP(c, hipMalloc((void**)&w.nlist, (size_t)images * npx * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.counts, mdvt::telea_counter_words(rounds) * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.remaining, (size_t)kTeleaChunk * sizeof(uint32_t)));
-        MDVT_HIP(c, hipMalloc((void**)&w.last_round, (size_t)kTeleaChunk * sizeof(uint32_t)));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.stamp, (size_t)images * npx * sizeof(uint16_t)));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.T, (size_t)images * npx * sizeof(float)));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.img, (size_t)images * npx * 3 + 4));      // + 4: pixels are fetched as unaligned dwords
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.need, (size_t)images * npx));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.nlist, (size_t)images * npx * sizeof(uint32_t)));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.counts, mdvt::telea_counter_words(rounds) * sizeof(uint32_t)));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.remaining, (size_t)kTeleaChunk * sizeof(uint32_t)));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.last_round, (size_t)kTeleaChunk * sizeof(uint32_t)));
         c->telea_images = images; c->telea_rounds = rounds;
     }
     c->telea.offs = c->telea.counts + (max_rounds + 2);
@@ -1018,7 +1062,7 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
     if (!c->telea_levels_host) {
         void *h = nullptr, *d = nullptr;
         size_t got = 0;
-        MDVT_HIP(c, pool_take(64, false, &h, &d, &got));          // pinned, from the process-wide pool (see pool_take)
+        MDVT_HIP(c, pool_take(64, false, -1, &h, &d, &got));          // pinned, from the process-wide pool (see pool_take)
         c->telea_levels_host = (uint32_t*)h;
     }
     const uint32_t key = (uint32_t)c->cfg.key_rgb[0] | ((uint32_t)c->cfg.key_rgb[1] << 8) | ((uint32_t)c->cfg.key_rgb[2] << 16);

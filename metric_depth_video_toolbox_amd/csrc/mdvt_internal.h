@@ -10,6 +10,15 @@
 
 namespace mdvt {
 
+// Tuning / ablation / test hooks.  The PRODUCT library (libmdvt_hip.so) has none: tuning_env() is `return nullptr` there
+// (mdvt_tuning_off.hip) and not even the hooks' names are in the binary; its one opt-in switch, MDVT_MESH_CONV, is read
+// once, in mdvt_create.  `make tuning` links the same objects with mdvt_tuning_on.hip into libmdvt_hip_tuning.so, where
+// tuning_env(TUNE_X) is getenv("MDVT_X"), re-read per launch: that library is what tools/ and the tests that force a kernel
+// family load (MDVT_LIB_VARIANT=tuning, _lib.py).  Some hooks change results by design (MDVT_DEBUG_SKIP bits 0-4, MDVT_NI_SKIP).
+enum TuneKey { TUNE_BLUR_ONE_PASS, TUNE_DEBUG_SKIP, TUNE_FORCE_GLOBAL, TUNE_LDS_PAD, TUNE_MESH_BAND, TUNE_MESH_CONV, TUNE_MESH_OLD, TUNE_MESH_TPB, TUNE_NI_DUMP, TUNE_NI_SKIP, TUNE_PARAM_UPLOAD, TUNE_POINTS_CFG, TUNE_POINTS_NT, TUNE_RASTER_CONV_OFF, TUNE_TELEA_BLOCKS, TUNE_TELEA_DUMP, TUNE_WS_CHUNK, TUNE_COUNT };
+const char* tuning_env(TuneKey k);
+bool tuning_build();
+
 // Near plane of the reference's render call: ctr.set_constant_z_near(0.0001) (dmt:1520).
 constexpr float kNear = 1e-4f;
 // Rasteriser sub-pixel grid and the clamp applied before snapping (DESIGN.md "Arithmetic decree").
@@ -103,6 +112,7 @@ struct RenderPlan {
     int vec4;            // W%4==0 and every pointer/pitch 4-byte aligned
     int fused_bits;      // set by launch_render when the render kernel itself produced maskbits / hole_counts
     int n;               // frames in this launch
+    int allow_conv;      // MDVT_MESH_CONV=1 when the context was created (mdvt_create): k_mesh_conv may take convergence-only frames
     int edge_rows_max;   // pure-shift launches with edge points: the most scanlines any frame leaves to k_edge_rows_exact (0: none)
 };
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);

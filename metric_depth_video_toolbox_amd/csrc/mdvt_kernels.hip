@@ -328,7 +328,7 @@ __device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[
 // loads are all issued before the LDS clear, so 2*ITERS 768-byte wave loads are in flight per wave
 // while the z-buffer is initialised.  ITERS == 0: plain strided loop (any W).
 template <int PX, int FLAGS, int TPB, int ITERS>
-__global__ void __launch_bounds__(TPB) k_points_rows(RenderArgs a)
+__global__ void __launch_bounds__(TPB, ((FLAGS & 5) == 4) ? 6 : 1) k_points_rows(RenderArgs a)
 {
     constexpr bool ZOUT = FLAGS & 1, UNUSED = FLAGS & 2, EDGE = FLAGS & 4, SEED = FLAGS & 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2342,11 +2342,11 @@ hipError_t launch_telea_rounds(const TeleaWorkspace& ws, int W, int H, int level
     // both passes wait on memory, not on arithmetic (PMC: `need` spends 90 % of its wave cycles waiting): a grid large enough
     // for one entry per thread takes 7.1 -> 5.8 ms off a 32-image pass compared with 512 workgroups looping
     int nb = 2048;
-    if (const char* e = getenv("MDVT_TELEA_BLOCKS")) { const int v = atoi(e); if (v > 0) nb = (v + 7) & ~7; }      // tuning hook (a multiple of 8: XCDs)
+    if (const char* e = tuning_env(TUNE_TELEA_BLOCKS)) { const int v = atoi(e); if (v > 0) nb = (v + 7) & ~7; }      // tuning hook (a multiple of 8: XCDs)
     const dim3 grid(nb), block(256);
     for (int r = levels; r >= 2; --r) hipLaunchKernelGGL(k_telea_need, grid, block, 0, s, a, (uint32_t)r);
     for (int r = 1; r <= levels; ++r) hipLaunchKernelGGL(k_telea_fill, dim3(4 * nb), block, 0, s, a, (uint32_t)r);
-    if (getenv("MDVT_TELEA_DUMP")) {         // tuning hook: level sizes / needed pixels of this pass on stderr
+    if (tuning_env(TUNE_TELEA_DUMP)) {         // tuning hook: level sizes / needed pixels of this pass on stderr
         std::vector<uint32_t> c(levels + 2), nc((size_t)(levels + 2) * kNcStride);
         hipError_t e = hipStreamSynchronize(s);
         if (e == hipSuccess) e = hipMemcpy(c.data(), ws.counts, c.size() * 4, hipMemcpyDeviceToHost);
@@ -2362,7 +2362,7 @@ hipError_t launch_masked_blur(const ImageSet& img, const ImageSet* seed, const I
 {
     const dim3 grid((W + 255) / 256, H, n), block(256);
     const ImageSet none{nullptr, 0, 0, 0, 1};
-    if (list && count && getenv("MDVT_BLUR_ONE_PASS") == nullptr) {          // list: n * W * H entries, count: n * H row counters
+    if (list && count && tuning_env(TUNE_BLUR_ONE_PASS) == nullptr) {          // list: n * W * H entries, count: n * H row counters
         hipError_t e = hipMemsetAsync(count, 0, (size_t)n * H * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
         auto dwords = [](const ImageSet& i) { return !i.base || (((uintptr_t)i.base | i.pitch | i.stride | (size_t)i.eye_offset) & 3) == 0; };
@@ -2457,7 +2457,7 @@ static hipError_t launch_points_rows_cfg(const RenderPlan& plan, const RenderArg
 // templated kernel with that geometry instead of the defaults.  Re-read on every launch.
 static int points_cfg_override()
 {
-    const char* e = getenv("MDVT_POINTS_CFG");
+    const char* e = tuning_env(TUNE_POINTS_CFG);
     int t = 0, it = 0;
     if (e && sscanf(e, "%dx%d", &t, &it) == 2) return t * 16 + it;
     return 0;
@@ -2471,7 +2471,7 @@ static hipError_t launch_points_rows_fast_cfg(const RenderPlan& plan, const Rend
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)k_points_rows_fast<TPB, ZOUT, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (!ZOUT && !BITS && lds <= 48 * 1024) {       // tuning hook (tools/kbench.py --env MDVT_POINTS_NT): 0 = temporal loads and stores
-        const char* e = getenv("MDVT_POINTS_NT");
+        const char* e = tuning_env(TUNE_POINTS_NT);
         if (e && *e) {
             const int nt = atoi(e);
             if (nt == 0) { hipLaunchKernelGGL((k_points_rows_fast<TPB, false, false, 0>), grid, block, lds, s, a); return hipGetLastError(); }
@@ -2568,7 +2568,7 @@ template <int PX>
 static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
     RenderArgs a = a_in;
-    if (const char* e = getenv("MDVT_DEBUG_SKIP")) a.debug_skip = atoi(e);
+    if (const char* e = tuning_env(TUNE_DEBUG_SKIP)) a.debug_skip = atoi(e);
     const size_t lds = render_lds_bytes(plan, a.W);
     if (lds > kMaxLds) return hipErrorNotSupported;         // W > ~4300 with edge points (5120 without)
     const bool vrgb = lds == 2 * (size_t)a.W * 16 + (size_t)a.W * 8 + (plan.edge_points ? (size_t)a.W * 4 + 2 * (size_t)a.W + 16 : 0) +
@@ -2576,7 +2576,7 @@ static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a_i
     // two 512-thread workgroups per CU when two fit in the 160 KB LDS, otherwise one 1024-thread workgroup:
     // either way 16 waves per CU
     int tpb = (2 * lds <= kMaxLds) ? 512 : 1024;
-    if (const char* e = getenv("MDVT_MESH_TPB")) tpb = atoi(e);
+    if (const char* e = tuning_env(TUNE_MESH_TPB)) tpb = atoi(e);
     if (tpb == 1024) return launch_mesh_rows_tpb<PX, 1024>(plan, a, lds, vrgb, s);
     return launch_mesh_rows_tpb<PX, 512>(plan, a, lds, vrgb, s);
 }
@@ -2597,7 +2597,7 @@ hipError_t launch_edge_points_splat(const RenderArgs& a, int n, hipStream_t s)
 static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
     RenderArgs a = a_in;
-    if (const char* e = getenv("MDVT_DEBUG_SKIP")) a.debug_skip = atoi(e);
+    if (const char* e = tuning_env(TUNE_DEBUG_SKIP)) a.debug_skip = atoi(e);
     const bool edge = plan.remove_edges && plan.edge_points;
     hipError_t e;
     const dim3 grid_v((a.W + 255) / 256, a.H, plan.n);
@@ -2620,7 +2620,7 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
 // and paints them where the render left a hole (sr:776, 813-814), after the row kernel wrote the scanline.  One workgroup
 // per (frame, scanline of the range, eye); W x 8 B of LDS.
 template <bool MESH>
-__global__ void __launch_bounds__(256) k_edge_rows_exact(RenderArgs a, int rows_max)
+__global__ void __launch_bounds__(1024) k_edge_rows_exact(RenderArgs a, int rows_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* ek = (u64*)smem;
@@ -2632,14 +2632,14 @@ __global__ void __launch_bounds__(256) k_edge_rows_exact(RenderArgs a, int rows_
     if (fp.erow_lo >= fp.erow_hi) return;
     const int y = fp.erow_lo + r;
     if (y > fp.erow_hi || y >= H) return;
-    for (int x = tid; x < W; x += 256) ek[x] = kEmpty64;
+    for (int x = tid; x < W; x += 1024) ek[x] = kEmpty64;
     __syncthreads();
     const uint8_t* dbase = a.depth + (size_t)f * a.depth_stride;
     for (int si = y - 1; si <= y; ++si) {
         if (si < 0) continue;
         const uint8_t* urow = a.unused + (size_t)fr * a.ws_stride_px + (size_t)si * W;
         const uint8_t* drow = dbase + (size_t)si * a.depth_pitch;
-        for (int j = tid; j < W; j += 256) {
+        for (int j = tid; j < W; j += 1024) {
             if (!urow[j]) continue;
             const uint32_t code = code16_of(load_px_bytes(drow, j));
             const float z = decode_z(code, fp.mult, fp.scale);
@@ -2652,7 +2652,7 @@ __global__ void __launch_bounds__(256) k_edge_rows_exact(RenderArgs a, int rows_
     __syncthreads();
     const uint8_t* mrow = a.mask[eye] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch;
     uint8_t* orow = a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)y * a.rgb_pitch;
-    for (int x = tid; x < W; x += 256) {
+    for (int x = tid; x < W; x += 1024) {
         const u64 k = ek[x];
         if (k == kEmpty64 || !mrow[x]) continue;
         const int sj = (int)(k & 0xFFFFu), si = y - 1 + (int)((k >> 16) & 1u);
@@ -2665,7 +2665,7 @@ __global__ void __launch_bounds__(256) k_edge_rows_exact(RenderArgs a, int rows_
 static hipError_t launch_edge_rows_exact(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     if (!(plan.remove_edges && plan.edge_points) || plan.edge_rows_max <= 0) return hipSuccess;
-    const dim3 grid((unsigned)(plan.n * plan.edge_rows_max), 2u), block(256);
+    const dim3 grid((unsigned)(plan.n * plan.edge_rows_max), 2u), block(1024);
     const size_t lds = (size_t)a.W * sizeof(u64);
     if (plan.mode == MDVT_MODE_MESH) hipLaunchKernelGGL(k_edge_rows_exact<true>, grid, block, lds, s, a, plan.edge_rows_max);
     else hipLaunchKernelGGL(k_edge_rows_exact<false>, grid, block, lds, s, a, plan.edge_rows_max);
@@ -2683,7 +2683,7 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
     if (plan.conv) return launch_mesh_conv(plan, a, s);
     if (plan.general) return launch_mesh_general(plan, a, s);
     hipError_t e;
-    if (mesh_band_supported(plan, a) && getenv("MDVT_MESH_OLD") == nullptr) e = launch_mesh_band(plan, a, s);
+    if (mesh_band_supported(plan, a) && tuning_env(TUNE_MESH_OLD) == nullptr) e = launch_mesh_band(plan, a, s);
     else e = plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);
     return e != hipSuccess ? e : launch_edge_rows_exact(plan, a, s);
 }

@@ -504,7 +504,7 @@ template <int TPB>
 static hipError_t launch_mesh_band_tpb(const RenderPlan& plan, const RenderArgs& a, int rows, hipStream_t s)
 {
     size_t lds = mesh_band_lds_bytes(a.W, TPB, plan.remove_edges, plan.edge_points);
-    if (const char* e = getenv("MDVT_LDS_PAD")) lds += (size_t)atoi(e);      // occupancy probe (tools/kbench.py)
+    if (const char* e = tuning_env(TUNE_LDS_PAD)) lds += (size_t)atoi(e);      // occupancy probe (tools/kbench.py)
     const int nbands = (a.H + rows - 1) / rows;
     const dim3 grid((unsigned)(plan.n * nbands)), block(TPB);
     const bool zout = a.zout[0] || a.zout[1];
@@ -527,9 +527,9 @@ static hipError_t launch_mesh_band_tpb(const RenderPlan& plan, const RenderArgs&
 hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
     RenderArgs a = a_in;
-    if (const char* e = getenv("MDVT_DEBUG_SKIP")) a.debug_skip = atoi(e);
+    if (const char* e = tuning_env(TUNE_DEBUG_SKIP)) a.debug_skip = atoi(e);
     int rows = 8;
-    if (const char* e = getenv("MDVT_MESH_BAND")) { const int v = atoi(e); if (v > 0) rows = v; }     // tuning hook
+    if (const char* e = tuning_env(TUNE_MESH_BAND)) { const int v = atoi(e); if (v > 0) rows = v; }     // tuning hook
     if (rows > a.H) rows = a.H;
     if (mesh_band_tpb(plan, a.W) == 512) return launch_mesh_band_tpb<512>(plan, a, rows, s);
     return launch_mesh_band_tpb<1024>(plan, a, rows, s);

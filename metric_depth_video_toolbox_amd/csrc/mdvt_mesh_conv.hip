@@ -630,8 +630,7 @@ bool mesh_conv_supported(const RenderPlan& plan, const RenderArgs& a)
     // frame where the general path moves 438, but it is VALU bound like the general rasteriser and only draws level with it
     // without edge removal (89.7 against 91.7 us per frame) and loses with it (the product default: 123 against 91 us per
     // frame): the general vertex programme runs once per eye AND per band here.  The general path stays the default.
-    const char* on = getenv("MDVT_MESH_CONV");
-    if (!(on && on[0] == '1')) return false;
+    if (!plan.allow_conv) return false;
     if (a.W < 8 || a.W > 4096 || a.H < 2) return false;
     return mesh_conv_lds_bytes(a.W, mesh_conv_tpb(a.W)) <= 160 * 1024;
 }
@@ -662,9 +661,9 @@ static hipError_t launch_mesh_conv_tpb(const RenderPlan& plan, const RenderArgs&
 hipError_t launch_mesh_conv(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
     RenderArgs a = a_in;
-    if (const char* e = getenv("MDVT_DEBUG_SKIP")) a.debug_skip = atoi(e);
+    if (const char* e = tuning_env(TUNE_DEBUG_SKIP)) a.debug_skip = atoi(e);
     int rows = 16;
-    if (const char* e = getenv("MDVT_MESH_BAND")) { const int v = atoi(e); if (v > 0) rows = v; }     // tuning hook
+    if (const char* e = tuning_env(TUNE_MESH_BAND)) { const int v = atoi(e); if (v > 0) rows = v; }     // tuning hook
     if (rows > a.H) rows = a.H;
     hipError_t e;
     const bool edge = plan.remove_edges && plan.edge_points;

@@ -386,7 +386,7 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
     if (e != hipSuccess) return e;
     const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
     // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
-    if (plan.conv_raster && getenv("MDVT_RASTER_CONV_OFF") == nullptr) {
+    if (plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr) {
         if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_c, dim3(128), 0, s, a);
         else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_c, dim3(128), 0, s, a);
     } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2>), grid_c, dim3(128), 0, s, a);

@@ -765,7 +765,7 @@ hipError_t launch_normal_infill(const ImageSet& img, const ImageSet& mask, const
     a.bg = zero_end;
     a.filled = a.bg + (size_t)n * npx;
     a.debug_skip = 0;
-    if (const char* ev = getenv("MDVT_NI_SKIP")) a.debug_skip = atoi(ev);
+    if (const char* ev = tuning_env(TUNE_NI_SKIP)) a.debug_skip = atoi(ev);
     hipError_t e = hipMemsetAsync(a.count, 0, (size_t)(zero_end - (uint8_t*)a.count), s);
     if (e != hipSuccess) return e;
     auto dwords = [](const ImageSet& i) { return (((uintptr_t)i.base | i.pitch | i.stride) & 3) == 0; };
@@ -785,7 +785,7 @@ hipError_t launch_normal_infill(const ImageSet& img, const ImageSet& mask, const
     hipLaunchKernelGGL(k_ni_collect<1>, tiles, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_ni_run<3>, lanes, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_ni_run<4>, lanes, dim3(256), 0, s, a);
-    if (getenv("MDVT_NI_DUMP")) {            // tuning hook: list sizes of this call on stderr
+    if (tuning_env(TUNE_NI_DUMP)) {            // tuning hook: list sizes of this call on stderr
         std::vector<uint32_t> c((size_t)n * 4 * kNSub);
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         if ((e = hipMemcpy(c.data(), a.count, c.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess) return e;

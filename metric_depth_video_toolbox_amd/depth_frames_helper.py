@@ -14,7 +14,8 @@ _ctx_cache = {}
 
 
 def _ctx(device_index: int, W: int, H: int):
-    key = (device_index, W, H)
+    import os
+    key = (device_index, W, H, os.environ.get("MDVT_LIB_VARIANT", ""))      # a context belongs to the library that made it
     if key not in _ctx_cache:
         _ctx_cache[key] = _lib.Context(device_index, W, H)
     return _ctx_cache[key]

@@ -282,6 +282,7 @@ class StereoRerenderer:
       remove_edges / infill_mask / do_basic_infill   turn the 89-degree edge filter on (sr:568-570)
       dont_remove_edges                              overrides the above (sr:572-573)
       dont_place_points_in_edges                     no edge points (sr:589)
+      workspace_mib                                  budget for the posed / converged mesh path's workspace (mdvt.h; 0 = 4096 MiB)
       cull                                           0 draw both faces of the mesh (default), 1 cull back faces, 2 front faces
                                                      (dmt:1507-1556 leaves Open3D's mesh_show_back_face at its default)
     """
@@ -289,7 +290,8 @@ class StereoRerenderer:
     def __init__(self, width: int, height: int, *, device: Optional[int] = None, pupillary_distance=63,
                  max_depth=100, master_xfov: float = 45.0, render_as_pointcloud: bool = False,
                  remove_edges: bool = False, infill_mask: bool = False, do_basic_infill: bool = False,
-                 dont_remove_edges: bool = False, dont_place_points_in_edges: bool = False, cull: int = 0):
+                 dont_remove_edges: bool = False, dont_place_points_in_edges: bool = False, cull: int = 0,
+                 workspace_mib: int = 0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no ROCm GPU visible: the stereo-rerender path has no CPU fallback")
@@ -313,6 +315,7 @@ class StereoRerenderer:
         cfg.remove_edges = int(self.remove_edges)
         cfg.edge_points = (2 if self.do_basic_infill else 1) if self.edge_points else 0
         cfg.cull = int(cull)
+        cfg.workspace_mib = int(workspace_mib)                             # 0: the library's default (4096)
         self.cull = int(cull)
         cfg.ipd_m = self.pupillary_distance / 1000                         # sr:458-459
         cfg.max_depth = float(self.max_depth)

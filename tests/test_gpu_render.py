@@ -205,6 +205,7 @@ def test_mesh_convergence_only_band_kernel(mods, orc, W, H, flags, monkeypatch):
     instead of the global-key kernels' round trips.  Several toe-in angles in one batch (incl. one too strong for the kernel,
     which the host sends down the general path), depth planes and seed images; then the same batch without MDVT_MESH_CONV=1
     (general path for every frame) must give the same bytes."""
+    monkeypatch.setenv("MDVT_LIB_VARIANT", "tuning")          # the hooks below exist in the tuning build only (csrc/mdvt_internal.h)
     _lib, sr, synthetic = mods
     monkeypatch.setenv("MDVT_MESH_CONV", "1")                # the kernel is opt-in (it does not beat the general path: profiles/r03_conv_band.md)
     convs = [2.5, 8.0, 1.2, 0.9, 0.25]
@@ -239,6 +240,7 @@ def test_mesh_convergence_band_kernel_on_hard_scenes(mods, orc, monkeypatch, ker
     rasteriser for such frames) on what stresses their special cases: the contention band of C4 (hundreds of cells folded onto a few
     pixels: exact depth ties, stretched cells, twisted cells), alternating near / far columns, sub-millimetre and zero depths
     (near plane), face culling, a toe-in just inside the kernel's admission bound, and forced tie passes."""
+    monkeypatch.setenv("MDVT_LIB_VARIANT", "tuning")          # the hooks below exist in the tuning build only (csrc/mdvt_internal.h)
     from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
     _lib, sr, synthetic = mods
     if kernel == "k_mesh_conv":
@@ -309,6 +311,7 @@ def test_mesh_face_culling(mods, orc, cull, variant, monkeypatch):
     """mdvt_config.cull: Open3D's legacy mesh_show_back_face defaults to off and dmt:1507-1556 never sets it; whether that
     means GL_CULL_FACE cannot be observed here, so both candidates exist.  The grid's own winding is the front face:
     culling back faces removes the fold-over triangles of the rubber sheet, culling front faces leaves only those."""
+    monkeypatch.setenv("MDVT_LIB_VARIANT", "tuning")          # the hooks below exist in the tuning build only (csrc/mdvt_internal.h)
     _lib, sr, synthetic = mods
     W, H = (250, 61) if variant == "rows_odd_width" else (256, 64)
     depth_rgb, color = _scene(synthetic, W, H, seed=90 + cull)
@@ -338,6 +341,7 @@ def test_exact_depth_ties_follow_the_draw_order(mods, orc, monkeypatch):
     the global-key kernels (draw id in the z-buffer word, colour recomputed from it).  MDVT_DEBUG_SKIP=32 additionally
     makes the row kernels treat every pixel that received a second fragment as tied, so the extra passes run on every
     fold: the images must not change."""
+    monkeypatch.setenv("MDVT_LIB_VARIANT", "tuning")          # the hooks below exist in the tuning build only (csrc/mdvt_internal.h)
     from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
     _lib, sr, synthetic = mods
     ties = 0
@@ -511,6 +515,7 @@ def test_extreme_frame_shapes(mods, orc, W, H):
 def test_global_key_kernels_keep_the_pure_shift_arithmetic(mods, orc, monkeypatch):
     """MDVT_FORCE_GLOBAL=1 routes pure-shift frames through the kernels of the general path (as too-wide frames are);
     the frame's arithmetic is its own, so every plane still equals the oracle's pure-shift evaluation."""
+    monkeypatch.setenv("MDVT_LIB_VARIANT", "tuning")          # the hooks below exist in the tuning build only (csrc/mdvt_internal.h)
     _lib, sr, synthetic = mods
     monkeypatch.setenv("MDVT_FORCE_GLOBAL", "1")
     for W, H in ((250, 37), (64, 48)):
@@ -1101,6 +1106,7 @@ def test_finish_infill_mask_with_a_starved_grid(mods, orc, monkeypatch, blocks):
     """The level passes of the completion with 1 / 3 workgroups (MDVT_TELEA_BLOCKS, re-read per call): every workgroup then
     loops over many list entries and marks far more pixels per target level than its LDS stage holds, so the direct
     append path, the multi-iteration loops and appends racing between workgroups all run -- same bits as the oracle."""
+    monkeypatch.setenv("MDVT_LIB_VARIANT", "tuning")          # the hooks below exist in the tuning build only (csrc/mdvt_internal.h)
     _lib, sr, synthetic = mods
     monkeypatch.setenv("MDVT_TELEA_BLOCKS", blocks)
     W, H = 320, 180
@@ -1308,3 +1314,48 @@ def test_hip_against_reference_renders(mods):
             d = np.abs(sbs[:, sl].astype(int) - g[eye + "_rgb"].astype(int))[keep]
             assert d.max(initial=0) <= 1, f"{f} {eye}: RGB differs by up to {d.max()} LSB from the reference render"
         r.close()
+
+
+def test_general_mesh_workspace_follows_the_budget_and_the_chunk_submitted(mods):
+    """The posed / converged mesh path owns ~125 B per pixel and frame in flight (z keys, vertex records, colour side buffer,
+    triangle queue, edge keys).  It is sized by what is submitted -- one frame: one slot -- and by mdvt_config.workspace_mib:
+    with a 1 GiB budget a 16-frame 1080p batch of the product default stays under 1 GiB (4 frames per launch set instead of
+    16) and renders the same bytes as with the default budget (16 slots, 4 GB)."""
+    _lib, sr, synthetic = mods
+    W, H, N = 1920, 1080, 16
+    d, c = synthetic.SyntheticScene(W, H, config_id=2).clip(N)
+    d, c = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    outs, sizes = [], []
+    for mib in (1024, 0):
+        r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True, workspace_mib=mib)
+        ps = [r.frame_params(xfov=45.0, convergence_distance=2.5) for _ in range(N)]
+        r.render(d[:1], c[:1], ps[:1])
+        torch.cuda.synchronize()
+        one = r.ctx.workspace_bytes()
+        assert one < 300 << 20, f"a single 1080p frame allocated {one >> 20} MiB"
+        got = r.render(d, c, ps, want_seed=True)
+        torch.cuda.synchronize()
+        sizes.append(r.ctx.workspace_bytes())
+        outs.append({k: v.clone() for k, v in got.items()})
+        r.close()
+    assert sizes[0] <= (1024 << 20) + (8 << 20), f"{sizes[0] >> 20} MiB with a 1 GiB budget"
+    assert sizes[1] > 3 * sizes[0]
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_contexts_on_two_gpus_do_not_share_parameter_blocks(mods, orc):
+    """the process-wide pool of pinned + device parameter blocks hands a block back only to a context on the GPU its
+    device half was allocated on.  create / render / destroy on GPU 0, then create / render on GPU 1, then GPU 0 again."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _lib, sr, synthetic = mods
+    W, H = 96, 64
+    depth_rgb, color = _scene(synthetic, W, H, seed=7)
+    for dev in (0, 1, 0, 1):
+        with torch.cuda.device(dev):
+            r = sr.StereoRerenderer(W, H, device=dev, pupillary_distance=65)
+            p = r.frame_params(xfov=45.0)
+            got = r.render(torch.from_numpy(depth_rgb).cuda(dev), torch.from_numpy(color).cuda(dev), p, want_depth=True)
+            _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"device {dev}")
+            r.close()

@@ -281,3 +281,23 @@ def test_basic_nomal_infill_list_files(tmp_path):
         bni.pairs_from_arguments(str(tmp_path / "c.txt"), str(tmp_path / "m1.txt"))
     with pytest.raises(Exception, match="does not exist"):
         bni.process_pair(str(tmp_path / "missing.npy"), str(tmp_path / "m.txt"))
+
+
+def test_the_product_library_has_no_tuning_hooks():
+    """the ablation / tuning hooks (MDVT_DEBUG_SKIP, MDVT_NI_SKIP, MDVT_LDS_PAD, MDVT_MESH_OLD, ...) exist in
+    libmdvt_hip_tuning.so only; libmdvt_hip.so carries none of their names -- its one switch, MDVT_MESH_CONV, is read once at
+    mdvt_create -- and both libraries export every symbol of include/mdvt.h."""
+    import ctypes
+    from metric_depth_video_toolbox_amd import _lib
+    hooks = [b"MDVT_DEBUG_SKIP", b"MDVT_NI_SKIP", b"MDVT_LDS_PAD", b"MDVT_MESH_OLD", b"MDVT_MESH_BAND", b"MDVT_MESH_TPB",
+             b"MDVT_POINTS_CFG", b"MDVT_POINTS_NT", b"MDVT_WS_CHUNK", b"MDVT_TELEA_BLOCKS", b"MDVT_TELEA_DUMP", b"MDVT_NI_DUMP",
+             b"MDVT_BLUR_ONE_PASS", b"MDVT_FORCE_GLOBAL", b"MDVT_RASTER_CONV_OFF", b"MDVT_PARAM_UPLOAD"]
+    product = open(_lib.lib_path(), "rb").read()
+    tuning = open(_lib.lib_path("tuning"), "rb").read()
+    for h in hooks:
+        assert h not in product, f"{h.decode()} is in the product library"
+        assert h in tuning
+    assert b"MDVT_MESH_CONV" in product
+    L = ctypes.CDLL(_lib.lib_path("tuning"))
+    for sym in _lib.SYMBOLS:
+        assert hasattr(L, sym)

@@ -2,6 +2,7 @@
 """In-process A/B timing of kernel configurations (env MDVT_POINTS_CFG is re-read per launch).
 usage: python tools/kbench.py cfgA cfgB ... [--rounds R] [--calls C] [--mode points|mesh]"""
 import os, sys, argparse, statistics
+os.environ.setdefault("MDVT_LIB_VARIANT", "tuning")      # the hooks this tool drives live in the tuning build (csrc/mdvt_internal.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 if os.environ.get('KB_DIST'):
