@@ -86,6 +86,9 @@ def test_bench_line_under_torchrun_with_one_rank():
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "weak" and line["roofline"]["bound"] == "hbm"
     assert line["extra"]["clip_c3"]["frames"] == 12 and line["extra"]["clip_c3"]["scaling"] == "strong"
     assert "mesh" in line["extra"] and "product_default" in line["extra"]
+    for k in ("c4_4k_pose_points", "c4_4k_pose_mesh", "c5_model_hop"):       # BASELINE configs[3] and [4] ride on the N = 1 line
+        assert k in line["extra"] and line["extra"][k]["fps"] > 0, line["extra"].get("c4_error") or line["extra"].get("c5_error")
+    assert line["extra"]["c4_4k_pose_mesh"]["frames_per_launch"] == 8 and 0 < line["extra"]["c5_model_hop"]["render_share"] < 0.5
 
 
 def test_bench_line_with_two_ranks_sharing_the_gpu():
@@ -115,6 +118,36 @@ def test_bench_line_with_two_ranks_sharing_the_gpu():
     assert ex["clip_c3"]["frames"] == 30 and ex["clip_c3"]["n_gpus"] == 2 and ex["clip_c3"]["scaling"] == "strong"
     assert ex["clip_c3_long"]["frames"] == 90 and ex["clip_c3_long"]["repeats"] == 3 and ex["clip_c3_long"]["n_gpus"] == 2
     assert "mesh" not in ex                               # the N = 1 extras stay at N = 1
+
+
+def test_bench_line_with_eight_ranks_sharing_the_gpu():
+    """The width the driver's SCALE run uses, before it does: the driver's launch line with EIGHT ranks (gloo, all on cuda:0).
+    One line from rank 0, n_gpus == 8 with eight device names, the weak-scaling value counts all eight ranks' frames, both
+    strong-scaling clips split their frames eight ways (clip_c3_long is the entry to read for the >= 6x criterion), and the
+    host-side setup time of every rank is on the line and on stderr."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MDVT_DIST_BACKEND="gloo", MDVT_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--frames", "4", "--prewarm-ms", "0", "--clip-frames", "40", "--clip-repeats", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and len(line["config"]["devices"]) == 8 and line["scaling"] == "weak"
+    assert abs(line["value"] - 8 * 4 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
+    assert len(line["config"]["setup_seconds_per_rank"]) == 8 and "host-side setup per rank" in p.stderr
+    ex = line["extra"]
+    assert ex["clip_c3"]["frames"] == 40 and ex["clip_c3"]["n_gpus"] == 8 and "clip_c3_long" in ex["clip_c3"]["note"]
+    assert ex["clip_c3_long"]["frames"] == 80 and ex["clip_c3_long"]["n_gpus"] == 8 and ex["clip_c3_long"]["scaling"] == "strong"
+    assert "mesh" not in ex and "c4_4k_pose_mesh" not in ex
+    # a 40-frame clip over 8 ranks is 5 frames each: contiguous, complete, disjoint
+    from metric_depth_video_toolbox_amd import distributed as D
+    ranges = [D.frame_range(r, 8, 40) for r in range(8)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == 40 and all(ranges[k][1] == ranges[k + 1][0] for k in range(7))
 
 
 @pytest.mark.parametrize("variant", ["points", "product_default"])
