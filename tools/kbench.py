@@ -26,6 +26,7 @@ ap.add_argument("--infill", action="store_true")
 ap.add_argument("--zout", action="store_true")
 ap.add_argument("--conv", type=float, default=None)
 ap.add_argument("--pose", action="store_true")
+ap.add_argument("--c4", action="store_true", help="BASELINE configs[3] as bench.py's extra.c4_* runs it: scene 4 + contention band + frames 40, 70, ... of the pose track (use with --width 3840 --height 2160 --frames 8)")
 ap.add_argument("--bits", action="store_true")
 ap.add_argument("--counts", action="store_true")
 ap.add_argument("--edges", action="store_true", help="remove_edges without --infill_mask (edge points painted, no seed image)")
@@ -44,6 +45,17 @@ else:
     r = StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=not a.mesh, infill_mask=a.infill, remove_edges=a.edges or a.infill, dont_place_points_in_edges=a.noedgepts)
 from metric_depth_video_toolbox_amd.synthetic import synthetic_pose_track
 Ts = synthetic_pose_track(N) if a.pose else [None] * N
+if a.c4:
+    from metric_depth_video_toolbox_amd.synthetic import contention_band, quantise_depth_to_rgb
+    from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
+    sc4, K4, NH = SyntheticScene(W, H, config_id=4), compute_camera_matrix(45.0, None, W, H), min(4, N)
+    for t in range(NH):
+        d[t] = torch.from_numpy(quantise_depth_to_rgb(contention_band(sc4.depth_m(t), K4[0, 0], 0.065, row0=H // 2 - 32 + 8 * t, rows=64))).cuda()
+        c[t] = torch.from_numpy(sc4.frame(t)[1]).cuda()
+    for k in range(NH, N):
+        d[k] = torch.roll(d[k % NH], shifts=(16 * (k // NH), 24 * (k // NH)), dims=(0, 1))
+        c[k] = torch.roll(c[k % NH], shifts=(16 * (k // NH), 24 * (k // NH)), dims=(0, 1))
+    Ts = list(synthetic_pose_track(40 + 30 * N)[40:40 + N * 30:30])
 p = [r.frame_params(xfov=45.0, convergence_distance=a.conv, transformation=Ts[k]) for k in range(N)]
 sbs = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device="cuda")
 mask = torch.empty((N, H, 2 * W), dtype=torch.uint8, device="cuda")
