@@ -15,7 +15,7 @@ namespace mdvt {
 // once, in mdvt_create.  `make tuning` links the same objects with mdvt_tuning_on.hip into libmdvt_hip_tuning.so, where
 // tuning_env(TUNE_X) is getenv("MDVT_X"), re-read per launch: that library is what tools/ and the tests that force a kernel
 // family load (MDVT_LIB_VARIANT=tuning, _lib.py).  Some hooks change results by design (MDVT_DEBUG_SKIP bits 0-4, MDVT_NI_SKIP).
-enum TuneKey { TUNE_BLUR_ONE_PASS, TUNE_DEBUG_SKIP, TUNE_FORCE_GLOBAL, TUNE_LDS_PAD, TUNE_MESH_BAND, TUNE_MESH_CONV, TUNE_MESH_OLD, TUNE_MESH_TPB, TUNE_NI_DUMP, TUNE_NI_SKIP, TUNE_PARAM_UPLOAD, TUNE_POINTS_CFG, TUNE_POINTS_NT, TUNE_RASTER_CONV_OFF, TUNE_TELEA_BLOCKS, TUNE_TELEA_DUMP, TUNE_WS_CHUNK, TUNE_COUNT };
+enum TuneKey { TUNE_BLUR_ONE_PASS, TUNE_DEBUG_SKIP, TUNE_FORCE_GLOBAL, TUNE_LDS_PAD, TUNE_MESH_BAND, TUNE_MESH_BAND3, TUNE_MESH_CONV, TUNE_MESH_OLD, TUNE_MESH_TPB, TUNE_NI_DUMP, TUNE_NI_SKIP, TUNE_PARAM_UPLOAD, TUNE_POINTS_CFG, TUNE_POINTS_NT, TUNE_RASTER_CONV_OFF, TUNE_TELEA_BLOCKS, TUNE_TELEA_DUMP, TUNE_WS_CHUNK, TUNE_COUNT };
 const char* tuning_env(TuneKey k);
 bool tuning_build();
 
@@ -119,6 +119,9 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 // mdvt_mesh_band.hip: the pure-shift mesh rows as bands (no edge removal)
 bool mesh_band_supported(const RenderPlan& plan, const RenderArgs& a);
 hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+// mdvt_mesh_band3.hip: the same rows with no vertex records in LDS, both eyes per pass, three workgroups per CU
+bool mesh_band3_supported(const RenderPlan& plan, const RenderArgs& a);
+hipError_t launch_mesh_band3(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 // mdvt_mesh_conv.hip: mesh + convergence only, z-buffer in LDS (the product default of movie_2_3D.py:433-445)
 bool mesh_conv_supported(const RenderPlan& plan, const RenderArgs& a);
 hipError_t launch_mesh_conv(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);

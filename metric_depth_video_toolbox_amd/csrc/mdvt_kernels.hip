@@ -2683,7 +2683,11 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
     if (plan.conv) return launch_mesh_conv(plan, a, s);
     if (plan.general) return launch_mesh_general(plan, a, s);
     hipError_t e;
-    if (mesh_band_supported(plan, a) && tuning_env(TUNE_MESH_OLD) == nullptr) e = launch_mesh_band(plan, a, s);
+    // (tuning build: MDVT_MESH_BAND3=0 / 1 picks k_mesh_band / k_mesh_band3 for the A/B)
+    const char* b3 = tuning_env(TUNE_MESH_BAND3);
+    const bool band3 = b3 ? b3[0] == '1' : false;
+    if (band3 && mesh_band3_supported(plan, a) && tuning_env(TUNE_MESH_OLD) == nullptr) e = launch_mesh_band3(plan, a, s);
+    else if (mesh_band_supported(plan, a) && tuning_env(TUNE_MESH_OLD) == nullptr) e = launch_mesh_band(plan, a, s);
     else e = plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);
     return e != hipSuccess ? e : launch_edge_rows_exact(plan, a, s);
 }
