@@ -607,7 +607,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     general = (any_global || any_conv) ? 1 : 0;          // some run uses the global workspace
     const bool need_keys = any_global;
     const bool need_ekeys = general && plan.edge_points;
-    const bool need_gverts = (any_global || any_conv) && plan.mode == MDVT_MODE_MESH;      // (k_mesh_conv reads the vertex records too)
+    const bool need_gverts = any_global && plan.mode == MDVT_MODE_MESH;
     // frames per launch set.  Point splat, general: two frames keep the 64-bit key buffers (33 MB per 1080p frame)
     // inside the 256 MiB Infinity Cache between splat and resolve (measured +12 %); the mesh needs the slack of
     // eight (rows full of slivers leave a long tail), and the edge filter alone streams, so 8 as well.

@@ -2594,25 +2594,21 @@ hipError_t launch_edge_points_splat(const RenderArgs& a, int n, hipStream_t s)
     return hipGetLastError();
 }
 
-// every vertex of the launch set's frames projected once per eye into a.gverts (16-byte records)
-hipError_t launch_mesh_vertices_general(const RenderArgs& a, int n, hipStream_t s)
-{
-    const dim3 grid_v((a.W + 255) / 256, a.H, n);
-    // rows that are dword-addressable are staged through LDS as aligned dwords; the rest take byte loads
-    const bool aligned = (a.W % 4 == 0) && (a.depth_pitch % 4 == 0) && (a.color_pitch % 4 == 0) && (a.depth_stride % 4 == 0) &&
-                         (a.color_stride % 4 == 0) && ((uintptr_t)a.depth % 4 == 0) && ((uintptr_t)a.color % 4 == 0);
-    if (aligned) hipLaunchKernelGGL(k_mesh_vertices_general<true>, grid_v, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_mesh_vertices_general<false>, grid_v, dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
 static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
     RenderArgs a = a_in;
     if (const char* e = tuning_env(TUNE_DEBUG_SKIP)) a.debug_skip = atoi(e);
     const bool edge = plan.remove_edges && plan.edge_points;
     hipError_t e;
-    if ((e = launch_mesh_vertices_general(a, plan.n, s)) != hipSuccess) return e;
+    const dim3 grid_v((a.W + 255) / 256, a.H, plan.n);
+    {
+        // rows that are dword-addressable are staged through LDS as aligned dwords; the rest take byte loads
+        const bool aligned = (a.W % 4 == 0) && (a.depth_pitch % 4 == 0) && (a.color_pitch % 4 == 0) && (a.depth_stride % 4 == 0) &&
+                             (a.color_stride % 4 == 0) && ((uintptr_t)a.depth % 4 == 0) && ((uintptr_t)a.color % 4 == 0);
+        if (aligned) hipLaunchKernelGGL(k_mesh_vertices_general<true>, grid_v, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_mesh_vertices_general<false>, grid_v, dim3(256), 0, s, a);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = launch_mesh_raster_general(plan, a, s)) != hipSuccess) return e;
     if (edge && (e = launch_edge_points_splat(a, plan.n, s)) != hipSuccess) return e;
     return launch_resolve_general<true>(plan, a, s);

@@ -158,9 +158,7 @@ __device__ __forceinline__ void conv_exotic_cell(int XA, int YA, float izA, uint
 
 // FLAGS bit 0: depth planes; bit 1: triangles removed by the 89-degree filter draw nothing; bit 2: edge points (global edge
 // keys, posted by k_edge_points_splat4 before this kernel); bit 3: the infill-mask seed image (sr:787-803).
-// RECS (r04): the vertices come as the 16-byte records k_mesh_vertices_general wrote for this launch set (a.gverts) instead of
-// from the source frame through the vertex programme -- the programme then runs once per vertex and eye, not 1.19 x per band.
-template <int FLAGS, int TPB, bool RECS>
+template <int FLAGS, int TPB>
 __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per_band, int nbands)
 {
     constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4, SEED = FLAGS & 8;
@@ -196,25 +194,8 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     const uint8_t* tinv = EDGES ? a.tri_invalid + (size_t)fr * a.ws_stride_tri : nullptr;
 
-    const uint4* gv = RECS ? a.gverts[eye] + (size_t)fr * a.ws_stride_px : nullptr;
-    // a record of k_mesh_vertices_general as this kernel wants it: a vertex behind the near plane (1/Z' = 0) gets its analytic row
-    // as Y (conv_vertex), the colour word takes the cell's flags and the row's tag
-    auto from_record = [&](uint4 r, uint32_t cw_extra, int row, int col) -> int4 {
-        int Y = (int)r.y;
-        if (r.z == 0u) Y = snap((((float)row * fp.sy - fp.cy) * (fp.fyr / fp.fy)) / rz_of(fp, M, col) + fp.cyr);
-        return make_int4((int)r.x, Y, (int)r.z, (int)((r.w & 0xFFFFFFu) | cw_extra));
-    };
-    auto cell_flags = [&](int row, int col) -> uint32_t {
-        uint32_t cw = ((uint32_t)row & 31u) << 27;
-        if (EDGES && row <= H - 2 && col <= W - 2) {
-            const uint8_t* ti = tinv + (size_t)row * (W - 1) + col;
-            cw |= (ti[0] ? 1u << 24 : 0u) | (ti[ncell] ? 2u << 24 : 0u);
-        }
-        return cw;
-    };
     // the vertex (row, col) from the source frame
     auto vertex_at = [&](int row, int col) -> int4 {
-        if (RECS) return from_record(gv[(size_t)row * W + col], cell_flags(row, col), row, col);
         const uint32_t dpx = load_px_bytes(dbase + (size_t)row * a.depth_pitch, col);
         uint32_t cw = load_px_bytes(cbase + (size_t)row * a.color_pitch, col);
         if (EDGES && row <= H - 2 && col <= W - 2) {
@@ -262,7 +243,6 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
     // stage_to).
     // prefetch registers of column tid + q * TPB: depth pixel | 1 << 31 (valid), colour word incl. flags and the row's tag
     uint32_t pdx[4] = {0, 0, 0, 0}, pcw[4] = {0, 0, 0, 0};
-    uint32_t prx[RECS ? 4 : 1], pry[RECS ? 4 : 1];             // RECS: pdx holds the record's 1/Z' bits, prx / pry its X / Y, pcw bit 26 = valid
     auto column_state = [&](int col, int ib, int& arow, int& Ybot) {
         const int4 r0 = ring[col], r1 = ring[W + col];
         const bool t0 = r0.y < r1.y;
@@ -275,18 +255,11 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
         for (int q = 0; q < 4; ++q) {            // W <= 4 * TPB (launcher)
             const int col = tid + q * TPB;
             pdx[q] = 0u;
-            if (RECS) pcw[q] = 0u;
             if (col >= W) continue;
             int arow, Ybot;
             column_state(col, ib, arow, Ybot);
             if (!(Ybot <= Ycn && arow + 2 <= H - 1)) continue;
             const int row = arow + 2;
-            if (RECS) {
-                const uint4 r = gv[(size_t)row * W + col];
-                prx[q] = r.x; pry[q] = r.y; pdx[q] = r.z;
-                pcw[q] = (r.w & 0xFFFFFFu) | cell_flags(row, col) | (1u << 26);
-                continue;
-            }
             pdx[q] = load_px_bytes(dbase + (size_t)row * a.depth_pitch, col) | 0x80000000u;
             uint32_t cw = load_px_bytes(cbase + (size_t)row * a.color_pitch, col) | (((uint32_t)row & 31u) << 27);
             if (EDGES && row <= H - 2 && col <= W - 2) {
@@ -301,19 +274,6 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
         bool more = false;
         // (one copy of the vertex programme, four trips: unrolled, the four independent programmes cost 60 more VGPRs than the
         //  kernel has at four waves per SIMD)
-        if (RECS) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!(pcw[q] & (1u << 26))) continue;
-                const uint32_t cw = pcw[q] & ~(1u << 26);
-                const int row = ib + (int)(((cw >> 27) - (uint32_t)ib) & 31u);
-                const int col = tid + q * TPB;
-                const int4 rec = from_record(make_uint4(prx[q & (RECS ? 3 : 0)], pry[q & (RECS ? 3 : 0)], pdx[q], cw), cw & 0xFF000000u, row, col);
-                ring[(size_t)(row & 1) * W + col] = rec;
-                more |= rec.y <= Ycn && row + 1 <= H - 1;
-            }
-            return more;
-        }
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
             const uint32_t dpv = q == 0 ? pdx[0] : (q == 1 ? pdx[1] : (q == 2 ? pdx[2] : pdx[3]));
@@ -676,7 +636,7 @@ bool mesh_conv_supported(const RenderPlan& plan, const RenderArgs& a)
 }
 
 template <int TPB>
-static hipError_t launch_mesh_conv_tpb(const RenderPlan& plan, const RenderArgs& a, int rows, bool recs, hipStream_t s)
+static hipError_t launch_mesh_conv_tpb(const RenderPlan& plan, const RenderArgs& a, int rows, hipStream_t s)
 {
     const size_t lds = mesh_conv_lds_bytes(a.W, TPB);
     const int nbands = (a.H + rows - 1) / rows;
@@ -686,13 +646,8 @@ static hipError_t launch_mesh_conv_tpb(const RenderPlan& plan, const RenderArgs&
                       (plan.remove_edges && a.seed[0] ? 8 : 0);
 #define MDVT_CASE(F)                                                                                                        \
     case F:                                                                                                                 \
-        if (recs) {                                                                                                         \
-            (void)hipFuncSetAttribute((const void*)k_mesh_conv<F, TPB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL((k_mesh_conv<F, TPB, true>), grid, block, lds, s, a, rows, nbands);                               \
-        } else {                                                                                                            \
-            (void)hipFuncSetAttribute((const void*)k_mesh_conv<F, TPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL((k_mesh_conv<F, TPB, false>), grid, block, lds, s, a, rows, nbands);                              \
-        }                                                                                                                   \
+        (void)hipFuncSetAttribute((const void*)k_mesh_conv<F, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL((k_mesh_conv<F, TPB>), grid, block, lds, s, a, rows, nbands);                                   \
         break;
     switch (flags) {
         MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(2) MDVT_CASE(3) MDVT_CASE(6) MDVT_CASE(7)
@@ -713,11 +668,7 @@ hipError_t launch_mesh_conv(const RenderPlan& plan, const RenderArgs& a_in, hipS
     hipError_t e;
     const bool edge = plan.remove_edges && plan.edge_points;
     if (edge && (e = launch_edge_points_splat(a, plan.n, s)) != hipSuccess) return e;     // the edge keys this kernel's resolve reads
-    // (r04) the vertex programme once per vertex and eye, as 16-byte records; MDVT_CONV_RECS=0 (tuning build): per eye and band, from the source frame
-    const char* rv = tuning_env(TUNE_CONV_RECS);
-    const bool recs = a.gverts[0] != nullptr && !(rv && rv[0] == '0');
-    if (recs && (e = launch_mesh_vertices_general(a, plan.n, s)) != hipSuccess) return e;
-    e = mesh_conv_tpb(a.W) == 512 ? launch_mesh_conv_tpb<512>(plan, a, rows, recs, s) : launch_mesh_conv_tpb<1024>(plan, a, rows, recs, s);
+    e = mesh_conv_tpb(a.W) == 512 ? launch_mesh_conv_tpb<512>(plan, a, rows, s) : launch_mesh_conv_tpb<1024>(plan, a, rows, s);
     if (e != hipSuccess) return e;
     if (edge) return launch_edge_keys_reset(a, plan.n, s);
     return hipSuccess;
