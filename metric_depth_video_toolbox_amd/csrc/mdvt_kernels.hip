@@ -151,7 +151,93 @@ __device__ __forceinline__ int tri_oblique_screen(const double (&a)[3], const do
     return 2;
 }
 
-// One thread per grid cell: both triangles of the cell.  `unused` must be zeroed beforehand.
+// f32 pre-screen of the same test (r04), from the closed form of a triangle whose vertices are P_k = z_k (u_k, v_k, 1) on the
+// grid's rays u in {a, a + px}, v in {b, b + py}:  n = (P1 - P0) x (P2 - P0) and n . P_k = z0 z1 z2 det(r0, r1, r2) = -px py z0 z1 z2
+// for both triangles of a cell, so with s = P0 + P1 + P2 (the view vector is -s / 3)
+//     3 dot = -n . s = 3 px py z0 z1 z2 > 0,    tri1 (A, B, C): nx = py zA (zC - zB), ny = px zC (zB - zA),
+//                                               tri2 (A, C, D): nx = py zC (zD - zA), ny = px zA (zC - zD),
+//     nz = -(a nx + b ny) - px py z1 z2   (from n . P0),
+// and the test cos < cos 89 is  (3 dot)^2 < c0^2 |n|^2 |s|^2.  No difference of nearly equal PRODUCTS is left (the generic
+// cross product of the edge vectors cancels ~4 digits): every factor is an input or one f32 subtraction of inputs, |n|^2 and
+// |s|^2 are sums of squares, and nz's one cancellation is bounded by eps (|a nx| + |b ny| + ...) <= eps (|a| + |b| + 1) |n|.
+// With |a|, |b| <= 64 both sides are good to ~1e-5 relative in f32, the f64 formula of the reference's order differs from
+// the exact value by ~1e-15, its 1e-15 term moves the threshold by < 1e-7 when (3 |n||v|)^2 > 9e-16: a margin of 1e-3
+// decides the same way for sure.  The rest -- a fraction of a per cent of the triangles -- takes the f64 screen and, inside
+// its own margin, the exact formula.  returns 0 = valid, 1 = oblique (removed), 2 = undecided
+__device__ __forceinline__ int tri_oblique_screen_f32(float a, float b, float px, float py, float z0, float z1, float z2,
+                                                      float nx, float ny, float sx, float sy)
+{
+    const float pp = px * py;
+    const float nz = -((a * nx + b * ny) + (pp * z1) * z2);
+    const float sz = (z0 + z1) + z2;
+    const float nn = (nx * nx + ny * ny) + nz * nz;
+    const float ss = (sx * sx + sy * sy) + sz * sz;
+    const float d3 = 3.0f * (((pp * z0) * z1) * z2);
+    const float lhs = d3 * d3;
+    const float c0 = 0x1.1df0b2p-6f;                                    // cos 89 degrees (f32: 3e-8 relative, inside the margin)
+    const float rhs = (c0 * c0) * (nn * ss);
+    if (!(nn * ss > 1.0e-15f)) return 2;                                // degenerate / zero depth / tiny: the f64 paths
+    if (lhs < rhs * 0.999f) return 1;
+    if (lhs > rhs * 1.001f) return 0;
+    return 2;                                                           // (NaN / inf land here too)
+}
+
+// Both triangles of cell (i, j): bit 0 = tri1 (A, B, C) removed, bit 1 = tri2 (A, C, D) removed.  x0r.. are the cell's ray
+// coordinates (g - c) * (1 / f) in f64 (screening only; the exact path recomputes the vertices in the reference's own order).
+struct CellRaysF32 { float a, a1, b, b1, px, py; bool ok; };     // the f32 pre-screen's view of the cell's rays (ok: all within +-64)
+__device__ __forceinline__ CellRaysF32 cell_rays_f32(double x0r, double x1r, double y0r, double y1r)
+{
+    CellRaysF32 r;
+    r.a = (float)x0r; r.b = (float)y0r; r.a1 = (float)x1r; r.b1 = (float)y1r;
+    r.px = (float)(x1r - x0r); r.py = (float)(y1r - y0r);
+    r.ok = fabsf(r.a) <= 64.0f && fabsf(r.b) <= 64.0f && fabsf(r.a1) <= 64.0f && fabsf(r.b1) <= 64.0f;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t edge_filter_cell(const FrameDev& f, int i, int j, int of_by_one, double x0r, double x1r, double y0r,
+                                                     double y1r, const CellRaysF32& r, float zA, float zB, float zC, float zD)
+{
+    int s1 = 2, s2 = 2;
+    if (r.ok) {
+        // tri1 = (A, B, C) = rays (a, b), (a, b'), (a', b');  tri2 = (A, C, D) = (a, b), (a', b'), (a', b)
+        s1 = tri_oblique_screen_f32(r.a, r.b, r.px, r.py, zA, zB, zC, r.py * zA * (zC - zB), r.px * zC * (zB - zA),
+                                    r.a * (zA + zB) + r.a1 * zC, r.b * zA + r.b1 * (zB + zC));
+        s2 = tri_oblique_screen_f32(r.a, r.b, r.px, r.py, zA, zC, zD, r.py * zC * (zD - zA), r.px * zA * (zC - zD),
+                                    r.a * zA + r.a1 * (zC + zD), r.b * (zA + zD) + r.b1 * zC);
+    }
+    if (s1 == 2 || s2 == 2) {
+        asm volatile("; f64 screen" ::: "memory");
+        const double dA = (double)zA, dB = (double)zB, dC = (double)zC, dD = (double)zD;
+        const double A[3] = {x0r * dA, y0r * dA, dA};
+        const double B[3] = {x0r * dB, y1r * dB, dB};
+        const double Cc[3] = {x1r * dC, y1r * dC, dC};
+        const double D[3] = {x1r * dD, y0r * dD, dD};
+        if (s1 == 2) s1 = tri_oblique_screen(A, B, Cc);      // tri1 = (v[i,j], v[i+1,j], v[i+1,j+1])
+        if (s2 == 2) s2 = tri_oblique_screen(A, Cc, D);      // tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
+    }
+    if (s1 == 2 || s2 == 2) {
+        // exact path: the reference's own evaluation order (dmt:1127-1128, 1283-1294)
+        double Ae[3], Be[3], Ce[3], De[3];
+        vertex_f64(f, i, j, of_by_one, zA, Ae);
+        vertex_f64(f, i + 1, j, of_by_one, zB, Be);
+        vertex_f64(f, i + 1, j + 1, of_by_one, zC, Ce);
+        vertex_f64(f, i, j + 1, of_by_one, zD, De);
+        if (s1 == 2) s1 = tri_oblique(Ae, Be, Ce) ? 1 : 0;
+        if (s2 == 2) s2 = tri_oblique(Ae, Ce, De) ? 1 : 0;
+    }
+    return (s1 == 1 ? 1u : 0u) | (s2 == 1 ? 2u : 0u);
+}
+
+__device__ __forceinline__ void edge_filter_mark_unused(uint8_t* u, int W, int i, int j, uint32_t inv)
+{
+    const size_t a = (size_t)i * W + j;
+    u[a] = 1;                          // A
+    u[a + W + 1] = 1;                  // C
+    if (inv & 1u) u[a + W] = 1;        // B
+    if (inv & 2u) u[a + 1] = 1;        // D
+}
+
+// One thread per grid cell: both triangles of the cell.  `unused` must be zeroed beforehand.  (Any width / alignment.)
 // NOTE f.sx / f.sy hold the mesh grid scale only when the frame was prepared for mesh mode; the host
 // passes scale factors explicitly so the filter can be run standalone for either grid.
 __global__ void __launch_bounds__(128) k_edge_filter(const uint8_t* __restrict__ depth_rgb, size_t pitch, size_t stride,
@@ -166,7 +252,6 @@ __global__ void __launch_bounds__(128) k_edge_filter(const uint8_t* __restrict__
     if (j >= W - 1 || i >= H - 1) return;
     const uint8_t* r0 = depth_rgb + (size_t)(frame0 + fr) * stride + (size_t)i * pitch;
     const uint8_t* r1 = r0 + pitch;
-    // (byte loads: the kernel is bound by f64 arithmetic; staging the rows through LDS made it 10 % slower)
     const uint32_t pA = load_px_bytes(r0, j), pD = load_px_bytes(r0, j + 1);
     const uint32_t pB = load_px_bytes(r1, j), pC = load_px_bytes(r1, j + 1);
     FrameDev f = fp[frame0 + fr];
@@ -182,38 +267,91 @@ __global__ void __launch_bounds__(128) k_edge_filter(const uint8_t* __restrict__
     const double y0 = (of_by_one ? (double)((float)i * f.sy) : (double)i) - f.Kd[3];
     const double y1 = (of_by_one ? (double)((float)(i + 1) * f.sy) : (double)(i + 1)) - f.Kd[3];
     const double x0r = x0 * rfx, x1r = x1 * rfx, y0r = y0 * rfy, y1r = y1 * rfy;
-    const double dA = (double)zA, dB = (double)zB, dC = (double)zC, dD = (double)zD;
-    const double A[3] = {x0r * dA, y0r * dA, dA};
-    const double B[3] = {x0r * dB, y1r * dB, dB};
-    const double Cc[3] = {x1r * dC, y1r * dC, dC};
-    const double D[3] = {x1r * dD, y0r * dD, dD};
-    int s1 = tri_oblique_screen(A, B, Cc);      // tri1 = (v[i,j], v[i+1,j], v[i+1,j+1])
-    int s2 = tri_oblique_screen(A, Cc, D);      // tri2 = (v[i,j], v[i+1,j+1], v[i,j+1])
-    if (s1 == 2 || s2 == 2) {
-        // exact path: the reference's own evaluation order (dmt:1127-1128, 1283-1294)
-        double Ae[3], Be[3], Ce[3], De[3];
-        vertex_f64(f, i, j, of_by_one, zA, Ae);
-        vertex_f64(f, i + 1, j, of_by_one, zB, Be);
-        vertex_f64(f, i + 1, j + 1, of_by_one, zC, Ce);
-        vertex_f64(f, i, j + 1, of_by_one, zD, De);
-        if (s1 == 2) s1 = tri_oblique(Ae, Be, Ce) ? 1 : 0;
-        if (s2 == 2) s2 = tri_oblique(Ae, Ce, De) ? 1 : 0;
-    }
-    const bool inv1 = s1 == 1, inv2 = s2 == 1;
+    const uint32_t inv = edge_filter_cell(f, i, j, of_by_one, x0r, x1r, y0r, y1r, cell_rays_f32(x0r, x1r, y0r, y1r), zA, zB, zC, zD);
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     const size_t cell = (size_t)i * (W - 1) + j;
     if (tri_invalid) {
         uint8_t* t = tri_invalid + (size_t)fr * tri_stride;
-        t[cell] = inv1;
-        t[ncell + cell] = inv2;
+        t[cell] = inv & 1u;
+        t[ncell + cell] = (inv >> 1) & 1u;
     }
-    if (unused && (inv1 || inv2)) {
+    if (unused && inv) edge_filter_mark_unused(unused + (size_t)fr * unused_stride, W, i, j, inv);
+}
+
+// The same for dword-addressable rows (W % 4 == 0, 4-byte aligned base / pitch / stride): a thread takes FOUR cells of a
+// row -- five pixels of two rows as 2 x 4 dwords instead of 2 x 10 byte loads, the eight validity bytes as two dword stores.
+// (r04: with the f32 pre-screen no f64 instruction runs on ordinary content, and the one-cell kernel turned out to be bound
+// by its byte accesses, not by the f64 rate its design assumed: 10.4 -> see DESIGN.md us per 1080p frame.)
+typedef uint32_t u32_unaligned_t __attribute__((aligned(1)));
+__global__ void __launch_bounds__(128) k_edge_filter4(const uint8_t* __restrict__ depth_rgb, size_t pitch, size_t stride,
+                              const FrameDev* __restrict__ fp, int frame0, int W, int H, int of_by_one,
+                              float sx, float sy,
+                              uint8_t* __restrict__ tri_invalid, size_t tri_stride,
+                              uint8_t* __restrict__ unused, size_t unused_stride)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    const int fr = blockIdx.z;
+    const int j0 = 4 * g;
+    if (j0 >= W - 1 || i >= H - 1) return;
+    const uint32_t* r0 = (const uint32_t*)(depth_rgb + (size_t)(frame0 + fr) * stride + (size_t)i * pitch) + 3 * g;
+    const uint32_t* r1 = (const uint32_t*)((const uint8_t*)r0 + pitch);
+    const bool five = j0 + 4 < W;                          // (the last group of a row has no fifth pixel -- and no fourth cell)
+    uint32_t p0[5], p1[5];
+    unpack4(r0[0], r0[1], r0[2], *(uint32_t(*)[4])p0);
+    unpack4(r1[0], r1[1], r1[2], *(uint32_t(*)[4])p1);
+    p0[4] = five ? r0[3] & 0xFFFFFFu : 0u;
+    p1[4] = five ? r1[3] & 0xFFFFFFu : 0u;
+    FrameDev f = fp[frame0 + fr];
+    f.sx = sx; f.sy = sy;
+    float z0[5], z1[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        z0[q] = decode_z(code16_of(p0[q]), f.mult, f.scale);
+        z1[q] = decode_z(code16_of(p1[q]), f.mult, f.scale);
+    }
+    const double rfx = f.rKd[0], rfy = f.rKd[1];
+    const double y0r = ((of_by_one ? (double)((float)i * f.sy) : (double)i) - f.Kd[3]) * rfy;
+    const double y1r = ((of_by_one ? (double)((float)(i + 1) * f.sy) : (double)(i + 1)) - f.Kd[3]) * rfy;
+    double xr[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) xr[q] = ((of_by_one ? (double)((float)(j0 + q) * f.sx) : (double)(j0 + q)) - f.Kd[2]) * rfx;
+    const int ncells = five ? 4 : 3;
+    float fx[5];
+    const float fb = (float)y0r, fb1 = (float)y1r, fpy = (float)(y1r - y0r);
+    bool rays_ok = fabsf(fb) <= 64.0f && fabsf(fb1) <= 64.0f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { fx[q] = (float)xr[q]; rays_ok = rays_ok && fabsf(fx[q]) <= 64.0f; }
+    uint32_t w1 = 0, w2 = 0, any = 0;
+    uint32_t inv[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < ncells) {
+            CellRaysF32 r;
+            r.a = fx[q]; r.a1 = fx[q + 1]; r.b = fb; r.b1 = fb1; r.px = (float)(xr[q + 1] - xr[q]); r.py = fpy;
+            r.ok = rays_ok;
+            inv[q] = edge_filter_cell(f, i, j0 + q, of_by_one, xr[q], xr[q + 1], y0r, y1r, r, z0[q], z1[q], z1[q + 1], z0[q + 1]);
+        }
+        w1 |= (inv[q] & 1u) << (8 * q);
+        w2 |= ((inv[q] >> 1) & 1u) << (8 * q);
+        any |= inv[q];
+    }
+    const size_t ncell = (size_t)(W - 1) * (H - 1);
+    const size_t cell = (size_t)i * (W - 1) + j0;
+    if (tri_invalid) {
+        uint8_t* t = tri_invalid + (size_t)fr * tri_stride;
+        if (five) {
+            *(u32_unaligned_t*)(t + cell) = w1;
+            *(u32_unaligned_t*)(t + ncell + cell) = w2;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { t[cell + q] = (w1 >> (8 * q)) & 1u; t[ncell + cell + q] = (w2 >> (8 * q)) & 1u; }
+        }
+    }
+    if (unused && any) {
         uint8_t* u = unused + (size_t)fr * unused_stride;
-        const size_t a = (size_t)i * W + j;
-        u[a] = 1;                      // A
-        u[a + W + 1] = 1;              // C
-        if (inv1) u[a + W] = 1;        // B
-        if (inv2) u[a + 1] = 1;        // D
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (inv[q]) edge_filter_mark_unused(u, W, i, j0 + q, inv[q]);
     }
 }
 
@@ -223,9 +361,16 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
 {
     const float sx = of_by_one ? (float)(((double)W + 1.0) / (double)W) : 1.0f;
     const float sy = of_by_one ? (float)(((double)H + 1.0) / (double)H) : 1.0f;
-    dim3 grid((W - 1 + 127) / 128, H - 1, n);
-    hipLaunchKernelGGL(k_edge_filter, grid, dim3(128), 0, s, depth_rgb, pitch, stride, fp, frame0, W, H, of_by_one,
-                       sx, sy, tri_invalid, tri_stride, unused, unused_stride);
+    const bool dwords = W % 4 == 0 && W >= 8 && pitch % 4 == 0 && stride % 4 == 0 && ((uintptr_t)depth_rgb % 4) == 0;
+    if (dwords) {
+        dim3 grid((W / 4 + 127) / 128, H - 1, n);
+        hipLaunchKernelGGL(k_edge_filter4, grid, dim3(128), 0, s, depth_rgb, pitch, stride, fp, frame0, W, H, of_by_one,
+                           sx, sy, tri_invalid, tri_stride, unused, unused_stride);
+    } else {
+        dim3 grid((W - 1 + 127) / 128, H - 1, n);
+        hipLaunchKernelGGL(k_edge_filter, grid, dim3(128), 0, s, depth_rgb, pitch, stride, fp, frame0, W, H, of_by_one,
+                           sx, sy, tri_invalid, tri_stride, unused, unused_stride);
+    }
     return hipGetLastError();
 }
 

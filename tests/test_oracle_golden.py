@@ -554,3 +554,17 @@ def test_normal_infill_golden(orc, golden, scene):
     got = orc.blur_under_mask(img, g[f"{scene}_bum_mask"])
     assert np.abs(got.astype(int) - g[f"{scene}_bum_out"].astype(int)).max() <= 1
     assert np.array_equal(got[~g[f"{scene}_bum_mask"]], img[~g[f"{scene}_bum_mask"]])
+
+
+def test_level_order_downstream_of_the_infill_mask_trip_wire(orc):
+    """VERDICT r03 item 5b, as a loose trip wire (the numbers live in profiles/r04_infill_order_downstream.md, produced by
+    tests/report_infill_order_downstream.py at 1080p): finishing a product-default infill mask in the device's level order instead
+    of cv2.inpaint's sequential order turns the (r, g) direction of a hole pixel by well under 2 degrees in the median and a
+    few degrees at the 90th percentile; the infilled image changes in hole pixels (and their blur band) only."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import report_infill_order_downstream as rep
+    rows = rep.one_frame(480, 270, 2, 0, 2.5) + rep.one_frame(480, 270, 2, 0, 0.0)
+    for r in rows:
+        assert r["holes"] > 3000
+        assert r["a50"] < 2.0 and r["a90"] < 15.0, r
+        assert r["px_diff"] < 0.08 and r["px_diff_holes"] < 0.85, r
