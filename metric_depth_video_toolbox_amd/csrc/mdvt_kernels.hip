@@ -164,26 +164,23 @@ __device__ __forceinline__ int tri_oblique_screen(const double (&a)[3], const do
 // the exact value by ~1e-15, its 1e-15 term moves the threshold by < 1e-7 when (3 |n||v|)^2 > 9e-16: a margin of 1e-3
 // decides the same way for sure.  The rest -- a fraction of a per cent of the triangles -- takes the f64 screen and, inside
 // its own margin, the exact formula.  returns 0 = valid, 1 = oblique (removed), 2 = undecided
-__device__ __forceinline__ int tri_oblique_screen_f32(float a, float b, float px, float py, float z0, float z1, float z2,
-                                                      float nx, float ny, float sx, float sy)
+__device__ __forceinline__ int tri_oblique_screen_f32(float a, float b, float pp, float z0, float t12 /* pp z1 z2 */,
+                                                      float nx, float ny, float sx, float sy, float sz)
 {
-    const float pp = px * py;
-    const float nz = -((a * nx + b * ny) + (pp * z1) * z2);
-    const float sz = (z0 + z1) + z2;
-    const float nn = (nx * nx + ny * ny) + nz * nz;
-    const float ss = (sx * sx + sy * sy) + sz * sz;
-    const float d3 = 3.0f * (((pp * z0) * z1) * z2);
+    // (explicit fused multiply-adds: the screen only has to be accurate, not bit-identical to anything)
+    const float nz = -__builtin_fmaf(a, nx, __builtin_fmaf(b, ny, t12));
+    const float nn = __builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx));
+    const float ss = __builtin_fmaf(sz, sz, __builtin_fmaf(sy, sy, sx * sx));
+    const float d3 = (3.0f * z0) * t12;
     const float lhs = d3 * d3;
-    const float c0 = 0x1.1df0b2p-6f;                                    // cos 89 degrees (f32: 3e-8 relative, inside the margin)
-    const float rhs = (c0 * c0) * (nn * ss);
-    if (!(nn * ss > 1.0e-15f)) return 2;                                // degenerate / zero depth / tiny: the f64 paths
+    const float nnss = nn * ss;
+    const float rhs = 0x1.3f61d0p-12f * nnss;                           // cos^2 89 degrees (f32: 6e-8 relative, inside the margin)
+    if (!(nnss > 1.0e-15f)) return 2;                                   // degenerate / zero depth / tiny: the f64 paths
     if (lhs < rhs * 0.999f) return 1;
     if (lhs > rhs * 1.001f) return 0;
     return 2;                                                           // (NaN / inf land here too)
 }
 
-// Both triangles of cell (i, j): bit 0 = tri1 (A, B, C) removed, bit 1 = tri2 (A, C, D) removed.  x0r.. are the cell's ray
-// coordinates (g - c) * (1 / f) in f64 (screening only; the exact path recomputes the vertices in the reference's own order).
 struct CellRaysF32 { float a, a1, b, b1, px, py; bool ok; };     // the f32 pre-screen's view of the cell's rays (ok: all within +-64)
 __device__ __forceinline__ CellRaysF32 cell_rays_f32(double x0r, double x1r, double y0r, double y1r)
 {
@@ -194,17 +191,26 @@ __device__ __forceinline__ CellRaysF32 cell_rays_f32(double x0r, double x1r, dou
     return r;
 }
 
-__device__ __forceinline__ uint32_t edge_filter_cell(const FrameDev& f, int i, int j, int of_by_one, double x0r, double x1r, double y0r,
-                                                     double y1r, const CellRaysF32& r, float zA, float zB, float zC, float zD)
+// f32 pre-screen of both triangles of a cell: s1 | s2 << 2, each 0 = valid, 1 = oblique (removed), 2 = undecided
+__device__ __forceinline__ uint32_t edge_filter_prescreen(const CellRaysF32& r, float zA, float zB, float zC, float zD)
 {
-    int s1 = 2, s2 = 2;
-    if (r.ok) {
-        // tri1 = (A, B, C) = rays (a, b), (a, b'), (a', b');  tri2 = (A, C, D) = (a, b), (a', b'), (a', b)
-        s1 = tri_oblique_screen_f32(r.a, r.b, r.px, r.py, zA, zB, zC, r.py * zA * (zC - zB), r.px * zC * (zB - zA),
-                                    r.a * (zA + zB) + r.a1 * zC, r.b * zA + r.b1 * (zB + zC));
-        s2 = tri_oblique_screen_f32(r.a, r.b, r.px, r.py, zA, zC, zD, r.py * zC * (zD - zA), r.px * zA * (zC - zD),
-                                    r.a * zA + r.a1 * (zC + zD), r.b * (zA + zD) + r.b1 * zC);
-    }
+    if (!r.ok) return 2u | (2u << 2);
+    // tri1 = (A, B, C) = rays (a, b), (a, b'), (a', b');  tri2 = (A, C, D) = (a, b), (a', b'), (a', b)
+    const float pp = r.px * r.py;
+    const int s1 = tri_oblique_screen_f32(r.a, r.b, pp, zA, (pp * zB) * zC, (r.py * zA) * (zC - zB), (r.px * zC) * (zB - zA),
+                                          __builtin_fmaf(r.a1, zC, r.a * (zA + zB)), __builtin_fmaf(r.b1, zB + zC, r.b * zA), (zA + zB) + zC);
+    const int s2 = tri_oblique_screen_f32(r.a, r.b, pp, zA, (pp * zC) * zD, (r.py * zC) * (zD - zA), (r.px * zA) * (zC - zD),
+                                          __builtin_fmaf(r.a1, zC + zD, r.a * zA), __builtin_fmaf(r.b1, zC, r.b * (zA + zD)), (zA + zC) + zD);
+    return (uint32_t)s1 | ((uint32_t)s2 << 2);
+}
+
+// Both triangles of cell (i, j): bit 0 = tri1 (A, B, C) removed, bit 1 = tri2 (A, C, D) removed.  `pre` = edge_filter_prescreen's
+// verdict; x0r.. are the cell's ray coordinates (g - c) * (1 / f) in f64 (the f64 screen; the exact path recomputes the vertices
+// in the reference's own order).
+__device__ __forceinline__ uint32_t edge_filter_cell(const FrameDev& f, int i, int j, int of_by_one, double x0r, double x1r, double y0r,
+                                                     double y1r, uint32_t pre, float zA, float zB, float zC, float zD)
+{
+    int s1 = (int)(pre & 3u), s2 = (int)(pre >> 2);
     if (s1 == 2 || s2 == 2) {
         asm volatile("; f64 screen" ::: "memory");
         const double dA = (double)zA, dB = (double)zB, dC = (double)zC, dD = (double)zD;
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(128) k_edge_filter(const uint8_t* __restrict__
     const double y0 = (of_by_one ? (double)((float)i * f.sy) : (double)i) - f.Kd[3];
     const double y1 = (of_by_one ? (double)((float)(i + 1) * f.sy) : (double)(i + 1)) - f.Kd[3];
     const double x0r = x0 * rfx, x1r = x1 * rfx, y0r = y0 * rfy, y1r = y1 * rfy;
-    const uint32_t inv = edge_filter_cell(f, i, j, of_by_one, x0r, x1r, y0r, y1r, cell_rays_f32(x0r, x1r, y0r, y1r), zA, zB, zC, zD);
+    const uint32_t inv = edge_filter_cell(f, i, j, of_by_one, x0r, x1r, y0r, y1r, edge_filter_prescreen(cell_rays_f32(x0r, x1r, y0r, y1r), zA, zB, zC, zD), zA, zB, zC, zD);
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     const size_t cell = (size_t)i * (W - 1) + j;
     if (tri_invalid) {
@@ -323,15 +329,27 @@ __global__ void __launch_bounds__(128) k_edge_filter4(const uint8_t* __restrict_
 #pragma unroll
     for (int q = 0; q < 5; ++q) { fx[q] = (float)xr[q]; rays_ok = rays_ok && fabsf(fx[q]) <= 64.0f; }
     uint32_t w1 = 0, w2 = 0, any = 0;
-    uint32_t inv[4] = {0, 0, 0, 0};
+    uint32_t inv[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
+    // all eight triangles through the f32 pre-screen first (straight-line code); the f64 paths behind ONE branch
+    uint32_t und = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (q < ncells) {
             CellRaysF32 r;
             r.a = fx[q]; r.a1 = fx[q + 1]; r.b = fb; r.b1 = fb1; r.px = (float)(xr[q + 1] - xr[q]); r.py = fpy;
             r.ok = rays_ok;
-            inv[q] = edge_filter_cell(f, i, j0 + q, of_by_one, xr[q], xr[q + 1], y0r, y1r, r, z0[q], z1[q], z1[q + 1], z0[q + 1]);
+            pre[q] = edge_filter_prescreen(r, z0[q], z1[q], z1[q + 1], z0[q + 1]);
         }
+        und |= pre[q] & 0xAu;                                // (a 2 in either field)
+        inv[q] = (pre[q] & 1u) | ((pre[q] >> 1) & 2u);       // decided: 1 -> removed
+    }
+    if (und) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (pre[q] & 0xAu) inv[q] = edge_filter_cell(f, i, j0 + q, of_by_one, xr[q], xr[q + 1], y0r, y1r, pre[q], z0[q], z1[q], z1[q + 1], z0[q + 1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
         w1 |= (inv[q] & 1u) << (8 * q);
         w2 |= ((inv[q] >> 1) & 1u) << (8 * q);
         any |= inv[q];
