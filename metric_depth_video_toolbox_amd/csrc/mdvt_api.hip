@@ -379,7 +379,7 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         if (nfq > nf) nfq = nf;
         const size_t cap = nfq * npx * 4;
         c->bigq_cap = (uint32_t)cap;
-        MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 1) * sizeof(uint32_t)));   // entries, counters, prefix sums
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 2 + 2 * (size_t)mdvt::kHugeCap + 2) * sizeof(uint32_t)));   // entries, counters, prefix sums; row blocks of huge triangles + their counter
         c->ws_gverts = true;
     }
     if (need_edges && !c->ws_edges) {
@@ -681,6 +681,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.tri_invalid = c->tri_invalid; a.unused = c->unused;
     if (c->bigq) {
         a.bigq = c->bigq; a.bigq_cap = c->bigq_cap; a.bigq_count = c->bigq + (size_t)c->bigq_cap * mdvt::kBigRecDwords;
+        a.hugeq = a.bigq_count + 2 * (size_t)c->ws_frames * H + 2;      // (8-byte aligned: entries are uint2)
     }
     a.ws_stride_px = (size_t)W * H;
     a.ws_stride_tri = 2 * (size_t)(W - 1) * (H - 1);

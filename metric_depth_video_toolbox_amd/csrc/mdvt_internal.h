@@ -15,7 +15,7 @@ namespace mdvt {
 // once, in mdvt_create.  `make tuning` links the same objects with mdvt_tuning_on.hip into libmdvt_hip_tuning.so, where
 // tuning_env(TUNE_X) is getenv("MDVT_X"), re-read per launch: that library is what tools/ and the tests that force a kernel
 // family load (MDVT_LIB_VARIANT=tuning, _lib.py).  Some hooks change results by design (MDVT_DEBUG_SKIP bits 0-4, MDVT_NI_SKIP).
-enum TuneKey { TUNE_BLUR_ONE_PASS, TUNE_DEBUG_SKIP, TUNE_FORCE_GLOBAL, TUNE_LDS_PAD, TUNE_MESH_BAND, TUNE_MESH_BAND3, TUNE_MESH_CONV, TUNE_MESH_OLD, TUNE_MESH_TPB, TUNE_NI_DUMP, TUNE_NI_SKIP, TUNE_PARAM_UPLOAD, TUNE_POINTS_CFG, TUNE_POINTS_NT, TUNE_RASTER_CONV_OFF, TUNE_TELEA_BLOCKS, TUNE_TELEA_DUMP, TUNE_WS_CHUNK, TUNE_COUNT };
+enum TuneKey { TUNE_BLUR_ONE_PASS, TUNE_DEBUG_SKIP, TUNE_FORCE_GLOBAL, TUNE_LDS_PAD, TUNE_MESH_BAND, TUNE_MESH_BAND3, TUNE_MESH_CONV, TUNE_MESH_OLD, TUNE_MESH_TPB, TUNE_NI_DUMP, TUNE_NI_SKIP, TUNE_PARAM_UPLOAD, TUNE_POINTS_CFG, TUNE_POINTS_NT, TUNE_QUEUE_DUMP, TUNE_RASTER_CONV_OFF, TUNE_TELEA_BLOCKS, TUNE_TELEA_DUMP, TUNE_WS_CHUNK, TUNE_COUNT };
 const char* tuning_env(TuneKey k);
 bool tuning_build();
 
@@ -83,6 +83,7 @@ struct RenderArgs {
     uint8_t* unused;             // [slot][H*W]
     // general mesh path: queue of the triangles that are not small (kBigRecDwords dwords each), rasterised by k_mesh_raster_queue
     uint32_t* bigq; uint32_t* bigq_count; uint32_t bigq_cap;
+    uint32_t* hugeq;             // [kHugeCap] x 2 dwords + counter + overflow slack: row blocks of the queued triangles too large for 16 lanes (k_mesh_raster_huge)
     size_t ws_stride_px;         // H*W (elements) between slots
     size_t ws_stride_tri;        // 2*(H-1)*(W-1)
     int32_t edge_paint;          // 1: edge points are painted into the holes (sr:813-814); 0: seed image only (--do_basic_infill, sr:809-812)
@@ -100,6 +101,7 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
                               int n, int W, int H, int of_by_one, uint8_t* tri_invalid, size_t tri_stride,
                               uint8_t* unused, size_t unused_stride, hipStream_t s);
 
+constexpr int kHugeCap = 1 << 17;     // row-block entries of huge triangles per launch set (overflow: the queue kernel keeps the triangle)
 constexpr int kBigRecDwords = 2;     // a queued triangle: draw id, frame slot << 1 | eye
 
 struct RenderPlan {

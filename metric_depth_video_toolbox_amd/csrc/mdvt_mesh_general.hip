@@ -15,11 +15,14 @@
 // atomics per frame on one address (150 us per 1080p frame when the rubber sheet is not filtered out) -- and every
 // segment holds all four triangles of every cell of its row, so nothing can overflow.
 #include "mdvt_device.h"
+#include <stdio.h>
 
 namespace mdvt {
 
 namespace {
 
+constexpr int kHugeArea = 8192;    // pixel centres in the box of a queued triangle above which its rows are dealt over the chip
+constexpr int kHugeRows = 16;      // rows per entry of the huge list
 constexpr int kSmallBox = 12;      // pixel centres in the bounding box of a triangle the owning lane walks itself
 
 __device__ __forceinline__ void mesh_global_fragment(u64* keys, u64* cbuf, uint32_t parity, size_t o, float q0, float q1, float q2,
@@ -366,15 +369,120 @@ __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nse
         int px0 = floordiv_subpix(t.minX - kSubpix / 2 + kSubpix - 1), px1 = floordiv_subpix(t.maxX - kSubpix / 2);
         int py0 = floordiv_subpix(t.minY - kSubpix / 2 + kSubpix - 1), py1 = floordiv_subpix(t.maxY - kSubpix / 2);
         px0 = max(px0, 0); py0 = max(py0, 0); px1 = min(px1, W - 1); py1 = min(py1, H - 1);
+        // A triangle that COVERS more than kHugeArea pixels (a cell the camera has almost walked into: its vertices project far
+        // outside the frame) is not for 16 lanes.  Its rows go, in blocks of kHugeRows, to the list k_mesh_raster_huge deals over
+        // the whole chip, a wave per block.
+        if ((t.area2 >> 17) > (i64)kHugeArea && (i64)(px1 - px0 + 1) * (py1 - py0 + 1) > (i64)kHugeArea && px1 >= px0 && py1 >= py0) {
+            const uint32_t nblk = (uint32_t)(py1 - py0) / kHugeRows + 1u;
+            uint32_t base = 0;
+            if (sub == 0) base = atomicAdd(&a.hugeq[2 * kHugeCap], nblk);
+            base = __shfl(base, (int)(threadIdx.x & 63u) & ~15);
+            if (base + nblk <= (uint32_t)kHugeCap) {
+                for (uint32_t b = sub; b < nblk; b += 16)
+                    *(uint2*)(a.hugeq + 2 * (size_t)(base + b)) = make_uint2(id, e.y | (b << 8));
+                continue;
+            }
+            // list full: the triangle stays here, and the entries from `base` on were never written (every later push fails too)
+            if (sub == 0 && base < (uint32_t)kHugeCap) atomicMax(&a.hugeq[2 * kHugeCap + 1], (uint32_t)kHugeCap - base);
+        }
         u64* keys = a.keys[eye] + (size_t)slot * a.ws_stride_px;
         u64* cbuf = a.cbuf[eye] + (size_t)slot * a.ws_stride_px;
+        // (r04) what is constant for the triangle -- 1 / f32(area2), the colour planes' conversions are the fragment's -- and the edge
+        // values advanced by exact integer steps along a row (16 pixels: w_k -= 16 * 256 dy_k) instead of six 32 x 32 -> 64
+        // products per pixel centre; the same integers, the same f32 operations as tri_sample / tri_weights, so the same bits
+        const bool small = t.area2 < 0x7FFFFFFFll;                      // 0 <= w_k <= area2 inside: every value fits int32
+        const float ra = rcp_exact(i64_to_f32(t.area2, small));
+        const i64 st0 = (i64)t.dy0 * (16 * kSubpix), st1 = (i64)t.dy1 * (16 * kSubpix), st2 = (i64)t.dy2 * (16 * kSubpix);
+        const uint32_t parity = (a.key_parity >> slot) & 1u;
+        if (py1 - py0 >= 3) {
+            // Four rows or more: a ROW per lane, each lane walking its own short span pixel by pixel -- the rubber sheet between a
+            // near object and the background under a pose with vertical parallax is a diagonal sliver hundreds of rows tall and two
+            // or three pixels wide per row, and 16 lanes striding along each of its rows in turn did one row's set-up per two pixels
+            const i64 s0 = (i64)t.dy0 * kSubpix, s1 = (i64)t.dy1 * kSubpix, s2 = (i64)t.dy2 * kSubpix;
+            for (int pyb = py0; pyb <= py1; pyb += 16) {
+                const int py = pyb + sub;
+                int lo, hi;
+                if (py > py1 || !tri_row_range(t, py, px0, px1, lo, hi)) continue;
+                const int Xc = lo * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
+                i64 w0 = mul64(t.dx0, Yc - t.by0) - mul64(t.dy0, Xc - t.bx0);
+                i64 w1 = mul64(t.dx1, Yc - t.by1) - mul64(t.dy1, Xc - t.bx1);
+                i64 w2 = mul64(t.dx2, Yc - t.by2) - mul64(t.dy2, Xc - t.bx2);
+                for (int px = lo; px <= hi; ++px, w0 -= s0, w1 -= s1, w2 -= s2) {
+                    if (!(edge_in(w0, t.dx0, t.dy0) && edge_in(w1, t.dx1, t.dy1) && edge_in(w2, t.dx2, t.dy2))) continue;
+                    const float f0 = i64_to_f32(w0, small), f1 = i64_to_f32(w1, small), f2 = i64_to_f32(w2, small);
+                    const float q0 = (f0 * ra) * t.iz0, q1 = (f1 * ra) * t.iz1, q2 = (f2 * ra) * t.iz2;
+                    mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
+                }
+            }
+            continue;
+        }
         for (int py = py0; py <= py1; ++py) {
             int lo, hi;
             if (!tri_row_range(t, py, px0, px1, lo, hi)) continue;
-            for (int px = lo + sub; px <= hi; px += 16) {
-                float q0, q1, q2;
-                if (tri_sample(t, px, py, q0, q1, q2))
-                    mesh_global_fragment(keys, cbuf, (a.key_parity >> slot) & 1u, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
+            int px = lo + sub;
+            if (px > hi) continue;
+            const int Xc = px * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
+            i64 w0 = mul64(t.dx0, Yc - t.by0) - mul64(t.dy0, Xc - t.bx0);
+            i64 w1 = mul64(t.dx1, Yc - t.by1) - mul64(t.dy1, Xc - t.bx1);
+            i64 w2 = mul64(t.dx2, Yc - t.by2) - mul64(t.dy2, Xc - t.bx2);
+            for (; px <= hi; px += 16, w0 -= st0, w1 -= st1, w2 -= st2) {
+                if (!(edge_in(w0, t.dx0, t.dy0) && edge_in(w1, t.dx1, t.dy1) && edge_in(w2, t.dx2, t.dy2))) continue;
+                float f0, f1, f2;
+                if (__ballot(!small) == 0ull) { f0 = (float)(int)w0; f1 = (float)(int)w1; f2 = (float)(int)w2; }     // (as tri_weights)
+                else { f0 = i64_to_f32(w0, small); f1 = i64_to_f32(w1, small); f2 = i64_to_f32(w2, small); }
+                const float q0 = (f0 * ra) * t.iz0, q1 = (f1 * ra) * t.iz1, q2 = (f2 * ra) * t.iz2;
+                mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
+            }
+        }
+    }
+}
+
+// The row blocks of the huge triangles: a wave per entry, its 64 lanes along the rows (edge values advanced by 64 pixels per step).
+// Same set-up, same integers, same f32 operations as k_mesh_raster_queue.
+__global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a)
+{
+    const int W = a.W, H = a.H;
+    const uint32_t cnt = a.hugeq[2 * kHugeCap];
+    const uint32_t lim = (uint32_t)kHugeCap - a.hugeq[2 * kHugeCap + 1];              // (what did not fit was rasterised by the queue kernel)
+    const uint32_t total = cnt < lim ? cnt : lim;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t g = wave; g < total; g += nwaves) {
+        const uint2 e = *(const uint2*)(a.hugeq + 2 * (size_t)g);
+        const uint32_t id = e.x;
+        const int eye = (int)(e.y & 1u), slot = (int)((e.y >> 1) & 0x7Fu), blk = (int)(e.y >> 8);
+        const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
+        const uint4* r0 = a.gverts[eye] + (size_t)slot * a.ws_stride_px + (size_t)ci * W + cj;
+        const uint4 A = r0[0];
+        const uint4 v1 = pass == 0 ? r0[W] : r0[W + 1], v2 = pass == 0 ? r0[W + 1] : r0[1];
+        TriSetup t;
+        if (!tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
+                               (int)v2.x, (int)v2.y, __uint_as_float(v2.z), a.cull))
+            continue;
+        int px0 = floordiv_subpix(t.minX - kSubpix / 2 + kSubpix - 1), px1 = floordiv_subpix(t.maxX - kSubpix / 2);
+        int py0 = floordiv_subpix(t.minY - kSubpix / 2 + kSubpix - 1), py1 = floordiv_subpix(t.maxY - kSubpix / 2);
+        px0 = max(px0, 0); py0 = max(py0, 0); px1 = min(px1, W - 1); py1 = min(py1, H - 1);
+        const int ya = py0 + blk * kHugeRows, yb = min(ya + kHugeRows - 1, py1);
+        u64* keys = a.keys[eye] + (size_t)slot * a.ws_stride_px;
+        u64* cbuf = a.cbuf[eye] + (size_t)slot * a.ws_stride_px;
+        const bool small = t.area2 < 0x7FFFFFFFll;
+        const float ra = rcp_exact(i64_to_f32(t.area2, small));
+        const i64 st0 = (i64)t.dy0 * (64 * kSubpix), st1 = (i64)t.dy1 * (64 * kSubpix), st2 = (i64)t.dy2 * (64 * kSubpix);
+        const uint32_t parity = (a.key_parity >> slot) & 1u;
+        for (int py = ya; py <= yb; ++py) {
+            int lo, hi;
+            if (!tri_row_range(t, py, px0, px1, lo, hi)) continue;
+            int px = lo + lane;
+            if (px > hi) continue;
+            const int Xc = px * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
+            i64 w0 = mul64(t.dx0, Yc - t.by0) - mul64(t.dy0, Xc - t.bx0);
+            i64 w1 = mul64(t.dx1, Yc - t.by1) - mul64(t.dy1, Xc - t.bx1);
+            i64 w2 = mul64(t.dx2, Yc - t.by2) - mul64(t.dy2, Xc - t.bx2);
+            for (; px <= hi; px += 64, w0 -= st0, w1 -= st1, w2 -= st2) {
+                if (!(edge_in(w0, t.dx0, t.dy0) && edge_in(w1, t.dx1, t.dy1) && edge_in(w2, t.dx2, t.dy2))) continue;
+                const float f0 = i64_to_f32(w0, small), f1 = i64_to_f32(w1, small), f2 = i64_to_f32(w2, small);
+                const float q0 = (f0 * ra) * t.iz0, q1 = (f1 * ra) * t.iz1, q2 = (f2 * ra) * t.iz2;
+                mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
             }
         }
     }
@@ -384,6 +492,7 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
 {
     hipError_t e = hipMemsetAsync(a.bigq_count, 0, (size_t)plan.n * a.H * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(a.hugeq + 2 * (size_t)kHugeCap, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;
     const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
     // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
     if (plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr) {
@@ -394,7 +503,13 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const int nseg = plan.n * a.H;
     hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg);
+    if (tuning_env(TUNE_QUEUE_DUMP)) {       // tuning hook: queued (large) triangles of this launch set on stderr
+        uint32_t total = 0;
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&total, a.bigq_count + 2 * nseg, 4, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "queued triangles: %u in %d frames (%d x %d)\n", total, plan.n, a.W, a.H);
+    }
     hipLaunchKernelGGL(k_mesh_raster_queue, dim3(2048), dim3(256), 0, s, a, nseg);
+    hipLaunchKernelGGL(k_mesh_raster_huge, dim3(2048), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
