@@ -14,7 +14,10 @@
  *     the library never frees or retains it beyond the stream-ordered work of the call.
  *   - calls are asynchronous w.r.t. the host on the given stream.
  *   - return 0 (MDVT_OK) or a negative mdvt_status; mdvt_last_error() gives the text.
- *   - one ctx per (device, stream) user; a ctx is not thread-safe, distinct ctxs are independent.
+ *   - one ctx per (device, stream) user; a ctx is not thread-safe, distinct ctxs are independent.  The entry points that use
+ *     a library-owned workspace (render, edge filter, infill-mask completion, normal_infill, infill_using_[mask_]normals,
+ *     mark_lower_side) must be issued to ONE stream per ctx at a time: two calls on one ctx in two streams would share
+ *     the workspace unordered, and growing a workspace synchronises the device.
  *   - there is NO CPU fallback: without a HIP device mdvt_create fails with MDVT_ERR_NO_DEVICE.
  */
 #ifndef MDVT_H

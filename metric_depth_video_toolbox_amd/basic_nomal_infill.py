@@ -69,14 +69,20 @@ def process_pair(sbs_color_video_path: str, sbs_mask_video_path: str, max_frames
     clip means "no holes" for the remaining frames (basic_nomal_infill.py:165-167).  Returns the output path."""
     import torch
     from .clip import verify_and_move
-    if not os.path.isfile(sbs_color_video_path):
+    from .clip import open_output
+    # (a clip rendered by several ranks exists as per-rank segments + index: open_output reads either form)
+    if not (os.path.isfile(sbs_color_video_path) or os.path.isfile(sbs_color_video_path + ".index.json")):
         raise Exception(f"input sbs_color_video does not exist: {sbs_color_video_path}")
-    if not os.path.isfile(sbs_mask_video_path):
+    if not (os.path.isfile(sbs_mask_video_path) or os.path.isfile(sbs_mask_video_path + ".index.json")):
         raise Exception(f"input sbs_mask_video does not exist: {sbs_mask_video_path}")
-    color = np.load(sbs_color_video_path, mmap_mode="r")
-    mask = np.load(sbs_mask_video_path, mmap_mode="r")
+    color = open_output(sbs_color_video_path)
+    mask = open_output(sbs_mask_video_path)
     assert color.ndim == 4 and color.shape[-1] == 3 and color.dtype == np.uint8, "uint8 [N, H, 2W, 3] expected"
     assert color.shape[1:] == mask.shape[1:], "mask and color video not same resolution"
+    if color.shape[2] % 2:
+        raise ValueError(f"side-by-side frames need an even width, got {color.shape[2]}")     # (the reference gives the right eye the odd column: bni:180-181)
+    if max_frames == 0:
+        raise ValueError("max_frames = 0: the reference still processes one frame (bni:226-228); ask for -1 (all) or a positive count")
     n = color.shape[0] if max_frames == -1 else min(color.shape[0], max_frames)
     tmp, final = sbs_color_video_path + "_tmp_infilled.npy", sbs_color_video_path + "_infilled.npy"      # bni:140-141
     out = np.lib.format.open_memmap(tmp, mode="w+", dtype=np.uint8, shape=(n,) + tuple(color.shape[1:]))

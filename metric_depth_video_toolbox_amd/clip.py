@@ -541,6 +541,7 @@ class SegmentedFrames:
         self.parts, self.bounds = parts, bounds          # bounds[k] = first frame of part k; bounds[-1] = N
         self.shape = (bounds[-1],) + tuple(parts[0].shape[1:])
         self.dtype = parts[0].dtype
+        self.ndim = len(self.shape)
 
     def __len__(self):
         return self.bounds[-1]
@@ -565,8 +566,10 @@ class SegmentedFrames:
 
 
 def open_output(path: str, mmap_mode: Optional[str] = "r"):
-    """An output of run(): the single dump `<path>` if it exists, else the per-rank segments named by `<path>.index.json`."""
-    if os.path.exists(path):
+    """An output of run(): the single dump `<path>` or the per-rank segments named by `<path>.index.json` (run() leaves only the
+    form it wrote; should both exist -- files copied together by hand -- the newer one is taken)."""
+    ip = path + ".index.json"
+    if os.path.exists(path) and not (os.path.exists(ip) and os.path.getmtime(ip) > os.path.getmtime(path)):
         return np.load(path, mmap_mode=mmap_mode)
     with open(path + ".index.json") as fh:
         idx = json.load(fh)
@@ -577,6 +580,22 @@ def open_output(path: str, mmap_mode: Optional[str] = "r"):
         if p.shape[0] != s["hi"] - s["lo"]:
             raise RuntimeError(f"{s['file']}: {p.shape[0]} frames, the index says {s['hi'] - s['lo']}")
     return SegmentedFrames(parts, bounds)
+
+
+def _remove_segments(path: str):
+    """Remove `<path>.index.json` and the segment files it names (an earlier multi-rank run's form of the output)."""
+    ip = path + ".index.json"
+    if not os.path.exists(ip):
+        return
+    try:
+        with open(ip) as fh:
+            idx = json.load(fh)
+        for s in idx.get("segments", []):
+            f = os.path.join(os.path.dirname(path), s["file"])
+            if os.path.exists(f):
+                os.remove(f)
+    finally:
+        os.remove(ip)
 
 
 def merge_output(path: str, remove_segments: bool = True) -> str:
@@ -697,6 +716,13 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
             with open(pl["final"] + ".index.json.tmp", "w") as fh:
                 json.dump(idx, fh)
             os.replace(pl["final"] + ".index.json.tmp", pl["final"] + ".index.json")
+            # a single-file dump of an earlier one-rank run (or merge) of the same clip would shadow these segments in open_output
+            if os.path.exists(pl["final"]):
+                os.remove(pl["final"])
+    elif world == 1:
+        # ... and the segments + index of an earlier multi-rank run would outlive this run's single file
+        for k, pl in plan.items():
+            _remove_segments(pl["final"])
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -301,3 +301,25 @@ def test_the_product_library_has_no_tuning_hooks():
     L = ctypes.CDLL(_lib.lib_path("tuning"))
     for sym in _lib.SYMBOLS:
         assert hasattr(L, sym)
+
+
+def test_outputs_of_an_earlier_run_do_not_shadow_the_fresh_ones(tmp_path):
+    """open_output prefers whichever form is newer, _remove_segments clears an earlier multi-rank run's files, and
+    process_pair refuses max_frames = 0 and odd side-by-side widths instead of silently diverging from the reference."""
+    import json
+    import numpy as np
+    from metric_depth_video_toolbox_amd import clip
+    base = str(tmp_path / "x_stereo.npy")
+    np.save(base, np.zeros((4, 2, 4, 3), np.uint8))
+    seg0, seg1 = base + ".rank0of2.npy", base + ".rank1of2.npy"
+    np.save(seg0, np.ones((2, 2, 4, 3), np.uint8)); np.save(seg1, np.full((2, 2, 4, 3), 2, np.uint8))
+    with open(base + ".index.json", "w") as fh:
+        json.dump({"frames": 4, "world": 2, "frame_shape": [2, 4, 3], "dtype": "uint8",
+                   "segments": [{"rank": 0, "lo": 0, "hi": 2, "file": os.path.basename(seg0)},
+                                {"rank": 1, "lo": 2, "hi": 4, "file": os.path.basename(seg1)}]}, fh)
+    os.utime(base, (1, 1))                                   # the single file is the OLD one
+    got = clip.open_output(base)
+    assert got.ndim == 4 and int(np.asarray(got[3]).max()) == 2
+    clip._remove_segments(base)
+    assert not os.path.exists(seg0) and not os.path.exists(base + ".index.json")
+    assert int(np.asarray(clip.open_output(base)).max()) == 0
