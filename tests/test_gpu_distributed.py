@@ -88,7 +88,7 @@ def test_bench_line_under_torchrun_with_one_rank():
     assert "mesh" in line["extra"] and "product_default" in line["extra"]
     for k in ("c4_4k_pose_points", "c4_4k_pose_mesh", "c5_model_hop"):       # BASELINE configs[3] and [4] ride on the N = 1 line
         assert k in line["extra"] and line["extra"][k]["fps"] > 0, line["extra"].get("c4_error") or line["extra"].get("c5_error")
-    assert line["extra"]["c4_4k_pose_mesh"]["frames_per_launch"] == 8 and 0 < line["extra"]["c5_model_hop"]["render_share"] < 0.5
+    assert line["extra"]["c4_4k_pose_mesh"]["frames_per_launch"] == 8 and 0 < line["extra"]["c5_model_hop"]["render_share"] < 0.5 and line["extra"]["c5_model_hop"]["quantise_and_render_ms_per_frame"] > 0
 
 
 def test_bench_line_with_two_ranks_sharing_the_gpu():
