@@ -27,8 +27,9 @@ from .depth_map_tools import compute_camera_matrix, fov_from_camera_matrix
 def convergence_angle(distance, pupillary_distance):
     """Angle (rad) each eye rotates inward to converge at `distance`.  Reference: sr:94-112."""
     if distance == 0:
-        raise ValueError("Distance must be non-zero to compute a valid angle.")
-    return math.atan((pupillary_distance / 2) / distance)
+        raise ValueError("convergence_angle: a convergence distance of 0 has no toe-in angle")
+    half_baseline = pupillary_distance / 2
+    return math.atan(half_baseline / distance)
 
 
 def fill_nan_with_closest(values):
@@ -52,7 +53,8 @@ def curve_fit(values):
         window -= 1
     out = savgol_filter(y_ext, window_length=window, polyorder=2)
     out = out[:-n_tail] if n_tail > 0 else out
-    assert len(out) == len(y), f"curve_fit output length {len(out)} != input length {len(y)}"
+    if len(out) != len(y):
+        raise AssertionError(f"curve_fit: smoothed series has {len(out)} samples for {len(y)} inputs")
     return out
 
 

@@ -568,3 +568,29 @@ def test_level_order_downstream_of_the_infill_mask_trip_wire(orc):
         assert r["holes"] > 3000
         assert r["a50"] < 2.0 and r["a90"] < 15.0, r
         assert r["px_diff"] < 0.08 and r["px_diff_holes"] < 0.85, r
+
+
+def test_cull_risk_is_bounded(orc):
+    """The open parity risk "does Open3D's legacy renderer cull back faces?" (INTEGRATION.md 2b), bounded
+    instead of only reported (tests/report_cull_risk.py prints the 1080p numbers): whichever way the answer falls, the hole
+    mask is the same in every kind of view, the colour differs at under half a per cent of the pixels without edge removal,
+    and at none with it (the product default: the 89-degree filter removes every folding triangle before either rule)."""
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene, synthetic_pose_track
+    W, H = 480, 270
+    K = onp.compute_camera_matrix(45.0, None, W, H)
+    d, c = SyntheticScene(W, H, config_id=2).frame(0)
+    views = ({}, {"conv_angle": math.atan((0.065 / 2) / 2.5)}, {"T": synthetic_pose_track(30)[29]})
+    seen_colour_diff = 0
+    for kw in views:
+        for re_ in (False, True):
+            outs = [orc.render_stereo(orc.make_params(W, H, K, ipd_m=0.065, mode=orc.MODE_MESH, remove_edges=re_, edge_points=1 if re_ else 0,
+                                                      cull=cull, key_rgb=(0, 255, 0) if re_ else (0, 0, 0), **kw), d, c) for cull in (0, 1)]
+            for e in ("left", "right"):
+                assert np.array_equal(outs[0][e + "_mask"], outs[1][e + "_mask"]), (kw, re_, e)
+                dc = int(np.any(outs[0][e + "_rgb"] != outs[1][e + "_rgb"], -1).sum())
+                if re_:
+                    assert dc == 0, (kw, e, dc)
+                else:
+                    assert dc < 0.005 * W * H, (kw, e, dc)
+                    seen_colour_diff += dc
+    assert seen_colour_diff > 0, "the scene no longer folds: the test bounds nothing"
