@@ -175,10 +175,10 @@ __device__ __forceinline__ int tri_oblique_screen_f32(float a, float b, float pp
     const float lhs = d3 * d3;
     const float nnss = nn * ss;
     const float rhs = 0x1.3f61d0p-12f * nnss;                           // cos^2 89 degrees (f32: 6e-8 relative, inside the margin)
-    if (!(nnss > 1.0e-15f)) return 2;                                   // degenerate / zero depth / tiny: the f64 paths
-    if (lhs < rhs * 0.999f) return 1;
-    if (lhs > rhs * 1.001f) return 0;
-    return 2;                                                           // (NaN / inf land here too)
+    // (no branches: 0 = valid, 1 = oblique (removed), 2 = undecided -- degenerate / zero depth / tiny / NaN / inside the margin)
+    const bool ok = nnss > 1.0e-15f;
+    const bool rem = ok && lhs < rhs * 0.999f, val = ok && lhs > rhs * 1.001f;
+    return rem ? 1 : (val ? 0 : 2);
 }
 
 struct CellRaysF32 { float a, a1, b, b1, px, py; bool ok; };     // the f32 pre-screen's view of the cell's rays (ok: all within +-64)
