@@ -1359,3 +1359,23 @@ def test_contexts_on_two_gpus_do_not_share_parameter_blocks(mods, orc):
             got = r.render(torch.from_numpy(depth_rgb).cuda(dev), torch.from_numpy(color).cuda(dev), p, want_depth=True)
             _compare(got, _oracle(orc, r, p, depth_rgb, color), W, f"device {dev}")
             r.close()
+
+
+def test_finish_infill_mask_in_two_concurrent_halves(mods):
+    """finish_infill_mask_sbs splits a call of FINISH_SPLIT_FRAMES frames or more into two halves on two contexts and two streams
+    (the marking pass of the completion waits most of its cycles; a second pass beside it fills them).  A frame's finished mask
+    does not depend on its batch: the split call gives the bytes of the unsplit one, and the same counts of unreached pixels."""
+    _lib, sr, synthetic = mods
+    W, H, N = 320, 180, 8
+    d, c = synthetic.SyntheticScene(W, H, config_id=3, n_fg=8).clip(N)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
+    ps = [r.frame_params(xfov=45.0, convergence_distance=2.5 if k % 2 else None) for k in range(N)]
+    seed = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), ps, want_seed=True)["seed"]
+    whole, rem_w = r.finish_infill_mask_sbs(seed, want_remaining=True, max_rounds=20)
+    r.FINISH_SPLIT_FRAMES = 4                      # (instance attribute: this renderer only)
+    for _ in range(2):                             # second time: the second context and its workspace exist
+        halves, rem_h = r.finish_infill_mask_sbs(seed, want_remaining=True, max_rounds=20)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, halves) and torch.equal(rem_w, rem_h)
+    assert int(rem_w.sum()) > 0, "max_rounds = 20 should leave deep holes unreached in some frame (the counts are being compared)"
+    r.close()
