@@ -320,19 +320,49 @@ __global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __rest
 {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024, lo = min(t * per, n), hi = min(lo + per, n);
+    // a thread's chunk: a multiple of four counters, read as 16-byte vectors and kept in registers (one counter per trip made the
+    // pass 17 dependent round trips long, twice: 21 us for a 16-frame 1080p launch set; `counts` is 16-byte aligned)
+    constexpr int kMaxVec = 16;                                    // up to 64 counters per thread: 65 536 segments
+    const int per4 = (n + 4095) / 4096, lo = min(t * per4 * 4, n), hi = min(lo + per4 * 4, n);
+    uint4 v[kMaxVec];
     uint32_t sum = 0;
-    for (int k = lo; k < hi; ++k) sum += counts[k];
+    if (per4 <= kMaxVec) {
+#pragma unroll
+        for (int k = 0; k < kMaxVec; ++k) {
+            v[k] = make_uint4(0, 0, 0, 0);
+            const int e = lo + 4 * k;
+            if (k < per4 && e < hi) {
+                if (e + 4 <= n) v[k] = *(const uint4*)(counts + e);
+                else { v[k].x = counts[e]; if (e + 1 < n) v[k].y = counts[e + 1]; if (e + 2 < n) v[k].z = counts[e + 2]; }
+            }
+            sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+    } else {
+        for (int k = lo; k < hi; ++k) sum += counts[k];
+    }
     part[t] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = t >= off ? part[t - off] : 0u;
+        const uint32_t u = t >= off ? part[t - off] : 0u;
         __syncthreads();
-        part[t] += v;
+        part[t] += u;
         __syncthreads();
     }
     uint32_t run = part[t] - sum;
-    for (int k = lo; k < hi; ++k) { prefix[k] = run; run += counts[k]; }
+    if (per4 <= kMaxVec) {
+#pragma unroll
+        for (int k = 0; k < kMaxVec; ++k) {
+            const int e = lo + 4 * k;
+            if (k < per4 && e < hi) {
+                prefix[e] = run; run += v[k].x;
+                if (e + 1 < n) { prefix[e + 1] = run; run += v[k].y; }
+                if (e + 2 < n) { prefix[e + 2] = run; run += v[k].z; }
+                if (e + 3 < n) { prefix[e + 3] = run; run += v[k].w; }
+            }
+        }
+    } else {
+        for (int k = lo; k < hi; ++k) { prefix[k] = run; run += counts[k]; }
+    }
     if (t == 1023) prefix[n] = part[1023];
 }
 
