@@ -164,48 +164,42 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
     constexpr int kCoord = 1 << 19, kMaxH = 512, kMaxSpan = 12;
     const int W = a.W, H = a.H;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    // (r04) a workgroup takes TWO rows of cells: three record rows for two rows of cells instead of four -- the stage moved
-    // 214 MB per 1080p frame at 5.7 TB/s, 132 MB of them record reads (every record row read twice)
-    const int i0 = 2 * blockIdx.y;
+    const int i = blockIdx.y;
     const int fr = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
     const uint32_t parity = (a.key_parity >> fr) & 1u;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
-    __shared__ uint4 sv[2][3][129];
-    __shared__ uint32_t glist[512];           // cells (thread | eye << 8 | row << 9) for the generic code
+    __shared__ uint4 sv[2][2][129];
+    __shared__ uint32_t glist[256];           // cells (thread | eye << 8) for the generic code
     __shared__ uint32_t gcount;
-    uint32_t invbits = 0;                     // bit 2 r: tri1 of cell row i0 + r removed, bit 2 r + 1: tri2
+    uint32_t inv0 = 0, inv1 = 0;
     {
         const int t = threadIdx.x;
         const int j0 = blockIdx.x * blockDim.x;
-        const size_t base = (size_t)fr * a.ws_stride_px;
+        const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
         const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);
-        const int ra = i0, rb = min(i0 + 1, H - 1), rc = min(i0 + 2, H - 1);          // the three record rows (clamped: never used past the grid)
         uint4 rx = make_uint4(0, 0, 0, 0);
-        if (t < 6) rx = (t >= 3 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t % 3 == 0 ? ra : (t % 3 == 1 ? rb : rc)) * W + jx];
-        const uint4 r0 = a.gverts[0][base + (size_t)ra * W + jc], r1 = a.gverts[0][base + (size_t)rb * W + jc], r2 = a.gverts[0][base + (size_t)rc * W + jc];
-        const uint4 r3 = a.gverts[1][base + (size_t)ra * W + jc], r4 = a.gverts[1][base + (size_t)rb * W + jc], r5 = a.gverts[1][base + (size_t)rc * W + jc];
+        if (t < 4) rx = (t & 2 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t & 1) * W + jx];
+        const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
+        const uint4 r2 = a.gverts[1][base + jc], r3 = a.gverts[1][base + W + jc];
         if (EDGES && act) {
-            const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i0 * (W - 1) + j;
-            invbits = (tinv[0] ? 1u : 0u) | (tinv[ncell] ? 2u : 0u);
-            if (i0 + 1 <= H - 2) invbits |= (tinv[W - 1] ? 4u : 0u) | (tinv[ncell + W - 1] ? 8u : 0u);
+            const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
+            inv0 = tinv[0]; inv1 = tinv[ncell];
         }
-        if (t < 6) sv[t / 3][t % 3][128] = rx;
-        sv[0][0][t] = r0; sv[0][1][t] = r1; sv[0][2][t] = r2; sv[1][0][t] = r3; sv[1][1][t] = r4; sv[1][2][t] = r5;
+        if (t < 4) sv[t >> 1][t & 1][128] = rx;
+        sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
         if (t == 0) gcount = 0u;
     }
     __syncthreads();
     const uint32_t cull = (uint32_t)a.cull;
 #pragma unroll 1
-    for (int re = 0; re < 4; ++re) {
-        const int eye = re & 1, r = re >> 1, i = i0 + r;
-        const uint32_t inv0 = (invbits >> (2 * r)) & 1u, inv1 = (invbits >> (2 * r + 1)) & 1u;
-        if (!act || i > H - 2 || (inv0 && inv1)) continue;
+    for (int eye = 0; eye < 2; ++eye) {
+        if (!act || (inv0 && inv1)) continue;
         u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
         u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
         const int t = threadIdx.x;
-        const uint4 A = sv[eye][r][t], D = sv[eye][r][t + 1], B = sv[eye][r + 1][t], Cv = sv[eye][r + 1][t + 1];
+        const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
         const int XA = (int)A.x, YA = (int)A.y, XB = (int)B.x, YB = (int)B.y, XC = (int)Cv.x, YC = (int)Cv.y, XD = (int)D.x, YD = (int)D.y;
         const float izA = __uint_as_float(A.z), izB = __uint_as_float(B.z), izC = __uint_as_float(Cv.z), izD = __uint_as_float(D.z);
         if (!(izA > 0.0f)) continue;                                   // A is a vertex of both triangles: near plane, both dropped
@@ -255,7 +249,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
                 }
             }
         }
-        if (generic) glist[atomicAdd(&gcount, 1u)] = (uint32_t)t | ((uint32_t)eye << 8) | ((uint32_t)r << 9);
+        if (generic) glist[atomicAdd(&gcount, 1u)] = (uint32_t)t | ((uint32_t)eye << 8);
     }
     __syncthreads();
     // ---- the listed cells: k_mesh_raster_small's code, a listed TRIANGLE per lane ----
@@ -264,12 +258,11 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
         const uint32_t idx = base + threadIdx.x;
         const bool on = idx < ng;
         const uint32_t ent = glist[on ? idx >> 1 : 0];
-        const int t = (int)(ent & 0xFFu), eye = (int)((ent >> 8) & 1u), r = (int)(ent >> 9), pass = (int)(idx & 1u);
-        const int i = i0 + r;
+        const int t = (int)(ent & 0xFFu), eye = (int)(ent >> 8), pass = (int)(idx & 1u);
         const int cj = blockIdx.x * blockDim.x + t;
         u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
         u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
-        const uint4 A = sv[eye][r][t], D = sv[eye][r][t + 1], B = sv[eye][r + 1][t], Cv = sv[eye][r + 1][t + 1];
+        const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
         const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
         const uint32_t did = draw_id_global(pass, i, cj);
         bool removed = false;
@@ -533,9 +526,8 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
     const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
     // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
     if (plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr) {
-        const dim3 grid_c2((a.W - 1 + 127) / 128, (a.H - 1 + 1) / 2, plan.n);         // two rows of cells per workgroup
-        if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_c2, dim3(128), 0, s, a);
-        else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_c2, dim3(128), 0, s, a);
+        if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_c, dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_c, dim3(128), 0, s, a);
     } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2>), grid_c, dim3(128), 0, s, a);
     else hipLaunchKernelGGL((k_mesh_raster_small<0>), grid_c, dim3(128), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
