@@ -134,8 +134,15 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                 if (held != need && pf_row != need) fetch_row(need);
             }
         }
-        const int4* vt = verts + (size_t)(g.c & 1) * W;             // vertex row c
-        const int4* vb = verts + (size_t)((g.c + 1) & 1) * W;       // vertex row c + 1
+        // The row constants every lane computes with, in VECTOR registers (r04): the kernel needs ~250 scalar registers for its
+        // arguments, loop state and lane masks and has 102; what did not fit was spilled to VGPR lanes and read back with
+        // v_readlane -- a VALU instruction each, 22 of them per pass of the cell loop.  A VGPR operand costs nothing.
+        RowGeom gv = g;
+        int vt_i = (g.c & 1) * W, vb_i = ((g.c + 1) & 1) * W, Wv = W;       // (likewise: the two vertex rows' slots, the width)
+        if (!EDGEPTS) {                      // (the edge-point variants sit at the 128-VGPR limit: there the scalars stay where they are)
+            asm volatile("" : "+v"(gv.tt), "+v"(gv.bb), "+v"(gv.hh), "+v"(gv.D), "+v"(gv.c128), "+v"(gv.rD));
+            asm volatile("" : "+v"(vt_i), "+v"(vb_i), "+v"(Wv));
+        }
 
 #pragma unroll 1
         for (int eye = 0; eye < 2; ++eye) {
@@ -154,19 +161,19 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                     const bool final_pass = c0 >= W - 1;
                     const int j = c0 + wave * 63 + lane;
                     // (columns past the row end read the last column: never used, `cell` below masks them)
-                    const int jc = j < W ? j : W - 1;
-                    const int4 A = vt[jc], B = vb[jc];
+                    const int jc = j < Wv ? j : Wv - 1;
+                    const int4 A = verts[vt_i + jc], B = verts[vb_i + jc];
                     const int XA = eye == 0 ? A.x : A.y, XB = eye == 0 ? B.x : B.y;
                     const float izA = __int_as_float(A.z), izB = __int_as_float(B.z);
                     const uint32_t cA = (uint32_t)A.w & 0xFFFFFFu, cB = (uint32_t)B.w & 0xFFFFFFu;
                     const int colok = (izA > 0.0f && izB > 0.0f && (((uint32_t)(XA + kCoordBound) | (uint32_t)(XB + kCoordBound)) >> 21) == 0u) ? 1 : 0;
-                    const int kcol0 = mad24(XB - XA, g.tt, mul24(g.hh, XA));
-                    const int pA = first_pixel(kcol0, g.c128, g.D, g.rD, W);
+                    const int kcol0 = mad24(XB - XA, gv.tt, mul24(gv.hh, XA));
+                    const int pA = first_pixel(kcol0, gv.c128, gv.D, gv.rD, Wv);
                     const int XD = from_next_lane(XA), XC = from_next_lane(XB), kcol1 = from_next_lane(kcol0), pD = from_next_lane(pA);
                     const float izD = from_next_lane(izA), izC = from_next_lane(izB);
                     const uint32_t cD = from_next_lane(cA), cC = from_next_lane(cB);
                     const int okD = from_next_lane(colok);
-                    const bool cell = lane < 63 && j < W - 1 && !final_pass;
+                    const bool cell = lane < 63 && j < Wv - 1 && !final_pass;
                     const int s1 = XC - XB, s2 = XD - XA;
                     const bool regular = s2 > 0;
                     const bool fast = cell && colok && okD && ((s1 > 0 && s2 > 0) || (s1 < 0 && s2 < 0));
@@ -177,7 +184,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                     const int plo = regular ? pA : pD;
                     int n = drawn ? (regular ? pD - pA : pA - pD) : 0;
                     if (n > 0 && !(a.debug_skip & 16))
-                        cell_pixel(XA, XB, XC, XD, izA, izB, izC, izD, cA, cB, cC, cD, kcol0, kcol1, plo, j, skip, g, zb, ties);
+                        cell_pixel(XA, XB, XC, XD, izA, izB, izC, izD, cA, cB, cC, cD, kcol0, kcol1, plo, j, skip, gv, zb, ties);
                     // Further pixels of the cell become (cell, pixel) items on the wave's stack, shaded 64 at a time: first
                     // one item per lane and round (spans of up to 4 px), then the long spans (rubber sheet across a depth
                     // edge), one cell at a time written by the whole wave.  One loop, so that the shading code exists once.
@@ -192,12 +199,12 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                                 if (lane < cnt) {
                                     const uint32_t it = wq[qn + lane];
                                     const int ij = (int)(it >> 16), px = (int)(it & 0xFFFFu);
-                                    const int4 A = vt[ij], D = vt[ij + 1], B = vb[ij], Cv = vb[ij + 1];
+                                    const int4 A = verts[vt_i + ij], D = verts[vt_i + ij + 1], B = verts[vb_i + ij], Cv = verts[vb_i + ij + 1];
                                     const int iXA = eye == 0 ? A.x : A.y, iXB = eye == 0 ? B.x : B.y, iXC = eye == 0 ? Cv.x : Cv.y, iXD = eye == 0 ? D.x : D.y;
                                     cell_pixel(iXA, iXB, iXC, iXD, __int_as_float(A.z), __int_as_float(B.z), __int_as_float(Cv.z), __int_as_float(D.z),
                                                (uint32_t)A.w & 0xFFFFFFu, (uint32_t)B.w & 0xFFFFFFu, (uint32_t)Cv.w & 0xFFFFFFu, (uint32_t)D.w & 0xFFFFFFu,
-                                               mad24(iXB - iXA, g.tt, mul24(g.hh, iXA)), mad24(iXC - iXD, g.tt, mul24(g.hh, iXD)), px, ij,
-                                               EDGES ? ((uint32_t)A.w >> 24) & 3u : 0u, g, zb, ties);
+                                               mad24(iXB - iXA, gv.tt, mul24(gv.hh, iXA)), mad24(iXC - iXD, gv.tt, mul24(gv.hh, iXD)), px, ij,
+                                               EDGES ? ((uint32_t)A.w >> 24) & 3u : 0u, gv, zb, ties);
                                 }
                                 continue;
                             }
