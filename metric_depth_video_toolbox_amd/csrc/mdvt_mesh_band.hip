@@ -34,9 +34,11 @@ namespace mdvt {
 // FLAGS bit 0: depth planes; bit 1: triangles removed by the 89-degree filter draw nothing (remove_edges; tri_invalid /
 // unused come from k_edge_filter); bit 2: the vertices of removed triangles are splatted into the holes (sr:589-606,
 // 745-781); bit 3: the infill-mask seed image (sr:787-803).
-template <int FLAGS, int TPB>
+// DBG: the ablation / test hooks of RenderArgs.debug_skip are compiled in (the launcher picks it when a hook is set: tuning build only)
+template <int FLAGS, int TPB, bool DBG>
 __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderArgs a, int rows_per_band, int nbands)
 {
+    const int dbg = DBG ? a.debug_skip : 0;
     constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4, SEED = FLAGS & 8;
     const uint32_t cull = (uint32_t)a.cull;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -48,7 +50,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
     ties.bits = queue + (TPB / 64) * kQueueWave;
     ties.nwords = (W + 31) / 32;
     ties.mode = 0;
-    ties.force = (a.debug_skip & 32) != 0;
+    ties.force = (dbg & 32) != 0;
     // With edge removal a vertex record's colour word carries three flags in its top byte: bit 24 / 25 = tri1 / tri2 of the
     // cell whose top-left corner the vertex is were removed (dmt:1372), bit 26 = the vertex belongs to a removed triangle
     // (its edge point is splatted, sr:589-606).  The edge-point keys of a (scanline, eye) (code16 << 16 | column, nearest wins)
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
             // (passes 1 and 2 only for a row with exact depth ties between different colours: RowTies in mdvt_device.h)
 #pragma unroll 1
             for (ties.mode = 0; ties.mode < 3; ++ties.mode) {
-            if (g.c >= 0 && !(a.debug_skip & 1)) {
+            if (g.c >= 0 && !(dbg & 1)) {
                 int qn = 0;                                          // items on this wave's stack (uniform)
                 // A wave takes 63 consecutive cells per pass: lane l works out column c0 + l (its crossing of the scanline and
                 // the first pixel at or after it) and owns the cell between its column and the next lane's, whose values
@@ -183,12 +185,12 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                     const bool drawn = fast && skip != 3u && !(cull && (cull == 1u) != regular);
                     const int plo = regular ? pA : pD;
                     int n = drawn ? (regular ? pD - pA : pA - pD) : 0;
-                    if (n > 0 && !(a.debug_skip & 16))
+                    if (n > 0 && !(dbg & 16))
                         cell_pixel(XA, XB, XC, XD, izA, izB, izC, izD, cA, cB, cC, cD, kcol0, kcol1, plo, j, skip, gv, zb, ties);
                     // Further pixels of the cell become (cell, pixel) items on the wave's stack, shaded 64 at a time: first
                     // one item per lane and round (spans of up to 4 px), then the long spans (rubber sheet across a depth
                     // edge), one cell at a time written by the whole wave.  One loop, so that the shading code exists once.
-                    if (a.debug_skip & 8) n = 0;
+                    if (dbg & 8) n = 0;
                     u64 lm = __ballot(n > 4);
                     if (__ballot(n > 1) != 0ull || final_pass) {
                         int round = 1, lcell = 0, lpix = 0, lrem = 0;
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                     }
                     if (final_pass) break;
                     // exotic cells (near plane, out of the 24-bit range, twisted, zero width): generic path, whole wave
-                    u64 em = (a.debug_skip & 8) ? 0ull : __ballot(exotic);
+                    u64 em = (dbg & 8) ? 0ull : __ballot(exotic);
                     while (em) {
                         const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)em) - 1);
                         em &= em - 1;
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
             }
 
             // ---- resolve this eye: LDS keys -> colour-key hole test -> coalesced stores; the keys are reset on the way ----
-            const bool resolving = act4 && k >= k0 && !(a.debug_skip & 2);
+            const bool resolving = act4 && k >= k0 && !(dbg & 2);
             uint4 k01 = make_uint4(~0u, ~0u, ~0u, ~0u), k23 = k01, ek4 = k01;
             if (resolving) {
                 uint4* zq = (uint4*)zb + 2 * tid;
@@ -400,8 +402,13 @@ static hipError_t launch_mesh_band_tpb(const RenderPlan& plan, const RenderArgs&
                       (plan.remove_edges && a.seed[0] ? 8 : 0);
 #define MDVT_CASE(F)                                                                                                        \
     case F:                                                                                                                 \
-        (void)hipFuncSetAttribute((const void*)k_mesh_band<F, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-        hipLaunchKernelGGL((k_mesh_band<F, TPB>), grid, block, lds, s, a, rows, nbands);                                   \
+        if (a.debug_skip) {                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)k_mesh_band<F, TPB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL((k_mesh_band<F, TPB, true>), grid, block, lds, s, a, rows, nbands);                               \
+        } else {                                                                                                            \
+            (void)hipFuncSetAttribute((const void*)k_mesh_band<F, TPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL((k_mesh_band<F, TPB, false>), grid, block, lds, s, a, rows, nbands);                              \
+        }                                                                                                                   \
         break;
     switch (flags) {
         MDVT_CASE(0) MDVT_CASE(1) MDVT_CASE(2) MDVT_CASE(3) MDVT_CASE(6) MDVT_CASE(7)
