@@ -34,13 +34,14 @@ namespace mdvt {
 // FLAGS bit 0: depth planes; bit 1: triangles removed by the 89-degree filter draw nothing (remove_edges; tri_invalid /
 // unused come from k_edge_filter); bit 2: the vertices of removed triangles are splatted into the holes (sr:589-606,
 // 745-781); bit 3: the infill-mask seed image (sr:787-803).
-// DBG: the ablation / test hooks of RenderArgs.debug_skip are compiled in (the launcher picks it when a hook is set: tuning build only)
+// DBG: the ablation / test hooks of RenderArgs.debug_skip and face culling (mdvt_config.cull) are compiled in: the launcher picks
+// it when a hook is set (tuning build only) or cull != 0; the common case carries none of their scalar state
 template <int FLAGS, int TPB, bool DBG>
 __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderArgs a, int rows_per_band, int nbands)
 {
     const int dbg = DBG ? a.debug_skip : 0;
+    const uint32_t cull = DBG ? (uint32_t)a.cull : 0u;
     constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4, SEED = FLAGS & 8;
-    const uint32_t cull = (uint32_t)a.cull;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = a.W, H = a.H, W4 = W >> 2;
     u64* zb = (u64*)smem;                                   // [W] z keys of the eye being rendered
@@ -402,7 +403,7 @@ static hipError_t launch_mesh_band_tpb(const RenderPlan& plan, const RenderArgs&
                       (plan.remove_edges && a.seed[0] ? 8 : 0);
 #define MDVT_CASE(F)                                                                                                        \
     case F:                                                                                                                 \
-        if (a.debug_skip) {                                                                                                 \
+        if (a.debug_skip || a.cull) {                                                                                       \
             (void)hipFuncSetAttribute((const void*)k_mesh_band<F, TPB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             hipLaunchKernelGGL((k_mesh_band<F, TPB, true>), grid, block, lds, s, a, rows, nbands);                               \
         } else {                                                                                                            \
