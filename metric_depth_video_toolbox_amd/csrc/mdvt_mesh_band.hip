@@ -76,8 +76,9 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
     int pf_row = -1;                            // vertex row sitting in the prefetch registers (uniform)
     uint32_t pd0 = 0, pd1 = 0, pd2 = 0, pc0 = 0, pc1 = 0, pc2 = 0;
     uint32_t pfl = 0;                            // EDGES: the four columns' flags of that row, one byte each
-    int etx[4] = {-1, -1, -1, -1};               // EDGEPTS: where this thread's edge points of the current (row, eye) land,
-    uint32_t ekey[4] = {0, 0, 0, 0};             //          and their keys code16 << 16 | source column
+    // EDGEPTS: this thread's edge points of the current (row, eye), one word each: depth code << 16 | (target column + 1), 0 = none
+    // (their keys code16 << 16 | source column follow from it: the source column is tid + q * TPB)
+    uint32_t ept[4] = {0, 0, 0, 0};
 
     auto fetch_row = [&](int r) {
         if (act4) {
@@ -271,7 +272,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                          // W <= 4 * TPB (launcher)
                     const int jj = tid + q * TPB;
-                    etx[q] = -1;
+                    ept[q] = 0u;
                     if (jj >= W) continue;
                     const bool un = vk ? (((uint32_t)vk[jj].w >> 26) & 1u) != 0u
                                        : a.unused[(size_t)fr * a.ws_stride_px + (size_t)k * W + jj] != 0;
@@ -280,11 +281,11 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                     const float z = decode_z(code, fp.mult, fp.scale);
                     if (!(z > kNear)) continue;
                     const int x = edge_col_pure(fp, eye, (float)jj * fp.sx, z, fp.dl / z, W, guard);      // sr:599-600, 746
-                    if (x >= 0) { etx[q] = x; ekey[q] = (code << 16) | (uint32_t)jj; }
+                    if (x >= 0) ept[q] = (code << 16) | (uint32_t)(x + 1);
                 }
             } else if (EDGEPTS && ties.mode == 0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) etx[q] = -1;
+                for (int q = 0; q < 4; ++q) ept[q] = 0u;
             }
             __syncthreads();
             if (ties.mode == 0) {
@@ -317,7 +318,8 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                 uint32_t* eb = reinterpret_cast<uint32_t*>(zb);
                 __syncthreads();
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (etx[q] >= 0) atomicMin(&eb[etx[q]], ekey[q]);
+                for (int q = 0; q < 4; ++q)
+                    if (ept[q] & 0xFFFFu) atomicMin(&eb[(ept[q] & 0xFFFFu) - 1u], (ept[q] & 0xFFFF0000u) | (uint32_t)(tid + q * TPB));
                 __syncthreads();
                 if (resolving) {
                     uint4* eq = reinterpret_cast<uint4*>(eb) + tid;
