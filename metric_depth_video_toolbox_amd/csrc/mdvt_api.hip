@@ -379,7 +379,7 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         if (nfq > nf) nfq = nf;
         const size_t cap = nfq * npx * 4;
         c->bigq_cap = (uint32_t)cap;
-        MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 2 + 2 * (size_t)mdvt::kHugeCap + 2) * sizeof(uint32_t)));   // entries, counters, prefix sums; row blocks of huge triangles + their counter
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 2 + 2 * (size_t)mdvt::kHugeCap + 2 + nf * (1 + 2 * mdvt::tie_words_of(c->W, c->H))) * sizeof(uint32_t)));   // entries, counters, prefix sums; row blocks of huge triangles + their counter; tie flags and tile bits
         c->ws_gverts = true;
     }
     if (need_edges && !c->ws_edges) {
@@ -682,6 +682,10 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     if (c->bigq) {
         a.bigq = c->bigq; a.bigq_cap = c->bigq_cap; a.bigq_count = c->bigq + (size_t)c->bigq_cap * mdvt::kBigRecDwords;
         a.hugeq = a.bigq_count + 2 * (size_t)c->ws_frames * H + 2;      // (8-byte aligned: entries are uint2)
+        a.tie_flag = a.hugeq + 2 * (size_t)mdvt::kHugeCap + 2;
+        a.tie_tiles = a.tie_flag + c->ws_frames;
+        a.tie_words = (int32_t)mdvt::tie_words_of(W, H);
+        a.tie_tiles_x = (W + mdvt::kTieTile - 1) / mdvt::kTieTile;
     }
     a.ws_stride_px = (size_t)W * H;
     a.ws_stride_tri = 2 * (size_t)(W - 1) * (H - 1);

@@ -210,8 +210,13 @@ __device__ __forceinline__ bool tri_setup(TriSetup& t, const Vert& a, const Vert
 // GL_LESS the triangle drawn first keeps the pixel, and the reference draws all tri1 row-major, then all tri2
 // (dmt:1243-1254).  Such ties are not rare (a few per 10^5 fragments on the benchmark scenes), so both kinds of
 // kernel implement that rule exactly:
-//   * global-key kernels (general path): low half = draw id = pass << 31 | i << 16 | j, so that the 64-bit minimum IS
-//     "nearest, then first drawn"; the colour is recomputed from the id by the resolve pass (deferred shading);
+//   * global-key kernels (general path, points): low half = source index, so that the 64-bit minimum IS "nearest, then lower
+//     source index";
+//   * global-key kernels (general path, mesh): low half = "no tie yet" bit | the shaded colour (the resolve stays a plain read of
+//     ONE word per pixel).  A fragment that meets its own depth with another colour in the word clears the bit (ColourKeys
+//     below), and the frames where that happened are rasterised once more (only the cells near such pixels do any work) to
+//     post draw id << 32 | colour of the fragments at the winning depth of each tied pixel into a side word: its minimum is
+//     "first drawn";
 //   * LDS row kernels (pure shift): low half = the shaded colour (the resolve stays a plain read); a fragment that meets
 //     its own depth with another colour in the word raises the pixel's tie bit, and a row with tie bits is rasterised
 //     twice more -- once to find the lowest draw id among the fragments at the winning depth of each tied pixel, once
@@ -238,6 +243,38 @@ __device__ __forceinline__ void zkey_post(u64* word, uint32_t parity, uint32_t d
     if (parity == 0u) atomicMin(word, ((u64)d_min << 32) | tie);
     else atomicMax(word, (1ull << 63) | ((u64)(0x7FFFFFFFu - d_min) << 32) | (uint32_t)~tie);
 }
+// The word zkey_post would post.
+template <bool NEARER_IS_LARGER>
+__device__ __forceinline__ u64 zkey_word(uint32_t parity, uint32_t depth31, uint32_t tie)
+{
+    const uint32_t d_min = NEARER_IS_LARGER ? 0x7FFFFFFFu - depth31 : depth31;
+    return parity == 0u ? ((u64)d_min << 32) | tie : (1ull << 63) | ((u64)(0x7FFFFFFFu - d_min) << 32) | (uint32_t)~tie;
+}
+__device__ __forceinline__ u64 zkey_post_word(u64* word, uint32_t parity, u64 w)          // returns what the word held
+{
+    return parity == 0u ? atomicMin(word, w) : atomicMax(word, w);
+}
+
+// ---- colour keys of the general mesh path ----------------------------------------------------------------------------
+// tie breaker field = kNoTie | rgb.  Clearing kNoTie in a word (in the posted representation: parity 1 stores the field
+// complemented) makes it beat every unmarked word of the same depth, whatever its colour: once a pixel is marked at the winning
+// depth it stays marked; a nearer fragment replaces the word, mark and all.  A mark that lands on a word other than the one it
+// was meant for (a nearer fragment got in between) is harmless: a marked pixel is settled by draw id among the fragments AT ITS
+// FINAL DEPTH, which is right whether or not there was a tie.
+constexpr uint32_t kNoTie = 1u << 24;
+__device__ __forceinline__ void zkey_mark_tied(u64* word, uint32_t parity)
+{
+    if (parity == 0u) atomicAnd(word, ~(u64)kNoTie); else atomicOr(word, (u64)kNoTie);
+}
+// same depth (and parity), other colour, not yet marked?  `old` is what a post of `mine` returned.
+__device__ __forceinline__ bool zkey_colour_conflict(u64 old, u64 mine, uint32_t parity)
+{
+    const u64 x = old ^ mine;
+    const bool unmarked = (((uint32_t)old >> 24) & 1u) != parity;
+    return (x >> 32) == 0ull && ((uint32_t)x & 0xFFFFFFu) != 0u && unmarked;
+}
+__device__ __forceinline__ bool zkey_is_tied(u64 key, uint32_t parity) { return (((uint32_t)key >> 24) & 1u) == parity; }
+
 template <bool NEARER_IS_LARGER>
 __device__ __forceinline__ void zkey_decode(u64 key, uint32_t parity, uint32_t& depth31, uint32_t& tie)
 {

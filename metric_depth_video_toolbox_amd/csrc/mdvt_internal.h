@@ -78,7 +78,11 @@ struct RenderArgs {
     uint32_t* elist;             // the edge-key words written since the last resolve, one segment of 2 W entries (eye << 31 | pixel) per
     uint32_t* elist_count;       //   (slot, source row) and its counter: k_edge_keys_reset empties exactly those words
     uint4* gverts[2];            // general mesh path: per-eye projected vertices {X, Y (snapped), 1/Z', rgb}, [slot][H*W]
-    unsigned long long* cbuf[2]; // general mesh path: per-eye colour side buffer, draw id << 32 | rgb of some fragment of the pixel
+    unsigned long long* cbuf[2]; // general mesh path: per-eye side words of the pixels with an exact depth tie between colours (draw id << 32 | rgb,
+                                 //   minimum over the fragments at the winning depth); touched at those pixels only
+    uint32_t* tie_flag;          // [slot]: a pixel of the slot's frame was marked as tied in this use (zeroed per launch set)
+    uint32_t* tie_tiles;         // [slot][2][tie_words]: bit per kTieTile x kTieTile tile of an eye holding a marked pixel (zeroed per launch set)
+    int32_t tie_words, tie_tiles_x;
     uint8_t* tri_invalid;        // [slot][2*(H-1)*(W-1)]
     uint8_t* unused;             // [slot][H*W]
     // general mesh path: queue of the triangles that are not small (kBigRecDwords dwords each), rasterised by k_mesh_raster_queue
@@ -101,6 +105,8 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
                               int n, int W, int H, int of_by_one, uint8_t* tri_invalid, size_t tri_stride,
                               uint8_t* unused, size_t unused_stride, hipStream_t s);
 
+constexpr int kTieTile = 32;          // pixels: side of the tiles whose "holds a pixel marked as tied" bits gate the second rasteriser pass of the general mesh path
+inline size_t tie_words_of(int W, int H) { return ((size_t)((W + kTieTile - 1) / kTieTile) * (size_t)((H + kTieTile - 1) / kTieTile) + 31) / 32; }
 constexpr int kHugeCap = 1 << 17;     // row-block entries of huge triangles per launch set (overflow: the queue kernel keeps the triangle)
 constexpr int kBigRecDwords = 2;     // a queued triangle: draw id, frame slot << 1 | eye
 

@@ -967,8 +967,8 @@ hipError_t launch_edge_keys_reset(const RenderArgs& a, int n, hipStream_t s)
 }
 
 // Resolve of both general paths: PX pixels per thread, coalesced key reads; the z keys need no clearing pass (parity
-// scheme, mdvt_device.h: only the uncovered words are rewritten; the edge keys: k_edge_keys_reset), colour from the key (mesh) or gathered
-// from the source frame by the winning source index (points).
+// scheme, mdvt_device.h: only the uncovered words are rewritten; the edge keys: k_edge_keys_reset), colour from the key word (mesh: colour
+// keys) or gathered from the source frame by the winning source index (points).
 template <int PX, int FLAGS, bool MESH>
 __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
 {
@@ -991,13 +991,7 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
         if (!zkey_covered(key[q], parity)) krow[q] = zkey_empty(parity ^ 1u);
     uint32_t opx[PX], om[PX], spx[PX];
     float oz[PX];
-    const uint4* gv = MESH ? a.gverts[eye] + (size_t)fr * a.ws_stride_px : nullptr;
-    u64 cw[PX];
-    if (MESH) {
-        const u64* crow = a.cbuf[eye] + (size_t)fr * a.ws_stride_px + (size_t)y * W + (size_t)g * PX;
-#pragma unroll
-        for (int q = 0; q < PX; ++q) cw[q] = crow[q];
-    }
+    const u64* crow = MESH ? a.cbuf[eye] + (size_t)fr * a.ws_stride_px + (size_t)y * W + (size_t)g * PX : nullptr;
 #pragma unroll
     for (int q = 0; q < PX; ++q) {
         const bool covered = zkey_covered(key[q], parity);
@@ -1007,26 +1001,11 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
         if (covered) {
             if (MESH) zkey_decode<true>(key[q], parity, kdepth, ktie); else zkey_decode<false>(key[q], parity, kdepth, ktie);
             if (MESH) {
-                // the key names the winning triangle (pass << 31 | i << 16 | j).  Its colour is in the side buffer unless another
-                // fragment of this pixel stored last: then its three projected vertices are read back and the fragment is
-                // evaluated exactly as the rasteriser evaluated it
-                const uint32_t id = ktie;
+                // the word carries the nearest fragment's colour -- unless the pixel was marked as an exact depth tie between colours:
+                // then the rasteriser's second pass left draw id << 32 | colour of the first-drawn fragment at that depth in the side word
                 if (ZOUT) zval = 1.0f / __uint_as_float(kdepth);
-                if ((uint32_t)(cw[q] >> 32) == id && !(a.debug_skip & 64)) { rgb = (uint32_t)cw[q]; }     // (bit 6: test hook, always re-shade)
-                else {
-                const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
-                const uint4* r0 = gv + (size_t)ci * W + cj;
-                const uint4 A = r0[0];
-                const uint4 v1 = pass == 0 ? r0[W] : r0[W + 1], v2 = pass == 0 ? r0[W + 1] : r0[1];
-                TriSetup t;
-                (void)tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
-                                        (int)v2.x, (int)v2.y, __uint_as_float(v2.z));
-                float q0, q1, q2;
-                (void)tri_sample(t, g * PX + q, y, q0, q1, q2);
-                const float iz = (q0 + q1) + q2;
-                const float riz = rcp_exact(iz);
-                rgb = shade_px(q0, q1, q2, riz, A.w, v1.w, v2.w);
-                }
+                rgb = ktie & 0xFFFFFFu;
+                if (!(ktie & kNoTie)) rgb = (uint32_t)crow[q] & 0xFFFFFFu;
             } else {
                 const uint32_t src = ktie;
                 rgb = load_px_bytes(cbase + (size_t)(src >> 16) * a.color_pitch, (int)(src & 0xFFFFu));

@@ -25,36 +25,121 @@ constexpr int kHugeArea = 8192;    // pixel centres in the box of a queued trian
 constexpr int kHugeRows = 16;      // rows per entry of the huge list
 constexpr int kSmallBox = 12;      // pixel centres in the bounding box of a triangle the owning lane walks itself
 
-__device__ __forceinline__ void mesh_global_fragment(u64* keys, u64* cbuf, uint32_t parity, size_t o, float q0, float q1, float q2,
-                                                     uint32_t c0, uint32_t c1, uint32_t c2, uint32_t did)
+// Where the fragments of one (frame slot, eye) go.
+struct FragOut {
+    u64* keys; u64* cbuf;
+    uint32_t* tiles; uint32_t* flag;
+    uint32_t parity;
+    int tiles_x;
+};
+__device__ __forceinline__ FragOut frag_out(const RenderArgs& a, int slot, int eye)
+{
+    FragOut f;
+    f.keys = a.keys[eye] + (size_t)slot * a.ws_stride_px;
+    f.cbuf = a.cbuf[eye] + (size_t)slot * a.ws_stride_px;
+    f.tiles = a.tie_tiles + ((size_t)slot * 2 + (size_t)eye) * (size_t)a.tie_words;
+    f.flag = a.tie_flag + slot;
+    f.parity = (a.key_parity >> slot) & 1u;
+    f.tiles_x = a.tie_tiles_x;
+    return f;
+}
+
+// What a first-pass fragment's post returned is looked at just before the lane's next post (or at the kernel's end).  The post is a
+// RETURNING atomic -- the word it replaced is what tells a tie -- a round trip to the L2 that costs the rasterisers ~12 us per 1080p
+// frame when it is waited for at once.  Settling the pending word BEFORE the next post frees its registers for the next return (the
+// atomic writes them directly; with the opposite order the compiler copies the pair and waits for it right behind the atomic), so
+// the round trip overlaps the next fragment's set-up and shading: half of the cost back (profiles/r04_colour_keys.md; batches of
+// 2-4 posts per lane and an XCD-aware block order did not help).
+struct Pending {
+    u64 old, mine;
+    uint32_t o, se;      // pixel index (~0u: nothing pending), frame slot << 1 | eye
+};
+__device__ __forceinline__ Pending pending_none() { Pending p; p.old = p.mine = 0ull; p.o = ~0u; p.se = 0u; return p; }
+__device__ __forceinline__ void pending_settle(const RenderArgs& a, const Pending& p)
+{
+    if (p.o == ~0u) return;
+    const int slot = (int)(p.se >> 1);
+    const uint32_t parity = (a.key_parity >> slot) & 1u;
+    if (zkey_colour_conflict(p.old, p.mine, parity) || ((a.debug_skip & 32) && zkey_covered(p.old, parity))) {   // (bit 5: test hook,
+        const FragOut f = frag_out(a, slot, (int)(p.se & 1u));                                                         //  tuning build)
+        zkey_mark_tied(&f.keys[p.o], parity);
+        f.cbuf[p.o] = ~0ull;                                // (every marker stores the same value; the second pass is a later kernel)
+        *f.flag = 1u;
+        const int px = (int)(p.o % (uint32_t)a.W), py = (int)(p.o / (uint32_t)a.W);
+        const int t = (py / kTieTile) * f.tiles_x + px / kTieTile;
+        atomicOr(&f.tiles[t >> 5], 1u << (t & 31));
+    }
+}
+
+// One shaded fragment.  MODE 0 (first pass): nearest fragment's depth and colour into the pixel's key word; a fragment that finds
+// its own depth there with another colour marks the pixel (mdvt_device.h, colour keys), its tile and its frame -- when it is
+// settled (pending_settle: by the next fragment of the lane, or by the kernel's end).  MODE 1 (second pass, marked frames only):
+// at a marked pixel, the fragments at the word's depth compete by draw id in the side word.
+template <int MODE>
+__device__ __forceinline__ void mesh_global_fragment(const RenderArgs& a, int slot, int eye, const FragOut& f, Pending& pd, int W, int px, int py,
+                                                     float q0, float q1, float q2, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t did)
 {
     asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));     // (the colour conversions belong to the fragment, not to every triangle's set-up)
+    const uint32_t o = (uint32_t)py * (uint32_t)W + (uint32_t)px;
     const float iz = (q0 + q1) + q2;
-    zkey_post<true>(&keys[o], parity, __float_as_uint(iz), did);          // iz > 0: its bits are a 31-bit order key
-    cbuf[o] = ((u64)did << 32) | shade_px(q0, q1, q2, rcp_exact(iz), c0, c1, c2);
+    const uint32_t rgb = shade_px(q0, q1, q2, rcp_exact(iz), c0, c1, c2);
+    const u64 mine = zkey_word<true>(f.parity, __float_as_uint(iz), kNoTie | rgb);      // iz > 0: its bits are a 31-bit order key
+    if (MODE == 0) {
+        pending_settle(a, pd);            // (before the post: the pending word's registers are then free to take the next return)
+        pd.old = zkey_post_word(&f.keys[o], f.parity, mine);
+        pd.mine = mine; pd.o = o; pd.se = (uint32_t)slot * 2u + (uint32_t)eye;
+    } else {
+        const u64 key = f.keys[o];
+        if (zkey_covered(key, f.parity) && zkey_is_tied(key, f.parity) && ((key ^ mine) >> 32) == 0ull)
+            atomicMin(&f.cbuf[o], ((u64)did << 32) | rgb);
+    }
+}
+
+// The 128-cell block of a workgroup of the one-thread-per-cell kernels: row-major over the frame's cells, grid x = cell_block_grid.
+// (Measured and not kept, r04: an XCD-aware deal -- workgroup b runs on XCD b % 8, each XCD with its own L2, so each XCD took a
+// contiguous eighth of the blocks and the second reader of a vertex-record row found it in the L2 the first one had filled.  The
+// rasteriser's fetch traffic fell from 145 to 71 MB per 1080p frame and its time did not move, 6 % slower under a pose: these
+// kernels wait for their atomics, not for bytes.)
+__host__ __device__ __forceinline__ uint32_t cell_blocks(int W, int H) { return (uint32_t)((W - 1 + 127) / 128) * (uint32_t)(H - 1); }
+inline uint32_t cell_block_grid(int W, int H) { return cell_blocks(W, H); }
+__device__ __forceinline__ bool cell_block_of(int W, int H, int& bx, int& i)
+{
+    const uint32_t v = blockIdx.x, nbx = (uint32_t)((W - 1 + 127) / 128);
+    if (v >= cell_blocks(W, H)) return false;
+    bx = (int)(v % nbx); i = (int)(v / nbx);
+    return true;
+}
+
+// second pass: does the pixel box touch a tile with a marked pixel?
+__device__ __forceinline__ bool tie_tiles_hit(const FragOut& f, int bx0, int by0, int bx1, int by1)
+{
+    bool hit = false;
+    for (int ty = by0 / kTieTile; ty <= by1 / kTieTile; ++ty)
+        for (int tx = bx0 / kTieTile; tx <= bx1 / kTieTile; ++tx) {
+            const int t = ty * f.tiles_x + tx;
+            hit |= ((f.tiles[t >> 5] >> (t & 31)) & 1u) != 0u;
+        }
+    return hit;
 }
 
 }  // namespace
 
-// One thread per cell, both triangles, both eyes.
-template <int FLAGS>
-__global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
+// One thread per cell, both triangles, both eyes.  MODE as mesh_global_fragment's; the second pass runs for the frames with a marked
+// pixel only, and only the triangles whose pixel box touches a marked tile get as far as their set-up.
+template <int FLAGS, int MODE>
+__device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][129], Pending& pd)
 {
     constexpr bool EDGES = FLAGS & 2;
     const int W = a.W, H = a.H;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    const int fr = blockIdx.z;
+    const int j = bx * 128 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
-    const uint32_t parity = (a.key_parity >> fr) & 1u;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     // the 2 x 129 vertex records of both eyes, fetched once per workgroup with all loads in flight together
-    __shared__ uint4 sv[2][2][129];
     uint32_t inv0 = 0, inv1 = 0;
     {
         const int t = threadIdx.x;
-        const int j0 = blockIdx.x * blockDim.x;
+        const int j0 = bx * 128;
         const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
         const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);      // (clamped: columns past the row end are never used)
         uint4 rx = make_uint4(0, 0, 0, 0);
@@ -71,8 +156,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
     __syncthreads();
 #pragma unroll 1
     for (int eye = 0; eye < 2; ++eye) {
-        u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
-        u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
+        const FragOut fo = frag_out(a, fr, eye);
         uint4 A = make_uint4(0, 0, 0, 0), B = A, Cv = A, D = A;
         if (act) {
             const int t = threadIdx.x;
@@ -96,7 +180,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
                         // (a small extent bounds the box at 33 x 33: the count fits any integer)
                         if (max(mxX - mnX, mxY - mnY) >= kSmallTriExtent || (bx1 - bx0 + 1) * (by1 - by0 + 1) > kSmallBox) {
                             toq = true;
-                        } else {
+                        } else if (MODE == 0 || tie_tiles_hit(fo, bx0, by0, bx1, by1)) {
                             TriSmall ts;
                             if (tri_small_setup(ts, X0, Y0, iz0, X1, Y1, iz1, X2, Y2, iz2, a.cull) && !(a.debug_skip & 16)) {
                                 TriWalk32 row = tri_small_start(ts, bx0, by0);
@@ -106,7 +190,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
                                         if (tri_small_inside(ts, w)) {
                                             float q0, q1, q2;
                                             tri_small_weights(ts, w, q0, q1, q2);
-                                            mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
+                                            mesh_global_fragment<MODE>(a, fr, eye, fo, pd, W, px, py, q0, q1, q2, A.w, v1.w, v2.w, did);
                                         }
                                         tri_small_right(ts, w);
                                     }
@@ -128,6 +212,30 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a)
                     uint2* q = (uint2*)a.bigq + seg * (size_t)(4 * W);
                     q[base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = make_uint2(did, (uint32_t)fr * 2u + (uint32_t)eye);
                 }
+            }
+        }
+    }
+}
+
+// First pass: a workgroup per block of cells (grid: cell_block_grid x 1 x frames).  Second pass: a fixed number of workgroups that
+// walk the blocks of the frames with a marked pixel -- normally there is none, and the launch is over after `nframes` loads.
+template <int FLAGS, int MODE>
+__global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a, int nframes)
+{
+    __shared__ uint4 sv[2][2][129];
+    Pending pd = pending_none();
+    if (MODE == 0) {
+        int bx, i;
+        if (!cell_block_of(a.W, a.H, bx, i)) return;
+        mesh_raster_small_block<FLAGS, 0>(a, (int)blockIdx.z, bx, i, sv, pd);
+        pending_settle(a, pd);
+    } else {
+        const uint32_t nblk = cell_blocks(a.W, a.H), nbx = (uint32_t)((a.W - 1 + 127) / 128);
+        for (int fr = 0; fr < nframes; ++fr) {
+            if (a.tie_flag[fr] == 0u) continue;                               // (workgroup uniform)
+            for (uint32_t v = blockIdx.x; v < nblk; v += gridDim.x) {
+                mesh_raster_small_block<FLAGS, 1>(a, fr, (int)(v % nbx), (int)(v / nbx), sv, pd);
+                __syncthreads();
             }
         }
     }
@@ -163,12 +271,13 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
     constexpr bool EDGES = FLAGS & 2;
     constexpr int kCoord = 1 << 19, kMaxH = 512, kMaxSpan = 12;
     const int W = a.W, H = a.H;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
     const int fr = blockIdx.z;
+    int bx, i;
+    if (!cell_block_of(W, H, bx, i)) return;
+    const int j = bx * 128 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
-    const uint32_t parity = (a.key_parity >> fr) & 1u;
+    Pending pd = pending_none();
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     __shared__ uint4 sv[2][2][129];
     __shared__ uint32_t glist[256];           // cells (thread | eye << 8) for the generic code
@@ -176,7 +285,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
     uint32_t inv0 = 0, inv1 = 0;
     {
         const int t = threadIdx.x;
-        const int j0 = blockIdx.x * blockDim.x;
+        const int j0 = bx * 128;
         const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
         const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);
         uint4 rx = make_uint4(0, 0, 0, 0);
@@ -196,8 +305,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
 #pragma unroll 1
     for (int eye = 0; eye < 2; ++eye) {
         if (!act || (inv0 && inv1)) continue;
-        u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
-        u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
+        const FragOut fo = frag_out(a, fr, eye);
         const int t = threadIdx.x;
         const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
         const int XA = (int)A.x, YA = (int)A.y, XB = (int)B.x, YB = (int)B.y, XC = (int)Cv.x, YC = (int)Cv.y, XD = (int)D.x, YD = (int)D.y;
@@ -243,8 +351,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
                         const float q0 = ((float)(w0 < 0 ? -w0 : w0) * ra) * izA;
                         const float q1 = ((float)(w1 < 0 ? -w1 : w1) * ra) * (in1 ? izB : izC);
                         const float q2 = ((float)(w2 < 0 ? -w2 : w2) * ra) * (in1 ? izC : izD);
-                        mesh_global_fragment(keys, cbuf, parity, (size_t)k * W + (size_t)px, q0, q1, q2, A.w, in1 ? B.w : Cv.w, in1 ? Cv.w : D.w,
-                                             draw_id_global(in1 ? 0 : 1, i, j));
+                        mesh_global_fragment<0>(a, fr, eye, fo, pd, W, px, k, q0, q1, q2, A.w, in1 ? B.w : Cv.w, in1 ? Cv.w : D.w, draw_id_global(in1 ? 0 : 1, i, j));
                     }
                 }
             }
@@ -259,9 +366,8 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
         const bool on = idx < ng;
         const uint32_t ent = glist[on ? idx >> 1 : 0];
         const int t = (int)(ent & 0xFFu), eye = (int)(ent >> 8), pass = (int)(idx & 1u);
-        const int cj = blockIdx.x * blockDim.x + t;
-        u64* keys = a.keys[eye] + (size_t)fr * a.ws_stride_px;
-        u64* cbuf = a.cbuf[eye] + (size_t)fr * a.ws_stride_px;
+        const int cj = bx * 128 + t;
+        const FragOut fo = frag_out(a, fr, eye);
         const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
         const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
         const uint32_t did = draw_id_global(pass, i, cj);
@@ -289,7 +395,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
                                     if (tri_small_inside(ts, w)) {
                                         float q0, q1, q2;
                                         tri_small_weights(ts, w, q0, q1, q2);
-                                        mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, did);
+                                        mesh_global_fragment<0>(a, fr, eye, fo, pd, W, px, py, q0, q1, q2, A.w, v1.w, v2.w, did);
                                     }
                                     tri_small_right(ts, w);
                                 }
@@ -313,13 +419,24 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
             }
         }
     }
+    pending_settle(a, pd);
 }
 
 // Exclusive prefix sums of the segment counters (n <= a few 10^4): one workgroup.  prefix[n] = number of queued triangles.
-__global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ prefix, int n)
+// `flags` (second pass): nothing is queued unless one of the nflags frames has a marked pixel -- then only prefix[n] = 0 is written.
+__global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ prefix, int n,
+                                                          const uint32_t* __restrict__ flags, int nflags)
 {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
+    if (flags) {
+        uint32_t any = 0;
+        for (int k = t; k < nflags; k += 1024) any |= flags[k];
+        if (!__syncthreads_or((int)any)) {
+            if (t == 0) prefix[n] = 0u;
+            return;
+        }
+    }
     // a thread's chunk: a multiple of four counters, read as 16-byte vectors and kept in registers (one counter per trip made the
     // pass 17 dependent round trips long, twice: 21 us for a 16-frame 1080p launch set; `counts` is 16-byte aligned)
     constexpr int kMaxVec = 16;                                    // up to 64 counters per thread: 65 536 segments
@@ -369,6 +486,7 @@ __global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __rest
 // The queued triangles, dealt over the whole chip (a horizontal depth edge under vertical parallax turns an entire row
 // of cells into large triangles: one workgroup per segment would leave that segment's workgroup running alone): 16 lanes
 // per triangle, generic 64-bit set-up, rows walked by their own column range.
+template <int MODE>
 __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nseg)
 {
     const int W = a.W, H = a.H;
@@ -376,6 +494,7 @@ __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nse
     const uint32_t total = prefix[nseg];
     const int sub = threadIdx.x & 15;
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = (gridDim.x * blockDim.x) >> 4;
+    Pending pd = pending_none();
     for (uint32_t g = group; g < total; g += ngroups) {
         int lo_s = 0, hi_s = nseg - 1;                              // the segment holding global entry g: last s with prefix[s] <= g
         while (lo_s < hi_s) {
@@ -415,15 +534,13 @@ __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nse
             // list full: the triangle stays here, and the entries from `base` on were never written (every later push fails too)
             if (sub == 0 && base < (uint32_t)kHugeCap) atomicMax(&a.hugeq[2 * kHugeCap + 1], (uint32_t)kHugeCap - base);
         }
-        u64* keys = a.keys[eye] + (size_t)slot * a.ws_stride_px;
-        u64* cbuf = a.cbuf[eye] + (size_t)slot * a.ws_stride_px;
+        const FragOut fo = frag_out(a, slot, eye);
         // (r04) what is constant for the triangle -- 1 / f32(area2), the colour planes' conversions are the fragment's -- and the edge
         // values advanced by exact integer steps along a row (16 pixels: w_k -= 16 * 256 dy_k) instead of six 32 x 32 -> 64
         // products per pixel centre; the same integers, the same f32 operations as tri_sample / tri_weights, so the same bits
         const bool small = t.area2 < 0x7FFFFFFFll;                      // 0 <= w_k <= area2 inside: every value fits int32
         const float ra = rcp_exact(i64_to_f32(t.area2, small));
         const i64 st0 = (i64)t.dy0 * (16 * kSubpix), st1 = (i64)t.dy1 * (16 * kSubpix), st2 = (i64)t.dy2 * (16 * kSubpix);
-        const uint32_t parity = (a.key_parity >> slot) & 1u;
         if (py1 - py0 >= 3) {
             // Four rows or more: a ROW per lane, each lane walking its own short span pixel by pixel -- the rubber sheet between a
             // near object and the background under a pose with vertical parallax is a diagonal sliver hundreds of rows tall and two
@@ -441,7 +558,7 @@ __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nse
                     if (!(edge_in(w0, t.dx0, t.dy0) && edge_in(w1, t.dx1, t.dy1) && edge_in(w2, t.dx2, t.dy2))) continue;
                     const float f0 = i64_to_f32(w0, small), f1 = i64_to_f32(w1, small), f2 = i64_to_f32(w2, small);
                     const float q0 = (f0 * ra) * t.iz0, q1 = (f1 * ra) * t.iz1, q2 = (f2 * ra) * t.iz2;
-                    mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
+                    mesh_global_fragment<MODE>(a, slot, eye, fo, pd, W, px, py, q0, q1, q2, A.w, v1.w, v2.w, id);
                 }
             }
             continue;
@@ -461,14 +578,16 @@ __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nse
                 if (__ballot(!small) == 0ull) { f0 = (float)(int)w0; f1 = (float)(int)w1; f2 = (float)(int)w2; }     // (as tri_weights)
                 else { f0 = i64_to_f32(w0, small); f1 = i64_to_f32(w1, small); f2 = i64_to_f32(w2, small); }
                 const float q0 = (f0 * ra) * t.iz0, q1 = (f1 * ra) * t.iz1, q2 = (f2 * ra) * t.iz2;
-                mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
+                mesh_global_fragment<MODE>(a, slot, eye, fo, pd, W, px, py, q0, q1, q2, A.w, v1.w, v2.w, id);
             }
         }
     }
+    if (MODE == 0) pending_settle(a, pd);
 }
 
 // The row blocks of the huge triangles: a wave per entry, its 64 lanes along the rows (edge values advanced by 64 pixels per step).
 // Same set-up, same integers, same f32 operations as k_mesh_raster_queue.
+template <int MODE>
 __global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a)
 {
     const int W = a.W, H = a.H;
@@ -477,6 +596,7 @@ __global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a)
     const uint32_t total = cnt < lim ? cnt : lim;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    Pending pd = pending_none();
     for (uint32_t g = wave; g < total; g += nwaves) {
         const uint2 e = *(const uint2*)(a.hugeq + 2 * (size_t)g);
         const uint32_t id = e.x;
@@ -493,12 +613,10 @@ __global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a)
         int py0 = floordiv_subpix(t.minY - kSubpix / 2 + kSubpix - 1), py1 = floordiv_subpix(t.maxY - kSubpix / 2);
         px0 = max(px0, 0); py0 = max(py0, 0); px1 = min(px1, W - 1); py1 = min(py1, H - 1);
         const int ya = py0 + blk * kHugeRows, yb = min(ya + kHugeRows - 1, py1);
-        u64* keys = a.keys[eye] + (size_t)slot * a.ws_stride_px;
-        u64* cbuf = a.cbuf[eye] + (size_t)slot * a.ws_stride_px;
+        const FragOut fo = frag_out(a, slot, eye);
         const bool small = t.area2 < 0x7FFFFFFFll;
         const float ra = rcp_exact(i64_to_f32(t.area2, small));
         const i64 st0 = (i64)t.dy0 * (64 * kSubpix), st1 = (i64)t.dy1 * (64 * kSubpix), st2 = (i64)t.dy2 * (64 * kSubpix);
-        const uint32_t parity = (a.key_parity >> slot) & 1u;
         for (int py = ya; py <= yb; ++py) {
             int lo, hi;
             if (!tri_row_range(t, py, px0, px1, lo, hi)) continue;
@@ -512,35 +630,53 @@ __global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a)
                 if (!(edge_in(w0, t.dx0, t.dy0) && edge_in(w1, t.dx1, t.dy1) && edge_in(w2, t.dx2, t.dy2))) continue;
                 const float f0 = i64_to_f32(w0, small), f1 = i64_to_f32(w1, small), f2 = i64_to_f32(w2, small);
                 const float q0 = (f0 * ra) * t.iz0, q1 = (f1 * ra) * t.iz1, q2 = (f2 * ra) * t.iz2;
-                mesh_global_fragment(keys, cbuf, parity, (size_t)py * W + (size_t)px, q0, q1, q2, A.w, v1.w, v2.w, id);
+                mesh_global_fragment<MODE>(a, slot, eye, fo, pd, W, px, py, q0, q1, q2, A.w, v1.w, v2.w, id);
             }
         }
     }
+    if (MODE == 0) pending_settle(a, pd);
 }
 
 hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(a.bigq_count, 0, (size_t)plan.n * a.H * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(a.hugeq + 2 * (size_t)kHugeCap, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;
-    const dim3 grid_c((a.W - 1 + 127) / 128, a.H - 1, plan.n);
-    // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
-    if (plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr) {
-        if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_c, dim3(128), 0, s, a);
-        else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_c, dim3(128), 0, s, a);
-    } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2>), grid_c, dim3(128), 0, s, a);
-    else hipLaunchKernelGGL((k_mesh_raster_small<0>), grid_c, dim3(128), 0, s, a);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
     const int nseg = plan.n * a.H;
-    hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg);
-    if (tuning_env(TUNE_QUEUE_DUMP)) {       // tuning hook: queued (large) triangles of this launch set on stderr
-        uint32_t total = 0;
-        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&total, a.bigq_count + 2 * nseg, 4, hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "queued triangles: %u in %d frames (%d x %d)\n", total, plan.n, a.W, a.H);
+    const dim3 grid_c(cell_block_grid(a.W, a.H), 1, plan.n);
+    hipError_t e = hipMemsetAsync(a.tie_flag, 0, (size_t)a.tie_words * 2 * plan.n * sizeof(uint32_t) + (size_t)(a.tie_tiles - a.tie_flag) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    // pass 0: every triangle; pass 1: the frames in which pass 0 marked a pixel as an exact depth tie between colours, to settle those
+    // pixels by draw id (mdvt_device.h, colour keys) -- normally none, and every kernel of the pass ends at its first test
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((e = hipMemsetAsync(a.bigq_count, 0, (size_t)nseg * sizeof(uint32_t), s)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(a.hugeq + 2 * (size_t)kHugeCap, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;
+        if (pass == 1) {
+            if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2, 1>), dim3(1024), dim3(128), 0, s, a, plan.n);
+            else hipLaunchKernelGGL((k_mesh_raster_small<0, 1>), dim3(1024), dim3(128), 0, s, a, plan.n);
+        } else if (plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr) {
+            // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
+            if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_c, dim3(128), 0, s, a);
+            else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_c, dim3(128), 0, s, a);
+        } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2, 0>), grid_c, dim3(128), 0, s, a, plan.n);
+        else hipLaunchKernelGGL((k_mesh_raster_small<0, 0>), grid_c, dim3(128), 0, s, a, plan.n);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg,
+                           pass ? a.tie_flag : (const uint32_t*)nullptr, plan.n);
+        if (tuning_env(TUNE_QUEUE_DUMP)) {       // tuning hook: queued (large) triangles of this launch set on stderr
+            uint32_t total = 0, marked = 0;
+            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&total, a.bigq_count + 2 * nseg, 4, hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int f = 0; f < plan.n; ++f) { uint32_t v = 0; if (hipMemcpy(&v, a.tie_flag + f, 4, hipMemcpyDeviceToHost) == hipSuccess) marked += v; }
+                fprintf(stderr, "pass %d: queued triangles: %u in %d frames (%d x %d), %u frames with marked pixels\n", pass, total, plan.n, a.W, a.H, marked);
+            }
+        }
+        if (pass == 0) {
+            hipLaunchKernelGGL(k_mesh_raster_queue<0>, dim3(2048), dim3(256), 0, s, a, nseg);
+            hipLaunchKernelGGL(k_mesh_raster_huge<0>, dim3(2048), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(k_mesh_raster_queue<1>, dim3(512), dim3(256), 0, s, a, nseg);
+            hipLaunchKernelGGL(k_mesh_raster_huge<1>, dim3(512), dim3(256), 0, s, a);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_mesh_raster_queue, dim3(2048), dim3(256), 0, s, a, nseg);
-    hipLaunchKernelGGL(k_mesh_raster_huge, dim3(2048), dim3(256), 0, s, a);
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 }  // namespace mdvt

@@ -361,10 +361,10 @@ def test_exact_depth_ties_follow_the_draw_order(mods, orc, monkeypatch):
         ties += orc.stats()["depth_ties"]
         got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
         _compare(got, want, W, f"ties {W}x{H} t={t} {kw} global={force_global}")
-        if force_global:     # ... and with the resolve pass distrusting the colour side buffer: every pixel re-shaded from its draw id
-            monkeypatch.setenv("MDVT_DEBUG_SKIP", "64")
+        if force_global:     # ... and with every pixel that receives a second fragment marked as tied: the second rasteriser pass settles them all by draw id
+            monkeypatch.setenv("MDVT_DEBUG_SKIP", "32")
             got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True)
-            _compare(got, want, W, "ties, re-shaded")
+            _compare(got, want, W, "ties, every overdrawn pixel through the second pass")
             monkeypatch.delenv("MDVT_DEBUG_SKIP")
         monkeypatch.delenv("MDVT_FORCE_GLOBAL", raising=False)
         r.close()
