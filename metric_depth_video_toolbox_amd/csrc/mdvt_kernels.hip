@@ -2814,6 +2814,184 @@ static hipError_t launch_edge_rows_exact(const RenderPlan& plan, const RenderArg
     return hipGetLastError();
 }
 
+// Edge points of every OTHER scanline of a pure-shift frame (sr:589-606, 745-781, 813-814): there a point of source row y lands
+// on scanline y, in the column edge_col_pure gives (f32 estimate, the reference's f64 chain inside the guard band), nearest first
+// (depth code, then the lower column), and is painted where the render left a hole -- after the row kernel, which then renders
+// WITHOUT edge points: inside k_mesh_band they cost 11 us per 1080p frame (keys through the z-buffer row's LDS, two more barriers
+// per scanline and eye, 17 VGPRs at the 128 limit).  One workgroup per (kEdgeRowsPer scanlines, frame), both eyes; 2 x W x 4 B of LDS.
+constexpr int kEdgeRowsPer = 8;           // scanlines per workgroup of k_edge_rows_pure (<= 16: hit list entries)
+constexpr int kEdgeHitCap = 1024;         // entries of its hit list (a workgroup with more paints the rest where it finds them)
+
+// what a thread of k_edge_rows_pure<., true> reads from memory for one scanline: flags, depth codes, both eyes' hole masks of its 4-column groups
+template <int NIT> struct EdgeRowRegs { uint32_t u4[NIT], dw[NIT][3], m0[NIT], m1[NIT]; };
+template <int NIT>
+__device__ __forceinline__ void edge_row_fetch(const RenderArgs& a, int fr, int f, int y, int tid, EdgeRowRegs<NIT>& r)
+{
+    const int W = a.W;
+    const uint8_t* urow = a.unused + (size_t)fr * a.ws_stride_px + (size_t)y * W;
+    const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)y * a.depth_pitch;
+    const uint8_t* mrow0 = a.mask[0] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch;
+    const uint8_t* mrow1 = a.mask[1] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int j0 = tid * 4 + it * 1024;
+        r.u4[it] = 0; r.m0[it] = r.m1[it] = 0; r.dw[it][0] = r.dw[it][1] = r.dw[it][2] = 0;
+        if (j0 < W && y < a.H) {
+            r.u4[it] = *(const uint32_t*)(urow + j0);
+            const uint32_t* dp = (const uint32_t*)(drow + 3 * (size_t)j0);
+            r.dw[it][0] = dp[0]; r.dw[it][1] = dp[1]; r.dw[it][2] = dp[2];
+            r.m0[it] = *(const uint32_t*)(mrow0 + j0); r.m1[it] = *(const uint32_t*)(mrow1 + j0);
+        }
+    }
+}
+
+// NIT: 4-column groups per thread (W <= 1024 NIT), 0: rows that are not dword-addressable, column by column
+template <bool MESH, int NIT>
+__global__ void __launch_bounds__(256) k_edge_rows_pure(RenderArgs a)
+{
+    constexpr bool VEC = NIT > 0;
+    constexpr int NR = NIT > 0 ? NIT : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* ek = (uint32_t*)smem;                       // [2][W]: depth code << 16 | source column; EMPTY between scanlines
+    const int W = a.W, H = a.H, fr = blockIdx.y, tid = threadIdx.x;
+    // the workgroup's hits (a key in a hole), painted together at the end: x | source column << 16, scanline - y0 | eye << 4
+    uint2* hitq = (uint2*)(ek + 2 * W);
+    __shared__ uint32_t nhit;
+    if (tid == 0) nhit = 0u;
+    const int f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const int y0 = blockIdx.x * kEdgeRowsPer, y1 = min(y0 + kEdgeRowsPer, H);
+    // VEC (dword-addressable rows, W <= 4096): everything a scanline needs from memory -- flags, depth codes, both hole masks -- is
+    // requested together, and a scanline ahead: taken one after the other (flags, then the flagged columns' depth, then the mask
+    // under a key) by a workgroup per scanline, the round trips made this a 14 us workgroup for a microsecond of work
+    EdgeRowRegs<NR> cur, nxt;
+    if (VEC) edge_row_fetch(a, fr, f, y0, tid, cur);
+    for (int x = tid; x < 2 * W; x += 256) ek[x] = kEmpty32;
+    __syncthreads();
+    const float guard = edge_col_guard(W);
+    auto paint = [&](int eye, int x, int y, int sj) {                          // sr:776, 813-814: the caller has seen the hole
+        if (a.edge_paint)
+            store_px_bytes(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)y * a.rgb_pitch, x,
+                           load_px_bytes(a.color + (size_t)f * a.color_stride + (size_t)y * a.color_pitch, sj));
+        if (a.seed[eye])
+            store_px_bytes(a.seed[eye] + (size_t)f * a.seed_stride + (size_t)y * a.seed_pitch, x, edge_normal_colour(a, fp, f, eye, y, sj, MESH ? 1 : 0));
+    };
+#pragma unroll 1
+    for (int y = y0; y < y1; ++y) {
+        if (VEC) edge_row_fetch(a, fr, f, y + 1 < y1 ? y + 1 : H, tid, nxt);      // (row H: nothing is read)
+        bool any = false;
+        if (!edge_row_deferred(fp, y)) {                  // (those are k_edge_rows_exact's)
+            const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)y * a.depth_pitch;
+            auto splat = [&](int j, uint32_t px) {
+                const uint32_t code = code16_of(px);
+                const float z = decode_z(code, fp.mult, fp.scale);
+                if (!(z > kNear)) return;
+                const float gx = (float)j * fp.sx, d = fp.dl / z;
+#pragma unroll
+                for (int eye = 0; eye < 2; ++eye) {
+                    const int x = edge_col_pure(fp, eye, gx, z, d, W, guard);      // sr:599-600, 746
+                    if (x >= 0) { atomicMin(&ek[eye * W + x], (code << 16) | (uint32_t)j); any = true; }
+                }
+            };
+            if (VEC) {
+                // the flagged columns of the thread, one bit each; ONE copy of the splat code walks them (unrolled over the 16 columns
+                // the kernel was 14 000 instructions, 110 KB: every wave stalled on instruction fetch)
+                uint32_t todo = 0;
+#pragma unroll
+                for (int it = 0; it < NR; ++it)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((cur.u4[it] >> (8 * q)) & 0xFFu) todo |= 1u << (it * 4 + q);
+#pragma unroll 1
+                while (todo) {
+                    const int b = __ffs((int)todo) - 1, it = b >> 2, q = b & 3;
+                    todo &= todo - 1u;
+                    uint32_t d0 = cur.dw[0][0], d1 = cur.dw[0][1], d2 = cur.dw[0][2];
+#pragma unroll
+                    for (int k = 1; k < NR; ++k)
+                        if (it == k) { d0 = cur.dw[k][0]; d1 = cur.dw[k][1]; d2 = cur.dw[k][2]; }
+                    const u64 lo = (u64)d0 | ((u64)d1 << 32), hi = (u64)d1 | ((u64)d2 << 32);
+                    const uint32_t px = (q < 2 ? (uint32_t)(lo >> (24 * q)) : (uint32_t)(hi >> (24 * q - 32))) & 0xFFFFFFu;
+                    splat(tid * 4 + it * 1024 + q, px);
+                }
+            } else {
+                const uint8_t* urow = a.unused + (size_t)fr * a.ws_stride_px + (size_t)y * W;
+                for (int j = tid; j < W; j += 256)
+                    if (urow[j]) splat(j, load_px_bytes(drow, j));
+            }
+        }
+        if (__syncthreads_or((int)any)) {                 // (workgroup uniform)
+            if (VEC) {
+                uint32_t hits = 0;                       // bit (it * 2 + eye) * 4 + q: a key in a hole
+#pragma unroll
+                for (int it = 0; it < NR; ++it) {
+                    const int x0 = tid * 4 + it * 1024;
+                    if (x0 >= W) continue;
+#pragma unroll
+                    for (int eye = 0; eye < 2; ++eye) {
+                        const uint32_t m = eye ? cur.m1[it] : cur.m0[it];
+                        if (!m) continue;                                           // no hole among the four
+                        const uint4 k4 = *(const uint4*)(ek + eye * W + x0);
+                        const uint32_t kq[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (kq[q] != kEmpty32 && ((m >> (8 * q)) & 0xFFu)) hits |= 1u << ((it * 2 + eye) * 4 + q);
+                    }
+                }
+                // the hits go to the workgroup's list and are painted when all its scanlines are through: painting is a chain of
+                // dependent loads (source colour; for the seed image the 3 x 3 neighbourhood of the vertex) that a lane walking its own
+                // hits one after the other waited 5 us per scanline for
+#pragma unroll 1
+                while (hits) {
+                    const int b = __ffs((int)hits) - 1, it = b >> 3, eye = (b >> 2) & 1, q = b & 3;
+                    hits &= hits - 1u;
+                    const int x = tid * 4 + it * 1024 + q;
+                    const int sj = (int)(ek[eye * W + x] & 0xFFFFu);
+                    const uint32_t slot = atomicAdd(&nhit, 1u);
+                    if (slot < (uint32_t)kEdgeHitCap) hitq[slot] = make_uint2((uint32_t)x | ((uint32_t)sj << 16), (uint32_t)(y - y0) | ((uint32_t)eye << 4));
+                    else paint(eye, x, y, sj);           // (list full: at once)
+                }
+#pragma unroll
+                for (int it = 0; it < NR; ++it) {         // (every thread leaves its own words EMPTY for the next scanline)
+                    const int x0 = tid * 4 + it * 1024;
+                    if (x0 >= W) continue;
+                    *(uint4*)(ek + x0) = make_uint4(kEmpty32, kEmpty32, kEmpty32, kEmpty32);
+                    *(uint4*)(ek + W + x0) = make_uint4(kEmpty32, kEmpty32, kEmpty32, kEmpty32);
+                }
+            } else {
+                for (int eye = 0; eye < 2; ++eye) {
+                    const uint8_t* mrow = a.mask[eye] + (size_t)f * a.mask_stride + (size_t)y * a.mask_pitch;
+                    for (int x = tid; x < W; x += 256) {
+                        const uint32_t key = ek[eye * W + x];
+                        ek[eye * W + x] = kEmpty32;
+                        if (key != kEmpty32 && mrow[x]) paint(eye, x, y, (int)(key & 0xFFFFu));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (VEC) cur = nxt;
+    }
+    __syncthreads();
+    const uint32_t nh = min(nhit, (uint32_t)kEdgeHitCap);
+    for (uint32_t e = tid; e < nh; e += 256) {
+        const uint2 h = hitq[e];
+        paint((int)(h.y >> 4), (int)(h.x & 0xFFFFu), y0 + (int)(h.y & 15u), (int)(h.x >> 16));
+    }
+}
+
+static hipError_t launch_edge_rows_pure(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+{
+    const dim3 grid((unsigned)((a.H + kEdgeRowsPer - 1) / kEdgeRowsPer), (unsigned)plan.n), block(256);
+    const size_t lds = 2 * (size_t)a.W * sizeof(uint32_t) + (size_t)kEdgeHitCap * sizeof(uint2);
+    const int nit = !(plan.vec4 && a.W <= 4096) ? 0 : a.W <= 1024 ? 1 : a.W <= 2048 ? 2 : 4;
+#define MDVT_CASE(M, N) hipLaunchKernelGGL((k_edge_rows_pure<M, N>), grid, block, lds, s, a)
+    if (plan.mode == MDVT_MODE_MESH) { if (nit == 0) MDVT_CASE(true, 0); else if (nit == 1) MDVT_CASE(true, 1); else if (nit == 2) MDVT_CASE(true, 2); else MDVT_CASE(true, 4); }
+    else { if (nit == 0) MDVT_CASE(false, 0); else if (nit == 1) MDVT_CASE(false, 1); else if (nit == 2) MDVT_CASE(false, 2); else MDVT_CASE(false, 4); }
+#undef MDVT_CASE
+    return hipGetLastError();
+}
+
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     plan.fused_bits = 0;
@@ -2825,12 +3003,19 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
     if (plan.conv) return launch_mesh_conv(plan, a, s);
     if (plan.general) return launch_mesh_general(plan, a, s);
     hipError_t e;
+    // pure-shift mesh frames: the row kernel renders without edge points, k_edge_rows_pure / k_edge_rows_exact place them afterwards
+    // (tuning build: MDVT_EDGE_INBAND=1 keeps them inside the row kernels, as until r04, for the A/B)
+    const bool edge_after = plan.remove_edges && plan.edge_points && a.W <= 65535 && tuning_env(TUNE_EDGE_INBAND) == nullptr;
+    RenderPlan rp = plan;
+    if (edge_after) rp.edge_points = 0;
     // (tuning build: MDVT_MESH_BAND3=0 / 1 picks k_mesh_band / k_mesh_band3 for the A/B)
     const char* b3 = tuning_env(TUNE_MESH_BAND3);
     const bool band3 = b3 ? b3[0] == '1' : false;
-    if (band3 && mesh_band3_supported(plan, a) && tuning_env(TUNE_MESH_OLD) == nullptr) e = launch_mesh_band3(plan, a, s);
-    else if (mesh_band_supported(plan, a) && tuning_env(TUNE_MESH_OLD) == nullptr) e = launch_mesh_band(plan, a, s);
-    else e = plan.vec4 ? launch_mesh_rows<4>(plan, a, s) : launch_mesh_rows<1>(plan, a, s);
+    if (band3 && mesh_band3_supported(rp, a) && tuning_env(TUNE_MESH_OLD) == nullptr) e = launch_mesh_band3(rp, a, s);
+    else if (mesh_band_supported(rp, a) && tuning_env(TUNE_MESH_OLD) == nullptr) e = launch_mesh_band(rp, a, s);
+    else e = rp.vec4 ? launch_mesh_rows<4>(rp, a, s) : launch_mesh_rows<1>(rp, a, s);
+    plan.fused_bits = rp.fused_bits;
+    if (e == hipSuccess && edge_after) e = launch_edge_rows_pure(plan, a, s);
     return e != hipSuccess ? e : launch_edge_rows_exact(plan, a, s);
 }
 
