@@ -2986,8 +2986,8 @@ static hipError_t launch_edge_rows_pure(const RenderPlan& plan, const RenderArgs
     const size_t lds = 2 * (size_t)a.W * sizeof(uint32_t) + (size_t)kEdgeHitCap * sizeof(uint2);
     const int nit = !(plan.vec4 && a.W <= 4096) ? 0 : a.W <= 1024 ? 1 : a.W <= 2048 ? 2 : 4;
 #define MDVT_CASE(M, N) hipLaunchKernelGGL((k_edge_rows_pure<M, N>), grid, block, lds, s, a)
-    if (plan.mode == MDVT_MODE_MESH) { if (nit == 0) MDVT_CASE(true, 0); else if (nit == 1) MDVT_CASE(true, 1); else if (nit == 2) MDVT_CASE(true, 2); else MDVT_CASE(true, 4); }
-    else { if (nit == 0) MDVT_CASE(false, 0); else if (nit == 1) MDVT_CASE(false, 1); else if (nit == 2) MDVT_CASE(false, 2); else MDVT_CASE(false, 4); }
+    if (plan.mode != MDVT_MODE_MESH) return hipErrorInvalidValue;          // (points: see launch_render)
+    if (nit == 0) MDVT_CASE(true, 0); else if (nit == 1) MDVT_CASE(true, 1); else if (nit == 2) MDVT_CASE(true, 2); else MDVT_CASE(true, 4);
 #undef MDVT_CASE
     return hipGetLastError();
 }
@@ -2997,6 +2997,7 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
     plan.fused_bits = 0;
     if (plan.mode == MDVT_MODE_POINTS) {
         if (plan.general) return launch_points_general(plan, a, s);
+        // (the edge points stay inside k_points_rows: placed afterwards, as for the mesh below, 58.5 k against 61 k frames/s at 1080p)
         const hipError_t e = plan.vec4 ? launch_points_rows_vec4(plan, a, s) : launch_points_rows_cfg<1, 256, 0>(plan, a, s);
         return e != hipSuccess ? e : launch_edge_rows_exact(plan, a, s);
     }

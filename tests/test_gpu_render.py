@@ -851,6 +851,38 @@ def test_infill_mask_seed_image(mods, orc, mode, kind):
     r.close()
 
 
+@pytest.mark.parametrize("inband", [False, True])
+@pytest.mark.parametrize("size", [(250, 37), (256, 64), (1280, 24), (2560, 20), (3840, 12)])
+def test_mesh_edge_points_after_the_row_kernel(mods, orc, monkeypatch, size, inband):
+    """Pure-shift mesh frames with edge points: the row kernel renders without them and k_edge_rows_pure places them afterwards
+    (a workgroup per 8 scanlines; 1, 2 or 4 four-column groups per thread, or column by column when the rows are not
+    dword-addressable -- one size per variant), k_edge_rows_exact on the scanlines whose points move a row.  Images, masks, depth
+    planes and seed images against the oracle; and the same with MDVT_EDGE_INBAND=1 (tuning build), which keeps the points
+    inside the row kernels as until r04 -- the A/B the choice was made on."""
+    _lib, sr, synthetic = mods
+    if inband:
+        monkeypatch.setenv("MDVT_LIB_VARIANT", "tuning")
+        monkeypatch.setenv("MDVT_EDGE_INBAND", "1")
+    W, H = size
+    for seed, xfov in ((11, 45.0), (12, 97.3)):
+        depth_rgb, color = _scene(synthetic, W, H, seed=seed, n_fg=9)
+        r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
+        p = r.frame_params(xfov=xfov)
+        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_seed=True, want_depth=True)
+        op = orc.make_params(W, H, _K(p), ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_MESH, remove_edges=True,
+                             edge_points=r.edge_points, conv_angle=0.0, T=None, key_rgb=(0, 255, 0))
+        want = orc.render_stereo(op, depth_rgb, color, want_seed=True, want_depth=True)
+        _compare({k: v for k, v in got.items() if k != "seed"}, want, W, f"edge points after {W}x{H} inband={inband}")
+        seed_img = got["seed"].cpu().numpy()
+        painted = 0
+        for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+            assert np.array_equal(seed_img[:, sl], want[eye + "_seed"]), f"{W}x{H} {eye} seed, inband={inband}"
+            hole = want[eye + "_mask"] > 0
+            painted += int((hole & np.any(want[eye + "_rgb"] != 0, axis=-1)).sum())
+        assert painted > 0, "no edge point landed in a hole: the scene no longer tests the pass"
+        r.close()
+
+
 @pytest.mark.parametrize("tmax,tmin", [(5, 0), (5.0, 0.5), (12.5, 1.0)])
 def test_touchly_depth_plane(mods, tmax, tmin):
     """sr:549-551 evaluated literally with NumPy (the reference's expression is script-level code) vs the kernel,
