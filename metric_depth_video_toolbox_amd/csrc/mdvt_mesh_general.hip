@@ -127,7 +127,7 @@ __device__ __forceinline__ bool tie_tiles_hit(const FragOut& f, int bx0, int by0
 // One thread per cell, both triangles, both eyes.  MODE as mesh_global_fragment's; the second pass runs for the frames with a marked
 // pixel only, and only the triangles whose pixel box touches a marked tile get as far as their set-up.
 template <int FLAGS, int MODE>
-__device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][129], Pending& pd)
+__device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][129], Pending (&pds)[2])
 {
     constexpr bool EDGES = FLAGS & 2;
     const int W = a.W, H = a.H;
@@ -154,8 +154,10 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
         sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
     }
     __syncthreads();
-#pragma unroll 1
+    // (unrolled: each eye has its own pending word, so the left eye's last post is in flight while the right eye is rasterised)
+#pragma unroll
     for (int eye = 0; eye < 2; ++eye) {
+        Pending& pd = pds[eye];
         const FragOut fo = frag_out(a, fr, eye);
         uint4 A = make_uint4(0, 0, 0, 0), B = A, Cv = A, D = A;
         if (act) {
@@ -223,18 +225,19 @@ template <int FLAGS, int MODE>
 __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a, int nframes)
 {
     __shared__ uint4 sv[2][2][129];
-    Pending pd = pending_none();
+    Pending pds[2] = {pending_none(), pending_none()};
     if (MODE == 0) {
         int bx, i;
         if (!cell_block_of(a.W, a.H, bx, i)) return;
-        mesh_raster_small_block<FLAGS, 0>(a, (int)blockIdx.z, bx, i, sv, pd);
-        pending_settle(a, pd);
+        mesh_raster_small_block<FLAGS, 0>(a, (int)blockIdx.z, bx, i, sv, pds);
+        pending_settle(a, pds[0]);
+        pending_settle(a, pds[1]);
     } else {
         const uint32_t nblk = cell_blocks(a.W, a.H), nbx = (uint32_t)((a.W - 1 + 127) / 128);
         for (int fr = 0; fr < nframes; ++fr) {
             if (a.tie_flag[fr] == 0u) continue;                               // (workgroup uniform)
             for (uint32_t v = blockIdx.x; v < nblk; v += gridDim.x) {
-                mesh_raster_small_block<FLAGS, 1>(a, fr, (int)(v % nbx), (int)(v / nbx), sv, pd);
+                mesh_raster_small_block<FLAGS, 1>(a, fr, (int)(v % nbx), (int)(v / nbx), sv, pds);
                 __syncthreads();
             }
         }
@@ -302,6 +305,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
     }
     __syncthreads();
     const uint32_t cull = (uint32_t)a.cull;
+    // (not unrolled with a pending word per eye, as k_mesh_raster_small is: measured, product default 2640 -> 2750 us per 32 frames)
 #pragma unroll 1
     for (int eye = 0; eye < 2; ++eye) {
         if (!act || (inv0 && inv1)) continue;
