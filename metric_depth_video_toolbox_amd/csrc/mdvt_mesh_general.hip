@@ -95,16 +95,17 @@ __device__ __forceinline__ void mesh_global_fragment(const RenderArgs& a, int sl
     }
 }
 
-// The 128-cell block of a workgroup of the one-thread-per-cell kernels: row-major over the frame's cells, grid x = cell_block_grid.
+constexpr int kCellTPB = 64;          // cells (threads) per workgroup of k_mesh_raster_small
+// The block of cells of a workgroup of the one-thread-per-cell kernels: row-major over the frame's cells, grid x = cell_block_grid.
 // (Measured and not kept, r04: an XCD-aware deal -- workgroup b runs on XCD b % 8, each XCD with its own L2, so each XCD took a
 // contiguous eighth of the blocks and the second reader of a vertex-record row found it in the L2 the first one had filled.  The
 // rasteriser's fetch traffic fell from 145 to 71 MB per 1080p frame and its time did not move, 6 % slower under a pose: these
 // kernels wait for their atomics, not for bytes.)
-__host__ __device__ __forceinline__ uint32_t cell_blocks(int W, int H) { return (uint32_t)((W - 1 + 127) / 128) * (uint32_t)(H - 1); }
+__host__ __device__ __forceinline__ uint32_t cell_blocks(int W, int H) { return (uint32_t)((W - 1 + kCellTPB - 1) / kCellTPB) * (uint32_t)(H - 1); }
 inline uint32_t cell_block_grid(int W, int H) { return cell_blocks(W, H); }
 __device__ __forceinline__ bool cell_block_of(int W, int H, int& bx, int& i)
 {
-    const uint32_t v = blockIdx.x, nbx = (uint32_t)((W - 1 + 127) / 128);
+    const uint32_t v = blockIdx.x, nbx = (uint32_t)((W - 1 + kCellTPB - 1) / kCellTPB);
     if (v >= cell_blocks(W, H)) return false;
     bx = (int)(v % nbx); i = (int)(v / nbx);
     return true;
@@ -127,21 +128,21 @@ __device__ __forceinline__ bool tie_tiles_hit(const FragOut& f, int bx0, int by0
 // One thread per cell, both triangles, both eyes.  MODE as mesh_global_fragment's; the second pass runs for the frames with a marked
 // pixel only, and only the triangles whose pixel box touches a marked tile get as far as their set-up.
 template <int FLAGS, int MODE>
-__device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][129], Pending (&pds)[2])
+__device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kCellTPB + 1], Pending (&pds)[2])
 {
     constexpr bool EDGES = FLAGS & 2;
     const int W = a.W, H = a.H;
-    const int j = bx * 128 + threadIdx.x;
+    const int j = bx * kCellTPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
-    // the 2 x 129 vertex records of both eyes, fetched once per workgroup with all loads in flight together
+    // the 2 x (kCellTPB + 1) vertex records of both eyes, fetched once per workgroup with all loads in flight together
     uint32_t inv0 = 0, inv1 = 0;
     {
         const int t = threadIdx.x;
-        const int j0 = bx * 128;
+        const int j0 = bx * kCellTPB;
         const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
-        const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);      // (clamped: columns past the row end are never used)
+        const int jc = min(j0 + t, W - 1), jx = min(j0 + kCellTPB, W - 1);      // (clamped: columns past the row end are never used)
         uint4 rx = make_uint4(0, 0, 0, 0);
         if (t < 4) rx = (t & 2 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t & 1) * W + jx];
         const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
@@ -150,7 +151,7 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
             const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
             inv0 = tinv[0]; inv1 = tinv[ncell];
         }
-        if (t < 4) sv[t >> 1][t & 1][128] = rx;
+        if (t < 4) sv[t >> 1][t & 1][kCellTPB] = rx;
         sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
     }
     __syncthreads();
@@ -222,9 +223,9 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
 // First pass: a workgroup per block of cells (grid: cell_block_grid x 1 x frames).  Second pass: a fixed number of workgroups that
 // walk the blocks of the frames with a marked pixel -- normally there is none, and the launch is over after `nframes` loads.
 template <int FLAGS, int MODE>
-__global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a, int nframes)
+__global__ void __launch_bounds__(kCellTPB) k_mesh_raster_small(RenderArgs a, int nframes)
 {
-    __shared__ uint4 sv[2][2][129];
+    __shared__ uint4 sv[2][2][kCellTPB + 1];
     Pending pds[2] = {pending_none(), pending_none()};
     if (MODE == 0) {
         int bx, i;
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_small(RenderArgs a, int nfr
         pending_settle(a, pds[0]);
         pending_settle(a, pds[1]);
     } else {
-        const uint32_t nblk = cell_blocks(a.W, a.H), nbx = (uint32_t)((a.W - 1 + 127) / 128);
+        const uint32_t nblk = cell_blocks(a.W, a.H), nbx = (uint32_t)((a.W - 1 + kCellTPB - 1) / kCellTPB);
         for (int fr = 0; fr < nframes; ++fr) {
             if (a.tie_flag[fr] == 0u) continue;                               // (workgroup uniform)
             for (uint32_t v = blockIdx.x; v < nblk; v += gridDim.x) {
@@ -268,29 +269,31 @@ __device__ __forceinline__ int conv_first_pixel(int k, int h, int W)
     return q > W ? W : q;
 }
 
+constexpr int kConvTPB = 64;          // cells (threads) per workgroup of k_mesh_raster_conv
 template <int FLAGS>
-__global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
+__global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
 {
     constexpr bool EDGES = FLAGS & 2;
     constexpr int kCoord = 1 << 19, kMaxH = 512, kMaxSpan = 12;
     const int W = a.W, H = a.H;
     const int fr = blockIdx.z;
-    int bx, i;
-    if (!cell_block_of(W, H, bx, i)) return;
-    const int j = bx * 128 + threadIdx.x;
+    const uint32_t nbx = (uint32_t)((W - 1 + kConvTPB - 1) / kConvTPB);
+    if (blockIdx.x >= nbx * (uint32_t)(H - 1)) return;
+    const int bx = (int)(blockIdx.x % nbx), i = (int)(blockIdx.x / nbx);
+    const int j = bx * kConvTPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
     Pending pd = pending_none();
     const size_t ncell = (size_t)(W - 1) * (H - 1);
-    __shared__ uint4 sv[2][2][129];
-    __shared__ uint32_t glist[256];           // cells (thread | eye << 8) for the generic code
+    __shared__ uint4 sv[2][2][kConvTPB + 1];
+    __shared__ uint32_t glist[2 * kConvTPB];          // cells (thread | eye << 8) for the generic code
     __shared__ uint32_t gcount;
     uint32_t inv0 = 0, inv1 = 0;
     {
         const int t = threadIdx.x;
-        const int j0 = bx * 128;
+        const int j0 = bx * kConvTPB;
         const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
-        const int jc = min(j0 + t, W - 1), jx = min(j0 + 128, W - 1);
+        const int jc = min(j0 + t, W - 1), jx = min(j0 + kConvTPB, W - 1);
         uint4 rx = make_uint4(0, 0, 0, 0);
         if (t < 4) rx = (t & 2 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t & 1) * W + jx];
         const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
             const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
             inv0 = tinv[0]; inv1 = tinv[ncell];
         }
-        if (t < 4) sv[t >> 1][t & 1][128] = rx;
+        if (t < 4) sv[t >> 1][t & 1][kConvTPB] = rx;
         sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
         if (t == 0) gcount = 0u;
     }
@@ -365,12 +368,12 @@ __global__ void __launch_bounds__(128) k_mesh_raster_conv(RenderArgs a)
     __syncthreads();
     // ---- the listed cells: k_mesh_raster_small's code, a listed TRIANGLE per lane ----
     const uint32_t ng = 2u * gcount;
-    for (uint32_t base = 0; base < ng; base += 128u) {                   // (workgroup uniform)
+    for (uint32_t base = 0; base < ng; base += (uint32_t)kConvTPB) {                   // (workgroup uniform)
         const uint32_t idx = base + threadIdx.x;
         const bool on = idx < ng;
         const uint32_t ent = glist[on ? idx >> 1 : 0];
         const int t = (int)(ent & 0xFFu), eye = (int)(ent >> 8), pass = (int)(idx & 1u);
-        const int cj = bx * 128 + t;
+        const int cj = bx * kConvTPB + t;
         const FragOut fo = frag_out(a, fr, eye);
         const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
         const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
@@ -653,14 +656,15 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
         if ((e = hipMemsetAsync(a.bigq_count, 0, (size_t)nseg * sizeof(uint32_t), s)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(a.hugeq + 2 * (size_t)kHugeCap, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;
         if (pass == 1) {
-            if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2, 1>), dim3(1024), dim3(128), 0, s, a, plan.n);
-            else hipLaunchKernelGGL((k_mesh_raster_small<0, 1>), dim3(1024), dim3(128), 0, s, a, plan.n);
+            if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2, 1>), dim3(1024), dim3(kCellTPB), 0, s, a, plan.n);
+            else hipLaunchKernelGGL((k_mesh_raster_small<0, 1>), dim3(1024), dim3(kCellTPB), 0, s, a, plan.n);
         } else if (plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr) {
             // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
-            if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_c, dim3(128), 0, s, a);
-            else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_c, dim3(128), 0, s, a);
-        } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2, 0>), grid_c, dim3(128), 0, s, a, plan.n);
-        else hipLaunchKernelGGL((k_mesh_raster_small<0, 0>), grid_c, dim3(128), 0, s, a, plan.n);
+            const dim3 grid_v((unsigned)((a.W - 1 + kConvTPB - 1) / kConvTPB) * (unsigned)(a.H - 1), 1, plan.n);
+            if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_v, dim3(kConvTPB), 0, s, a);
+            else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_v, dim3(kConvTPB), 0, s, a);
+        } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2, 0>), grid_c, dim3(kCellTPB), 0, s, a, plan.n);
+        else hipLaunchKernelGGL((k_mesh_raster_small<0, 0>), grid_c, dim3(kCellTPB), 0, s, a, plan.n);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg,
                            pass ? a.tie_flag : (const uint32_t*)nullptr, plan.n);
