@@ -367,7 +367,7 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     if (need_gverts && !c->ws_gverts) {
         for (int e = 0; e < 2; ++e) {
             MDVT_HIP(c, ws_malloc(c, (void**)&c->gverts[e], nf * npx * sizeof(uint4)));
-            MDVT_HIP(c, ws_malloc(c, (void**)&c->cbuf[e], nf * npx * sizeof(unsigned long long)));   // validated by draw id: needs no clearing
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->cbuf[e], nf * npx * sizeof(unsigned long long)));   // tie side words: a word is initialised by the fragment that marks its pixel, so the plane needs no clearing
         }
         if (c->bigq) ws_free(c, c->bigq);
         c->bigq = nullptr;
@@ -619,13 +619,13 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         int ws_chunk = (r.general && plan.mode == MDVT_MODE_POINTS) ? 2 : kWorkspaceChunk;
         if (r.general && plan.mode == MDVT_MODE_MESH) {
             ws_chunk = 2 * kWorkspaceChunk;      // 16: measured -4 % (convergence) / -11 % (pose) vs 8
-            // ~100 B/px per slot (records, z keys, colour side buffer, triangle queue): 3.3 GB at 1080p, 13 GB at 4K; the queue's
+            // ~100 B/px per slot (records, z keys, tie side words, triangle queue): 3.3 GB at 1080p, 13 GB at 4K; the queue's
             // entry indices are 32-bit, so very large frames get fewer slots (4 entries per pixel and slot)
             const size_t fit = (size_t)0xFFFFFFF0u / (4 * (size_t)W * (size_t)H);
             if ((size_t)ws_chunk > fit) ws_chunk = fit < 1 ? 1 : (int)fit;
             // ... and the slots have to fit the context's workspace budget (mdvt_config.workspace_mib, default 4 GiB: 16 slots at
             // 1080p, 4 at 3840 x 2160 -- where 16 would be 16 GB): per slot and pixel 16 B of z keys, 48 B of vertex records and
-            // colour side buffer, 32 B of triangle queue, with edge points 24 B of edge keys and their list, 3 B of filter flags
+            // tie side words, 32 B of triangle queue, with edge points 24 B of edge keys and their list, 3 B of filter flags
             const size_t per_slot = (size_t)W * (size_t)H * (16 + 48 + 32 + (plan.edge_points ? 24 : 0) + (plan.remove_edges ? 3 : 0));
             const size_t budget = (size_t)(c->cfg.workspace_mib ? c->cfg.workspace_mib : 4096u) << 20;
             const size_t afford = budget / per_slot;

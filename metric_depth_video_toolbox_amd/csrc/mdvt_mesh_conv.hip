@@ -5,7 +5,7 @@
 // Same results as the general path (k_mesh_vertices_general -> k_mesh_raster_small/queue -> k_resolve_general) and the
 // oracle -- the vertex programme IS vertex_general, triangles, tie rule and shading are the decree's -- but with the
 // z-buffer of a scanline in LDS and no intermediate in HBM at all (the general path round-trips 16-byte vertex
-// records, 64-bit z keys and a 64-bit colour side buffer per pixel and eye: 438 MB per 1080p frame, 15 x the
+// records, 64-bit z keys and (until r04) a 64-bit colour side buffer per pixel and eye: 438 MB per 1080p frame, 15 x the
 // algorithmic bytes).  What makes that possible:
 //
 //   * a rotation about the y axis leaves Y' = yc untouched and gives Z' = z (m10 + m8 (gx - cx) / fx): the projected ROW
