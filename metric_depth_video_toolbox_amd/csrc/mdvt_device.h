@@ -603,6 +603,18 @@ __device__ __forceinline__ int edge_col_pure(const FrameDev& f, int eye, float g
     return (x >= 0 && x < W) ? x : -1;
 }
 
+// The same without the chain: -2 = inside the guard band (the caller runs edge_col_chain, once, outside its unrolled loops).
+__device__ __forceinline__ int edge_col_estimate(const FrameDev& f, int eye, float gx, float d, int W, float guard)
+{
+    const float ex = ((gx - f.cx) * f.sW) + f.cx;
+    const float u = eye == 0 ? ex + d : ex - d;
+    if (!(u > -1.0f && u < (float)W + 1.0f)) return -1;
+    const float r = rintf(u);
+    if (fabsf(u - r) > 0.5f - guard) return -2;
+    const int x = (int)r;
+    return (x >= 0 && x < W) ? x : -1;
+}
+
 // scanlines whose edge points the LDS row kernels leave to k_edge_rows_exact
 __device__ __forceinline__ bool edge_row_deferred(const FrameDev& f, int k) { return k >= f.erow_lo && k <= f.erow_hi && f.erow_lo < f.erow_hi; }
 

@@ -457,11 +457,15 @@ struct RowIO<1> {
 
 // FLAGS bit 0: optional depth planes, bit 1: `unused` vertices are not drawn (remove_edges),
 // bit 2: edge points splatted into holes.
+// `need`: bit 2 q + eye set for the edge points whose column the f32 estimate cannot decide (inside the guard band): the caller
+// runs the reference's chain for those in ONE loop behind its unrolled ones (points_edge_chain) -- inlined at each of the 32
+// (group, pixel, eye) sites the chain made the edge variants 9 600 instructions, 77 KB, more than the instruction cache.
 template <int PX, int FLAGS>
-__device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[PX], const uint32_t (&cpx)[PX],
-                                                   const uint32_t (&un)[PX], u64* zb, uint32_t* eb, int W,
-                                                   float mult, float scale, float dl, const FrameDev& fp, bool edge_on, float guard)
+__device__ __forceinline__ uint32_t points_splat_group(int g, const uint32_t (&dpx)[PX], const uint32_t (&cpx)[PX],
+                                                       const uint32_t (&un)[PX], u64* zb, uint32_t* eb, int W,
+                                                       float mult, float scale, float dl, const FrameDev& fp, bool edge_on, float guard)
 {
+    uint32_t need = 0;
     constexpr bool UNUSED = FLAGS & 2, EDGE = FLAGS & 4;
     const float fW = (float)W;
 #pragma unroll
@@ -480,10 +484,34 @@ __device__ __forceinline__ void points_splat_group(int g, const uint32_t (&dpx)[
         } else if (EDGE && edge_on) {
             // sr:599-600, 746: the column the reference's f64 chain rounds to (mdvt_device.h "edge points")
             const uint32_t ekey = (code << 16) | (uint32_t)j;
-            const int xL = edge_col_pure(fp, 0, fj, z, d, W, guard), xR = edge_col_pure(fp, 1, fj, z, d, W, guard);
+            const int xL = edge_col_estimate(fp, 0, fj, d, W, guard), xR = edge_col_estimate(fp, 1, fj, d, W, guard);
             if (xL >= 0) atomicMin(&eb[xL], ekey);
             if (xR >= 0) atomicMin(&eb[W + xR], ekey);
+            need |= (xL == -2 ? 1u : 0u) << (2 * q) | (xR == -2 ? 2u : 0u) << (2 * q);
         }
+    }
+    return need;
+}
+
+// the edge points points_splat_group left undecided: bit (it * PX + q) * 2 + eye of `need`, group of iteration `it` = g0 + it * gstep
+template <int PX, int NIT>
+__device__ __forceinline__ void points_edge_chain(uint32_t need, int g0, int gstep, const uint32_t (&dpx)[NIT][PX], uint32_t* eb, int W,
+                                                  float mult, float scale, const FrameDev& fp)
+{
+#pragma unroll 1
+    while (need) {
+        const int b = __ffs((int)need) - 1, eye = b & 1, q = (b >> 1) % PX, it = (b >> 1) / PX;
+        need &= need - 1u;
+        uint32_t px = dpx[0][0];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+#pragma unroll
+            for (int r = 0; r < PX; ++r)
+                if (k == it && r == q) px = dpx[k][r];
+        const int j = (g0 + it * gstep) * PX + q;
+        const uint32_t code = code16_of(px);
+        const int x = edge_col_chain(fp, eye, (float)j, decode_z(code, mult, scale), W);
+        if (x >= 0 && x < W) atomicMin(&eb[eye * W + x], (code << 16) | (uint32_t)j);
     }
 }
 
@@ -538,18 +566,21 @@ __global__ void __launch_bounds__(TPB, ((FLAGS & 5) == 4) ? 6 : 1) k_points_rows
     __syncthreads();
 
     if (ITERS > 0) {
+        uint32_t need = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int g = tid + it * TPB;
             if (g < ngroups)
-                points_splat_group<PX, FLAGS>(g, dpx[it], cpx[it], un[it], zb, eb, W, mult, scale, dl, fp, edge_on, guard);
+                need |= points_splat_group<PX, FLAGS>(g, dpx[it], cpx[it], un[it], zb, eb, W, mult, scale, dl, fp, edge_on, guard) << (2 * PX * it);
         }
+        if (EDGE) points_edge_chain<PX, NIT>(need, tid, TPB, dpx, eb, W, mult, scale, fp);
     } else {
         for (int g = tid; g < ngroups; g += TPB) {
             RowIO<PX>::load_nt(drow, g, dpx[0]);
             RowIO<PX>::load_nt(crow, g, cpx[0]);
             if (UNUSED) RowIO<PX>::load_u8(urow, g, un[0]);
-            points_splat_group<PX, FLAGS>(g, dpx[0], cpx[0], un[0], zb, eb, W, mult, scale, dl, fp, edge_on, guard);
+            const uint32_t need = points_splat_group<PX, FLAGS>(g, dpx[0], cpx[0], un[0], zb, eb, W, mult, scale, dl, fp, edge_on, guard);
+            if (EDGE) points_edge_chain<PX, NIT>(need, g, 0, dpx, eb, W, mult, scale, fp);
         }
     }
     __syncthreads();
@@ -563,7 +594,7 @@ __global__ void __launch_bounds__(TPB, ((FLAGS & 5) == 4) ? 6 : 1) k_points_rows
                           : nullptr;
         const u64* zrow_lds = zb + (size_t)eye * W;
         for (int g = tid; g < ngroups; g += TPB) {
-            uint32_t opx[PX], om[PX], spx[PX];
+            uint32_t opx[PX], om[PX], spx[PX], eseed = 0;
             float oz[PX];
 #pragma unroll
             for (int q = 0; q < PX; ++q) {
@@ -584,9 +615,19 @@ __global__ void __launch_bounds__(TPB, ((FLAGS & 5) == 4) ? 6 : 1) k_points_rows
                 om[q] = hole ? 255u : 0u;
                 if (ZOUT) oz[q] = covered ? decode_z((uint32_t)(key >> 40), mult, scale) : 0.0f;
                 if (SEED && a.seed[eye]) {
-                    uint32_t esrc = ~0u;
-                    if (EDGE && hole && edge_on) { const uint32_t ek = eb[(size_t)eye * W + x]; if (ek != kEmpty32) esrc = ((uint32_t)i << 16) | (ek & 0xFFFFu); }
-                    spx[q] = seed_pixel(a, fp, f, eye, x, i, hole, esrc, 0);
+                    spx[q] = seed_pixel(a, fp, f, eye, x, i, hole, ~0u, 0);
+                    if (EDGE && hole && edge_on) { const uint32_t ek = eb[(size_t)eye * W + x]; if (ek != kEmpty32) eseed |= 1u << q; }
+                }
+            }
+            if (SEED && EDGE) {
+                // the pixels whose seed colour is an edge point's normal (f64, a few hundred instructions): one copy of that code
+#pragma unroll 1
+                while (eseed) {
+                    const int q = __ffs((int)eseed) - 1;
+                    eseed &= eseed - 1u;
+                    const uint32_t c = edge_normal_colour(a, fp, f, eye, i, (int)(eb[(size_t)eye * W + g * PX + q] & 0xFFFFu), 0);
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) if (k == q) spx[k] = c;
                 }
             }
             RowIO<PX>::store_rgb(orow, g, opx);
