@@ -2888,7 +2888,7 @@ __device__ __forceinline__ void edge_row_fetch(const RenderArgs& a, int fr, int 
 
 // NIT: 4-column groups per thread (W <= 1024 NIT), 0: rows that are not dword-addressable, column by column
 template <bool MESH, int NIT>
-__global__ void __launch_bounds__(256) k_edge_rows_pure(RenderArgs a)
+__global__ void __launch_bounds__(256, 5) k_edge_rows_pure(RenderArgs a)      // (5 waves per SIMD: 94 VGPRs without a spill; unhinted the compiler takes 128)
 {
     constexpr bool VEC = NIT > 0;
     constexpr int NR = NIT > 0 ? NIT : 1;
