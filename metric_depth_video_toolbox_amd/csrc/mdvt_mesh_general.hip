@@ -182,7 +182,7 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
                     if (bx1 >= bx0 && by1 >= by0) {                      // else: no pixel centre in the box
                         // (a small extent bounds the box at 33 x 33: the count fits any integer)
                         if (max(mxX - mnX, mxY - mnY) >= kSmallTriExtent || (bx1 - bx0 + 1) * (by1 - by0 + 1) > kSmallBox) {
-                            toq = true;
+                            toq = MODE == 0;             // (second pass: nothing is queued -- the first pass's lists are walked again)
                         } else if (MODE == 0 || tie_tiles_hit(fo, bx0, by0, bx1, by1)) {
                             TriSmall ts;
                             if (tri_small_setup(ts, X0, Y0, iz0, X1, Y1, iz1, X2, Y2, iz2, a.cull) && !(a.debug_skip & 16)) {
@@ -220,29 +220,17 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
     }
 }
 
-// First pass: a workgroup per block of cells (grid: cell_block_grid x 1 x frames).  Second pass: a fixed number of workgroups that
-// walk the blocks of the frames with a marked pixel -- normally there is none, and the launch is over after `nframes` loads.
-template <int FLAGS, int MODE>
-__global__ void __launch_bounds__(kCellTPB) k_mesh_raster_small(RenderArgs a, int nframes)
+// First pass: a workgroup per block of cells (grid: cell_block_grid x 1 x frames).
+template <int FLAGS>
+__global__ void __launch_bounds__(kCellTPB) k_mesh_raster_small(RenderArgs a)
 {
     __shared__ uint4 sv[2][2][kCellTPB + 1];
     Pending pds[2] = {pending_none(), pending_none()};
-    if (MODE == 0) {
-        int bx, i;
-        if (!cell_block_of(a.W, a.H, bx, i)) return;
-        mesh_raster_small_block<FLAGS, 0>(a, (int)blockIdx.z, bx, i, sv, pds);
-        pending_settle(a, pds[0]);
-        pending_settle(a, pds[1]);
-    } else {
-        const uint32_t nblk = cell_blocks(a.W, a.H), nbx = (uint32_t)((a.W - 1 + kCellTPB - 1) / kCellTPB);
-        for (int fr = 0; fr < nframes; ++fr) {
-            if (a.tie_flag[fr] == 0u) continue;                               // (workgroup uniform)
-            for (uint32_t v = blockIdx.x; v < nblk; v += gridDim.x) {
-                mesh_raster_small_block<FLAGS, 1>(a, fr, (int)(v % nbx), (int)(v / nbx), sv, pds);
-                __syncthreads();
-            }
-        }
-    }
+    int bx, i;
+    if (!cell_block_of(a.W, a.H, bx, i)) return;
+    mesh_raster_small_block<FLAGS, 0>(a, (int)blockIdx.z, bx, i, sv, pds);
+    pending_settle(a, pds[0]);
+    pending_settle(a, pds[1]);
 }
 
 // ---- The same stage for frames whose vertex rows stay (almost) horizontal on screen: convergence only ---------------------
@@ -270,24 +258,19 @@ __device__ __forceinline__ int conv_first_pixel(int k, int h, int W)
 }
 
 constexpr int kConvTPB = 64;          // cells (threads) per workgroup of k_mesh_raster_conv
-template <int FLAGS>
-__global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
+// MODE as mesh_global_fragment's (second pass: the same classification of the cells as in the first, so that every fragment of the
+// first pass is met again -- here, or in the first pass's lists of queued triangles, which this pass does not add to).
+template <int FLAGS, int MODE>
+__device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kConvTPB + 1],
+                                                       uint32_t (&glist)[2 * kConvTPB], uint32_t& gcount, Pending& pd)
 {
     constexpr bool EDGES = FLAGS & 2;
     constexpr int kCoord = 1 << 19, kMaxH = 512, kMaxSpan = 12;
     const int W = a.W, H = a.H;
-    const int fr = blockIdx.z;
-    const uint32_t nbx = (uint32_t)((W - 1 + kConvTPB - 1) / kConvTPB);
-    if (blockIdx.x >= nbx * (uint32_t)(H - 1)) return;
-    const int bx = (int)(blockIdx.x % nbx), i = (int)(blockIdx.x / nbx);
     const int j = bx * kConvTPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool act = j < W - 1;
-    Pending pd = pending_none();
     const size_t ncell = (size_t)(W - 1) * (H - 1);
-    __shared__ uint4 sv[2][2][kConvTPB + 1];
-    __shared__ uint32_t glist[2 * kConvTPB];          // cells (thread | eye << 8) for the generic code
-    __shared__ uint32_t gcount;
     uint32_t inv0 = 0, inv1 = 0;
     {
         const int t = threadIdx.x;
@@ -358,7 +341,7 @@ __global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
                         const float q0 = ((float)(w0 < 0 ? -w0 : w0) * ra) * izA;
                         const float q1 = ((float)(w1 < 0 ? -w1 : w1) * ra) * (in1 ? izB : izC);
                         const float q2 = ((float)(w2 < 0 ? -w2 : w2) * ra) * (in1 ? izC : izD);
-                        mesh_global_fragment<0>(a, fr, eye, fo, pd, W, px, k, q0, q1, q2, A.w, in1 ? B.w : Cv.w, in1 ? Cv.w : D.w, draw_id_global(in1 ? 0 : 1, i, j));
+                        mesh_global_fragment<MODE>(a, fr, eye, fo, pd, W, px, k, q0, q1, q2, A.w, in1 ? B.w : Cv.w, in1 ? Cv.w : D.w, draw_id_global(in1 ? 0 : 1, i, j));
                     }
                 }
             }
@@ -391,7 +374,7 @@ __global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
                 bx0 = max(bx0, 0); by0 = max(by0, 0); bx1 = min(bx1, W - 1); by1 = min(by1, H - 1);
                 if (bx1 >= bx0 && by1 >= by0) {
                     if (max(mxX - mnX, mxY - mnY) >= kSmallTriExtent || (bx1 - bx0 + 1) * (by1 - by0 + 1) > kSmallBox) {
-                        toq = true;
+                        toq = MODE == 0;
                     } else {
                         TriSmall ts;
                         if (tri_small_setup(ts, X0, Y0, iz0, X1, Y1, iz1, X2, Y2, iz2, a.cull)) {
@@ -402,7 +385,7 @@ __global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
                                     if (tri_small_inside(ts, w)) {
                                         float q0, q1, q2;
                                         tri_small_weights(ts, w, q0, q1, q2);
-                                        mesh_global_fragment<0>(a, fr, eye, fo, pd, W, px, py, q0, q1, q2, A.w, v1.w, v2.w, did);
+                                        mesh_global_fragment<MODE>(a, fr, eye, fo, pd, W, px, py, q0, q1, q2, A.w, v1.w, v2.w, did);
                                     }
                                     tri_small_right(ts, w);
                                 }
@@ -426,24 +409,26 @@ __global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
             }
         }
     }
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
+{
+    __shared__ uint4 sv[2][2][kConvTPB + 1];
+    __shared__ uint32_t glist[2 * kConvTPB];  // cells (thread | eye << 8) for the generic code
+    __shared__ uint32_t gcount;
+    const uint32_t nbx = (uint32_t)((a.W - 1 + kConvTPB - 1) / kConvTPB);
+    if (blockIdx.x >= nbx * (uint32_t)(a.H - 1)) return;
+    Pending pd = pending_none();
+    mesh_raster_conv_block<FLAGS, 0>(a, (int)blockIdx.z, (int)(blockIdx.x % nbx), (int)(blockIdx.x / nbx), sv, glist, gcount, pd);
     pending_settle(a, pd);
 }
 
 // Exclusive prefix sums of the segment counters (n <= a few 10^4): one workgroup.  prefix[n] = number of queued triangles.
-// `flags` (second pass): nothing is queued unless one of the nflags frames has a marked pixel -- then only prefix[n] = 0 is written.
-__global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ prefix, int n,
-                                                          const uint32_t* __restrict__ flags, int nflags)
+__global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ prefix, int n)
 {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
-    if (flags) {
-        uint32_t any = 0;
-        for (int k = t; k < nflags; k += 1024) any |= flags[k];
-        if (!__syncthreads_or((int)any)) {
-            if (t == 0) prefix[n] = 0u;
-            return;
-        }
-    }
     // a thread's chunk: a multiple of four counters, read as 16-byte vectors and kept in registers (one counter per trip made the
     // pass 17 dependent round trips long, twice: 21 us for a 16-frame 1080p launch set; `counts` is 16-byte aligned)
     constexpr int kMaxVec = 16;                                    // up to 64 counters per thread: 65 536 segments
@@ -494,7 +479,7 @@ __global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __rest
 // of cells into large triangles: one workgroup per segment would leave that segment's workgroup running alone): 16 lanes
 // per triangle, generic 64-bit set-up, rows walked by their own column range.
 template <int MODE>
-__global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nseg)
+__device__ __forceinline__ void mesh_queue_walk(const RenderArgs& a, int nseg)
 {
     const int W = a.W, H = a.H;
     const uint32_t* prefix = a.bigq_count + nseg;
@@ -511,9 +496,11 @@ __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nse
         const uint2* q = (const uint2*)a.bigq + (size_t)lo_s * (size_t)(4 * W);
         const uint32_t k = g - prefix[lo_s];
 
-        const uint2 e = q[k];
+        uint2 e = q[k];
+        if (MODE == 1 && (e.y >> 31)) continue;                        // its row blocks are in the huge list (first pass, below)
         const uint32_t id = e.x;
         const int eye = (int)(e.y & 1u), slot = (int)(e.y >> 1);
+        if (MODE == 1 && a.tie_flag[slot] == 0u) continue;              // second pass: the frames with a marked pixel only
         const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
         const uint4* r0 = a.gverts[eye] + (size_t)slot * a.ws_stride_px + (size_t)ci * W + cj;
         const uint4 A = r0[0];
@@ -531,15 +518,16 @@ __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nse
         if ((t.area2 >> 17) > (i64)kHugeArea && (i64)(px1 - px0 + 1) * (py1 - py0 + 1) > (i64)kHugeArea && px1 >= px0 && py1 >= py0) {
             const uint32_t nblk = (uint32_t)(py1 - py0) / kHugeRows + 1u;
             uint32_t base = 0;
-            if (sub == 0) base = atomicAdd(&a.hugeq[2 * kHugeCap], nblk);
+            if (MODE == 0 && sub == 0) base = atomicAdd(&a.hugeq[2 * kHugeCap], nblk);
             base = __shfl(base, (int)(threadIdx.x & 63u) & ~15);
-            if (base + nblk <= (uint32_t)kHugeCap) {
+            if (MODE == 0 && base + nblk <= (uint32_t)kHugeCap) {
                 for (uint32_t b = sub; b < nblk; b += 16)
                     *(uint2*)(a.hugeq + 2 * (size_t)(base + b)) = make_uint2(id, e.y | (b << 8));
+                if (sub == 0) ((uint2*)q)[k].y = e.y | 0x80000000u;  // (the second pass skips it here and finds it in the huge list)
                 continue;
             }
             // list full: the triangle stays here, and the entries from `base` on were never written (every later push fails too)
-            if (sub == 0 && base < (uint32_t)kHugeCap) atomicMax(&a.hugeq[2 * kHugeCap + 1], (uint32_t)kHugeCap - base);
+            if (MODE == 0 && sub == 0 && base < (uint32_t)kHugeCap) atomicMax(&a.hugeq[2 * kHugeCap + 1], (uint32_t)kHugeCap - base);
         }
         const FragOut fo = frag_out(a, slot, eye);
         // (r04) what is constant for the triangle -- 1 / f32(area2), the colour planes' conversions are the fragment's -- and the edge
@@ -595,7 +583,7 @@ __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nse
 // The row blocks of the huge triangles: a wave per entry, its 64 lanes along the rows (edge values advanced by 64 pixels per step).
 // Same set-up, same integers, same f32 operations as k_mesh_raster_queue.
 template <int MODE>
-__global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a)
+__device__ __forceinline__ void mesh_huge_walk(const RenderArgs& a)
 {
     const int W = a.W, H = a.H;
     const uint32_t cnt = a.hugeq[2 * kHugeCap];
@@ -608,6 +596,7 @@ __global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a)
         const uint2 e = *(const uint2*)(a.hugeq + 2 * (size_t)g);
         const uint32_t id = e.x;
         const int eye = (int)(e.y & 1u), slot = (int)((e.y >> 1) & 0x7Fu), blk = (int)(e.y >> 8);
+        if (MODE == 1 && a.tie_flag[slot] == 0u) continue;              // second pass: the frames with a marked pixel only
         const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
         const uint4* r0 = a.gverts[eye] + (size_t)slot * a.ws_stride_px + (size_t)ci * W + cj;
         const uint4 A = r0[0];
@@ -644,47 +633,74 @@ __global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a)
     if (MODE == 0) pending_settle(a, pd);
 }
 
+__global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nseg) { mesh_queue_walk<0>(a, nseg); }
+__global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a) { mesh_huge_walk<0>(a); }
+
+// The second pass, ONE launch of a fixed number of workgroups: for the frames in which the first pass marked a pixel (normally none:
+// the launch is over after `nframes` loads per workgroup) every triangle near a marked tile posts draw id | colour into the side
+// words of the marked pixels at the word's depth -- the cells again (k_mesh_raster_small's code), then the first pass's own lists
+// of queued and huge triangles.  No order between the three: all they do is atomic minima.
+template <int FLAGS, bool CONV>
+__global__ void __launch_bounds__(kCellTPB) k_mesh_tie_pass(RenderArgs a, int nframes, int nseg)
+{
+    static_assert(kCellTPB == kConvTPB, "one workgroup size for both cell walks");
+    __shared__ uint4 sv[2][2][kCellTPB + 1];
+    __shared__ uint32_t glist[2 * kConvTPB];
+    __shared__ uint32_t gcount;
+    uint32_t any = 0;
+    for (int fr = 0; fr < nframes; ++fr) any |= a.tie_flag[fr];
+    if (!any) return;                                                          // (uniform)
+    Pending pds[2] = {pending_none(), pending_none()};                         // (unused in this mode)
+    const uint32_t nblk = cell_blocks(a.W, a.H), nbx = (uint32_t)((a.W - 1 + kCellTPB - 1) / kCellTPB);
+    for (int fr = 0; fr < nframes; ++fr) {
+        if (a.tie_flag[fr] == 0u) continue;                                    // (workgroup uniform)
+        for (uint32_t v = blockIdx.x; v < nblk; v += gridDim.x) {
+            // (the cells classified as the first pass classified them: k_mesh_raster_conv draws spans itself that k_mesh_raster_small
+            //  would have queued)
+            if (CONV) mesh_raster_conv_block<FLAGS, 1>(a, fr, (int)(v % nbx), (int)(v / nbx), sv, glist, gcount, pds[0]);
+            else mesh_raster_small_block<FLAGS, 1>(a, fr, (int)(v % nbx), (int)(v / nbx), sv, pds);
+            __syncthreads();
+        }
+    }
+    mesh_queue_walk<1>(a, nseg);
+    mesh_huge_walk<1>(a);
+}
+
 hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const int nseg = plan.n * a.H;
     const dim3 grid_c(cell_block_grid(a.W, a.H), 1, plan.n);
     hipError_t e = hipMemsetAsync(a.tie_flag, 0, (size_t)a.tie_words * 2 * plan.n * sizeof(uint32_t) + (size_t)(a.tie_tiles - a.tie_flag) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    // pass 0: every triangle; pass 1: the frames in which pass 0 marked a pixel as an exact depth tie between colours, to settle those
-    // pixels by draw id (mdvt_device.h, colour keys) -- normally none, and every kernel of the pass ends at its first test
-    for (int pass = 0; pass < 2; ++pass) {
-        if ((e = hipMemsetAsync(a.bigq_count, 0, (size_t)nseg * sizeof(uint32_t), s)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(a.hugeq + 2 * (size_t)kHugeCap, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;
-        if (pass == 1) {
-            if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2, 1>), dim3(1024), dim3(kCellTPB), 0, s, a, plan.n);
-            else hipLaunchKernelGGL((k_mesh_raster_small<0, 1>), dim3(1024), dim3(kCellTPB), 0, s, a, plan.n);
-        } else if (plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr) {
-            // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
-            const dim3 grid_v((unsigned)((a.W - 1 + kConvTPB - 1) / kConvTPB) * (unsigned)(a.H - 1), 1, plan.n);
-            if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_v, dim3(kConvTPB), 0, s, a);
-            else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_v, dim3(kConvTPB), 0, s, a);
-        } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2, 0>), grid_c, dim3(kCellTPB), 0, s, a, plan.n);
-        else hipLaunchKernelGGL((k_mesh_raster_small<0, 0>), grid_c, dim3(kCellTPB), 0, s, a, plan.n);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg,
-                           pass ? a.tie_flag : (const uint32_t*)nullptr, plan.n);
-        if (tuning_env(TUNE_QUEUE_DUMP)) {       // tuning hook: queued (large) triangles of this launch set on stderr
-            uint32_t total = 0, marked = 0;
-            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&total, a.bigq_count + 2 * nseg, 4, hipMemcpyDeviceToHost) == hipSuccess) {
-                for (int f = 0; f < plan.n; ++f) { uint32_t v = 0; if (hipMemcpy(&v, a.tie_flag + f, 4, hipMemcpyDeviceToHost) == hipSuccess) marked += v; }
-                fprintf(stderr, "pass %d: queued triangles: %u in %d frames (%d x %d), %u frames with marked pixels\n", pass, total, plan.n, a.W, a.H, marked);
-            }
+    if ((e = hipMemsetAsync(a.bigq_count, 0, (size_t)nseg * sizeof(uint32_t), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(a.hugeq + 2 * (size_t)kHugeCap, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;
+    const bool conv = plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr;
+    if (conv) {
+        // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
+        const dim3 grid_v((unsigned)((a.W - 1 + kConvTPB - 1) / kConvTPB) * (unsigned)(a.H - 1), 1, plan.n);
+        if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_v, dim3(kConvTPB), 0, s, a);
+        else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_v, dim3(kConvTPB), 0, s, a);
+    } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2>), grid_c, dim3(kCellTPB), 0, s, a);
+    else hipLaunchKernelGGL((k_mesh_raster_small<0>), grid_c, dim3(kCellTPB), 0, s, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg);
+    hipLaunchKernelGGL(k_mesh_raster_queue, dim3(2048), dim3(256), 0, s, a, nseg);
+    hipLaunchKernelGGL(k_mesh_raster_huge, dim3(2048), dim3(256), 0, s, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (tuning_env(TUNE_QUEUE_DUMP)) {       // tuning hook: queued (large) triangles and marked frames of this launch set on stderr
+        uint32_t total = 0, marked = 0;
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&total, a.bigq_count + 2 * nseg, 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int f = 0; f < plan.n; ++f) { uint32_t v = 0; if (hipMemcpy(&v, a.tie_flag + f, 4, hipMemcpyDeviceToHost) == hipSuccess) marked += v; }
+            fprintf(stderr, "queued triangles: %u in %d frames (%d x %d), %u frames with pixels marked as tied\n", total, plan.n, a.W, a.H, marked);
         }
-        if (pass == 0) {
-            hipLaunchKernelGGL(k_mesh_raster_queue<0>, dim3(2048), dim3(256), 0, s, a, nseg);
-            hipLaunchKernelGGL(k_mesh_raster_huge<0>, dim3(2048), dim3(256), 0, s, a);
-        } else {
-            hipLaunchKernelGGL(k_mesh_raster_queue<1>, dim3(512), dim3(256), 0, s, a, nseg);
-            hipLaunchKernelGGL(k_mesh_raster_huge<1>, dim3(512), dim3(256), 0, s, a);
-        }
-        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    return hipSuccess;
+    // the frames in which a pixel was marked as an exact depth tie between colours: those pixels settled by draw id (mdvt_device.h)
+    if (conv) {
+        if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_tie_pass<2, true>), dim3(2048), dim3(kCellTPB), 0, s, a, plan.n, nseg);
+        else hipLaunchKernelGGL((k_mesh_tie_pass<0, true>), dim3(2048), dim3(kCellTPB), 0, s, a, plan.n, nseg);
+    } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_tie_pass<2, false>), dim3(2048), dim3(kCellTPB), 0, s, a, plan.n, nseg);
+    else hipLaunchKernelGGL((k_mesh_tie_pass<0, false>), dim3(2048), dim3(kCellTPB), 0, s, a, plan.n, nseg);
+    return hipGetLastError();
 }
 
 }  // namespace mdvt
