@@ -2888,7 +2888,7 @@ __device__ __forceinline__ void edge_row_fetch(const RenderArgs& a, int fr, int 
 
 // NIT: 4-column groups per thread (W <= 1024 NIT), 0: rows that are not dword-addressable, column by column
 template <bool MESH, int NIT>
-__global__ void __launch_bounds__(256, 5) k_edge_rows_pure(RenderArgs a)      // (5 waves per SIMD: 94 VGPRs without a spill; unhinted the compiler takes 128)
+__global__ void __launch_bounds__(256, 5) k_edge_rows_pure(RenderArgs a, int rows_per)      // (5 waves per SIMD: 94 VGPRs without a spill; unhinted the compiler takes 128)
 {
     constexpr bool VEC = NIT > 0;
     constexpr int NR = NIT > 0 ? NIT : 1;
@@ -2901,7 +2901,7 @@ __global__ void __launch_bounds__(256, 5) k_edge_rows_pure(RenderArgs a)      //
     if (tid == 0) nhit = 0u;
     const int f = a.frame0 + fr;
     const FrameDev& fp = a.fp[f];
-    const int y0 = blockIdx.x * kEdgeRowsPer, y1 = min(y0 + kEdgeRowsPer, H);
+    const int y0 = blockIdx.x * rows_per, y1 = min(y0 + rows_per, H);          // (rows_per <= kEdgeRowsPer)
     // VEC (dword-addressable rows, W <= 4096): everything a scanline needs from memory -- flags, depth codes, both hole masks -- is
     // requested together, and a scanline ahead: taken one after the other (flags, then the flagged columns' depth, then the mask
     // under a key) by a workgroup per scanline, the round trips made this a 14 us workgroup for a microsecond of work
@@ -3023,10 +3023,13 @@ __global__ void __launch_bounds__(256, 5) k_edge_rows_pure(RenderArgs a)      //
 
 static hipError_t launch_edge_rows_pure(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
-    const dim3 grid((unsigned)((a.H + kEdgeRowsPer - 1) / kEdgeRowsPer), (unsigned)plan.n), block(256);
+    // (scanlines per workgroup: 8 for a launch of 32 frames, fewer for small launches -- as launch_mesh_band's bands)
+    int rows_per = (2 * plan.n * a.H + 2880) / (2 * 2880);
+    rows_per = rows_per < 1 ? 1 : (rows_per > kEdgeRowsPer ? kEdgeRowsPer : rows_per);
+    const dim3 grid((unsigned)((a.H + rows_per - 1) / rows_per), (unsigned)plan.n), block(256);
     const size_t lds = 2 * (size_t)a.W * sizeof(uint32_t) + (size_t)kEdgeHitCap * sizeof(uint2);
     const int nit = !(plan.vec4 && a.W <= 4096) ? 0 : a.W <= 1024 ? 1 : a.W <= 2048 ? 2 : 4;
-#define MDVT_CASE(M, N) hipLaunchKernelGGL((k_edge_rows_pure<M, N>), grid, block, lds, s, a)
+#define MDVT_CASE(M, N) hipLaunchKernelGGL((k_edge_rows_pure<M, N>), grid, block, lds, s, a, rows_per)
     if (plan.mode != MDVT_MODE_MESH) return hipErrorInvalidValue;          // (points: see launch_render)
     if (nit == 0) MDVT_CASE(true, 0); else if (nit == 1) MDVT_CASE(true, 1); else if (nit == 2) MDVT_CASE(true, 2); else MDVT_CASE(true, 4);
 #undef MDVT_CASE

@@ -426,7 +426,11 @@ hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a_in, hipS
 {
     RenderArgs a = a_in;
     if (const char* e = tuning_env(TUNE_DEBUG_SKIP)) a.debug_skip = atoi(e);
-    int rows = 8;
+    // scanlines per band: 8 for a launch of 32 frames (a band stages its own vertex rows: 9 for 8 scanlines); fewer when the launch is
+    // small, so that a single 1080p frame is still ~1000 workgroups -- at 8 it was 135 for 512 slots: 127 us per frame, now 59;
+    // 2 / 4 / 8 / 16 frames: 148 -> 100, 219 -> 170, 350 -> 317, 614 -> 598 us per launch (tools/kbench.py --mesh --frames N)
+    int rows = (2 * plan.n * a.H + 2880) / (2 * 2880);
+    rows = rows < 1 ? 1 : (rows > 8 ? 8 : rows);
     if (const char* e = tuning_env(TUNE_MESH_BAND)) { const int v = atoi(e); if (v > 0) rows = v; }     // tuning hook
     if (rows > a.H) rows = a.H;
     if (mesh_band_tpb(plan, a.W) == 512) return launch_mesh_band_tpb<512>(plan, a, rows, s);

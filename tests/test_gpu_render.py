@@ -883,6 +883,51 @@ def test_mesh_edge_points_after_the_row_kernel(mods, orc, monkeypatch, size, inb
         r.close()
 
 
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 8])
+def test_mesh_band_heights(mods, orc, monkeypatch, rows):
+    """k_mesh_band renders bands of 1..8 scanlines per workgroup, chosen by the size of the launch (a single frame gets short
+    bands so that it still fills the chip, a launch of 32 frames 8): every height must give the same images.  MDVT_MESH_BAND
+    (tuning build) pins the height; plain mesh and mesh + --infill_mask (edge filter, edge points afterwards, seed image), an
+    image height that is no multiple of any band height, depth planes."""
+    monkeypatch.setenv("MDVT_LIB_VARIANT", "tuning")
+    monkeypatch.setenv("MDVT_MESH_BAND", str(rows))
+    _lib, sr, synthetic = mods
+    W, H = 256, 77
+    for kw in (dict(), dict(infill_mask=True), dict(cull=1)):
+        depth_rgb, color = _scene(synthetic, W, H, seed=21 + rows, n_fg=8)
+        r = sr.StereoRerenderer(W, H, pupillary_distance=65, **kw)
+        p = r.frame_params(xfov=60.0)
+        seed = bool(kw.get("infill_mask"))
+        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True, want_seed=seed)
+        op = orc.make_params(W, H, _K(p), ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_MESH,
+                             remove_edges=r.remove_edges, edge_points=r.edge_points, conv_angle=0.0, T=None, key_rgb=(0, 255, 0),
+                             cull=kw.get("cull", 0))
+        want = orc.render_stereo(op, depth_rgb, color, want_depth=True, want_seed=seed)
+        _compare({k: v for k, v in got.items() if k != "seed"}, want, W, f"band height {rows} {kw}")
+        if seed:
+            for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+                assert np.array_equal(got["seed"][:, sl].cpu().numpy(), want[eye + "_seed"]), f"band height {rows} seed {eye}"
+        r.close()
+
+
+def test_mesh_band_height_follows_the_launch(mods, orc):
+    """... and without the hook (product library): launches of 1, 3, 9 and 40 frames of 256 x 270 take bands of 1, 1, 1 and 4
+    scanlines (launch_mesh_band); the same clip in every grouping gives the same frames."""
+    _lib, sr, synthetic = mods
+    W, H, N = 256, 270, 40
+    d, c = synthetic.SyntheticScene(W, H, seed=9, n_fg=6).clip(N)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65)
+    ps = [r.frame_params(xfov=45.0) for _ in range(N)]
+    dd, cc = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    whole = r.render(dd, cc, ps)
+    for lo, hi in ((0, 1), (1, 4), (4, 13)):
+        part = r.render(dd[lo:hi], cc[lo:hi], ps[lo:hi] if hi - lo > 1 else ps[lo])
+        assert torch.equal(part["sbs"], whole["sbs"][lo:hi]) and torch.equal(part["mask"], whole["mask"][lo:hi]), (lo, hi)
+    for k in (0, 17, 39):
+        _compare({"sbs": whole["sbs"][k], "mask": whole["mask"][k]}, _oracle(orc, r, ps[k], d[k], c[k], want_depth=False), W, f"frame {k} of 40")
+    r.close()
+
+
 @pytest.mark.parametrize("tmax,tmin", [(5, 0), (5.0, 0.5), (12.5, 1.0)])
 def test_touchly_depth_plane(mods, tmax, tmin):
     """sr:549-551 evaluated literally with NumPy (the reference's expression is script-level code) vs the kernel,
