@@ -1519,6 +1519,18 @@ __global__ void __launch_bounds__(256) k_mesh_vertices_general(RenderArgs a)
     const int fr = blockIdx.z;
     const int f = a.frame0 + fr;
     const FrameDev& fp = a.fp[f];
+    // The rasteriser's counters of this launch set are zeroed here, by the first workgroup of each row (three fill launches in
+    // front of the rasteriser cost a single-frame call 10 us): the row's queue segment counter; row 0: the frame's tie flag and
+    // tile bits; frame 0 as well: the huge list's two counters.  Nothing reads them before this kernel has finished.
+    if (blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t == 0) a.bigq_count[(size_t)fr * a.H + i] = 0u;
+        if (i == 0) {
+            if (t == 0) a.tie_flag[fr] = 0u;
+            for (int k = t; k < 2 * a.tie_words; k += (int)blockDim.x) a.tie_tiles[(size_t)fr * 2 * a.tie_words + k] = 0u;
+            if (fr == 0 && t < 2) a.hugeq[2 * (size_t)kHugeCap + t] = 0u;
+        }
+    }
     const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
     const uint8_t* crow = a.color + (size_t)f * a.color_stride + (size_t)i * a.color_pitch;
     uint32_t dpx, rgb;

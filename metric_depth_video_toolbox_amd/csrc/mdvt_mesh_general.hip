@@ -670,10 +670,8 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
 {
     const int nseg = plan.n * a.H;
     const dim3 grid_c(cell_block_grid(a.W, a.H), 1, plan.n);
-    hipError_t e = hipMemsetAsync(a.tie_flag, 0, (size_t)a.tie_words * 2 * plan.n * sizeof(uint32_t) + (size_t)(a.tie_tiles - a.tie_flag) * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(a.bigq_count, 0, (size_t)nseg * sizeof(uint32_t), s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(a.hugeq + 2 * (size_t)kHugeCap, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;
+    hipError_t e;
+    // (the queue segment counters, the huge list's counters, the tie flags and tile bits were zeroed by k_mesh_vertices_general)
     const bool conv = plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr;
     if (conv) {
         // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
