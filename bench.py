@@ -505,6 +505,23 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
     out["infill_mask_completion"] = {"frames_per_call": nf, "ms_per_call_median_of_5": ms[2], "ms_per_frame": ms[2] / nf,
                                      "what": "mdvt_finish_infill_mask_stereo on the product-default seed images of both eyes "
                                              "(level-synchronous Telea inpaint + masked blur, one host read-back per pass)"}
+    if n_have >= 32:       # a caller that holds 32 frames: the completion splits them over two contexts / streams (stereo_rerender.py)
+        nf2 = 32
+        pd2 = [rp.frame_params(xfov=45.0, convergence_distance=2.5) for _ in range(nf2)]
+        seed2 = rp.render(depth_rgb[:nf2], color_rgb[:nf2], pd2, want_seed=True)["seed"]
+        fin2 = torch.empty_like(seed2)
+        rp.finish_infill_mask_sbs(seed2, out=fin2)
+        ms2 = []
+        for _ in range(5):
+            torch.cuda.synchronize(dev)
+            ev[0].record()
+            rp.finish_infill_mask_sbs(seed2, out=fin2)
+            ev[1].record()
+            torch.cuda.synchronize(dev)
+            ms2.append(ev[0].elapsed_time(ev[1]))
+        ms2.sort()
+        out["infill_mask_completion"]["ms_per_frame_at_32_frames_per_call"] = ms2[2] / nf2
+        del seed2, fin2
     out["product_default_with_finished_infill_mask"] = {
         "fps": 1.0 / (1.0 / out["product_default"]["fps"] + ms[2] * 1e-3 / nf),
         "what": "render + completion, per-frame times added"}
