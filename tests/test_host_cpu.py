@@ -291,7 +291,8 @@ def test_the_product_library_has_no_tuning_hooks():
     from metric_depth_video_toolbox_amd import _lib
     hooks = [b"MDVT_DEBUG_SKIP", b"MDVT_NI_SKIP", b"MDVT_LDS_PAD", b"MDVT_MESH_OLD", b"MDVT_MESH_BAND", b"MDVT_MESH_TPB",
              b"MDVT_POINTS_CFG", b"MDVT_POINTS_NT", b"MDVT_WS_CHUNK", b"MDVT_TELEA_BLOCKS", b"MDVT_TELEA_DUMP", b"MDVT_NI_DUMP",
-             b"MDVT_BLUR_ONE_PASS", b"MDVT_FORCE_GLOBAL", b"MDVT_RASTER_CONV_OFF", b"MDVT_PARAM_UPLOAD"]
+             b"MDVT_BLUR_ONE_PASS", b"MDVT_FORCE_GLOBAL", b"MDVT_RASTER_CONV_OFF", b"MDVT_PARAM_UPLOAD", b"MDVT_EDGE_INBAND",
+             b"MDVT_QUEUE_DUMP", b"MDVT_MESH_BAND3"]
     product = open(_lib.lib_path(), "rb").read()
     tuning = open(_lib.lib_path("tuning"), "rb").read()
     for h in hooks:
