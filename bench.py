@@ -474,17 +474,19 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
     out["mesh"] = measure_variant(lambda: rm.prepare(depth_rgb[:nf], color_rgb[:nf], pm, out_sbs=sbs[:nf], out_mask=mask[:nf]), nf, W, H, dev, torch)
     out["mesh"]["what"] = "mesh mode (the reference's default draw mode), pure stereo shift: k_mesh_band"
     rm.close()
+    nfr = min(32, n_have)         # frames per call of the two converged-mesh renders: two launch sets of 16 as four of 8 on two banks
     nf = min(16, n_have)
     rp = StereoRerenderer(W, H, device=dev.index, pupillary_distance=65, infill_mask=True)
-    pd = [rp.frame_params(xfov=45.0, convergence_distance=2.5) for _ in range(nf)]
-    out["product_default"] = measure_variant(lambda: rp.prepare(depth_rgb[:nf], color_rgb[:nf], pd, out_sbs=sbs[:nf], out_mask=mask[:nf]),
-                                             nf, W, H, dev, torch)
+    pdr = [rp.frame_params(xfov=45.0, convergence_distance=2.5) for _ in range(nfr)]
+    pd = pdr[:nf]
+    out["product_default"] = measure_variant(lambda: rp.prepare(depth_rgb[:nfr], color_rgb[:nfr], pdr, out_sbs=sbs[:nfr], out_mask=mask[:nfr]),
+                                             nfr, W, H, dev, torch)
     out["product_default"]["what"] = ("mesh + --infill_mask (89-degree edge filter, edge points, green key) + per-frame convergence "
                                       "(movie_2_3D.py:433-445): the general path, k_mesh_raster_conv as its rasteriser")
     rc = StereoRerenderer(W, H, device=dev.index, pupillary_distance=65)
-    pc = [rc.frame_params(xfov=45.0, convergence_distance=2.5) for _ in range(nf)]
-    out["mesh_convergence"] = measure_variant(lambda: rc.prepare(depth_rgb[:nf], color_rgb[:nf], pc, out_sbs=sbs[:nf], out_mask=mask[:nf]),
-                                              nf, W, H, dev, torch)
+    pc = [rc.frame_params(xfov=45.0, convergence_distance=2.5) for _ in range(nfr)]
+    out["mesh_convergence"] = measure_variant(lambda: rc.prepare(depth_rgb[:nfr], color_rgb[:nfr], pc, out_sbs=sbs[:nfr], out_mask=mask[:nfr]),
+                                              nfr, W, H, dev, torch)
     out["mesh_convergence"]["what"] = "mesh + per-frame convergence, no edge removal: the general path"
     rc.close()
     # the finished infill-mask image of the same frames (sr:803-808): render with the seed image, then the completion

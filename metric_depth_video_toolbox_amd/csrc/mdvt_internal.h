@@ -122,6 +122,7 @@ struct RenderPlan {
     int n;               // frames in this launch
     int allow_conv;      // MDVT_MESH_CONV=1 when the context was created (mdvt_create): k_mesh_conv may take convergence-only frames
     int edge_rows_max;   // pure-shift launches with edge points: the most scanlines any frame leaves to k_edge_rows_exact (0: none)
+    hipEvent_t after_vertices;   // general mesh path: recorded on the launch's stream behind k_mesh_vertices_general (nullptr: none)
 };
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 // mdvt_mesh_band.hip: the pure-shift mesh rows as bands (no edge removal)

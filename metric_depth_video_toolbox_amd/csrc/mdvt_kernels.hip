@@ -2804,6 +2804,7 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
         else hipLaunchKernelGGL(k_mesh_vertices_general<false>, grid_v, dim3(256), 0, s, a);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (plan.after_vertices && (e = hipEventRecord(plan.after_vertices, s)) != hipSuccess) return e;
     if ((e = launch_mesh_raster_general(plan, a, s)) != hipSuccess) return e;
     if (edge && (e = launch_edge_points_splat(a, plan.n, s)) != hipSuccess) return e;
     return launch_resolve_general<true>(plan, a, s);

@@ -928,6 +928,58 @@ def test_mesh_band_height_follows_the_launch(mods, orc):
     r.close()
 
 
+@pytest.mark.parametrize("case", [dict(W=250, H=61, N=9, mib=8, kw=dict()), dict(W=320, H=64, N=14, mib=14, kw=dict(cull=1)),
+                                  dict(W=128, H=80, N=33, mib=9, kw=dict(infill_mask=True)), dict(W=640, H=48, N=10, mib=16, kw=dict(remove_edges=True))])
+def test_two_banks_on_other_shapes(mods, orc, case):
+    """The same on other frame shapes, set lengths and flag sets (a width that is no multiple of four, odd set counts, a last set
+    shorter than the others): every frame of the batch against the oracle, twice (both parities of the z-key slots)."""
+    _lib, sr, synthetic = mods
+    W, H, N = case["W"], case["H"], case["N"]
+    d, c = synthetic.SyntheticScene(W, H, seed=W + N, n_fg=5).clip(N)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, workspace_mib=case["mib"], **case["kw"])
+    T = synthetic.synthetic_pose_track(N + 8)
+    ps = [r.frame_params(xfov=50.0, convergence_distance=None if k % 2 else 2.2, transformation=T[k + 2] if k % 2 else None) for k in range(N)]
+    dd, cc = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    for rep in range(2):
+        got = r.render(dd, cc, ps, want_depth=True)
+        for k in range(N):
+            want = _oracle(orc, r, ps[k], d[k], c[k], T=T[k + 2] if k % 2 else None)
+            _compare({key: v[k] for key, v in got.items()}, want, W, f"banks {W}x{H} frame {k} of {N}, pass {rep}")
+    r.close()
+
+
+def test_converged_mesh_launch_sets_on_two_banks(mods, orc):
+    """A posed / converged mesh batch of more than one launch set is rendered set by set on two halves of the workspace slots and two
+    streams, a set starting when the one before it has projected its vertices (mdvt_render_stereo_batch).  21 frames under a
+    19 MiB budget are launch sets of 3 frames per bank here: every output plane must be what the same frames give one by one (single
+    sets, no banks), and what the oracle gives; with hole counts or packed masks requested the sets stay on one stream."""
+    _lib, sr, synthetic = mods
+    W, H, N = 256, 96, 21
+    d, c = synthetic.SyntheticScene(W, H, seed=12, n_fg=6).clip(N)
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True, workspace_mib=19)
+    T = synthetic.synthetic_pose_track(N + 5)
+    ps = [r.frame_params(xfov=45.0, convergence_distance=2.0 + 0.05 * k, transformation=T[k + 3] if k % 3 == 0 else None) for k in range(N)]
+    dd, cc = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    whole = r.render(dd, cc, ps, want_depth=True, want_seed=True)
+    again = r.render(dd, cc, ps, want_depth=True, want_seed=True)            # (the other parity of every slot)
+    counted = r.render(dd, cc, ps, want_depth=True, want_seed=True, want_hole_counts=True, want_maskbits=True)
+    torch.cuda.synchronize()
+    for key in ("sbs", "mask", "depth", "seed"):
+        assert torch.equal(whole[key], again[key]) and torch.equal(whole[key], counted[key]), key
+    for k in range(N):
+        one = r.render(dd[k], cc[k], ps[k], want_depth=True, want_seed=True)
+        for key in ("sbs", "mask", "depth", "seed"):
+            assert torch.equal(one[key], whole[key][k]), (key, k)
+    for k in (0, 10, 11, 20):
+        op = orc.make_params(W, H, _K(ps[k]), ipd_m=0.065, max_depth=100, depth_scale=ps[k].depth_scale, mode=orc.MODE_MESH, remove_edges=True,
+                             edge_points=r.edge_points, conv_angle=ps[k].convergence_angle, T=T[k + 3] if k % 3 == 0 else None, key_rgb=(0, 255, 0))
+        want = orc.render_stereo(op, d[k], c[k], want_depth=True, want_seed=True)
+        _compare({"sbs": whole["sbs"][k], "mask": whole["mask"][k], "depth": whole["depth"][k]}, want, W, f"banks, frame {k}")
+        for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+            assert np.array_equal(whole["seed"][k][:, sl].cpu().numpy(), want[eye + "_seed"]), (k, eye)
+    r.close()
+
+
 @pytest.mark.parametrize("tmax,tmin", [(5, 0), (5.0, 0.5), (12.5, 1.0)])
 def test_touchly_depth_plane(mods, tmax, tmin):
     """sr:549-551 evaluated literally with NumPy (the reference's expression is script-level code) vs the kernel,
