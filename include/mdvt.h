@@ -18,6 +18,8 @@
  *     a library-owned workspace (render, edge filter, infill-mask completion, normal_infill, infill_using_[mask_]normals,
  *     mark_lower_side) must be issued to ONE stream per ctx at a time: two calls on one ctx in two streams would share
  *     the workspace unordered, and growing a workspace synchronises the device.
+ *     (mdvt_render_stereo_batch may itself run part of a long posed / converged mesh batch on a second, library-owned stream;
+ *     it forks from and joins the given stream with events, so the call's results are still ordered on the given stream.)
  *   - there is NO CPU fallback: without a HIP device mdvt_create fails with MDVT_ERR_NO_DEVICE.
  */
 #ifndef MDVT_H
