@@ -622,7 +622,9 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     auto chunk_of = [&](const Run& r) {
         const int n = r.f1 - r.f0;
         if (!(r.general || plan.remove_edges || (r.conv && plan.edge_points))) return n;                  // no workspace: the whole run in one launch
-        int ws_chunk = (r.general && plan.mode == MDVT_MODE_POINTS) ? 2 : kWorkspaceChunk;
+        // (points, general path: four slots -- one launch set of four frames, or banks of two (below); two slots until r04:
+        //  1080p convergence 26.7 k -> 28.2 k frames/s, 4K pose + contention 5.4 k -> 6.1 k)
+        int ws_chunk = (r.general && plan.mode == MDVT_MODE_POINTS) ? 4 : kWorkspaceChunk;
         if (r.general && plan.mode == MDVT_MODE_MESH) {
             ws_chunk = 2 * kWorkspaceChunk;      // 16: measured -4 % (convergence) / -11 % (pose) vs 8
             // ~100 B/px per slot (records, z keys, tie side words, triangle queue): 3.3 GB at 1080p, 13 GB at 4K; the queue's
@@ -718,7 +720,8 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
       // different things (the vertex pass for its stores, the rasteriser for its atomics), and the next set's vertex pass and edge
       // filter fill the rasteriser's waits: 32 frames of 1080p product default +3 %, mesh + convergence +4 %, mesh under a pose +7 %,
       // 8 frames of 4K pose + contention (C4) +10 %; a run that fits ONE launch set stays as it is (16 frames: two sets of 8 lose 1.5 %).
-      const bool banks = r.general && plan.mode == MDVT_MODE_MESH && !r.conv && chunk >= 2 && r.f1 - r.f0 > chunk && !want_bits &&
+      // Points on the general path likewise (splat, then resolve: the next set's splat beside this set's resolve): C4 points +13 %.
+      const bool banks = r.general && !r.conv && chunk >= 2 && r.f1 - r.f0 > chunk && !want_bits &&
                          !io->hole_counts && tuning_env(TUNE_WS_CHUNK) == nullptr;
       const int bank_slots = chunk / 2;
       hipStream_t const s_call = s;
@@ -741,18 +744,21 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
             a = a_all;
             const size_t px0 = (size_t)slot0 * a.ws_stride_px;
             for (int e = 0; e < 2; ++e) {
-                a.keys[e] += px0; a.gverts[e] += px0; a.cbuf[e] += px0;
+                a.keys[e] += px0;
+                if (a.gverts[e]) { a.gverts[e] += px0; a.cbuf[e] += px0; }
                 if (a.ekeys[e]) a.ekeys[e] += px0;
             }
             if (a.elist) { a.elist += (size_t)slot0 * 2 * (size_t)W * H; a.elist_count += (size_t)slot0 * H; }
             if (a.tri_invalid) a.tri_invalid += (size_t)slot0 * a.ws_stride_tri;
             if (a.unused) a.unused += px0;
-            a.bigq += (size_t)slot0 * H * (size_t)(4 * W) * mdvt::kBigRecDwords;
-            a.bigq_count += (size_t)bank * ((2 * (size_t)bank_slots * H + 2 + 3) & ~(size_t)3);      // (counters and prefix sums of a set; 16-byte aligned)
-            a.hugeq += (size_t)bank * (2 * (size_t)mdvt::kHugeCap + 2);
-            a.tie_flag += slot0;
-            a.tie_tiles += (size_t)slot0 * 2 * a.tie_words;
-            if (set > 0) MDVT_HIP(c, hipStreamWaitEvent(s, c->ev_vert[bank ^ 1], 0));      // (the set before this one has projected its vertices)
+            if (a.bigq) {
+                a.bigq += (size_t)slot0 * H * (size_t)(4 * W) * mdvt::kBigRecDwords;
+                a.bigq_count += (size_t)bank * ((2 * (size_t)bank_slots * H + 2 + 3) & ~(size_t)3);      // (counters and prefix sums of a set; 16-byte aligned)
+                a.hugeq += (size_t)bank * (2 * (size_t)mdvt::kHugeCap + 2);
+                a.tie_flag += slot0;
+                a.tie_tiles += (size_t)slot0 * 2 * a.tie_words;
+            }
+            if (set > 0) MDVT_HIP(c, hipStreamWaitEvent(s, c->ev_vert[bank ^ 1], 0));      // (the set before this one has projected its vertices / splatted its points)
             plan.after_vertices = c->ev_vert[bank];
         }
         a.frame0 = f0;

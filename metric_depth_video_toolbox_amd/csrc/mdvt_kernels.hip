@@ -2727,6 +2727,7 @@ static hipError_t launch_points_general(const RenderPlan& plan, const RenderArgs
         default: hipLaunchKernelGGL((k_points_splat_general<6>), grid_s, block, 0, s, a); break;
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (plan.after_vertices && (e = hipEventRecord(plan.after_vertices, s)) != hipSuccess) return e;     // (banks: the next set may start)
     return launch_resolve_general<false>(plan, a, s);
 }
 

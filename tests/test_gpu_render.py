@@ -929,10 +929,13 @@ def test_mesh_band_height_follows_the_launch(mods, orc):
 
 
 @pytest.mark.parametrize("case", [dict(W=250, H=61, N=9, mib=8, kw=dict()), dict(W=320, H=64, N=14, mib=14, kw=dict(cull=1)),
-                                  dict(W=128, H=80, N=33, mib=9, kw=dict(infill_mask=True)), dict(W=640, H=48, N=10, mib=16, kw=dict(remove_edges=True))])
+                                  dict(W=128, H=80, N=33, mib=9, kw=dict(infill_mask=True)), dict(W=640, H=48, N=10, mib=16, kw=dict(remove_edges=True)),
+                                  dict(W=250, H=61, N=11, mib=0, kw=dict(render_as_pointcloud=True)),
+                                  dict(W=256, H=64, N=9, mib=0, kw=dict(render_as_pointcloud=True, infill_mask=True))])
 def test_two_banks_on_other_shapes(mods, orc, case):
     """The same on other frame shapes, set lengths and flag sets (a width that is no multiple of four, odd set counts, a last set
-    shorter than the others): every frame of the batch against the oracle, twice (both parities of the z-key slots)."""
+    shorter than the others), and for points on the general path (banks of two frames): every frame of the batch against the
+    oracle, twice (both parities of the z-key slots)."""
     _lib, sr, synthetic = mods
     W, H, N = case["W"], case["H"], case["N"]
     d, c = synthetic.SyntheticScene(W, H, seed=W + N, n_fg=5).clip(N)
