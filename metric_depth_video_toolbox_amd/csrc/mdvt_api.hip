@@ -83,6 +83,7 @@ struct mdvt_ctx {
     // posed / converged mesh runs of more than one launch set: the sets alternate between the caller's stream and this one, each on
     // its own half of the workspace slots (mdvt_render_stereo_batch); made on first use
     hipStream_t side = nullptr;
+    uint32_t* hugeq2 = nullptr;
     hipEvent_t ev_start = nullptr, ev_join = nullptr, ev_vert[2] = {nullptr, nullptr};
 };
 
@@ -383,7 +384,7 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         if (nfq > nf) nfq = nf;
         const size_t cap = nfq * npx * 4;
         c->bigq_cap = (uint32_t)cap;
-        MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 8 + 2 * (2 * (size_t)mdvt::kHugeCap + 2) + nf * (1 + 2 * mdvt::tie_words_of(c->W, c->H))) * sizeof(uint32_t)));   // entries, counters, prefix sums; row blocks of huge triangles + their counter; tie flags and tile bits
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 8 + (2 * (size_t)mdvt::kHugeCap + 2) + nf * (1 + 2 * mdvt::tie_words_of(c->W, c->H))) * sizeof(uint32_t)));   // entries, counters, prefix sums; row blocks of huge triangles + their counter; tie flags and tile bits
         c->ws_gverts = true;
     }
     if (need_edges && !c->ws_edges) {
@@ -479,6 +480,7 @@ int mdvt_destroy(mdvt_ctx* c)
     DeviceGuard g(c->device);
     (void)hipDeviceSynchronize();
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->hugeq2) ws_free(c, c->hugeq2);
     for (hipEvent_t ev : {c->ev_start, c->ev_join, c->ev_vert[0], c->ev_vert[1]}) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : c->slots) {
         pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev), c->device);
@@ -690,7 +692,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     if (c->bigq) {
         a.bigq = c->bigq; a.bigq_cap = c->bigq_cap; a.bigq_count = c->bigq + (size_t)c->bigq_cap * mdvt::kBigRecDwords;
         a.hugeq = a.bigq_count + 2 * (size_t)c->ws_frames * H + 8;      // (8-byte aligned: entries are uint2); two lists (banks, below)
-        a.tie_flag = a.hugeq + 2 * (2 * (size_t)mdvt::kHugeCap + 2);
+        a.tie_flag = a.hugeq + (2 * (size_t)mdvt::kHugeCap + 2);
         a.tie_tiles = a.tie_flag + c->ws_frames;
         a.tie_words = (int32_t)mdvt::tie_words_of(W, H);
         a.tie_tiles_x = (W + mdvt::kTieTile - 1) / mdvt::kTieTile;
@@ -754,7 +756,15 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
             if (a.bigq) {
                 a.bigq += (size_t)slot0 * H * (size_t)(4 * W) * mdvt::kBigRecDwords;
                 a.bigq_count += (size_t)bank * ((2 * (size_t)bank_slots * H + 2 + 3) & ~(size_t)3);      // (counters and prefix sums of a set; 16-byte aligned)
-                a.hugeq += (size_t)bank * (2 * (size_t)mdvt::kHugeCap + 2);
+                // The second bank's own huge list: a separate allocation, made when banks are first used.  (With both lists in the queue's
+                // block, that block grew from 1.1 to 2.2 MB for a 100 x 31 frame, and with 12 processes creating and destroying
+                // contexts on one GPU one FIRST render of a context in ~3 000 then lost a queued triangle or two -- never a later
+                // render, never with HSA_ENABLE_SDMA=0, not at 1080p (0 of 8 400), and with nothing in that block read before it is
+                // written.  Found by the round's last soak; not explained; profiles/r04_soak_summary.md.)
+                if (bank) {
+                    if (!c->hugeq2) MDVT_HIP(c, ws_malloc(c, (void**)&c->hugeq2, (2 * (size_t)mdvt::kHugeCap + 2) * sizeof(uint32_t)));
+                    a.hugeq = c->hugeq2;
+                }
                 a.tie_flag += slot0;
                 a.tie_tiles += (size_t)slot0 * 2 * a.tie_words;
             }
