@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 12
+#define MDVT_VERSION_MINOR 13
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -145,9 +145,22 @@ int mdvt_edge_filter(mdvt_ctx* ctx, const uint8_t* d_depth_rgb, size_t depth_pit
                      double depth_scale, int of_by_one, uint8_t* d_tri_invalid, uint8_t* d_unused, void* stream);
 
 /* Device memory the context currently owns (workspaces of the general paths, the edge filter, the infill-mask completion,
- * normal_infill; allocated on first use, kept until mdvt_destroy or until a larger request replaces them).  The render
- * calls themselves allocate nothing else: every image buffer is the caller's. */
+ * normal_infill; allocated on first use, kept until mdvt_destroy or until a larger request replaces them; sizes are rounded up
+ * to the pool's size classes: at most 6.25 % over the request below 1 MiB, 64 KiB steps above).  The render calls themselves allocate nothing else: every image
+ * buffer is the caller's. */
 int mdvt_workspace_bytes(mdvt_ctx* ctx, uint64_t* bytes);
+
+/* Workspace blocks of destroyed (or grown) contexts are kept by the process for the next context on the same GPU instead of going
+ * back to the driver (a block fresh from the driver is filled and synchronised once before its first use; see DESIGN.md section 9
+ * for the r04 finding behind this); beyond 8 GiB of idle blocks the oldest are released.  mdvt_release_cached_memory returns the
+ * idle blocks of GPU `device` (-1: of every GPU) to the driver -- torch.cuda.empty_cache()'s role; it synchronises the device.
+ * mdvt_cached_memory reports them (either pointer may be NULL).  No reference counterpart: Open3D / NumPy own their memory. */
+int mdvt_release_cached_memory(int device);
+int mdvt_cached_memory(int device, uint64_t* idle_bytes, uint64_t* idle_blocks);
+/* libmdvt_hip_tuning.so only (MDVT_ERR_UNSUPPORTED in the product library): what = 0 copies the general mesh path's triangle-queue
+ * block to h_dst (host, `capacity` bytes; NULL: sizes only) after a device synchronisation.  info: bytes of the block; dword offsets
+ * of the segment counters / the huge list / the tie flags; segments; W; H; frame slots.  tests/dbg_stress_case.py's diagnosis. */
+int mdvt_debug_read(mdvt_ctx* ctx, int what, void* h_dst, uint64_t capacity, uint64_t info[8]);
 
 /* Diagnostic: where the edge point of EVERY vertex of one frame lands (sr:589-606, 615-619, 727-735, 745-750, 838-858: the
  * vertices of removed triangles, undo-scaled, taken through pose / convergence / +-ipd/2, cv2.projectPoints with the f32-cast

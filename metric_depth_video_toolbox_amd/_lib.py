@@ -25,7 +25,7 @@ SYMBOLS = ("mdvt_version", "mdvt_create", "mdvt_destroy", "mdvt_last_error", "md
            "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side", "mdvt_touchly_depth",
            "mdvt_equirect_tables", "mdvt_equirect_remap", "mdvt_masked_blur", "mdvt_finish_infill_mask",
            "mdvt_finish_infill_mask_stereo", "mdvt_swap_rb", "mdvt_selftest", "mdvt_normal_infill", "mdvt_infill_using_mask_normals",
-           "mdvt_edge_point_pixels", "mdvt_workspace_bytes")
+           "mdvt_edge_point_pixels", "mdvt_workspace_bytes", "mdvt_release_cached_memory", "mdvt_cached_memory", "mdvt_debug_read")
 
 
 class MdvtError(RuntimeError):
@@ -128,8 +128,27 @@ def load():
     L.mdvt_edge_point_pixels.argtypes = [vp, C.POINTER(MdvtFrameParams), vp, C.c_size_t, C.c_int, vp, vp]
     L.mdvt_workspace_bytes.restype = C.c_int
     L.mdvt_workspace_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.mdvt_release_cached_memory.restype = C.c_int
+    L.mdvt_release_cached_memory.argtypes = [C.c_int]
+    L.mdvt_cached_memory.restype = C.c_int
+    L.mdvt_cached_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mdvt_debug_read.restype = C.c_int
+    L.mdvt_debug_read.argtypes = [vp, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     _libs[variant] = L
     return L
+
+
+def cached_memory(device: int = -1):
+    """(idle bytes, idle blocks) of the process-wide workspace pool for GPU `device` (-1: all): mdvt_cached_memory."""
+    L = load()
+    b, n = C.c_uint64(), C.c_uint64()
+    L.mdvt_cached_memory(int(device), C.byref(b), C.byref(n))
+    return int(b.value), int(n.value)
+
+
+def release_cached_memory(device: int = -1) -> None:
+    """Return the pool's idle workspace blocks to the driver (mdvt_release_cached_memory)."""
+    load().mdvt_release_cached_memory(int(device))
 
 
 def exported_symbols():
@@ -162,6 +181,16 @@ class Context:
         n = C.c_uint64()
         self.check(self._L.mdvt_workspace_bytes(self._h, C.byref(n)))
         return int(n.value)
+
+    def debug_read_queue_block(self):
+        """(bytes of the general mesh path's queue block as a uint32 array, info[8]) -- tuning library only (mdvt_debug_read)."""
+        import numpy as np
+        info = (C.c_uint64 * 8)()
+        self.check(self._L.mdvt_debug_read(self._h, 0, None, 0, info))
+        buf = np.zeros(int(info[0]) // 4, dtype=np.uint32)
+        if buf.size:
+            self.check(self._L.mdvt_debug_read(self._h, 0, buf.ctypes.data_as(C.c_void_p), buf.nbytes, info))
+        return buf, [int(v) for v in info]
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

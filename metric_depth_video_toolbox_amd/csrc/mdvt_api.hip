@@ -37,6 +37,7 @@ struct ParamSlot {
 
 struct mdvt_ctx {
     int device = 0;
+    int pool_tag = 0;                 // the GPU whose pooled workspace blocks this context may take (= device; tuning build: MDVT_POOL_TAG)
     int W = 0, H = 0;
     mdvt_config cfg{};
     bool cfg_set = false;
@@ -62,6 +63,8 @@ struct mdvt_ctx {
     uint8_t* unused = nullptr;
     uint32_t* bigq = nullptr;         // general mesh path: queue of large triangles + its counter (last dword)
     uint32_t bigq_cap = 0;
+    size_t bigq_bytes = 0;            // the queue block as laid out (without tuning padding)
+    int huge_lists = 1;               // huge lists inside the queue block (2: tuning layout "joint")
     mdvt::RowCell* rowcell = nullptr; // [H] scanline -> cell row table of the mesh grid (pure-shift band kernel)
     uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
     int row_counts_frames = 0;
@@ -106,26 +109,112 @@ int fail(mdvt_ctx* c, int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail((c), MDVT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-// device memory owned by a context, accounted for mdvt_workspace_bytes
-hipError_t ws_malloc(mdvt_ctx* c, void** p, size_t bytes)
-{
-    const hipError_t e = hipMalloc(p, bytes);
-    if (e == hipSuccess && *p) { c->allocs[*p] = bytes; c->ws_bytes += bytes; }
-    return e;
-}
-void ws_free(mdvt_ctx* c, void* p)
-{
-    if (!p) return;
-    auto it = c->allocs.find(p);
-    if (it != c->allocs.end()) { c->ws_bytes -= it->second; c->allocs.erase(it); }
-    (void)hipFree(p);
-}
-
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// ---- Device workspace: a process-wide pool ---------------------------------------------------------------------------------
+// A context's workspace blocks are NOT returned to the driver when the context goes: they wait here for the next context (of
+// the same GPU) that asks for the same size class.  Why: the r04 soak found one FIRST render of a fresh context in ~3 000
+// (12 processes sharing the GPU, a context created and destroyed per render) that lost entries of the triangle queue, and
+// one process killed by a GPU memory fault -- only when the queue's block was larger than 2 MB, i.e. when it no longer came
+// out of the runtime's own cache of sub-2 MB fragments but was mapped by hipMalloc and unmapped by hipFree once per context;
+// never on a context's later renders, never with HSA_ENABLE_SDMA=0.  DESIGN.md section 9 has the diagnosis (r05: what the
+// lost words held, which treatments of a fresh block stop it; tools/probe/fresh_alloc_probe.hip is the pattern without the
+// library).  Whatever the cause below the HIP API, the library no longer creates the condition: (1) a block that does come
+// fresh from hipMalloc is filled and the stream synchronised before anything uses it, (2) blocks are recycled here instead of
+// freed, so in steady state no render ever runs on memory that was mapped microseconds earlier, (3) idle blocks are only given
+// back to the driver beyond kDevPoolIdleCap bytes (oldest first) or on mdvt_release_cached_memory, each time behind a
+// hipDeviceSynchronize.  A recycled block holds a previous user's data: nothing in the library reads a workspace word before
+// the same call has written it (the soaks' sub-2 MB blocks always were recycled this way, by the runtime).
+// The same treatment the pinned parameter blocks got in r03 (pool_take / pool_give below).
+// Tuning build: MDVT_WS_POOL=off -> hipMalloc / hipFree per context as until r04; MDVT_WS_FRESH=none|canary|devsync|memset picks
+// the treatment of a fresh block (product: memset); MDVT_POOL_TAG=n labels this context's blocks as GPU n's (tests).
+struct DevBlock { void* p; size_t bytes; int tag; unsigned long long stamp; };
+std::mutex g_dev_pool_mutex;
+std::vector<DevBlock>& dev_pool() { static std::vector<DevBlock> p; return p; }
+size_t g_dev_pool_idle = 0;
+unsigned long long g_dev_pool_stamp = 0;
+constexpr size_t kDevPoolIdleCap = (size_t)8 << 30;      // idle bytes kept per process before the oldest blocks go back to the driver
+
+// Size classes: 4 KiB steps up to 64 KiB, 16 steps per power of two up to 1 MiB (at most 6.25 % over the request), 64 KiB steps
+// above (the large blocks are what mdvt_config.workspace_mib budgets: they stay what was asked for; a clip's contexts share
+// one frame size, so their blocks match exactly anyway).
+size_t ws_size_class(size_t bytes)
+{
+    if (bytes <= ((size_t)64 << 10)) return (bytes + 4095) & ~(size_t)4095;
+    if (bytes > ((size_t)1 << 20)) return (bytes + 65535) & ~(size_t)65535;
+    size_t step = (size_t)4096;
+    while ((step << 5) < bytes) step <<= 1;              // bytes in (16 step, 32 step]
+    return (bytes + step - 1) / step * step;
+}
+bool dev_pool_off() { const char* e = tuning_env(TUNE_WS_POOL); return e && strcmp(e, "off") == 0; }
+
+// device memory owned by a context, accounted for mdvt_workspace_bytes; `s`: the stream the fresh-block fill goes to
+hipError_t ws_malloc(mdvt_ctx* c, void** p, size_t bytes, hipStream_t s)
+{
+    *p = nullptr;
+    const bool pooled = !dev_pool_off();
+    const size_t want = pooled ? ws_size_class(bytes) : bytes;
+    if (pooled) {
+        std::lock_guard<std::mutex> lock(g_dev_pool_mutex);
+        auto& pool = dev_pool();
+        for (size_t k = pool.size(); k-- > 0;)            // newest first
+            if (pool[k].bytes == want && pool[k].tag == c->pool_tag) {
+                *p = pool[k].p;
+                g_dev_pool_idle -= want;
+                pool.erase(pool.begin() + (long)k);
+                break;
+            }
+    }
+    if (!*p) {
+        hipError_t e = hipMalloc(p, want);
+        if (e != hipSuccess && pooled) {                  // out of memory with idle blocks of other classes around: give them back, once
+            (void)hipGetLastError();
+            mdvt_release_cached_memory(-1);
+            e = hipMalloc(p, want);
+        }
+        if (e != hipSuccess) return e;
+        const char* fresh = tuning_env(TUNE_WS_FRESH);
+        if (!fresh || strcmp(fresh, "memset") == 0) {
+            if ((e = hipMemsetAsync(*p, 0, want, s)) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipFree(*p); *p = nullptr; return e; }
+        } else if (strcmp(fresh, "canary") == 0) {
+            if ((e = hipMemsetAsync(*p, 0xC5, want, s)) != hipSuccess) { (void)hipFree(*p); *p = nullptr; return e; }
+        } else if (strcmp(fresh, "devsync") == 0) {
+            if ((e = hipDeviceSynchronize()) != hipSuccess) { (void)hipFree(*p); *p = nullptr; return e; }
+        }                                                 // "none": as until r04
+    }
+    c->allocs[*p] = want; c->ws_bytes += want;
+    return hipSuccess;
+}
+// (the caller has made sure no submitted work still uses the block: mdvt_destroy and the growing paths synchronise the device)
+void ws_free(mdvt_ctx* c, void* p)
+{
+    if (!p) return;
+    size_t bytes = 0;
+    auto it = c->allocs.find(p);
+    if (it != c->allocs.end()) { bytes = it->second; c->ws_bytes -= bytes; c->allocs.erase(it); }
+    if (dev_pool_off() || bytes == 0 || bytes != ws_size_class(bytes)) { (void)hipFree(p); return; }
+    std::vector<void*> out;
+    {
+        std::lock_guard<std::mutex> lock(g_dev_pool_mutex);
+        auto& pool = dev_pool();
+        pool.push_back({p, bytes, c->pool_tag, ++g_dev_pool_stamp});
+        g_dev_pool_idle += bytes;
+        for (size_t k = 0; g_dev_pool_idle > kDevPoolIdleCap && k < pool.size();) {     // oldest first (the vector is in stamp order)
+            if (pool[k].tag != c->pool_tag) { ++k; continue; }                           // (this GPU's only: the device guard is the caller's)
+            out.push_back(pool[k].p);
+            g_dev_pool_idle -= pool[k].bytes;
+            pool.erase(pool.begin() + (long)k);
+        }
+    }
+    if (!out.empty()) {
+        (void)hipDeviceSynchronize();
+        for (void* q : out) (void)hipFree(q);
+    }
+}
 
 // Everything the kernels need about one frame, derived in f64 and rounded once to f32.
 // Pure-shift frames: on which row does the chain (mdvt_device.h "edge points") put an edge point of source row i?  Without
@@ -331,6 +420,9 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     const size_t npx = (size_t)c->W * c->H;
     const size_t ntri = 2 * (size_t)(c->W - 1) * (c->H - 1);
     const bool grow = frames > c->ws_frames;
+    // (blocks that are replaced go back to the pool, where another context may pick them up at once: whatever was submitted
+    //  with them -- to any stream -- has to be through first; hipFree used to wait for that implicitly)
+    if (grow && c->ws_bytes) MDVT_HIP(c, hipDeviceSynchronize());
     if (grow || (need_keys && !c->ws_keys)) {
         for (int e = 0; e < 2; ++e) { if (c->keys[e]) ws_free(c, c->keys[e]); c->keys[e] = nullptr; }
         c->ws_keys = false;
@@ -354,7 +446,7 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     const size_t nf = (size_t)c->ws_frames;
     if (need_keys && !c->ws_keys) {
         for (int e = 0; e < 2; ++e) {
-            MDVT_HIP(c, ws_malloc(c, (void**)&c->keys[e], nf * npx * sizeof(unsigned long long)));
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->keys[e], nf * npx * sizeof(unsigned long long), s));
             MDVT_HIP(c, hipMemsetAsync(c->keys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));     // parity 0's empty value
         }
         c->key_parity = 0;
@@ -362,17 +454,17 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     }
     if (need_ekeys && !c->ws_ekeys) {
         for (int e = 0; e < 2; ++e) {
-            MDVT_HIP(c, ws_malloc(c, (void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long)));
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long), s));
             MDVT_HIP(c, hipMemsetAsync(c->ekeys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));
         }
-        MDVT_HIP(c, ws_malloc(c, (void**)&c->elist, (nf * 2 * npx + nf * (size_t)c->H) * sizeof(uint32_t)));
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->elist, (nf * 2 * npx + nf * (size_t)c->H) * sizeof(uint32_t), s));
         MDVT_HIP(c, hipMemsetAsync(c->elist + nf * 2 * npx, 0, nf * (size_t)c->H * sizeof(uint32_t), s));   // counters; the reset pass keeps them 0
         c->ws_ekeys = true;
     }
     if (need_gverts && !c->ws_gverts) {
         for (int e = 0; e < 2; ++e) {
-            MDVT_HIP(c, ws_malloc(c, (void**)&c->gverts[e], nf * npx * sizeof(uint4)));
-            MDVT_HIP(c, ws_malloc(c, (void**)&c->cbuf[e], nf * npx * sizeof(unsigned long long)));   // tie side words: a word is initialised by the fragment that marks its pixel, so the plane needs no clearing
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->gverts[e], nf * npx * sizeof(uint4), s));
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->cbuf[e], nf * npx * sizeof(unsigned long long), s));   // tie side words: a word is initialised by the fragment that marks its pixel, so the plane needs no clearing
         }
         if (c->bigq) ws_free(c, c->bigq);
         c->bigq = nullptr;
@@ -384,12 +476,20 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         if (nfq > nf) nfq = nf;
         const size_t cap = nfq * npx * 4;
         c->bigq_cap = (uint32_t)cap;
-        MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 8 + (2 * (size_t)mdvt::kHugeCap + 2) + nf * (1 + 2 * mdvt::tie_words_of(c->W, c->H))) * sizeof(uint32_t)));   // entries, counters, prefix sums; row blocks of huge triangles + their counter; tie flags and tile bits
+        // entries, counters, prefix sums; row blocks of huge triangles + their counter; tie flags and tile bits
+        // (tuning build, the r04 diagnosis: MDVT_WS_LAYOUT=joint puts the second bank's huge list back into this block, as at
+        //  47b4117 -- 2.2 MB for a 100 x 31 frame; MDVT_WS_PAD=n appends n unused bytes)
+        c->huge_lists = 1;
+        if (const char* e = tuning_env(TUNE_WS_LAYOUT)) c->huge_lists = strcmp(e, "joint") == 0 ? 2 : 1;
+        size_t pad = 0;
+        if (const char* e = tuning_env(TUNE_WS_PAD)) pad = (size_t)strtoull(e, nullptr, 10);
+        c->bigq_bytes = (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 8 + (size_t)c->huge_lists * (2 * (size_t)mdvt::kHugeCap + 2) + nf * (1 + 2 * mdvt::tie_words_of(c->W, c->H))) * sizeof(uint32_t);
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, c->bigq_bytes + pad, s));
         c->ws_gverts = true;
     }
     if (need_edges && !c->ws_edges) {
-        MDVT_HIP(c, ws_malloc(c, (void**)&c->tri_invalid, nf * ntri));
-        MDVT_HIP(c, ws_malloc(c, (void**)&c->unused, nf * npx));
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->tri_invalid, nf * ntri, s));
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->unused, nf * npx, s));
         c->ws_edges = true;
     }
     return MDVT_OK;
@@ -424,7 +524,7 @@ int ensure_rowcell(mdvt_ctx* c, hipStream_t s)
         r.Yb = r.c >= 0 ? host_snap((float)(r.c + 1) * sy) : 1;
         t[(size_t)k] = r;
     }
-    MDVT_HIP(c, ws_malloc(c, (void**)&c->rowcell, (size_t)H * sizeof(mdvt::RowCell)));
+    MDVT_HIP(c, ws_malloc(c, (void**)&c->rowcell, (size_t)H * sizeof(mdvt::RowCell), s));
     MDVT_HIP(c, hipMemcpyAsync(c->rowcell, t.data(), (size_t)H * sizeof(mdvt::RowCell), hipMemcpyHostToDevice, s));
     MDVT_HIP(c, hipStreamSynchronize(s));      // `t` is pageable host memory
     return MDVT_OK;
@@ -459,6 +559,8 @@ int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flag
     mdvt_ctx* c = new (std::nothrow) mdvt_ctx();
     if (!c) return fail(nullptr, MDVT_ERR_OOM, "out of host memory");
     c->device = device; c->W = width; c->H = height;
+    c->pool_tag = device;
+    if (const char* t = tuning_env(TUNE_POOL_TAG)) c->pool_tag = atoi(t);
     { const char* e = getenv("MDVT_MESH_CONV"); c->opt_mesh_conv = e && e[0] == '1'; }     // the library's one switch, read here and nowhere else
     c->cfg.mode = MDVT_MODE_POINTS; c->cfg.ipd_m = 0.063; c->cfg.max_depth = 100.0;   // argparse defaults (sr:284, 288)
     *out = c;
@@ -670,9 +772,9 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.seed[0] = io->left_seed; a.seed[1] = io->right_seed; a.seed_pitch = io->seed_pitch; a.seed_stride = io->seed_stride;
     if (io->hole_counts) {
         if (c->row_counts_frames < count_frames) {
-            if (c->row_counts) ws_free(c, c->row_counts);
+            if (c->row_counts) { MDVT_HIP(c, hipDeviceSynchronize()); ws_free(c, c->row_counts); }     // (earlier submissions may still count into it)
             c->row_counts = nullptr; c->row_counts_frames = 0;
-            MDVT_HIP(c, ws_malloc(c, (void**)&c->row_counts, (size_t)count_frames * 2 * H * sizeof(uint32_t)));
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->row_counts, (size_t)count_frames * 2 * H * sizeof(uint32_t), s));
             c->row_counts_frames = count_frames;
         }
         a.row_counts = c->row_counts;
@@ -692,7 +794,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     if (c->bigq) {
         a.bigq = c->bigq; a.bigq_cap = c->bigq_cap; a.bigq_count = c->bigq + (size_t)c->bigq_cap * mdvt::kBigRecDwords;
         a.hugeq = a.bigq_count + 2 * (size_t)c->ws_frames * H + 8;      // (8-byte aligned: entries are uint2); two lists (banks, below)
-        a.tie_flag = a.hugeq + (2 * (size_t)mdvt::kHugeCap + 2);
+        a.tie_flag = a.hugeq + (size_t)c->huge_lists * (2 * (size_t)mdvt::kHugeCap + 2);
         a.tie_tiles = a.tie_flag + c->ws_frames;
         a.tie_words = (int32_t)mdvt::tie_words_of(W, H);
         a.tie_tiles_x = (W + mdvt::kTieTile - 1) / mdvt::kTieTile;
@@ -756,13 +858,11 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
             if (a.bigq) {
                 a.bigq += (size_t)slot0 * H * (size_t)(4 * W) * mdvt::kBigRecDwords;
                 a.bigq_count += (size_t)bank * ((2 * (size_t)bank_slots * H + 2 + 3) & ~(size_t)3);      // (counters and prefix sums of a set; 16-byte aligned)
-                // The second bank's own huge list: a separate allocation, made when banks are first used.  (With both lists in the queue's
-                // block, that block grew from 1.1 to 2.2 MB for a 100 x 31 frame, and with 12 processes creating and destroying
-                // contexts on one GPU one FIRST render of a context in ~3 000 then lost a queued triangle or two -- never a later
-                // render, never with HSA_ENABLE_SDMA=0, not at 1080p (0 of 8 400), and with nothing in that block read before it is
-                // written.  Found by the round's last soak; not explained; profiles/r04_soak_summary.md.)
-                if (bank) {
-                    if (!c->hugeq2) MDVT_HIP(c, ws_malloc(c, (void**)&c->hugeq2, (2 * (size_t)mdvt::kHugeCap + 2) * sizeof(uint32_t)));
+                // The second bank's own huge list: a separate allocation, made when banks are first used (r04: with both lists in the
+                // queue's block a 100 x 31 frame's block passed 2 MB and left the runtime's fragment cache -- see the workspace pool above).
+                if (bank && c->huge_lists == 2) a.hugeq += 2 * (size_t)mdvt::kHugeCap + 2;
+                else if (bank) {
+                    if (!c->hugeq2) MDVT_HIP(c, ws_malloc(c, (void**)&c->hugeq2, (2 * (size_t)mdvt::kHugeCap + 2) * sizeof(uint32_t), s));
                     a.hugeq = c->hugeq2;
                 }
                 a.tie_flag += slot0;
@@ -833,6 +933,63 @@ int mdvt_encode_depth(mdvt_ctx* c, const float* d_depth, size_t depth_pitch, uin
     return MDVT_OK;
 }
 
+int mdvt_release_cached_memory(int device)
+{
+    std::vector<DevBlock> out;
+    {
+        std::lock_guard<std::mutex> lock(g_dev_pool_mutex);
+        auto& pool = dev_pool();
+        for (size_t k = 0; k < pool.size();) {
+            if (device >= 0 && pool[k].tag != device) { ++k; continue; }
+            out.push_back(pool[k]);
+            g_dev_pool_idle -= pool[k].bytes;
+            pool.erase(pool.begin() + (long)k);
+        }
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
+    for (const DevBlock& b : out) {
+        // (a block tagged for a GPU this process does not have -- the tuning build's MDVT_POOL_TAG -- lives on the current one)
+        DeviceGuard g(b.tag >= 0 && b.tag < count ? b.tag : 0);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(b.p);
+    }
+    return MDVT_OK;
+}
+
+int mdvt_cached_memory(int device, uint64_t* idle_bytes, uint64_t* idle_blocks)
+{
+    uint64_t bytes = 0, blocks = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_dev_pool_mutex);
+        for (const DevBlock& b : dev_pool()) if (device < 0 || b.tag == device) { bytes += b.bytes; ++blocks; }
+    }
+    if (idle_bytes) *idle_bytes = bytes;
+    if (idle_blocks) *idle_blocks = blocks;
+    return MDVT_OK;
+}
+
+int mdvt_debug_read(mdvt_ctx* c, int what, void* h_dst, uint64_t capacity, uint64_t info[8])
+{
+    if (!c) return MDVT_ERR_INVALID_ARG;
+    if (!tuning_build()) return fail(c, MDVT_ERR_UNSUPPORTED, "mdvt_debug_read: tuning build only");
+    if (what != 0 || !info) return fail(c, MDVT_ERR_INVALID_ARG, "mdvt_debug_read: what must be 0, info not NULL");
+    DeviceGuard g(c->device);
+    MDVT_HIP(c, hipDeviceSynchronize());
+    const size_t cap_dw = (size_t)c->bigq_cap * mdvt::kBigRecDwords;
+    info[0] = c->bigq ? c->bigq_bytes : 0;                                   // bytes of the queue block
+    info[1] = cap_dw;                                                        // dword offset of the segment counters
+    info[2] = (uint64_t)c->ws_frames * (uint64_t)c->H;                       // segments the block has room for
+    info[3] = cap_dw + 2 * (uint64_t)c->ws_frames * (uint64_t)c->H + 8;      // dword offset of the (first) huge list
+    info[4] = info[3] + (uint64_t)c->huge_lists * (2 * (uint64_t)mdvt::kHugeCap + 2);   // dword offset of the tie flags
+    info[5] = (uint64_t)c->W; info[6] = (uint64_t)c->H; info[7] = (uint64_t)c->ws_frames;
+    if (h_dst && c->bigq) {
+        if (capacity < c->bigq_bytes) return fail(c, MDVT_ERR_INVALID_ARG, "mdvt_debug_read: %zu bytes needed", c->bigq_bytes);
+        MDVT_HIP(c, hipMemcpy(h_dst, c->bigq, c->bigq_bytes, hipMemcpyDeviceToHost));
+    }
+    return MDVT_OK;
+}
+
 int mdvt_workspace_bytes(mdvt_ctx* c, uint64_t* bytes)
 {
     if (!c) return MDVT_ERR_INVALID_ARG;
@@ -896,7 +1053,7 @@ int mdvt_edge_filter(mdvt_ctx* c, const uint8_t* d_depth_rgb, size_t depth_pitch
     return MDVT_OK;
 }
 
-static int ensure_ni_workspace(mdvt_ctx* c, int chunk);      // (the listed-pixel stages' workspace, below)
+static int ensure_ni_workspace(mdvt_ctx* c, int chunk, hipStream_t s);      // (the listed-pixel stages' workspace, below)
 
 int mdvt_infill_using_normals(mdvt_ctx* c, const uint8_t* d_color, size_t color_pitch, const uint8_t* d_hole,
                               size_t hole_pitch, const float* d_normal, size_t normal_pitch, uint8_t* d_out,
@@ -912,7 +1069,7 @@ int mdvt_infill_using_normals(mdvt_ctx* c, const uint8_t* d_color, size_t color_
     if (hole_pitch >= (1u << 24) || (unsigned long long)hole_pitch * c->H > 0xFFFFFFFFull)
         return fail(c, MDVT_ERR_UNSUPPORTED, "hole plane too large for the march's 32-bit offsets (pitch %zu, %d rows)", hole_pitch, c->H);
     DeviceGuard g(c->device);
-    if (int rc = ensure_ni_workspace(c, 1)) return rc;
+    if (int rc = ensure_ni_workspace(c, 1, (hipStream_t)stream)) return rc;
     MDVT_HIP(c, launch_infill_normals(d_color, color_pitch, d_hole, hole_pitch, d_normal, normal_pitch, d_out, out_pitch,
                                       c->W, c->H, max_steps, c->ni_ws, (hipStream_t)stream));
     return MDVT_OK;
@@ -929,7 +1086,7 @@ int mdvt_mark_lower_side(mdvt_ctx* c, const uint8_t* d_normals_img, size_t img_p
     if (img_pitch >= (1u << 24) || (unsigned long long)img_pitch * c->H > 0xFFFFFFFFull)
         return fail(c, MDVT_ERR_UNSUPPORTED, "image too large for the march's 32-bit offsets (pitch %zu, %d rows)", img_pitch, c->H);
     DeviceGuard g(c->device);
-    if (int rc = ensure_ni_workspace(c, 1)) return rc;
+    if (int rc = ensure_ni_workspace(c, 1, (hipStream_t)stream)) return rc;
     MDVT_HIP(c, launch_mark_lower_side(d_normals_img, img_pitch, d_out, out_pitch, c->W, c->H, max_steps, c->ni_ws, (hipStream_t)stream));
     return MDVT_OK;
 }
@@ -1029,13 +1186,13 @@ int mdvt_masked_blur(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, uint8_
 
 constexpr int kNormalInfillChunk = 16;       // images per launch set
 
-static int ensure_ni_workspace(mdvt_ctx* c, int chunk)
+static int ensure_ni_workspace(mdvt_ctx* c, int chunk, hipStream_t s)
 {
     if (c->ni_images >= chunk) return MDVT_OK;
     MDVT_HIP(c, hipDeviceSynchronize());                 // earlier submissions may still use the old workspace
     if (c->ni_ws) ws_free(c, c->ni_ws);
     c->ni_ws = nullptr; c->ni_images = 0;
-    MDVT_HIP(c, ws_malloc(c, (void**)&c->ni_ws, mdvt::normal_infill_workspace_bytes(chunk, c->W, c->H)));
+    MDVT_HIP(c, ws_malloc(c, (void**)&c->ni_ws, mdvt::normal_infill_workspace_bytes(chunk, c->W, c->H), s));
     c->ni_images = chunk;
     return MDVT_OK;
 }
@@ -1056,7 +1213,7 @@ int mdvt_normal_infill(mdvt_ctx* c, const uint8_t* d_img, size_t img_pitch, size
     DeviceGuard g(c->device);
     hipStream_t s = (hipStream_t)stream;
     const int chunk = n_images < kNormalInfillChunk ? n_images : kNormalInfillChunk;
-    if (int rc = ensure_ni_workspace(c, chunk)) return rc;
+    if (int rc = ensure_ni_workspace(c, chunk, s)) return rc;
     const mdvt::BlurKernel K = masked_blur_kernel();
     for (int i0 = 0; i0 < n_images; i0 += chunk) {
         const int n = n_images - i0 < chunk ? n_images - i0 : chunk;
@@ -1083,7 +1240,7 @@ int mdvt_infill_using_mask_normals(mdvt_ctx* c, uint8_t* d_img, size_t img_pitch
         return fail(c, MDVT_ERR_UNSUPPORTED, "hole plane too large for the march's 32-bit offsets (pitch %zu, %d rows)", hole_pitch, c->H);
     DeviceGuard g(c->device);
     const int chunk = n_images < kNormalInfillChunk ? n_images : kNormalInfillChunk;
-    if (int rc = ensure_ni_workspace(c, chunk)) return rc;
+    if (int rc = ensure_ni_workspace(c, chunk, (hipStream_t)stream)) return rc;
     for (int i0 = 0; i0 < n_images; i0 += chunk) {
         const int n = n_images - i0 < chunk ? n_images - i0 : chunk;
         const mdvt::ImageSet img{d_img + (size_t)i0 * img_stride, img_pitch, img_stride, 0, n};
@@ -1120,14 +1277,14 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
         const int rounds = max_rounds > c->telea_rounds ? max_rounds : c->telea_rounds;
         free_telea(c);
         mdvt::TeleaWorkspace& w = c->telea;
-        MDVT_HIP(c, ws_malloc(c, (void**)&w.stamp, (size_t)images * npx * sizeof(uint16_t)));
-        MDVT_HIP(c, ws_malloc(c, (void**)&w.T, (size_t)images * npx * sizeof(float)));
-        MDVT_HIP(c, ws_malloc(c, (void**)&w.img, (size_t)images * npx * 3 + 4));      // + 4: pixels are fetched as unaligned dwords
-        MDVT_HIP(c, ws_malloc(c, (void**)&w.need, (size_t)images * npx));
-        MDVT_HIP(c, ws_malloc(c, (void**)&w.nlist, (size_t)images * npx * sizeof(uint32_t)));
-        MDVT_HIP(c, ws_malloc(c, (void**)&w.counts, mdvt::telea_counter_words(rounds) * sizeof(uint32_t)));
-        MDVT_HIP(c, ws_malloc(c, (void**)&w.remaining, (size_t)kTeleaChunk * sizeof(uint32_t)));
-        MDVT_HIP(c, ws_malloc(c, (void**)&w.last_round, (size_t)kTeleaChunk * sizeof(uint32_t)));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.stamp, (size_t)images * npx * sizeof(uint16_t), s));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.T, (size_t)images * npx * sizeof(float), s));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.img, (size_t)images * npx * 3 + 4, s));      // + 4: pixels are fetched as unaligned dwords
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.need, (size_t)images * npx, s));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.nlist, (size_t)images * npx * sizeof(uint32_t), s));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.counts, mdvt::telea_counter_words(rounds) * sizeof(uint32_t), s));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.remaining, (size_t)kTeleaChunk * sizeof(uint32_t), s));
+        MDVT_HIP(c, ws_malloc(c, (void**)&w.last_round, (size_t)kTeleaChunk * sizeof(uint32_t), s));
         c->telea_images = images; c->telea_rounds = rounds;
     }
     c->telea.offs = c->telea.counts + (max_rounds + 2);

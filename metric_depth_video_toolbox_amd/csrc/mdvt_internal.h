@@ -15,7 +15,7 @@ namespace mdvt {
 // once, in mdvt_create.  `make tuning` links the same objects with mdvt_tuning_on.hip into libmdvt_hip_tuning.so, where
 // tuning_env(TUNE_X) is getenv("MDVT_X"), re-read per launch: that library is what tools/ and the tests that force a kernel
 // family load (MDVT_LIB_VARIANT=tuning, _lib.py).  Some hooks change results by design (MDVT_DEBUG_SKIP bits 0-4, MDVT_NI_SKIP).
-enum TuneKey { TUNE_BLUR_ONE_PASS, TUNE_DEBUG_SKIP, TUNE_EDGE_INBAND, TUNE_FORCE_GLOBAL, TUNE_LDS_PAD, TUNE_MESH_BAND, TUNE_MESH_BAND3, TUNE_MESH_CONV, TUNE_MESH_OLD, TUNE_MESH_TPB, TUNE_NI_DUMP, TUNE_NI_SKIP, TUNE_PARAM_UPLOAD, TUNE_POINTS_CFG, TUNE_POINTS_NT, TUNE_QUEUE_DUMP, TUNE_RASTER_CONV_OFF, TUNE_TELEA_BLOCKS, TUNE_TELEA_DUMP, TUNE_WS_CHUNK, TUNE_COUNT };
+enum TuneKey { TUNE_BLUR_ONE_PASS, TUNE_DEBUG_SKIP, TUNE_EDGE_INBAND, TUNE_FORCE_GLOBAL, TUNE_LDS_PAD, TUNE_MESH_BAND, TUNE_MESH_BAND3, TUNE_MESH_CONV, TUNE_MESH_OLD, TUNE_MESH_TPB, TUNE_NI_DUMP, TUNE_NI_SKIP, TUNE_PARAM_UPLOAD, TUNE_POINTS_CFG, TUNE_POINTS_NT, TUNE_POOL_TAG, TUNE_QUEUE_DUMP, TUNE_RASTER_CONV_OFF, TUNE_TELEA_BLOCKS, TUNE_TELEA_DUMP, TUNE_WS_CHUNK, TUNE_WS_FRESH, TUNE_WS_LAYOUT, TUNE_WS_PAD, TUNE_WS_POOL, TUNE_COUNT };
 const char* tuning_env(TuneKey k);
 bool tuning_build();
 
