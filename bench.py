@@ -588,25 +588,12 @@ def extra_c4_c5(args, dev, torch):
     out = {}
     try:
         W, H, N = 3840, 2160, 8
-        sc = SyntheticScene(W, H, config_id=4)
-        K = compute_camera_matrix(45.0, None, W, H)
-        NH = 4                                               # host-made scenes; the other frames are these rolled by whole pixels on the device
-        d_np = np.empty((NH, H, W, 3), np.uint8)
-        c_np = np.empty((NH, H, W, 3), np.uint8)
-        for t in range(NH):
-            z = contention_band(sc.depth_m(t), K[0, 0], 0.065, row0=H // 2 - 32 + 8 * t, rows=64)
-            d_np[t] = quantise_depth_to_rgb(z)
-            _, c_np[t] = sc.frame(t)
-        d = torch.empty((N, H, W, 3), dtype=torch.uint8, device=dev)
-        c = torch.empty((N, H, W, 3), dtype=torch.uint8, device=dev)
-        d[:NH], c[:NH] = torch.from_numpy(d_np).to(dev), torch.from_numpy(c_np).to(dev)
-        for k in range(NH, N):
-            d[k] = torch.roll(d[k % NH], shifts=(16 * (k // NH), 24 * (k // NH)), dims=(0, 1))
-            c[k] = torch.roll(c[k % NH], shifts=(16 * (k // NH), 24 * (k // NH)), dims=(0, 1))
+        from metric_depth_video_toolbox_amd.synthetic import c4_clip
+        d_np, c_np, Ts = c4_clip(N, W, H)                     # (the clip tests/test_gpu_bench_sizes.py holds to the oracle)
+        d, c = torch.from_numpy(d_np).to(dev), torch.from_numpy(c_np).to(dev)
         del d_np, c_np
         sbs = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=dev)
         mask = torch.empty((N, H, 2 * W), dtype=torch.uint8, device=dev)
-        Ts = synthetic_pose_track(300)[40:40 + N * 30:30]        # frames 40, 70, ... of the track: up to 5 deg of yaw, half a metre of travel
         for name, kw in (("c4_4k_pose_points", dict(render_as_pointcloud=True)), ("c4_4k_pose_mesh", dict())):
             r = StereoRerenderer(W, H, device=dev.index, pupillary_distance=65, **kw)
             ps = [r.frame_params(xfov=45.0, transformation=Ts[k]) for k in range(N)]

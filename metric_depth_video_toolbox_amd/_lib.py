@@ -192,6 +192,15 @@ class Context:
             self.check(self._L.mdvt_debug_read(self._h, 0, buf.ctypes.data_as(C.c_void_p), buf.nbytes, info))
         return buf, [int(v) for v in info]
 
+    def debug_coherence(self):
+        """mdvt_debug_read(what = 1): the cross-XCD coherence test on the queue block (tuning library; overwrites the block).
+        -> uint32[80]: [8 w + r] wrong pattern words by writer / reader XCD, [64 + r] wrong atomic sums, [72] total, [73..75] first."""
+        import numpy as np
+        info = (C.c_uint64 * 8)()
+        out = np.zeros(80, dtype=np.uint32)
+        self.check(self._L.mdvt_debug_read(self._h, 1, out.ctypes.data_as(C.c_void_p), out.nbytes, info))
+        return out
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.mdvt_destroy(self._h)

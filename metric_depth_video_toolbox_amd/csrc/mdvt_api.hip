@@ -54,9 +54,8 @@ struct mdvt_ctx {
     unsigned long long* keys[2] = {nullptr, nullptr};
     unsigned long long* ekeys[2] = {nullptr, nullptr};
     uint32_t* elist = nullptr;        // written edge-key words per (slot, source row) + counters (behind the entries)
-    uint4* gverts[2] = {nullptr, nullptr};
     unsigned long long* cbuf[2] = {nullptr, nullptr};
-    bool ws_gverts = false;
+    bool ws_mesh = false;
     bool keys_dirty = false;          // a general-path submission was interrupted between splat and resolve
     uint32_t key_parity = 0;          // bit s: parity of the next use of z-key slot s (mdvt_device.h, parity scheme)
     uint8_t* tri_invalid = nullptr;
@@ -150,7 +149,7 @@ size_t ws_size_class(size_t bytes)
     while ((step << 5) < bytes) step <<= 1;              // bytes in (16 step, 32 step]
     return (bytes + step - 1) / step * step;
 }
-bool dev_pool_off() { const char* e = tuning_env(TUNE_WS_POOL); return e && strcmp(e, "off") == 0; }
+bool dev_pool_off() { const char* e = tuning_env(TUNE_WS_POOL); return e && (strcmp(e, "off") == 0 || strcmp(e, "delay") == 0); }
 
 // device memory owned by a context, accounted for mdvt_workspace_bytes; `s`: the stream the fresh-block fill goes to
 hipError_t ws_malloc(mdvt_ctx* c, void** p, size_t bytes, hipStream_t s)
@@ -170,7 +169,11 @@ hipError_t ws_malloc(mdvt_ctx* c, void** p, size_t bytes, hipStream_t s)
             }
     }
     if (!*p) {
-        hipError_t e = hipMalloc(p, want);
+        const char* fresh0 = tuning_env(TUNE_WS_FRESH);
+        hipError_t e;
+        if (fresh0 && strcmp(fresh0, "uncached") == 0) e = hipExtMallocWithFlags(p, want, hipDeviceMallocUncached);          // (r05 diagnosis)
+        else if (fresh0 && strcmp(fresh0, "finegrained") == 0) e = hipExtMallocWithFlags(p, want, hipDeviceMallocFinegrained);
+        else e = hipMalloc(p, want);
         if (e != hipSuccess && pooled) {                  // out of memory with idle blocks of other classes around: give them back, once
             (void)hipGetLastError();
             mdvt_release_cached_memory(-1);
@@ -196,7 +199,19 @@ void ws_free(mdvt_ctx* c, void* p)
     size_t bytes = 0;
     auto it = c->allocs.find(p);
     if (it != c->allocs.end()) { bytes = it->second; c->ws_bytes -= bytes; c->allocs.erase(it); }
-    if (dev_pool_off() || bytes == 0 || bytes != ws_size_class(bytes)) { (void)hipFree(p); return; }
+    if (dev_pool_off() || bytes == 0 || bytes != ws_size_class(bytes)) {
+        // (r05 diagnosis, tuning build: MDVT_WS_POOL=delay -> a freed block waits behind the next 64 before it goes back to the driver,
+        //  so its address range is not handed out again at once)
+        const char* e = tuning_env(TUNE_WS_POOL);
+        if (e && strcmp(e, "delay") == 0) {
+            static std::vector<void*> ring;
+            ring.push_back(p);
+            if (ring.size() > 64) { (void)hipFree(ring.front()); ring.erase(ring.begin()); }
+            return;
+        }
+        (void)hipFree(p);
+        return;
+    }
     std::vector<void*> out;
     {
         std::lock_guard<std::mutex> lock(g_dev_pool_mutex);
@@ -415,7 +430,7 @@ int stage_params(mdvt_ctx* c, const std::vector<FrameDev>& v, hipStream_t s, con
 
 // (the EMPTY fill of fresh key buffers goes on the caller's stream: PyTorch's pool streams do not synchronise with the
 //  legacy null stream, so a fill issued there could land after the first splat)
-int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, bool need_edges, bool need_gverts, hipStream_t s)
+int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, bool need_edges, bool need_mesh_ws, hipStream_t s)
 {
     const size_t npx = (size_t)c->W * c->H;
     const size_t ntri = 2 * (size_t)(c->W - 1) * (c->H - 1);
@@ -438,9 +453,9 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         if (c->unused) ws_free(c, c->unused);
         c->tri_invalid = nullptr; c->unused = nullptr; c->ws_edges = false;
     }
-    if (grow || (need_gverts && !c->ws_gverts)) {
-        for (int e = 0; e < 2; ++e) { if (c->gverts[e]) ws_free(c, c->gverts[e]); c->gverts[e] = nullptr; if (c->cbuf[e]) ws_free(c, c->cbuf[e]); c->cbuf[e] = nullptr; }
-        c->ws_gverts = false;
+    if (grow || (need_mesh_ws && !c->ws_mesh)) {
+        for (int e = 0; e < 2; ++e) { if (c->cbuf[e]) ws_free(c, c->cbuf[e]); c->cbuf[e] = nullptr; }
+        c->ws_mesh = false;
     }
     if (grow) c->ws_frames = frames;
     const size_t nf = (size_t)c->ws_frames;
@@ -461,9 +476,8 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         MDVT_HIP(c, hipMemsetAsync(c->elist + nf * 2 * npx, 0, nf * (size_t)c->H * sizeof(uint32_t), s));   // counters; the reset pass keeps them 0
         c->ws_ekeys = true;
     }
-    if (need_gverts && !c->ws_gverts) {
+    if (need_mesh_ws && !c->ws_mesh) {
         for (int e = 0; e < 2; ++e) {
-            MDVT_HIP(c, ws_malloc(c, (void**)&c->gverts[e], nf * npx * sizeof(uint4), s));
             MDVT_HIP(c, ws_malloc(c, (void**)&c->cbuf[e], nf * npx * sizeof(unsigned long long), s));   // tie side words: a word is initialised by the fragment that marks its pixel, so the plane needs no clearing
         }
         if (c->bigq) ws_free(c, c->bigq);
@@ -485,7 +499,7 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
         if (const char* e = tuning_env(TUNE_WS_PAD)) pad = (size_t)strtoull(e, nullptr, 10);
         c->bigq_bytes = (cap * mdvt::kBigRecDwords + 2 * nf * (size_t)c->H + 8 + (size_t)c->huge_lists * (2 * (size_t)mdvt::kHugeCap + 2) + nf * (1 + 2 * mdvt::tie_words_of(c->W, c->H))) * sizeof(uint32_t);
         MDVT_HIP(c, ws_malloc(c, (void**)&c->bigq, c->bigq_bytes + pad, s));
-        c->ws_gverts = true;
+        c->ws_mesh = true;
     }
     if (need_edges && !c->ws_edges) {
         MDVT_HIP(c, ws_malloc(c, (void**)&c->tri_invalid, nf * ntri, s));
@@ -588,7 +602,7 @@ int mdvt_destroy(mdvt_ctx* c)
         pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev), c->device);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
-    for (int e = 0; e < 2; ++e) { if (c->keys[e]) ws_free(c, c->keys[e]); if (c->ekeys[e]) ws_free(c, c->ekeys[e]); if (c->gverts[e]) ws_free(c, c->gverts[e]); if (c->cbuf[e]) ws_free(c, c->cbuf[e]); }
+    for (int e = 0; e < 2; ++e) { if (c->keys[e]) ws_free(c, c->keys[e]); if (c->ekeys[e]) ws_free(c, c->ekeys[e]); if (c->cbuf[e]) ws_free(c, c->cbuf[e]); }
     if (c->bigq) ws_free(c, c->bigq);
     if (c->tri_invalid) ws_free(c, c->tri_invalid);
     if (c->unused) ws_free(c, c->unused);
@@ -717,7 +731,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     general = (any_global || any_conv) ? 1 : 0;          // some run uses the global workspace
     const bool need_keys = any_global;
     const bool need_ekeys = general && plan.edge_points;
-    const bool need_gverts = any_global && plan.mode == MDVT_MODE_MESH;
+    const bool need_mesh_ws = any_global && plan.mode == MDVT_MODE_MESH;
     // frames per launch set.  Point splat, general: two frames keep the 64-bit key buffers (33 MB per 1080p frame)
     // inside the 256 MiB Infinity Cache between splat and resolve (measured +12 %); the mesh needs the slack of
     // eight (rows full of slivers leave a long tail), and the edge filter alone streams, so 8 as well.
@@ -731,14 +745,14 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         int ws_chunk = (r.general && plan.mode == MDVT_MODE_POINTS) ? 4 : kWorkspaceChunk;
         if (r.general && plan.mode == MDVT_MODE_MESH) {
             ws_chunk = 2 * kWorkspaceChunk;      // 16: measured -4 % (convergence) / -11 % (pose) vs 8
-            // ~100 B/px per slot (records, z keys, tie side words, triangle queue): 3.3 GB at 1080p, 13 GB at 4K; the queue's
-            // entry indices are 32-bit, so very large frames get fewer slots (4 entries per pixel and slot)
+            // ~64 B/px per slot (z keys, tie side words, triangle queue; until r04 also 32 B/px of vertex records): 2.1 GB at 1080p,
+            // 8.5 GB at 4K; the queue's entry indices are 32-bit, so very large frames get fewer slots (4 entries per pixel and slot)
             const size_t fit = (size_t)0xFFFFFFF0u / (4 * (size_t)W * (size_t)H);
             if ((size_t)ws_chunk > fit) ws_chunk = fit < 1 ? 1 : (int)fit;
             // ... and the slots have to fit the context's workspace budget (mdvt_config.workspace_mib, default 4 GiB: 16 slots at
-            // 1080p, 4 at 3840 x 2160 -- where 16 would be 16 GB): per slot and pixel 16 B of z keys, 48 B of vertex records and
-            // tie side words, 32 B of triangle queue, with edge points 24 B of edge keys and their list, 3 B of filter flags
-            const size_t per_slot = (size_t)W * (size_t)H * (16 + 48 + 32 + (plan.edge_points ? 24 : 0) + (plan.remove_edges ? 3 : 0));
+            // 1080p, 8 at 3840 x 2160 -- where 16 would be 8.5 GB): per slot and pixel 16 B of z keys, 16 B of tie side words,
+            // 32 B of triangle queue, with edge points 24 B of edge keys and their list, 3 B of filter flags
+            const size_t per_slot = (size_t)W * (size_t)H * (16 + 16 + 32 + (plan.edge_points ? 24 : 0) + (plan.remove_edges ? 3 : 0));
             const size_t budget = (size_t)(c->cfg.workspace_mib ? c->cfg.workspace_mib : 4096u) << 20;
             const size_t afford = budget / per_slot;
             if ((size_t)ws_chunk > afford) ws_chunk = afford < 1 ? 1 : (int)afford;
@@ -758,7 +772,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         if ((r.general || r.conv || plan.remove_edges) && ch > ws_frames) ws_frames = ch;
         if (ch > count_frames) count_frames = ch;
     }
-    if (ws_frames && (rc = ensure_workspace(c, ws_frames, need_keys, need_ekeys, plan.remove_edges, need_gverts, s)) != MDVT_OK) return rc;
+    if (ws_frames && (rc = ensure_workspace(c, ws_frames, need_keys, need_ekeys, plan.remove_edges, need_mesh_ws, s)) != MDVT_OK) return rc;
 
     RenderArgs a{};
     a.depth = io->depth_rgb; a.depth_pitch = io->depth_pitch; a.depth_stride = io->depth_stride;
@@ -788,7 +802,6 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.keys[0] = c->keys[0]; a.keys[1] = c->keys[1];
     a.ekeys[0] = c->ekeys[0]; a.ekeys[1] = c->ekeys[1];
     a.elist = c->elist; a.elist_count = c->elist ? c->elist + (size_t)c->ws_frames * 2 * (size_t)W * H : nullptr;
-    a.gverts[0] = c->gverts[0]; a.gverts[1] = c->gverts[1];
     a.cbuf[0] = c->cbuf[0]; a.cbuf[1] = c->cbuf[1];
     a.tri_invalid = c->tri_invalid; a.unused = c->unused;
     if (c->bigq) {
@@ -829,6 +842,15 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                          !io->hole_counts && tuning_env(TUNE_WS_CHUNK) == nullptr;
       const int bank_slots = chunk / 2;
       hipStream_t const s_call = s;
+      // (every way out of the bank loop joins the side stream back into the caller's: an error return must not leave the side
+      //  stream working on its half of the workspace -- and on the caller's output buffers -- behind the caller's back; advisor, r04)
+      struct BankJoin {
+          mdvt_ctx* c; hipStream_t s_call; bool armed;
+          ~BankJoin() {
+              if (!armed) return;
+              if (hipEventRecord(c->ev_join, c->side) != hipSuccess || hipStreamWaitEvent(s_call, c->ev_join, 0) != hipSuccess) (void)hipStreamSynchronize(c->side);
+          }
+      } bank_join{c, s_call, false};
       if (banks) {
           chunk = bank_slots;
           if (!c->side) {
@@ -837,6 +859,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
           }
           MDVT_HIP(c, hipEventRecord(c->ev_start, s_call));            // (the inputs, the parameter block, the runs before this one)
           MDVT_HIP(c, hipStreamWaitEvent(c->side, c->ev_start, 0));
+          bank_join.armed = true;
       }
       const RenderArgs a_all = a;
       int set = 0;
@@ -849,7 +872,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
             const size_t px0 = (size_t)slot0 * a.ws_stride_px;
             for (int e = 0; e < 2; ++e) {
                 a.keys[e] += px0;
-                if (a.gverts[e]) { a.gverts[e] += px0; a.cbuf[e] += px0; }
+                if (a.cbuf[e]) a.cbuf[e] += px0;
                 if (a.ekeys[e]) a.ekeys[e] += px0;
             }
             if (a.elist) { a.elist += (size_t)slot0 * 2 * (size_t)W * H; a.elist_count += (size_t)slot0 * H; }
@@ -896,6 +919,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
           a = a_all;
           MDVT_HIP(c, hipEventRecord(c->ev_join, c->side));
           MDVT_HIP(c, hipStreamWaitEvent(s_call, c->ev_join, 0));
+          bank_join.armed = false;
       }
     }
     if (general) c->keys_dirty = false;
@@ -973,9 +997,25 @@ int mdvt_debug_read(mdvt_ctx* c, int what, void* h_dst, uint64_t capacity, uint6
 {
     if (!c) return MDVT_ERR_INVALID_ARG;
     if (!tuning_build()) return fail(c, MDVT_ERR_UNSUPPORTED, "mdvt_debug_read: tuning build only");
-    if (what != 0 || !info) return fail(c, MDVT_ERR_INVALID_ARG, "mdvt_debug_read: what must be 0, info not NULL");
+    if ((what != 0 && what != 1) || !info) return fail(c, MDVT_ERR_INVALID_ARG, "mdvt_debug_read: what must be 0 or 1, info not NULL");
     DeviceGuard g(c->device);
     MDVT_HIP(c, hipDeviceSynchronize());
+    if (what == 1) {
+        // the coherence test of mdvt_selftest.hip on the queue block itself (it OVERWRITES the block: the next render rewrites what it
+        // reads): h_dst receives 80 dwords; info[0] = the tag used
+        if (!c->bigq || !h_dst || capacity < 80 * sizeof(uint32_t)) return fail(c, MDVT_ERR_INVALID_ARG, "mdvt_debug_read: no queue block / 320 bytes needed");
+        static uint32_t tag = 0x1234567u;
+        tag = tag * 1664525u + 1013904223u;
+        uint32_t *d_xcc = nullptr, *d_out = nullptr;
+        MDVT_HIP(c, hipMalloc((void**)&d_xcc, (c->bigq_bytes / 256 + 1) * sizeof(uint32_t)));
+        MDVT_HIP(c, hipMalloc((void**)&d_out, 80 * sizeof(uint32_t)));
+        hipError_t e = launch_coherence_test(c->bigq, c->bigq_bytes / 4, tag, d_xcc, d_out, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(h_dst, d_out, 80 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        (void)hipFree(d_xcc); (void)hipFree(d_out);
+        if (e != hipSuccess) return fail(c, MDVT_ERR_HIP, "mdvt_debug_read: %s", hipGetErrorString(e));
+        info[0] = tag;
+        return MDVT_OK;
+    }
     const size_t cap_dw = (size_t)c->bigq_cap * mdvt::kBigRecDwords;
     info[0] = c->bigq ? c->bigq_bytes : 0;                                   // bytes of the queue block
     info[1] = cap_dw;                                                        // dword offset of the segment counters

@@ -77,7 +77,6 @@ struct RenderArgs {
     unsigned long long* ekeys[2];// edge-point keys per eye
     uint32_t* elist;             // the edge-key words written since the last resolve, one segment of 2 W entries (eye << 31 | pixel) per
     uint32_t* elist_count;       //   (slot, source row) and its counter: k_edge_keys_reset empties exactly those words
-    uint4* gverts[2];            // general mesh path: per-eye projected vertices {X, Y (snapped), 1/Z', rgb}, [slot][H*W]
     unsigned long long* cbuf[2]; // general mesh path: per-eye side words of the pixels with an exact depth tie between colours (draw id << 32 | rgb,
                                  //   minimum over the fragments at the winning depth); touched at those pixels only
     uint32_t* tie_flag;          // [slot]: a pixel of the slot's frame was marked as tied in this use (zeroed per launch set)
@@ -122,7 +121,7 @@ struct RenderPlan {
     int n;               // frames in this launch
     int allow_conv;      // MDVT_MESH_CONV=1 when the context was created (mdvt_create): k_mesh_conv may take convergence-only frames
     int edge_rows_max;   // pure-shift launches with edge points: the most scanlines any frame leaves to k_edge_rows_exact (0: none)
-    hipEvent_t after_vertices;   // general mesh path: recorded on the launch's stream behind k_mesh_vertices_general (nullptr: none)
+    hipEvent_t after_vertices;   // general paths: recorded on the launch's stream behind the first pass (the mesh's cell walk, the points' splat; nullptr: none)
 };
 hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 // mdvt_mesh_band.hip: the pure-shift mesh rows as bands (no edge removal)
@@ -183,6 +182,7 @@ hipError_t launch_infill_mask_normals(const ImageSet& img, const ImageSet& hole,
 hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_selftest(int which, unsigned long long seed, unsigned long long* d_mism, hipStream_t s);
+hipError_t launch_coherence_test(uint32_t* blk, size_t dwords, uint32_t tag, uint32_t* d_xcc, uint32_t* d_out, hipStream_t s);     // (mdvt_selftest.hip; r05 diagnosis)
 size_t render_lds_bytes(const RenderPlan& plan, int W);
 bool render_fits_lds(const RenderPlan& plan, int W);      // can the pure-shift row kernels hold a row of this width in LDS?
 

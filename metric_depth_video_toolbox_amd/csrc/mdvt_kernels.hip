@@ -921,46 +921,64 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
     }
 }
 
-// Mesh mode only splats the removed vertices (~3 % of the grid): four `unused` flags per thread as one dword, so the
-// pass is a 1 B/px scan with the vertex programme run for the few flagged vertices.  W % 4 == 0 (launcher).
+// Mesh mode only splats the removed vertices (~3 % of the grid).  The pass is a 1 B/px scan of the `unused` flags, four per thread as
+// one dword, and the vertex programme -- the reference's f64 chain, ~10^3 instructions -- for the few flagged vertices.  A workgroup
+// scans kSplatRows source rows and COMPACTS the flagged vertices of all of them into one list in LDS (r05), running the chain over
+// the list 256 vertices at a time: with the per-wave compaction of r03/r04 (a wave = 256 columns of one row) nearly every wave ran
+// the chain for the two or three vertices it had found, 12.7 us per 1080p frame for 3.8 MB of traffic.  W % 4 == 0 (launcher).
+constexpr int kSplatRows = 8;
+__device__ __forceinline__ void edge_point_splat_one(const RenderArgs& a, const FrameDev& fp, const uint8_t* dbase, int fr, uint32_t e)
+{
+    const int i = (int)(e >> 16), j = (int)(e & 0xFFFFu);
+    const float z = decode_z(code16_of(load_px_bytes(dbase + (size_t)i * a.depth_pitch, j)), fp.mult, fp.scale);
+    if (!(z > kNear)) return;
+    EdgePx ep;
+    edge_point_pixels(fp, a.W, a.H, i, j, 1, z, ep);                      // the reference's f64 chain (mdvt_device.h)
+#pragma unroll
+    for (int eye = 0; eye < 2; ++eye) {
+        if (!ep.ok[eye]) continue;
+        post_edge_key(a, eye, fr, i, (size_t)ep.y[eye] * a.W + ep.x[eye], ((u64)ep.zkey[eye] << 32) | e);
+    }
+}
 __global__ void __launch_bounds__(256) k_edge_points_splat4(RenderArgs a)
 {
     const int W = a.W, H = a.H;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    const int fr = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ uint16_t cols[4][256];                 // per wave: the columns of its flagged vertices, compacted
-    uint32_t flags = 0;
-    if (g < W / 4) flags = *(const uint32_t*)(a.unused + (size_t)fr * a.ws_stride_px + (size_t)i * W + (size_t)g * 4);
-    // The flagged vertices of the wave's 256 columns are gathered into its first lanes: the vertex programme below then runs
-    // once per 64 of them instead of once per flag position with a lane or two alive.
-    uint32_t total = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const bool on = ((flags >> (8 * q)) & 0xFFu) != 0u;
-        const u64 m = __ballot(on);
-        if (on) cols[wave][total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(g * 4 + q);
-        total += (uint32_t)__popcll(m);
-    }
-    if (total == 0u) return;                          // (wave-uniform)
-    __builtin_amdgcn_wave_barrier();
+    const int fr = blockIdx.y, tid = threadIdx.x;
+    const int i0 = blockIdx.x * kSplatRows, rows = min(kSplatRows, H - i0);
+    __shared__ uint32_t list[1024 + 256];             // source row << 16 | column: a step adds at most 1024, fewer than 256 stay behind
+    __shared__ uint32_t cnt;
+    if (tid == 0) cnt = 0u;
+    __syncthreads();
     const int f = a.frame0 + fr;
     const FrameDev& fp = a.fp[f];
-    const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
-    for (uint32_t k = lane; k < total; k += 64) {
-        const int j = cols[wave][k];
-        const float z = decode_z(code16_of(load_px_bytes(drow, j)), fp.mult, fp.scale);
-        if (!(z > kNear)) continue;
-        const uint32_t src = ((uint32_t)i << 16) | (uint32_t)j;
-        EdgePx ep;
-        edge_point_pixels(fp, W, H, i, j, 1, z, ep);                      // the reference's f64 chain (mdvt_device.h)
-#pragma unroll
-        for (int eye = 0; eye < 2; ++eye) {
-            if (!ep.ok[eye]) continue;
-            post_edge_key(a, eye, fr, i, (size_t)ep.y[eye] * W + ep.x[eye], ((u64)ep.zkey[eye] << 32) | src);
+    const uint8_t* dbase = a.depth + (size_t)f * a.depth_stride;
+    const uint8_t* ubase = a.unused + (size_t)fr * a.ws_stride_px + (size_t)i0 * W;
+    const int per_row = W / 4, total = rows * per_row;
+    for (int g0 = 0; g0 < total; g0 += 256) {         // (workgroup uniform)
+        const int g = g0 + tid;
+        uint32_t flags = 0;
+        if (g < total) flags = *(const uint32_t*)(ubase + (size_t)g * 4);          // (rows are contiguous: W % 4 == 0)
+        if (flags) {
+            const uint32_t b0 = (flags & 0xFFu) != 0u, b1 = (flags & 0xFF00u) != 0u, b2 = (flags & 0xFF0000u) != 0u, b3 = (flags >> 24) != 0u;
+            uint32_t pos = atomicAdd(&cnt, b0 + b1 + b2 + b3);
+            const uint32_t r = (uint32_t)(g / per_row), col = (uint32_t)(g - (int)r * per_row) * 4u;
+            const uint32_t base = (((uint32_t)i0 + r) << 16) | col;
+            if (b0) list[pos++] = base;
+            if (b1) list[pos++] = base + 1u;
+            if (b2) list[pos++] = base + 2u;
+            if (b3) list[pos++] = base + 3u;
         }
+        __syncthreads();
+        uint32_t n = cnt;
+        while (n >= 256u) {
+            n -= 256u;
+            edge_point_splat_one(a, fp, dbase, fr, list[n + tid]);
+        }
+        __syncthreads();
+        if (tid == 0) cnt = n;
+        __syncthreads();
     }
+    if ((uint32_t)tid < cnt) edge_point_splat_one(a, fp, dbase, fr, list[tid]);
 }
 
 // mdvt_edge_point_pixels: the pixel the edge point of EVERY vertex of one frame lands on, both eyes (INT32_MIN twice: outside
@@ -1019,6 +1037,7 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
     const int y = blockIdx.y;
     const int fr = blockIdx.z >> 1, eye = blockIdx.z & 1;
     if (g >= W / PX) return;
+    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
     const int f = a.frame0 + fr;
     const uint8_t* cbase = a.color + (size_t)f * a.color_stride;
     u64* krow = a.keys[eye] + (size_t)fr * a.ws_stride_px + (size_t)y * W + (size_t)g * PX;
@@ -1507,71 +1526,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
 //   colour only when the fragment takes the pixel: the returning atomic that needs stalls the rasteriser (product
 //   default 2508 us per 16 frames against 2392 for (1)).
 
-// Stage 1: every vertex is projected ONCE per eye (decode, unproject, 3x4 transform, pinhole, snap, 1/Z')
-// into a 16-byte record; the rasteriser then reads four records per cell instead of recomputing each
-// vertex for all six triangles that share it.
-template <bool STAGED>   // source rows staged through LDS as aligned dwords (else byte loads: any W / alignment)
-__global__ void __launch_bounds__(256) k_mesh_vertices_general(RenderArgs a)
-{
-    const int W = a.W;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    const int fr = blockIdx.z;
-    const int f = a.frame0 + fr;
-    const FrameDev& fp = a.fp[f];
-    // The rasteriser's counters of this launch set are zeroed here, by the first workgroup of each row (three fill launches in
-    // front of the rasteriser cost a single-frame call 10 us): the row's queue segment counter; row 0: the frame's tie flag and
-    // tile bits; frame 0 as well: the huge list's two counters.  Nothing reads them before this kernel has finished.
-    if (blockIdx.x == 0) {
-        const int t = threadIdx.x;
-        if (t == 0) a.bigq_count[(size_t)fr * a.H + i] = 0u;
-        if (i == 0) {
-            if (t == 0) a.tie_flag[fr] = 0u;
-            for (int k = t; k < 2 * a.tie_words; k += (int)blockDim.x) a.tie_tiles[(size_t)fr * 2 * a.tie_words + k] = 0u;
-            if (fr == 0 && t < 2) a.hugeq[2 * (size_t)kHugeCap + t] = 0u;
-        }
-    }
-    const uint8_t* drow = a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch;
-    const uint8_t* crow = a.color + (size_t)f * a.color_stride + (size_t)i * a.color_pitch;
-    uint32_t dpx, rgb;
-    if (STAGED) {
-        // 256 pixels = 192 dwords per plane; the launcher guarantees 4-byte aligned rows and W % 4 == 0
-        __shared__ uint32_t sd[2][193];
-        const int t = threadIdx.x;
-        const size_t b0 = (size_t)blockIdx.x * 768;
-        const size_t row_bytes = (size_t)W * 3;
-        if (t < 192) {
-            const size_t off = b0 + (size_t)t * 4;
-            if (off < row_bytes) {
-                sd[0][t] = *(const uint32_t*)(drow + off);
-                sd[1][t] = *(const uint32_t*)(crow + off);
-            }
-        }
-        __syncthreads();
-        if (j >= W) return;
-        const int bo = t * 3, w = bo >> 2, sh = (bo & 3) * 8;
-        dpx = (uint32_t)((((u64)sd[0][w + 1] << 32) | sd[0][w]) >> sh) & 0xFFFFFFu;
-        rgb = (uint32_t)((((u64)sd[1][w + 1] << 32) | sd[1][w]) >> sh) & 0xFFFFFFu;
-    } else {
-        if (j >= W) return;
-        dpx = load_px_bytes(drow, j);
-        rgb = load_px_bytes(crow, j);
-    }
-    const float z = decode_z(code16_of(dpx), fp.mult, fp.scale);
-    float xc, yc;
-    const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
-    camera_point(fp, gx, gy, z, xc, yc);
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int eye = 0; eye < 2; ++eye) {
-        const Vert v = vertex_for_eye(fp, eye, gx, gy, z, xc, yc);
-        const float iz = v.ok ? rcp_exact(v.z) : 0.0f;      // 0 flags a vertex behind the near plane
-        uint4* dst = &a.gverts[eye][(size_t)fr * a.ws_stride_px + (size_t)i * W + j];
-        // streamed: a launch set writes ~1 GB of records before the rasteriser reads the first one back
-        const u32x4 rec = {(uint32_t)snap(v.u), (uint32_t)snap(v.v), __float_as_uint(iz), rgb};
-        __builtin_nontemporal_store(rec, (u32x4*)dst);
-    }
-}
+// (Stage 1, the vertex records: computed by the rasterisers themselves since r05 -- mdvt_mesh_general.hip, vertex_records.)
 
 // (infill_using_normals and mark_lower_side: mdvt_normal_infill.hip)
 
@@ -2781,7 +2736,7 @@ static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a_i
 hipError_t launch_edge_points_splat(const RenderArgs& a, int n, hipStream_t s)
 {
     if (a.W % 4 == 0) {
-        const dim3 grid_s((a.W / 4 + 255) / 256, a.H, n);
+        const dim3 grid_s((a.H + kSplatRows - 1) / kSplatRows, n);
         hipLaunchKernelGGL(k_edge_points_splat4, grid_s, dim3(256), 0, s, a);
     } else {
         const dim3 grid_s((a.W + 255) / 256, a.H, n);
@@ -2796,16 +2751,6 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
     if (const char* e = tuning_env(TUNE_DEBUG_SKIP)) a.debug_skip = atoi(e);
     const bool edge = plan.remove_edges && plan.edge_points;
     hipError_t e;
-    const dim3 grid_v((a.W + 255) / 256, a.H, plan.n);
-    {
-        // rows that are dword-addressable are staged through LDS as aligned dwords; the rest take byte loads
-        const bool aligned = (a.W % 4 == 0) && (a.depth_pitch % 4 == 0) && (a.color_pitch % 4 == 0) && (a.depth_stride % 4 == 0) &&
-                             (a.color_stride % 4 == 0) && ((uintptr_t)a.depth % 4 == 0) && ((uintptr_t)a.color % 4 == 0);
-        if (aligned) hipLaunchKernelGGL(k_mesh_vertices_general<true>, grid_v, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_mesh_vertices_general<false>, grid_v, dim3(256), 0, s, a);
-    }
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (plan.after_vertices && (e = hipEventRecord(plan.after_vertices, s)) != hipSuccess) return e;
     if ((e = launch_mesh_raster_general(plan, a, s)) != hipSuccess) return e;
     if (edge && (e = launch_edge_points_splat(a, plan.n, s)) != hipSuccess) return e;
     return launch_resolve_general<true>(plan, a, s);

@@ -95,17 +95,63 @@ __device__ __forceinline__ void mesh_global_fragment(const RenderArgs& a, int sl
     }
 }
 
-constexpr int kCellTPB = 64;          // cells (threads) per workgroup of k_mesh_raster_small
+// ---- The projected vertex records {X, Y (snapped), 1/Z', rgb}: made where they are used (r05) ----------------------------------
+// Until r04 a vertex pass (k_mesh_vertices_general) projected every vertex once per eye into a 16-byte record -- 66 MB of stores
+// per 1080p frame, read back 2 to 5 times by the rasterisers (161 MB per frame of the product default, 596 MB per 4K frame
+// under a pose), 32 B/px of workspace per slot and the second longest kernel of every general mesh path (29 us per 1080p frame)
+// for ~150 instructions per vertex.  Now a workgroup of the cell walks computes the two vertex rows of its cells from the source
+// frame (6 B per vertex, read through the L2 by the row above and the row below) into LDS -- 64 threads, 64 columns, 63 cells, so no
+// second pass over a 65th column -- and the queue / huge walks recompute the three vertices of their triangle.  The same device
+// functions in the same order as the vertex pass ran them: the same bits.
+__device__ __forceinline__ void vertex_records(const RenderArgs& a, const FrameDev& fp, int f, int i, int j, uint4& r0, uint4& r1)
+{
+    const uint32_t dpx = load_px_bytes(a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch, j);
+    const uint32_t rgb = load_px_bytes(a.color + (size_t)f * a.color_stride + (size_t)i * a.color_pitch, j);
+    const float z = decode_z(code16_of(dpx), fp.mult, fp.scale);
+    const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
+    float xc, yc;
+    camera_point(fp, gx, gy, z, xc, yc);
+    const Vert v0 = vertex_for_eye(fp, 0, gx, gy, z, xc, yc), v1 = vertex_for_eye(fp, 1, gx, gy, z, xc, yc);
+    const float iz0 = v0.ok ? rcp_exact(v0.z) : 0.0f, iz1 = v1.ok ? rcp_exact(v1.z) : 0.0f;      // 0 flags a vertex behind the near plane
+    r0 = make_uint4((uint32_t)snap(v0.u), (uint32_t)snap(v0.v), __float_as_uint(iz0), rgb);
+    r1 = make_uint4((uint32_t)snap(v1.u), (uint32_t)snap(v1.v), __float_as_uint(iz1), rgb);
+}
+__device__ __forceinline__ uint4 vertex_record_eye(const RenderArgs& a, const FrameDev& fp, int f, int i, int j, int eye)
+{
+    const uint32_t dpx = load_px_bytes(a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch, j);
+    const uint32_t rgb = load_px_bytes(a.color + (size_t)f * a.color_stride + (size_t)i * a.color_pitch, j);
+    const float z = decode_z(code16_of(dpx), fp.mult, fp.scale);
+    const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
+    float xc, yc;
+    camera_point(fp, gx, gy, z, xc, yc);
+    const Vert v = vertex_for_eye(fp, eye, gx, gy, z, xc, yc);
+    const float iz = v.ok ? rcp_exact(v.z) : 0.0f;
+    return make_uint4((uint32_t)snap(v.u), (uint32_t)snap(v.v), __float_as_uint(iz), rgb);
+}
+
+constexpr int kCellTPB = 64;          // threads per workgroup of the cell walks = vertex columns it stages
+constexpr int kCellsWG = kCellTPB - 1;   // cells per workgroup: between its 64 columns
+// The two vertex rows (i, i + 1) of columns j0 .. j0 + 63 of both eyes into sv[eye][row][column].
+__device__ __forceinline__ void stage_vertex_rows(const RenderArgs& a, int fr, int i, int j0, uint4 (&sv)[2][2][kCellTPB])
+{
+    const int t = threadIdx.x, f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const int jc = min(j0 + t, a.W - 1);                                   // (clamped: columns past the row end are never used)
+    uint4 r0, r1, r2, r3;
+    vertex_records(a, fp, f, i, jc, r0, r1);
+    vertex_records(a, fp, f, i + 1, jc, r2, r3);
+    sv[0][0][t] = r0; sv[1][0][t] = r1; sv[0][1][t] = r2; sv[1][1][t] = r3;
+}
 // The block of cells of a workgroup of the one-thread-per-cell kernels: row-major over the frame's cells, grid x = cell_block_grid.
 // (Measured and not kept, r04: an XCD-aware deal -- workgroup b runs on XCD b % 8, each XCD with its own L2, so each XCD took a
 // contiguous eighth of the blocks and the second reader of a vertex-record row found it in the L2 the first one had filled.  The
 // rasteriser's fetch traffic fell from 145 to 71 MB per 1080p frame and its time did not move, 6 % slower under a pose: these
 // kernels wait for their atomics, not for bytes.)
-__host__ __device__ __forceinline__ uint32_t cell_blocks(int W, int H) { return (uint32_t)((W - 1 + kCellTPB - 1) / kCellTPB) * (uint32_t)(H - 1); }
+__host__ __device__ __forceinline__ uint32_t cell_blocks(int W, int H) { return (uint32_t)((W - 1 + kCellsWG - 1) / kCellsWG) * (uint32_t)(H - 1); }
 inline uint32_t cell_block_grid(int W, int H) { return cell_blocks(W, H); }
 __device__ __forceinline__ bool cell_block_of(int W, int H, int& bx, int& i)
 {
-    const uint32_t v = blockIdx.x, nbx = (uint32_t)((W - 1 + kCellTPB - 1) / kCellTPB);
+    const uint32_t v = blockIdx.x, nbx = (uint32_t)((W - 1 + kCellsWG - 1) / kCellsWG);
     if (v >= cell_blocks(W, H)) return false;
     bx = (int)(v % nbx); i = (int)(v / nbx);
     return true;
@@ -128,31 +174,20 @@ __device__ __forceinline__ bool tie_tiles_hit(const FragOut& f, int bx0, int by0
 // One thread per cell, both triangles, both eyes.  MODE as mesh_global_fragment's; the second pass runs for the frames with a marked
 // pixel only, and only the triangles whose pixel box touches a marked tile get as far as their set-up.
 template <int FLAGS, int MODE>
-__device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kCellTPB + 1], Pending (&pds)[2])
+__device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kCellTPB], Pending (&pds)[2])
 {
     constexpr bool EDGES = FLAGS & 2;
     const int W = a.W, H = a.H;
-    const int j = bx * kCellTPB + threadIdx.x;
+    const int j = bx * kCellsWG + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool act = j < W - 1;
+    const bool act = j < W - 1 && threadIdx.x < kCellsWG;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
-    // the 2 x (kCellTPB + 1) vertex records of both eyes, fetched once per workgroup with all loads in flight together
+    // the 2 x kCellTPB vertex records of both eyes, computed once per workgroup
     uint32_t inv0 = 0, inv1 = 0;
-    {
-        const int t = threadIdx.x;
-        const int j0 = bx * kCellTPB;
-        const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
-        const int jc = min(j0 + t, W - 1), jx = min(j0 + kCellTPB, W - 1);      // (clamped: columns past the row end are never used)
-        uint4 rx = make_uint4(0, 0, 0, 0);
-        if (t < 4) rx = (t & 2 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t & 1) * W + jx];
-        const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
-        const uint4 r2 = a.gverts[1][base + jc], r3 = a.gverts[1][base + W + jc];
-        if (EDGES && act) {
-            const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
-            inv0 = tinv[0]; inv1 = tinv[ncell];
-        }
-        if (t < 4) sv[t >> 1][t & 1][kCellTPB] = rx;
-        sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
+    stage_vertex_rows(a, fr, i, bx * kCellsWG, sv);
+    if (EDGES && act) {
+        const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
+        inv0 = tinv[0]; inv1 = tinv[ncell];
     }
     __syncthreads();
     // (unrolled: each eye has its own pending word, so the left eye's last post is in flight while the right eye is rasterised)
@@ -224,13 +259,15 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
 template <int FLAGS>
 __global__ void __launch_bounds__(kCellTPB) k_mesh_raster_small(RenderArgs a)
 {
-    __shared__ uint4 sv[2][2][kCellTPB + 1];
+    __shared__ uint4 sv[2][2][kCellTPB];
     Pending pds[2] = {pending_none(), pending_none()};
     int bx, i;
     if (!cell_block_of(a.W, a.H, bx, i)) return;
+    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
     mesh_raster_small_block<FLAGS, 0>(a, (int)blockIdx.z, bx, i, sv, pds);
     pending_settle(a, pds[0]);
     pending_settle(a, pds[1]);
+    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 // ---- The same stage for frames whose vertex rows stay (almost) horizontal on screen: convergence only ---------------------
@@ -261,34 +298,23 @@ constexpr int kConvTPB = 64;          // cells (threads) per workgroup of k_mesh
 // MODE as mesh_global_fragment's (second pass: the same classification of the cells as in the first, so that every fragment of the
 // first pass is met again -- here, or in the first pass's lists of queued triangles, which this pass does not add to).
 template <int FLAGS, int MODE>
-__device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kConvTPB + 1],
+__device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kConvTPB],
                                                        uint32_t (&glist)[2 * kConvTPB], uint32_t& gcount, Pending& pd)
 {
     constexpr bool EDGES = FLAGS & 2;
     constexpr int kCoord = 1 << 19, kMaxH = 512, kMaxSpan = 12;
     const int W = a.W, H = a.H;
-    const int j = bx * kConvTPB + threadIdx.x;
+    const int j = bx * kCellsWG + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool act = j < W - 1;
+    const bool act = j < W - 1 && threadIdx.x < kCellsWG;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     uint32_t inv0 = 0, inv1 = 0;
-    {
-        const int t = threadIdx.x;
-        const int j0 = bx * kConvTPB;
-        const size_t base = (size_t)fr * a.ws_stride_px + (size_t)i * W;
-        const int jc = min(j0 + t, W - 1), jx = min(j0 + kConvTPB, W - 1);
-        uint4 rx = make_uint4(0, 0, 0, 0);
-        if (t < 4) rx = (t & 2 ? a.gverts[1] : a.gverts[0])[base + (size_t)(t & 1) * W + jx];
-        const uint4 r0 = a.gverts[0][base + jc], r1 = a.gverts[0][base + W + jc];
-        const uint4 r2 = a.gverts[1][base + jc], r3 = a.gverts[1][base + W + jc];
-        if (EDGES && act) {
-            const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
-            inv0 = tinv[0]; inv1 = tinv[ncell];
-        }
-        if (t < 4) sv[t >> 1][t & 1][kConvTPB] = rx;
-        sv[0][0][t] = r0; sv[0][1][t] = r1; sv[1][0][t] = r2; sv[1][1][t] = r3;
-        if (t == 0) gcount = 0u;
+    stage_vertex_rows(a, fr, i, bx * kCellsWG, sv);
+    if (EDGES && act) {
+        const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
+        inv0 = tinv[0]; inv1 = tinv[ncell];
     }
+    if (threadIdx.x == 0) gcount = 0u;
     __syncthreads();
     const uint32_t cull = (uint32_t)a.cull;
     // (not unrolled with a pending word per eye, as k_mesh_raster_small is: measured, product default 2640 -> 2750 us per 32 frames)
@@ -356,7 +382,7 @@ __device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int 
         const bool on = idx < ng;
         const uint32_t ent = glist[on ? idx >> 1 : 0];
         const int t = (int)(ent & 0xFFu), eye = (int)(ent >> 8), pass = (int)(idx & 1u);
-        const int cj = bx * kConvTPB + t;
+        const int cj = bx * kCellsWG + t;
         const FragOut fo = frag_out(a, fr, eye);
         const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
         const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
@@ -414,21 +440,24 @@ __device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int 
 template <int FLAGS>
 __global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
 {
-    __shared__ uint4 sv[2][2][kConvTPB + 1];
+    __shared__ uint4 sv[2][2][kConvTPB];
     __shared__ uint32_t glist[2 * kConvTPB];  // cells (thread | eye << 8) for the generic code
     __shared__ uint32_t gcount;
-    const uint32_t nbx = (uint32_t)((a.W - 1 + kConvTPB - 1) / kConvTPB);
+    const uint32_t nbx = (uint32_t)((a.W - 1 + kCellsWG - 1) / kCellsWG);
     if (blockIdx.x >= nbx * (uint32_t)(a.H - 1)) return;
     Pending pd = pending_none();
+    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
     mesh_raster_conv_block<FLAGS, 0>(a, (int)blockIdx.z, (int)(blockIdx.x % nbx), (int)(blockIdx.x / nbx), sv, glist, gcount, pd);
     pending_settle(a, pd);
+    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 // Exclusive prefix sums of the segment counters (n <= a few 10^4): one workgroup.  prefix[n] = number of queued triangles.
-__global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ prefix, int n)
+__global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ prefix, int n, int fences)
 {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
+    if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                   // (r05 diagnosis, tuning build)
     // a thread's chunk: a multiple of four counters, read as 16-byte vectors and kept in registers (one counter per trip made the
     // pass 17 dependent round trips long, twice: 21 us for a 16-frame 1080p launch set; `counts` is 16-byte aligned)
     constexpr int kMaxVec = 16;                                    // up to 64 counters per thread: 65 536 segments
@@ -473,6 +502,7 @@ __global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __rest
         for (int k = lo; k < hi; ++k) { prefix[k] = run; run += counts[k]; }
     }
     if (t == 1023) prefix[n] = part[1023];
+    if (fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 // The queued triangles, dealt over the whole chip (a horizontal depth edge under vertical parallax turns an entire row
@@ -502,9 +532,11 @@ __device__ __forceinline__ void mesh_queue_walk(const RenderArgs& a, int nseg)
         const int eye = (int)(e.y & 1u), slot = (int)(e.y >> 1);
         if (MODE == 1 && a.tie_flag[slot] == 0u) continue;              // second pass: the frames with a marked pixel only
         const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
-        const uint4* r0 = a.gverts[eye] + (size_t)slot * a.ws_stride_px + (size_t)ci * W + cj;
-        const uint4 A = r0[0];
-        const uint4 v1 = pass == 0 ? r0[W] : r0[W + 1], v2 = pass == 0 ? r0[W + 1] : r0[1];
+        const int vf = a.frame0 + slot;
+        const FrameDev& vfp = a.fp[vf];
+        const uint4 A = vertex_record_eye(a, vfp, vf, ci, cj, eye);
+        const uint4 v1 = vertex_record_eye(a, vfp, vf, ci + 1, pass == 0 ? cj : cj + 1, eye);
+        const uint4 v2 = vertex_record_eye(a, vfp, vf, pass == 0 ? ci + 1 : ci, cj + 1, eye);
         TriSetup t;
         if (!tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
                                (int)v2.x, (int)v2.y, __uint_as_float(v2.z), a.cull))
@@ -598,9 +630,11 @@ __device__ __forceinline__ void mesh_huge_walk(const RenderArgs& a)
         const int eye = (int)(e.y & 1u), slot = (int)((e.y >> 1) & 0x7Fu), blk = (int)(e.y >> 8);
         if (MODE == 1 && a.tie_flag[slot] == 0u) continue;              // second pass: the frames with a marked pixel only
         const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
-        const uint4* r0 = a.gverts[eye] + (size_t)slot * a.ws_stride_px + (size_t)ci * W + cj;
-        const uint4 A = r0[0];
-        const uint4 v1 = pass == 0 ? r0[W] : r0[W + 1], v2 = pass == 0 ? r0[W + 1] : r0[1];
+        const int vf = a.frame0 + slot;
+        const FrameDev& vfp = a.fp[vf];
+        const uint4 A = vertex_record_eye(a, vfp, vf, ci, cj, eye);
+        const uint4 v1 = vertex_record_eye(a, vfp, vf, ci + 1, pass == 0 ? cj : cj + 1, eye);
+        const uint4 v2 = vertex_record_eye(a, vfp, vf, pass == 0 ? ci + 1 : ci, cj + 1, eye);
         TriSetup t;
         if (!tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
                                (int)v2.x, (int)v2.y, __uint_as_float(v2.z), a.cull))
@@ -633,7 +667,12 @@ __device__ __forceinline__ void mesh_huge_walk(const RenderArgs& a)
     if (MODE == 0) pending_settle(a, pd);
 }
 
-__global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nseg) { mesh_queue_walk<0>(a, nseg); }
+__global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nseg)
+{
+    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
+    mesh_queue_walk<0>(a, nseg);
+    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
 __global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a) { mesh_huge_walk<0>(a); }
 
 // The second pass, ONE launch of a fixed number of workgroups: for the frames in which the first pass marked a pixel (normally none:
@@ -644,14 +683,14 @@ template <int FLAGS, bool CONV>
 __global__ void __launch_bounds__(kCellTPB) k_mesh_tie_pass(RenderArgs a, int nframes, int nseg)
 {
     static_assert(kCellTPB == kConvTPB, "one workgroup size for both cell walks");
-    __shared__ uint4 sv[2][2][kCellTPB + 1];
+    __shared__ uint4 sv[2][2][kCellTPB];
     __shared__ uint32_t glist[2 * kConvTPB];
     __shared__ uint32_t gcount;
     uint32_t any = 0;
     for (int fr = 0; fr < nframes; ++fr) any |= a.tie_flag[fr];
     if (!any) return;                                                          // (uniform)
     Pending pds[2] = {pending_none(), pending_none()};                         // (unused in this mode)
-    const uint32_t nblk = cell_blocks(a.W, a.H), nbx = (uint32_t)((a.W - 1 + kCellTPB - 1) / kCellTPB);
+    const uint32_t nblk = cell_blocks(a.W, a.H), nbx = (uint32_t)((a.W - 1 + kCellsWG - 1) / kCellsWG);
     for (int fr = 0; fr < nframes; ++fr) {
         if (a.tie_flag[fr] == 0u) continue;                                    // (workgroup uniform)
         for (uint32_t v = blockIdx.x; v < nblk; v += gridDim.x) {
@@ -666,22 +705,41 @@ __global__ void __launch_bounds__(kCellTPB) k_mesh_tie_pass(RenderArgs a, int nf
     mesh_huge_walk<1>(a);
 }
 
+// The rasteriser's counters of a launch set: the queue's segment counters, the tie flags and tile bits of its frames, the huge
+// list's two counters.  (Until r04 the vertex pass zeroed them on its way.)
+__global__ void __launch_bounds__(256) k_mesh_queue_reset(RenderArgs a, int n)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, nt = gridDim.x * 256u;
+    const uint32_t nseg = (uint32_t)n * (uint32_t)a.H, ntile = (uint32_t)n * 2u * (uint32_t)a.tie_words;
+    if (a.debug_skip & 256) { for (uint32_t k = t; k < nseg; k += nt) atomicExch(&a.bigq_count[k], 0u); }      // (r05 diagnosis, tuning build)
+    else for (uint32_t k = t; k < nseg; k += nt) a.bigq_count[k] = 0u;
+    for (uint32_t k = t; k < ntile; k += nt) a.tie_tiles[k] = 0u;
+    if (t < (uint32_t)n) a.tie_flag[t] = 0u;
+    if (t < 2u) a.hugeq[2 * (size_t)kHugeCap + t] = 0u;
+    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+
 hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const int nseg = plan.n * a.H;
     const dim3 grid_c(cell_block_grid(a.W, a.H), 1, plan.n);
     hipError_t e;
-    // (the queue segment counters, the huge list's counters, the tie flags and tile bits were zeroed by k_mesh_vertices_general)
+    {
+        const uint32_t words = (uint32_t)nseg + (uint32_t)plan.n * 2u * (uint32_t)a.tie_words;
+        hipLaunchKernelGGL(k_mesh_queue_reset, dim3(words / 1024u + 1u), dim3(256), 0, s, a, plan.n);
+    }
     const bool conv = plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr;
     if (conv) {
         // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
-        const dim3 grid_v((unsigned)((a.W - 1 + kConvTPB - 1) / kConvTPB) * (unsigned)(a.H - 1), 1, plan.n);
+        const dim3 grid_v(cell_block_grid(a.W, a.H), 1, plan.n);
         if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_v, dim3(kConvTPB), 0, s, a);
         else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_v, dim3(kConvTPB), 0, s, a);
     } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2>), grid_c, dim3(kCellTPB), 0, s, a);
     else hipLaunchKernelGGL((k_mesh_raster_small<0>), grid_c, dim3(kCellTPB), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg);
+    // (banks, mdvt_render_stereo_batch: the next launch set starts once this one's cell walk is through)
+    if (plan.after_vertices && (e = hipEventRecord(plan.after_vertices, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg, (a.debug_skip & 512) ? 1 : 0);
     hipLaunchKernelGGL(k_mesh_raster_queue, dim3(2048), dim3(256), 0, s, a, nseg);
     hipLaunchKernelGGL(k_mesh_raster_huge, dim3(2048), dim3(256), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;

@@ -59,6 +59,53 @@ __global__ void __launch_bounds__(256) k_selftest_u8(unsigned long long* mism)
     if (bad) atomicAdd(mism, bad);
 }
 
+// ---- r05 diagnosis (mdvt_debug_read, what = 1; tuning build): is a device block coherent across the chip's eight XCDs from one kernel to
+// the next?  k_coh_fill: workgroup b writes slice b (64 dwords: tag ^ index) with plain stores and posts one device-scope atomic add
+// into the slice's last dword; k_coh_check (the next kernel in the stream): workgroup b reads slice b + 1 -- written by the workgroup on
+// the next XCD (workgroups are dealt round-robin: b % 8) -- and counts wrong words per (writer XCD, reader XCD).
+constexpr int kCohSlice = 64;
+__device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xFu; }      // HW_REG_XCC_ID[3:0]
+
+__global__ void __launch_bounds__(64) k_coh_fill(uint32_t* blk, uint32_t nslices, uint32_t tag, uint32_t* writer_xcc)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nslices) return;
+    uint32_t* sl = blk + (size_t)b * kCohSlice;
+    sl[threadIdx.x] = threadIdx.x == kCohSlice - 1 ? 0u : tag ^ (b * kCohSlice + threadIdx.x);
+    if (threadIdx.x == 0) writer_xcc[b] = xcc_id();
+}
+__global__ void __launch_bounds__(64) k_coh_add(uint32_t* blk, uint32_t nslices)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nslices) return;
+    atomicAdd(&blk[(size_t)((b + 3u) % nslices) * kCohSlice + kCohSlice - 1], 1u);      // one add per lane: 64 per slice, from another XCD than the zero's
+}
+__global__ void __launch_bounds__(64) k_coh_check(const uint32_t* blk, uint32_t nslices, uint32_t tag, const uint32_t* writer_xcc, uint32_t* out)
+{
+    const uint32_t b = (blockIdx.x + 1u) % nslices;
+    if (blockIdx.x >= nslices) return;
+    const uint32_t* sl = blk + (size_t)b * kCohSlice;
+    const uint32_t v = sl[threadIdx.x];
+    const uint32_t want = threadIdx.x == kCohSlice - 1 ? 64u : tag ^ (b * kCohSlice + threadIdx.x);
+    if (v != want) {
+        const uint32_t w = writer_xcc[b] & 7u, r = xcc_id() & 7u;
+        atomicAdd(&out[threadIdx.x == kCohSlice - 1 ? 64 + r : w * 8 + r], 1u);
+        if (atomicAdd(&out[72], 1u) == 0u) { out[73] = v; out[74] = want; out[75] = b * kCohSlice + threadIdx.x; }
+    }
+}
+// d_out: 80 dwords (zeroed here): [w * 8 + r] wrong pattern words by writer / reader XCD, [64 + r] wrong atomic sums by reader XCD,
+// [72] total, [73..75] first wrong word seen / wanted / dword index.  d_xcc: nslices dwords of scratch.
+hipError_t launch_coherence_test(uint32_t* blk, size_t dwords, uint32_t tag, uint32_t* d_xcc, uint32_t* d_out, hipStream_t s)
+{
+    const uint32_t nslices = (uint32_t)(dwords / kCohSlice);
+    hipError_t e = hipMemsetAsync(d_out, 0, 80 * sizeof(uint32_t), s);
+    if (e != hipSuccess || nslices == 0) return e;
+    hipLaunchKernelGGL(k_coh_fill, dim3(nslices), dim3(64), 0, s, blk, nslices, tag, d_xcc);
+    hipLaunchKernelGGL(k_coh_add, dim3(nslices), dim3(64), 0, s, blk, nslices);
+    hipLaunchKernelGGL(k_coh_check, dim3(nslices), dim3(64), 0, s, blk, nslices, tag, d_xcc, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_selftest(int which, unsigned long long seed, unsigned long long* d_mism, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(d_mism, 0, sizeof(unsigned long long), s);

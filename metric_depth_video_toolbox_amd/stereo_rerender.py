@@ -424,14 +424,12 @@ class StereoRerenderer:
         rem = torch.zeros((2, N), dtype=torch.int32, device=seed_sbs.device) if want_remaining else None
         s = torch.cuda.current_stream(seed_sbs.device)
 
-        def one_pass(ctx, a, b, stream):
-            r = torch.zeros((2, b - a), dtype=torch.int32, device=seed_sbs.device) if want_remaining else None
+        def one_pass(ctx, a, b, stream, r):
             sd, o = seed_sbs[a:b], out[a:b]
             ctx.check(self._L.mdvt_finish_infill_mask_stereo(
                 ctx.handle, sd.data_ptr(), sd.data_ptr() + 3 * W, sd.stride(1), sd.stride(0),
                 o.data_ptr(), o.data_ptr() + 3 * W, o.stride(1), o.stride(0), b - a, int(max_rounds),
                 r.data_ptr() if r is not None else None, C.c_void_p(stream.cuda_stream)))
-            return r
 
         if N >= self.FINISH_SPLIT_FRAMES:
             # Two halves, two contexts, two streams (r04): the completion is ~260 dependent launches per pass whose marking half
@@ -443,16 +441,21 @@ class StereoRerenderer:
                 self._ctx2.check(self._L.mdvt_set_config(self._ctx2.handle, C.byref(self._cfg)))
                 self._side = torch.cuda.Stream(device=seed_sbs.device)
             h = N // 2
+            # (the counters of both halves are allocated and zeroed on the caller's stream BEFORE the side stream waits for it, and
+            #  the second half's tensor is recorded on the side stream: the fill and the library's writes are ordered, and the
+            #  caching allocator will not hand the block on while the side stream may still write it -- advisor, r04)
+            r1 = torch.zeros((2, h), dtype=torch.int32, device=seed_sbs.device) if want_remaining else None
+            r2 = torch.zeros((2, N - h), dtype=torch.int32, device=seed_sbs.device) if want_remaining else None
             self._side.wait_stream(s)
-            r2 = one_pass(self._ctx2, h, N, self._side)        # (each call returns once its pass A has been read back)
-            r1 = one_pass(self.ctx, 0, h, s)
+            if r2 is not None:
+                r2.record_stream(self._side)
+            one_pass(self._ctx2, h, N, self._side, r2)         # (each call returns once its pass A has been read back)
+            one_pass(self.ctx, 0, h, s, r1)
             s.wait_stream(self._side)
             if rem is not None:
                 rem[:, :h], rem[:, h:] = r1, r2
         else:
-            r1 = one_pass(self.ctx, 0, N, s)
-            if rem is not None:
-                rem.copy_(r1)
+            one_pass(self.ctx, 0, N, s, rem)
         res = out[0] if single else out
         return (res, rem) if want_remaining else res
 

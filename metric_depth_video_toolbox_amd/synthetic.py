@@ -108,3 +108,25 @@ def synthetic_pose_track(n_frames: int) -> np.ndarray:
         T[:3, 3] = np.array([1.0, 0.5, 2.0]) * 1e-3 * t
         Ts[t] = T
     return Ts
+
+
+def c4_clip(n_frames: int = 8, W: int = 3840, H: int = 2160, host_frames: int = 4, xfov: float = 45.0, ipd_m: float = 0.065):
+    """BASELINE configs[3]'s clip as bench.py times it and tests/test_gpu_bench_sizes.py checks it: ``host_frames`` scenes of
+    SyntheticScene(config_id=4) with the contention band moving down 8 rows per frame; frame k >= host_frames is frame
+    k % host_frames rolled by (16, 24) * (k // host_frames) whole pixels.  -> (depth_rgb, color_rgb) u8[N, H, W, 3] (host) and
+    the poses: frames 40, 70, ... of synthetic_pose_track (up to 5 degrees of yaw, half a metre of travel)."""
+    sc = SyntheticScene(W, H, config_id=4)
+    fx = W / (2.0 * np.tan(np.deg2rad(xfov) / 2.0))          # dmt.compute_camera_matrix's fx (dmt:902-934)
+    nh = min(host_frames, n_frames)
+    d = np.empty((n_frames, H, W, 3), np.uint8)
+    c = np.empty((n_frames, H, W, 3), np.uint8)
+    for t in range(nh):
+        z = contention_band(sc.depth_m(t), fx, ipd_m, row0=H // 2 - 32 + 8 * t, rows=64)
+        d[t] = quantise_depth_to_rgb(z)
+        _, c[t] = sc.frame(t)
+    for k in range(nh, n_frames):
+        sh = (16 * (k // nh), 24 * (k // nh))
+        d[k] = np.roll(d[k % nh], shift=sh, axis=(0, 1))
+        c[k] = np.roll(c[k % nh], shift=sh, axis=(0, 1))
+    Ts = synthetic_pose_track(300)[40:40 + n_frames * 30:30]
+    return d, c, Ts

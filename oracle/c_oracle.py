@@ -84,6 +84,8 @@ def lib():
         L.orc_telea_levels.restype = C.c_int
         L.orc_telea_fmm.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_telea_fmm.restype = None
+        L.orc_telea_bands.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_float, u8p]
+        L.orc_telea_bands.restype = C.c_int
         L.orc_finish_infill_mask.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, u8p, u8p]
         L.orc_finish_infill_mask.restype = C.c_int
         L.orc_box_blur4.argtypes = [u8p, C.c_int, C.c_int, u8p]
@@ -343,6 +345,16 @@ def telea_fmm(img: np.ndarray, mask: np.ndarray, radius: int = 3) -> np.ndarray:
     out = np.empty_like(img)
     lib().orc_telea_fmm(_p(img, C.c_uint8), _p(mask, C.c_uint8), W, H, int(radius), _p(out, C.c_uint8))
     return out
+
+
+def telea_bands(img: np.ndarray, mask: np.ndarray, delta: float, radius: int = 3):
+    """The march of telea_fmm with its pops grouped into steps of `delta` in T (r05 experiment) -> (image, steps)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    H, W = mask.shape
+    out = np.empty_like(img)
+    steps = lib().orc_telea_bands(_p(img, C.c_uint8), _p(mask, C.c_uint8), W, H, int(radius), float(delta), _p(out, C.c_uint8))
+    return out, int(steps)
 
 
 def box_blur4(img: np.ndarray) -> np.ndarray:

@@ -1045,6 +1045,76 @@ void orc_telea_fmm(const uint8_t* img, const uint8_t* mask, int W, int H, int ra
     free(stamp); free(T); free(heap);
 }
 
+/* BAND-synchronous fast marching (r05 experiment, verdict r04 item 5a): the sequential march of orc_telea_fmm with its pops
+ * grouped by arrival time.  Step k pops -- together -- every BAND pixel with T < k * delta, then estimates -- together, from the
+ * state at that moment -- every INSIDE pixel that has one of the popped pixels as a 4-neighbour.  delta -> 0 is the heap order
+ * (up to ties); delta = 1 is close to the level-synchronous rounds of orc_telea_levels (T grows by about one per ring), except
+ * that diagonal directions, where T grows by ~0.7 per 4-connected ring, run ahead as they do under the heap.  A step is what a
+ * level is on the device: two dependent launches, so 1 / delta is also the factor on the completion's launch-bound time.
+ * Returns the number of steps that estimated at least one pixel.  Not used for parity: tests/report_infill_order_downstream.py. */
+int orc_telea_bands(const uint8_t* img, const uint8_t* mask, int W, int H, int radius, float delta, uint8_t* out)
+{
+    const size_t n = (size_t)W * H;
+    uint16_t* stamp = (uint16_t*)malloc(n * sizeof(uint16_t));          /* 0 = not INSIDE (known or band), 0xFFFF = INSIDE */
+    uint8_t* popped = (uint8_t*)calloc(n, 1);                            /* BAND pixel already popped (KNOWN) */
+    float* T = (float*)calloc(n, sizeof(float));
+    uint32_t* band = (uint32_t*)malloc(n * sizeof(uint32_t));            /* BAND pixels not yet popped */
+    uint32_t* fresh = (uint32_t*)malloc(n * sizeof(uint32_t));
+    uint32_t* cand = (uint32_t*)malloc(n * sizeof(uint32_t));
+    uint8_t* seen = (uint8_t*)calloc(n, 1);
+    float* ft = (float*)malloc(n * sizeof(float));
+    uint8_t* frgb = (uint8_t*)malloc(n * 3);
+    size_t nb = 0;
+    int steps = 0;
+    memcpy(out, img, n * 3);
+    for (size_t k = 0; k < n; ++k) stamp[k] = mask[k] ? ORC_T_UNKNOWN : 0;
+    orc_telea_state s = { W, H, stamp, T, out };
+    const int dx[4] = { 0, -1, 0, 1 }, dy[4] = { -1, 0, 1, 0 };
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (stamp[(size_t)y * W + x]) continue;
+            int b = 0;
+            for (int d = 0; d < 4; ++d) {
+                const int xx = x + dx[d], yy = y + dy[d];
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H && stamp[(size_t)yy * W + xx]) b = 1;
+            }
+            if (b) band[nb++] = (uint32_t)((size_t)y * W + x);
+        }
+    double theta = 0.0;
+    while (nb) {
+        float tmin = 1.0e30f;
+        for (size_t q = 0; q < nb; ++q) if (T[band[q]] < tmin) tmin = T[band[q]];
+        theta += (double)delta;
+        if ((double)tmin >= theta) theta = (floor((double)tmin / (double)delta) + 1.0) * (double)delta;      /* skip empty steps */
+        size_t nf = 0, keep = 0, nc = 0;
+        for (size_t q = 0; q < nb; ++q) {
+            if ((double)T[band[q]] < theta) { fresh[nf++] = band[q]; popped[band[q]] = 1; }
+            else band[keep++] = band[q];
+        }
+        nb = keep;
+        for (size_t q = 0; q < nf; ++q) {
+            const int y = (int)(fresh[q] / (uint32_t)W), x = (int)(fresh[q] % (uint32_t)W);
+            for (int d = 0; d < 4; ++d) {
+                const int xx = x + dx[d], yy = y + dy[d];
+                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                const size_t k = (size_t)yy * W + xx;
+                if (stamp[k] != ORC_T_UNKNOWN || seen[k]) continue;
+                seen[k] = 1; cand[nc++] = (uint32_t)k;
+            }
+        }
+        for (size_t q = 0; q < nc; ++q)
+            orc_telea_pixel(&s, (int)(cand[q] % (uint32_t)W), (int)(cand[q] / (uint32_t)W), 1, radius, &ft[q], frgb + 3 * q);
+        for (size_t q = 0; q < nc; ++q) {                                /* commit after the scan: the step read old state only */
+            const size_t k = cand[q];
+            stamp[k] = 0; T[k] = ft[q]; memcpy(out + 3 * k, frgb + 3 * q, 3);
+            band[nb++] = (uint32_t)k;
+        }
+        if (nc) ++steps;
+    }
+    free(stamp); free(popped); free(T); free(band); free(fresh); free(cand); free(seen); free(ft); free(frgb);
+    return steps;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* basic_nomal_infill.normal_infill (bni:87-119) and the helpers it is made of                 */
 /* ------------------------------------------------------------------------------------------ */

@@ -99,6 +99,11 @@ for cs in sweep_cases(synthetic):
                 if tuning and mesh:
                     try:
                         blk, info = r.ctx.debug_read_queue_block()
+                        for rep in range(3):                 # is the BLOCK itself incoherent between XCDs (mdvt_selftest.hip)?
+                            co = r.ctx.debug_coherence()
+                            print(f"pid {os.getpid()} iter {it}: coherence test {rep} on the bad render's block: {int(co[72])} wrong words"
+                                  + (f"; pattern words by writer x reader XCD {co[:64].reshape(8, 8).tolist()}, atomic sums by reader {co[64:72].tolist()}, "
+                                     f"first saw 0x{int(co[73]):08x} want 0x{int(co[74]):08x} at dword {int(co[75])}" if co[72] else ""), flush=True)
                         if blk.size: diagnose(r, blk, info, lambda: same(r.render(d, c, [p], want_depth=True)), f"pid {os.getpid()} iter {it}")
                     except Exception as e:      # the diagnosis must not hide the count
                         print("diagnosis failed:", repr(e), flush=True)

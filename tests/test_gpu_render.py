@@ -805,6 +805,97 @@ def test_randomised_parity_sweep(mods, orc):
         r.close()
 
 
+def batch_sweep_cases(synthetic):
+    """Seeded generator of MULTI-FRAME calls (the single-frame sweep above never submits one): 2 ... 40 frames per call, one
+    renderer configuration per call, every frame with its own depth content and its own kind -- pure shift, convergence, pose or
+    both -- in runs long enough that the posed / converged paths split into several launch sets on two banks of workspace slots
+    (mdvt_render_stereo_batch); a small `workspace_mib` makes the mesh path's sets short.  MDVT_SWEEP_SEED / MDVT_BATCH_CASES
+    widen it for tools/soak.py."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("MDVT_SWEEP_SEED", "20260927")) + 7_000_003)
+    sizes = [(8, 8), (17, 9), (36, 20), (61, 33), (64, 32), (100, 31), (128, 16), (200, 12), (96, 96), (257, 129), (320, 200)]
+    for case in range(int(os.environ.get("MDVT_BATCH_CASES", "24"))):
+        W, H = sizes[int(rng.integers(len(sizes)))]
+        N = int(rng.integers(2, 41))
+        if W * H > 20000:
+            N = min(N, 12)                                   # (the oracle's share)
+        mesh, infill, no_pts = bool(rng.integers(4) != 0), bool(rng.integers(2)), bool(rng.integers(4) == 0)
+        ipd = int(rng.choice([1, 30, 63, 65, 120]))
+        xfov = float(rng.choice([45.0, 60.0, 90.0, 120.0]))
+        max_depth = int(rng.choice([20, 100]))
+        # slots one launch set may take: 0 = the library's default budget; else a budget of 2 ... 6 slots (mesh, posed / converged)
+        slots = int(rng.choice([0, 2, 3, 4, 6]))
+        per_slot = W * H * (16 + 48 + 32 + 24 + 3)
+        ws_mib = 0 if slots == 0 else max(1, -(-slots * per_slot // (1 << 20)))
+        layout = int(rng.integers(4))                        # 0: one kind throughout, 1: random per frame, 2: two long runs, 3: general except a pure frame or two
+        kinds = []
+        base = int(rng.integers(1, 4))
+        for f in range(N):
+            if layout == 0: k = base
+            elif layout == 1: k = int(rng.integers(4))
+            elif layout == 2: k = base if f < N // 2 else (base % 3) + 1
+            else: k = 0 if rng.integers(8) == 0 else base
+            kinds.append(k)
+        d = np.zeros((N, H, W, 3), np.uint8)
+        for f in range(N):
+            style = int(rng.integers(4))
+            if style == 0:                                   # foreground rectangles over a far plane
+                code = np.full((H, W), int(rng.integers(3000, 60000)), np.uint32)
+                for _ in range(int(rng.integers(1, 6))):
+                    x0, y0 = int(rng.integers(W)), int(rng.integers(H))
+                    code[y0:y0 + int(rng.integers(1, H + 1)), x0:x0 + int(rng.integers(1, W + 1))] = int(rng.integers(50, 3000))
+            elif style == 1:                                 # one-code noise on a slope: ties and 1-LSB steps
+                code = (int(rng.integers(300, 40000)) + np.arange(W)[None, :] // 3 + rng.integers(0, 2, (H, W))).astype(np.uint32)
+            elif style == 2:                                 # near / far stripes: folding, large triangles
+                near, far = int(rng.integers(20, 400)), int(rng.integers(5000, 65000))
+                stripes = (np.arange(W)[None, :] if rng.integers(2) else np.arange(H)[:, None]) // int(rng.integers(1, 4)) % 2
+                code = np.where(np.broadcast_to(stripes, (H, W)) == 0, near, far).astype(np.uint32)
+            else:                                            # smooth plane + a step
+                code = (2000 + 40 * np.arange(W)[None, :] + 7 * np.arange(H)[:, None]).astype(np.uint32)
+                code[:, W // 2:] //= 3
+            code = np.minimum(code, 65535)
+            d[f, ..., 0] = (code >> 8) & 0xFF; d[f, ..., 1] = d[f, ..., 0]; d[f, ..., 2] = code & 0xFF
+        c = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+        track = synthetic.synthetic_pose_track(64)
+        Ts = [track[int(rng.integers(1, 64))] if k >= 2 else None for k in kinds]
+        convs = [float(rng.uniform(0.5, 8.0)) if k in (1, 3) else None for k in kinds]
+        if layout == 0 and base == 1 and rng.integers(2):
+            convs = [convs[0]] * N                           # a clip-constant convergence, as movie_2_3D.py passes it
+        yield dict(case=case, W=W, H=H, N=N, mesh=mesh, infill=infill, no_pts=no_pts, ipd=ipd, xfov=xfov, max_depth=max_depth,
+                   ws_mib=ws_mib, kinds=kinds, depth_rgb=d, color=c, Ts=Ts, convs=convs)
+
+
+def test_randomised_batch_sweep(mods, orc):
+    """Multi-frame calls against the oracle frame by frame: sbs, mask, depth planes and seed images; each call twice (slot parities)."""
+    _lib, sr, synthetic = mods
+    for cs in batch_sweep_cases(synthetic):
+        W, H, N = cs["W"], cs["H"], cs["N"]
+        r = sr.StereoRerenderer(W, H, pupillary_distance=cs["ipd"], max_depth=cs["max_depth"], render_as_pointcloud=not cs["mesh"],
+                                infill_mask=cs["infill"], dont_place_points_in_edges=cs["no_pts"], workspace_mib=cs["ws_mib"])
+        ps = [r.frame_params(xfov=cs["xfov"], convergence_distance=cs["convs"][f], transformation=cs["Ts"][f]) for f in range(N)]
+        want_seed = cs["infill"] and H >= 3 and W >= 3
+        dt, ct = torch.from_numpy(cs["depth_rgb"]).cuda(), torch.from_numpy(cs["color"]).cuda()
+        tag0 = (f"batch#{cs['case']} {W}x{H} x {N} mesh={cs['mesh']} infill={cs['infill']} no_pts={cs['no_pts']} ipd={cs['ipd']} xfov={cs['xfov']} "
+                f"md={cs['max_depth']} ws_mib={cs['ws_mib']} kinds={''.join(map(str, cs['kinds']))}")
+        for rep in range(2):
+            got = r.render(dt, ct, ps, want_depth=True, want_seed=want_seed)
+            for f in range(N):
+                op = orc.make_params(W, H, _K(ps[f]), ipd_m=cs["ipd"] / 1000, max_depth=cs["max_depth"], depth_scale=ps[f].depth_scale,
+                                     mode=orc.MODE_MESH if cs["mesh"] else orc.MODE_POINTS, remove_edges=r.remove_edges,
+                                     edge_points=int(r.edge_points), conv_angle=ps[f].convergence_angle, T=cs["Ts"][f], key_rgb=r.key_rgb)
+                want = orc.render_stereo(op, cs["depth_rgb"][f], cs["color"][f], want_depth=True, want_seed=want_seed) if rep == 0 else wants[f]
+                if rep == 0:
+                    if f == 0: wants = []
+                    wants.append(want)
+                tag = f"{tag0} call {rep} frame {f}"
+                _compare({k: got[k][f] for k in ("sbs", "mask", "depth")}, want, W, tag)
+                if want_seed:
+                    sd = got["seed"][f].cpu().numpy()
+                    for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
+                        assert np.array_equal(sd[:, sl], want[eye + "_seed"]), tag + " seed " + eye
+        r.close()
+
+
 def test_mark_lower_side_on_device(mods, orc, golden):
     from metric_depth_video_toolbox_amd import infill_common
     g = golden("infill")

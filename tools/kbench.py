@@ -2,7 +2,8 @@
 """In-process A/B timing of kernel configurations (env MDVT_POINTS_CFG is re-read per launch).
 usage: python tools/kbench.py cfgA cfgB ... [--rounds R] [--calls C] [--mode points|mesh]"""
 import os, sys, argparse, statistics
-os.environ.setdefault("MDVT_LIB_VARIANT", "tuning")      # the hooks this tool drives live in the tuning build (csrc/mdvt_internal.h)
+os.environ.setdefault("MDVT_LIB_VARIANT", "tuning")      # the hooks this tool drives live in the tuning build (csrc/mdvt_internal.h);
+                                                         # MDVT_LIB_VARIANT= (empty) times the product library
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 if os.environ.get('KB_DIST'):
@@ -46,16 +47,9 @@ else:
 from metric_depth_video_toolbox_amd.synthetic import synthetic_pose_track
 Ts = synthetic_pose_track(N) if a.pose else [None] * N
 if a.c4:
-    from metric_depth_video_toolbox_amd.synthetic import contention_band, quantise_depth_to_rgb
-    from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
-    sc4, K4, NH = SyntheticScene(W, H, config_id=4), compute_camera_matrix(45.0, None, W, H), min(4, N)
-    for t in range(NH):
-        d[t] = torch.from_numpy(quantise_depth_to_rgb(contention_band(sc4.depth_m(t), K4[0, 0], 0.065, row0=H // 2 - 32 + 8 * t, rows=64))).cuda()
-        c[t] = torch.from_numpy(sc4.frame(t)[1]).cuda()
-    for k in range(NH, N):
-        d[k] = torch.roll(d[k % NH], shifts=(16 * (k // NH), 24 * (k // NH)), dims=(0, 1))
-        c[k] = torch.roll(c[k % NH], shifts=(16 * (k // NH), 24 * (k // NH)), dims=(0, 1))
-    Ts = list(synthetic_pose_track(40 + 30 * N)[40:40 + N * 30:30])
+    from metric_depth_video_toolbox_amd.synthetic import c4_clip
+    d4, c4, Ts = c4_clip(N, W, H)          # (the clip bench.py times and tests/test_gpu_bench_sizes.py holds to the oracle)
+    d, c, Ts = torch.from_numpy(d4).cuda(), torch.from_numpy(c4).cuda(), list(Ts)
 p = [r.frame_params(xfov=45.0, convergence_distance=a.conv, transformation=Ts[k]) for k in range(N)]
 sbs = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device="cuda")
 mask = torch.empty((N, H, 2 * W), dtype=torch.uint8, device="cuda")
@@ -99,6 +93,7 @@ for _ in range(a.rounds):
             for _ in range(a.calls): run()
         e1.record(); torch.cuda.synchronize()
         res[k].append(e0.elapsed_time(e1) / a.calls * 1e3)
+print("library:", "libmdvt_hip_tuning.so" if os.environ.get("MDVT_LIB_VARIANT") else "libmdvt_hip.so (product)")
 bpp = 14 + (8 if a.zout else 0)
 for k in a.cfgs:
     med = statistics.median(res[k])

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--full-sizes", default="1920x1080,1280x720,3840x48,1000x1000")
     ap.add_argument("--aux-seeds", type=int, default=24)
     ap.add_argument("--aux-cases", type=int, default=200)
+    ap.add_argument("--batch-seeds", type=int, default=0, help="multi-frame call sweeps (test_randomised_batch_sweep: 2..40 frames per call, banks)")
+    ap.add_argument("--batch-cases", type=int, default=100, help="calls per batch seed")
     ap.add_argument("--finish", type=int, default=1, help="run tests/dbg_finish_fullsize.py (both seed kinds) this many times")
     ap.add_argument("--procs", type=int, default=12)
     ap.add_argument("--budget-min", type=float, default=60.0, help="stop starting new jobs after this many minutes")
@@ -51,6 +53,10 @@ def main():
     for k in range(a.seeds):
         jobs.append((f"sweep_{k:03d}", "render sweep, widened sizes", {"MDVT_SWEEP_SEED": str(a.seed0 + k), "MDVT_SWEEP_CASES": str(a.cases)},
                      [py, "-m", "pytest", "tests/test_gpu_render.py", "-x", "-q", "-k", "test_randomised_parity_sweep"], a.cases))
+    for k in range(a.batch_seeds):
+        jobs.append((f"batch_{k:03d}", "multi-frame calls (2..40 frames, mixed pure / converged / posed, launch sets on two banks)",
+                     {"MDVT_SWEEP_SEED": str(a.seed0 + 70000 + k), "MDVT_BATCH_CASES": str(a.batch_cases)},
+                     [py, "-m", "pytest", "tests/test_gpu_render.py", "-x", "-q", "-k", "test_randomised_batch_sweep"], a.batch_cases))
     for k in range(a.aux_seeds):
         jobs.append((f"aux_{k:03d}", "stand-alone entry points sweep", {"MDVT_SWEEP_SEED": str(a.seed0 + 90000 + k), "MDVT_SWEEP_CASES": str(a.aux_cases)},
                      [py, "-m", "pytest", "tests/test_gpu_render.py", "-x", "-q", "-k", "test_randomised_aux_sweep"], a.aux_cases))
@@ -99,7 +105,8 @@ def main():
         fh.write(f"* commit under test: `{a.commit}` (the tree gpurun shipped; `libmdvt_hip.so` built from it)\n")
         fh.write(f"* device: {dev}; {a.procs} parallel pytest processes; wall {(time.time() - t0) / 60:.1f} min\n")
         fh.write(f"* seeds: render sweep {a.seed0}..{a.seed0 + a.seeds - 1} x {a.cases} cases (sizes of `test_randomised_parity_sweep` + the soak sizes), "
-                 f"full size {a.seed0 + 50000}.. x {a.full_per_job} cases over {a.full_sizes}, aux {a.seed0 + 90000}.. x {a.aux_cases} cases\n")
+                 f"full size {a.seed0 + 50000}.. x {a.full_per_job} cases over {a.full_sizes}, multi-frame calls {a.seed0 + 70000}.. x {a.batch_cases} calls, "
+                 f"aux {a.seed0 + 90000}.. x {a.aux_cases} cases\n")
         fh.write(f"* jobs finished {len(done)} of {len(jobs)} ({len(skipped)} not started: time budget), **failed jobs: {len(fails)}**\n\n")
         fh.write("| kind | jobs | cases | failed jobs | CPU-seconds |\n|---|---|---|---|---|\n")
         for kind, k in kinds.items():
