@@ -253,6 +253,15 @@ def measure_variant(make_job, frames, W, H, dev, torch, budget_s=0.6, bytes_per_
             "groups": len(groups), "launches_per_group": per_group}
 
 
+def device_uuid(torch, index):
+    """The runtime's UUID of cuda:<index> (hipDeviceProp_t.uuid), else the PCI address: what tells two GPUs apart."""
+    p = torch.cuda.get_device_properties(index)
+    u = getattr(p, "uuid", None)
+    if u is not None:
+        return str(u)
+    return "pci:%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", index))
+
+
 def main():
     args = parse_args()
     if args.cpu_worker:
@@ -282,11 +291,21 @@ def main():
     dev = torch.device("cuda", local)
     W, H, N = args.width, args.height, args.frames
     barrier = torch.distributed.barrier if torch.distributed.is_initialized() else None
+    # Which physical GPU each rank really runs on: the UUID the runtime reports, so that N ranks on one device cannot pass as
+    # N GPUs (the only legitimate way to share is MDVT_BENCH_SHARE_GPU=1, a tests/-only setting the line then names).
+    if torch.cuda.current_device() != local:
+        sys.stderr.write(f"bench.py: rank {rank}: current device {torch.cuda.current_device()} is not LOCAL_RANK's {local}\n")
+        sys.exit(3)
     devices = [f"{torch.cuda.get_device_name(local)} (cuda:{local})"]
+    uuids = [device_uuid(torch, local)]
     if torch.distributed.is_initialized():
         names = [None] * world
-        torch.distributed.all_gather_object(names, devices[0])
-        devices = names
+        torch.distributed.all_gather_object(names, (devices[0], uuids[0]))
+        devices, uuids = [n[0] for n in names], [n[1] for n in names]
+    distinct_gpus = len(set(uuids))
+    if distinct_gpus != world and not share_gpu:
+        sys.stderr.write(f"bench.py: {world} rank(s) on {distinct_gpus} distinct GPU(s) ({uuids}): one rank per GPU is the contract\n")
+        sys.exit(3)
 
     # rank 0 owns the clip parameters and broadcasts them (RCCL over xGMI when world > 1)
     clip = None
@@ -301,6 +320,9 @@ def main():
                          max_depth=clip.max_depth, master_xfov=clip.master_xfov,
                          render_as_pointcloud=bool(clip.mode_flags & 1), remove_edges=bool(clip.mode_flags & 2),
                          dont_place_points_in_edges=not bool(clip.mode_flags & 4))
+    if r.device != local or r.ctx.device != local:
+        sys.stderr.write(f"bench.py: rank {rank}: the context sits on GPU {r.ctx.device}, LOCAL_RANK is {local}\n")
+        sys.exit(3)
     params = r.pack_params([r.frame_params(xfov=float(clip.xfov[t])) for t in range(lo, hi)], hi - lo)
 
     # synthetic frames of this rank's range, resident in HBM before the timed region: 32 distinct scenes from the host
@@ -373,6 +395,8 @@ def main():
                                    "inputs resident in HBM (BASELINE.json configs[1] shape, batched past the 256 MiB Infinity Cache)",
                        "frames_per_step_per_gpu": n_local, "parallelism": f"frames sharded over {world} rank(s), "
                        "one broadcast of the parameter block, no data-path collective", "devices": devices,
+                       "device_uuids": uuids, "distinct_gpus": distinct_gpus, "ranks_seen_by_the_process_group": world,
+                       "ranks_share_a_gpu": bool(share_gpu),
                        "host_made_frames_per_rank": n_host, "setup_seconds_per_rank": [round(v, 2) for v in setup_s]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,

@@ -201,6 +201,13 @@ class Context:
         self.check(self._L.mdvt_debug_read(self._h, 1, out.ctypes.data_as(C.c_void_p), out.nbytes, info))
         return out
 
+    def debug_pools(self):
+        """mdvt_debug_read(what = 2), tuning library: idle blocks of the two process-wide pools as this context's GPU sees them ->
+        dict(param_mine, param_other, ws_mine, ws_other, tag)."""
+        info = (C.c_uint64 * 8)()
+        self.check(self._L.mdvt_debug_read(self._h, 2, None, 0, info))
+        return dict(param_mine=int(info[0]), param_other=int(info[1]), ws_mine=int(info[2]), ws_other=int(info[3]), tag=int(info[4]))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.mdvt_destroy(self._h)

@@ -407,13 +407,13 @@ int stage_params(mdvt_ctx* c, const std::vector<FrameDev>& v, hipStream_t s, con
     c->next_slot = (c->next_slot + 1) % kParamSlots;
     if (sl.used) MDVT_HIP(c, hipEventSynchronize(sl.done));     // slot is being reused: its last user must be done
     if (sl.capacity < v.size()) {
-        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev), c->device);
+        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev), c->pool_tag);
         sl.host = nullptr; sl.dev = nullptr; sl.capacity = 0;
         size_t cap = 16;
         while (cap < v.size()) cap *= 2;
         void *h = nullptr, *d = nullptr;
         size_t got = 0;
-        MDVT_HIP(c, pool_take(cap * sizeof(FrameDev), true, c->device, &h, &d, &got));
+        MDVT_HIP(c, pool_take(cap * sizeof(FrameDev), true, c->pool_tag, &h, &d, &got));
         sl.host = (FrameDev*)h; sl.dev = (FrameDev*)d; sl.capacity = got / sizeof(FrameDev);
     }
     if (!sl.done) MDVT_HIP(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
@@ -599,7 +599,7 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->hugeq2) ws_free(c, c->hugeq2);
     for (hipEvent_t ev : {c->ev_start, c->ev_join, c->ev_vert[0], c->ev_vert[1]}) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : c->slots) {
-        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev), c->device);
+        pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev), c->pool_tag);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (int e = 0; e < 2; ++e) { if (c->keys[e]) ws_free(c, c->keys[e]); if (c->ekeys[e]) ws_free(c, c->ekeys[e]); if (c->cbuf[e]) ws_free(c, c->cbuf[e]); }
@@ -997,7 +997,22 @@ int mdvt_debug_read(mdvt_ctx* c, int what, void* h_dst, uint64_t capacity, uint6
 {
     if (!c) return MDVT_ERR_INVALID_ARG;
     if (!tuning_build()) return fail(c, MDVT_ERR_UNSUPPORTED, "mdvt_debug_read: tuning build only");
-    if ((what != 0 && what != 1) || !info) return fail(c, MDVT_ERR_INVALID_ARG, "mdvt_debug_read: what must be 0 or 1, info not NULL");
+    if (what < 0 || what > 2 || !info) return fail(c, MDVT_ERR_INVALID_ARG, "mdvt_debug_read: what must be 0, 1 or 2, info not NULL");
+    if (what == 2) {
+        // the two process-wide pools as this context's GPU sees them (its pool tag: the device, or MDVT_POOL_TAG): idle parameter
+        // blocks that carry device memory of this / of another GPU, idle workspace blocks of this / of another GPU
+        for (int k = 0; k < 8; ++k) info[k] = 0;
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mutex);
+            for (const PoolBlock& b : param_pool()) if (b.device >= 0) ++info[b.device == c->pool_tag ? 0 : 1];
+        }
+        {
+            std::lock_guard<std::mutex> lock(g_dev_pool_mutex);
+            for (const DevBlock& b : dev_pool()) ++info[b.tag == c->pool_tag ? 2 : 3];
+        }
+        info[4] = (uint64_t)c->pool_tag;
+        return MDVT_OK;
+    }
     DeviceGuard g(c->device);
     MDVT_HIP(c, hipDeviceSynchronize());
     if (what == 1) {

@@ -111,6 +111,9 @@ def test_bench_line_with_two_ranks_sharing_the_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and len(line["config"]["devices"]) == 2 and line["scaling"] == "weak"
     assert line["config"]["frames_per_step_per_gpu"] == 8
+    # the line says what the ranks really ran on: two ranks, ONE physical GPU, and that this was the tests-only sharing mode
+    cfg = line["config"]
+    assert len(cfg["device_uuids"]) == 2 and cfg["distinct_gpus"] == 1 and cfg["ranks_share_a_gpu"] is True and cfg["ranks_seen_by_the_process_group"] == 2
     # whole-job value: both ranks' frames over the slower rank's wall clock
     assert abs(line["value"] - 2 * 8 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert line["cpu_baseline"] is None and line["roofline"]["bound"] == "hbm"
@@ -118,6 +121,23 @@ def test_bench_line_with_two_ranks_sharing_the_gpu():
     assert ex["clip_c3"]["frames"] == 30 and ex["clip_c3"]["n_gpus"] == 2 and ex["clip_c3"]["scaling"] == "strong"
     assert ex["clip_c3_long"]["frames"] == 90 and ex["clip_c3_long"]["repeats"] == 3 and ex["clip_c3_long"]["n_gpus"] == 2
     assert "mesh" not in ex                               # the N = 1 extras stay at N = 1
+
+
+def test_ranks_sharing_a_gpu_without_the_opt_in_are_refused():
+    """Eight ranks on one device must not pass as eight GPUs: without MDVT_BENCH_SHARE_GPU every rank takes cuda:LOCAL_RANK,
+    and two ranks whose devices carry the same UUID (here: LOCAL_RANK 1 does not exist on a one-GPU box, or both map to the
+    same GPU) end the job with a message instead of a line."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if torch.cuda.device_count() > 1:
+        pytest.skip("needs a one-GPU box (with two GPUs the launch line is legitimate)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MDVT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--frames", "4", "--prewarm-ms", "0", "--clip-frames", "8", "--clip-repeats", "1", "--no-cpu-baseline", "--no-extra"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")], p.stdout + p.stderr
 
 
 def test_bench_line_with_eight_ranks_sharing_the_gpu():
@@ -138,6 +158,7 @@ def test_bench_line_with_eight_ranks_sharing_the_gpu():
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and len(line["config"]["devices"]) == 8 and line["scaling"] == "weak"
+    assert len(line["config"]["device_uuids"]) == 8 and line["config"]["distinct_gpus"] == 1 and line["config"]["ranks_share_a_gpu"] is True
     assert abs(line["value"] - 8 * 4 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert len(line["config"]["setup_seconds_per_rank"]) == 8 and "host-side setup per rank" in p.stderr
     ex = line["extra"]

@@ -12,9 +12,9 @@ n=0
 for cfg in "$@"; do
   n=$((n + 1))
   log="$out/cfg${n}.log"
-  echo "== config $n: $cfg (12 x $iters fresh contexts)" | tee "$log"
+  echo "== config $n: $cfg (${NPROC:-12} x $iters fresh contexts)" | tee "$log"
   t0=$(date +%s)
-  for k in 1 2 3 4 5 6 7 8 9 10 11 12; do
+  for k in $(seq 1 ${NPROC:-12}); do
     ( IFS=,; for kv in $cfg; do export "$kv"; done
       MDVT_SWEEP_SEED=${SWEEP_SEED:-504249} MDVT_SWEEP_CASES=400 CASE=${SWEEP_CASE:-231} FRESH=${FRESH:-1} ITERS=$iters \
         timeout 600 python tests/dbg_stress_case.py > "$out/cfg${n}_p${k}.log" 2>&1; echo "exit $?" >> "$out/cfg${n}_p${k}.log" ) &

@@ -122,8 +122,11 @@ int main(int argc, char** argv)
         if (he[0] != seen[0] || he[1] != seen[1]) {
             ++bad_iters;
             if (bad_iters <= 5)
-                printf("pid %d mode %d: iteration %llu: %u pattern words, %u append errors; first: kind %u at dword %u saw 0x%08x want 0x%08x\n",
-                       (int)getpid(), mode, (unsigned long long)it, he[0] - seen[0], he[1] - seen[1], he[5], he[4], he[2], he[3]);
+                printf("pid %d mode %d: iteration %llu: %u pattern words, %u append errors; first: kind %u at dword %u saw 0x%08x want 0x%08x "
+                       "(slice %u: filled by XCD %u, appended to by XCD %u, checked by XCD %u)\n",
+                       (int)getpid(), mode, (unsigned long long)it, he[0] - seen[0], he[1] - seen[1], he[5], he[4], he[2], he[3],
+                       he[4] / kSliceDw, (he[4] / kSliceDw) % 8u, (he[4] / kSliceDw + nslices - 5u) % nslices % 8u,
+                       (he[4] / kSliceDw + nslices - (he[5] == 1u ? 1u : 3u)) % nslices % 8u);
             seen[0] = he[0]; seen[1] = he[1];
             CK(hipMemset(err + 2, 0, 24));
             // reset the "first" latch: counts restart from what was seen
