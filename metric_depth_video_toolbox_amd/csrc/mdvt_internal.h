@@ -86,6 +86,8 @@ struct RenderArgs {
     uint8_t* unused;             // [slot][H*W]
     // general mesh path: queue of the triangles that are not small (kBigRecDwords dwords each), rasterised by k_mesh_raster_queue
     uint32_t* bigq; uint32_t* bigq_count; uint32_t bigq_cap;
+    uint32_t* bigq_coarse;       // [(segments >> bigq_shift) + 1] queued triangles per block of 2^bigq_shift segments (behind the segment counters;
+    int32_t bigq_shift;          //   set by launch_mesh_raster_general): the queue walk's first search level, summed up in LDS
     uint32_t* hugeq;             // [kHugeCap] x 2 dwords + counter + overflow slack: row blocks of the queued triangles too large for 16 lanes (k_mesh_raster_huge)
     size_t ws_stride_px;         // H*W (elements) between slots
     size_t ws_stride_tri;        // 2*(H-1)*(W-1)

@@ -16,6 +16,7 @@
 // segment holds all four triangles of every cell of its row, so nothing can overflow.
 #include "mdvt_device.h"
 #include <stdio.h>
+#include <vector>
 
 namespace mdvt {
 
@@ -129,6 +130,16 @@ __device__ __forceinline__ uint4 vertex_record_eye(const RenderArgs& a, const Fr
     return make_uint4((uint32_t)snap(v.u), (uint32_t)snap(v.v), __float_as_uint(iz), rgb);
 }
 
+__device__ __forceinline__ uint4 shfl_u4(const uint4& v, int src)
+{
+    return make_uint4((uint32_t)__shfl((int)v.x, src), (uint32_t)__shfl((int)v.y, src), (uint32_t)__shfl((int)v.z, src), (uint32_t)__shfl((int)v.w, src));
+}
+template <typename T> __device__ __forceinline__ uint4 readlane_u4(const uint4& v, T lane)
+{
+    return make_uint4((uint32_t)__builtin_amdgcn_readlane((int)v.x, lane), (uint32_t)__builtin_amdgcn_readlane((int)v.y, lane),
+                      (uint32_t)__builtin_amdgcn_readlane((int)v.z, lane), (uint32_t)__builtin_amdgcn_readlane((int)v.w, lane));
+}
+
 constexpr int kCellTPB = 64;          // threads per workgroup of the cell walks = vertex columns it stages
 constexpr int kCellsWG = kCellTPB - 1;   // cells per workgroup: between its 64 columns
 // The two vertex rows (i, i + 1) of columns j0 .. j0 + 63 of both eyes into sv[eye][row][column].
@@ -155,6 +166,77 @@ __device__ __forceinline__ bool cell_block_of(int W, int H, int& bx, int& i)
     if (v >= cell_blocks(W, H)) return false;
     bx = (int)(v % nbx); i = (int)(v / nbx);
     return true;
+}
+
+// The queue's two levels of counters.  A wave that appends n triangles to a segment (one returning atomic on the segment's counter:
+// its entries' places) also adds n to the counter of the block of 2^bigq_shift segments the segment belongs to -- a posted atomic,
+// nothing waits for it.  The queue walk sums the few thousand block counters up in LDS and finds the segment of a global entry from
+// there (queue_locate).  Until r05 a kernel of ONE workgroup between the cell walk and the queue walk turned the segment counters
+// into prefix sums (a dependent launch, 5 us per 1080p frame of the product default in the profile), and every entry of the queue
+// walk began with a 15-step binary search through them in the L2.
+__device__ __forceinline__ void queue_count_coarse(const RenderArgs& a, size_t seg, uint32_t n)
+{
+    atomicAdd(&a.bigq_coarse[seg >> a.bigq_shift], n);
+}
+constexpr int kQueueCoarseMax = 4096;          // block counters per launch set at most (launch_mesh_raster_general picks bigq_shift)
+inline int queue_shift_for(int nseg) { int sh = 4; while (((nseg + (1 << sh) - 1) >> sh) > kQueueCoarseMax) ++sh; return sh; }
+
+// cpre[0 .. nc]: exclusive prefix sums of the block counters, by the whole workgroup (any size); cpre[nc] = queued triangles.
+__device__ __forceinline__ void queue_prefix_lds(const RenderArgs& a, int nseg, uint32_t* cpre)
+{
+    const int nc = (nseg + (1 << a.bigq_shift) - 1) >> a.bigq_shift;
+    const int t = (int)threadIdx.x, nt = (int)blockDim.x;
+    const int per = (nc + nt - 1) / nt, lo = min(t * per, nc), hi = min(lo + per, nc);
+    uint32_t sum = 0;
+    for (int k = lo; k < hi; ++k) sum += a.bigq_coarse[k];
+    // (cpre[nc + 1 ..] is scratch for the per-thread sums: the launcher sized it nc + 1 + threads)
+    uint32_t* part = cpre + nc + 1;
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {
+        const uint32_t u = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += u;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int k = lo; k < hi; ++k) { cpre[k] = run; run += a.bigq_coarse[k]; }
+    if (t == nt - 1) cpre[nc] = part[nt - 1];
+    __syncthreads();
+}
+
+// Segment and place within it of global queue entry g (< cpre[nc]); the 16 lanes of a group call it together with the same g.
+__device__ __forceinline__ void queue_locate(const RenderArgs& a, int nseg, const uint32_t* cpre, uint32_t g, int sub, int& seg_out, uint32_t& k_out)
+{
+    const int nc = (nseg + (1 << a.bigq_shift) - 1) >> a.bigq_shift;
+    int lo_b = 0, hi_b = nc - 1;                                   // last block with cpre[b] <= g
+    while (lo_b < hi_b) {
+        const int mid = (lo_b + hi_b + 1) >> 1;
+        if (cpre[mid] <= g) lo_b = mid; else hi_b = mid - 1;
+    }
+    uint32_t rem = g - cpre[lo_b];
+    const int s0 = lo_b << a.bigq_shift, s1 = min(s0 + (1 << a.bigq_shift), nseg);
+    const int row15 = (int)(threadIdx.x & 63u) | 15;
+    seg_out = s1 - 1; k_out = 0u;
+    for (int c = s0; c < s1; c += 16) {                            // the block's segment counters, 16 at a time: one per lane
+        const int sgm = c + sub;
+        const uint32_t cnt = sgm < s1 ? a.bigq_count[sgm] : 0u;
+        uint32_t inc = cnt;                                        // inclusive sums along the group's 16 lanes (one DPP row)
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
+        const uint32_t tot = (uint32_t)__shfl((int)inc, row15);
+        if (rem < tot) {
+            const uint32_t m = (uint32_t)(__ballot(inc > rem) >> ((threadIdx.x & 63u) & ~15u)) & 0xFFFFu;     // this group's lanes
+            const int idx = __ffs((int)m) - 1;
+            const int src = (int)((threadIdx.x & 63u) & ~15u) + idx;
+            seg_out = c + idx;
+            k_out = rem - ((uint32_t)__shfl((int)inc, src) - (uint32_t)__shfl((int)cnt, src));
+            return;
+        }
+        rem -= tot;
+    }
 }
 
 // second pass: does the pixel box touch a tile with a marked pixel?
@@ -190,6 +272,7 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
         inv0 = tinv[0]; inv1 = tinv[ncell];
     }
     __syncthreads();
+    bool tq[2][2] = {{false, false}, {false, false}};          // [eye][triangle of the cell]: goes to the queue
     // (unrolled: each eye has its own pending word, so the left eye's last post is in flight while the right eye is rasterised)
 #pragma unroll
     for (int eye = 0; eye < 2; ++eye) {
@@ -239,17 +322,28 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
                     }
                 }
             }
-            const u64 mq = __ballot(toq);
-            if (mq) {
-                const size_t seg = (size_t)fr * H + i;                    // this row's segment: 4 (W - 1) entries at most
-                uint32_t base = 0;
-                const int first = __ffsll((long long)mq) - 1;
-                if (lane == first) base = atomicAdd(&a.bigq_count[seg], (uint32_t)__popcll(mq));
-                base = __shfl(base, first);
-                if (toq) {
-                    uint2* q = (uint2*)a.bigq + seg * (size_t)(4 * W);
-                    q[base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = make_uint2(did, (uint32_t)fr * 2u + (uint32_t)eye);
-                }
+            tq[eye][pass] = toq;
+        }
+    }
+    // The workgroup's (= wave's) queued triangles of both eyes in ONE append: one returning atomic on the segment's counter and one
+    // posted atomic on its block's (r05; an append per (eye, triangle of the cell) was four of each, and with everything in flight
+    // working on the same few rows those counters are where the rasteriser's atomics queue up: +10 % on its time under a pose).
+    if (MODE == 0) {
+        u64 m[4];
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { m[k] = __ballot(tq[k >> 1][k & 1]); total += (uint32_t)__popcll(m[k]); }
+        if (total) {                                                      // (wave uniform)
+            const size_t seg = (size_t)fr * H + i;                        // this row's segment: 4 (W - 1) entries at most
+            uint32_t base = 0;
+            if (lane == 0) { queue_count_coarse(a, seg, total); base = atomicAdd(&a.bigq_count[seg], total); }
+            base = __shfl(base, 0);
+            uint2* q = (uint2*)a.bigq + seg * (size_t)(4 * W);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (tq[k >> 1][k & 1])
+                    q[base + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull))] = make_uint2(draw_id_global(k & 1, i, j), (uint32_t)fr * 2u + (uint32_t)(k >> 1));
+                base += (uint32_t)__popcll(m[k]);
             }
         }
     }
@@ -377,6 +471,7 @@ __device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int 
     __syncthreads();
     // ---- the listed cells: k_mesh_raster_small's code, a listed TRIANGLE per lane ----
     const uint32_t ng = 2u * gcount;
+    uint32_t nqueued = 0;                                                               // (wave uniform) this workgroup's appends
     for (uint32_t base = 0; base < ng; base += (uint32_t)kConvTPB) {                   // (workgroup uniform)
         const uint32_t idx = base + threadIdx.x;
         const bool on = idx < ng;
@@ -429,12 +524,14 @@ __device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int 
             const int first = __ffsll((long long)mq) - 1;
             if (lane == first) qb = atomicAdd(&a.bigq_count[seg], (uint32_t)__popcll(mq));
             qb = __shfl(qb, first);
+            nqueued += (uint32_t)__popcll(mq);
             if (toq) {
                 uint2* q = (uint2*)a.bigq + seg * (size_t)(4 * W);
                 q[qb + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = make_uint2(did, (uint32_t)fr * 2u + (uint32_t)eye);
             }
         }
     }
+    if (MODE == 0 && nqueued && lane == 0) queue_count_coarse(a, (size_t)fr * H + i, nqueued);      // (one posted atomic per workgroup)
 }
 
 template <int FLAGS>
@@ -452,79 +549,23 @@ __global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
-// Exclusive prefix sums of the segment counters (n <= a few 10^4): one workgroup.  prefix[n] = number of queued triangles.
-__global__ void __launch_bounds__(1024) k_mesh_queue_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ prefix, int n, int fences)
-{
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                   // (r05 diagnosis, tuning build)
-    // a thread's chunk: a multiple of four counters, read as 16-byte vectors and kept in registers (one counter per trip made the
-    // pass 17 dependent round trips long, twice: 21 us for a 16-frame 1080p launch set; `counts` is 16-byte aligned)
-    constexpr int kMaxVec = 16;                                    // up to 64 counters per thread: 65 536 segments
-    const int per4 = (n + 4095) / 4096, lo = min(t * per4 * 4, n), hi = min(lo + per4 * 4, n);
-    uint4 v[kMaxVec];
-    uint32_t sum = 0;
-    if (per4 <= kMaxVec) {
-#pragma unroll
-        for (int k = 0; k < kMaxVec; ++k) {
-            v[k] = make_uint4(0, 0, 0, 0);
-            const int e = lo + 4 * k;
-            if (k < per4 && e < hi) {
-                if (e + 4 <= n) v[k] = *(const uint4*)(counts + e);
-                else { v[k].x = counts[e]; if (e + 1 < n) v[k].y = counts[e + 1]; if (e + 2 < n) v[k].z = counts[e + 2]; }
-            }
-            sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-        }
-    } else {
-        for (int k = lo; k < hi; ++k) sum += counts[k];
-    }
-    part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t u = t >= off ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += u;
-        __syncthreads();
-    }
-    uint32_t run = part[t] - sum;
-    if (per4 <= kMaxVec) {
-#pragma unroll
-        for (int k = 0; k < kMaxVec; ++k) {
-            const int e = lo + 4 * k;
-            if (k < per4 && e < hi) {
-                prefix[e] = run; run += v[k].x;
-                if (e + 1 < n) { prefix[e + 1] = run; run += v[k].y; }
-                if (e + 2 < n) { prefix[e + 2] = run; run += v[k].z; }
-                if (e + 3 < n) { prefix[e + 3] = run; run += v[k].w; }
-            }
-        }
-    } else {
-        for (int k = lo; k < hi; ++k) { prefix[k] = run; run += counts[k]; }
-    }
-    if (t == 1023) prefix[n] = part[1023];
-    if (fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-}
-
 // The queued triangles, dealt over the whole chip (a horizontal depth edge under vertical parallax turns an entire row
 // of cells into large triangles: one workgroup per segment would leave that segment's workgroup running alone): 16 lanes
 // per triangle, generic 64-bit set-up, rows walked by their own column range.
+// (cpre: queue_prefix_lds's sums, in the workgroup's LDS)
 template <int MODE>
-__device__ __forceinline__ void mesh_queue_walk(const RenderArgs& a, int nseg)
+__device__ __forceinline__ void mesh_queue_walk(const RenderArgs& a, int nseg, const uint32_t* cpre)
 {
     const int W = a.W, H = a.H;
-    const uint32_t* prefix = a.bigq_count + nseg;
-    const uint32_t total = prefix[nseg];
+    const uint32_t total = cpre[(nseg + (1 << a.bigq_shift) - 1) >> a.bigq_shift];
     const int sub = threadIdx.x & 15;
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = (gridDim.x * blockDim.x) >> 4;
     Pending pd = pending_none();
     for (uint32_t g = group; g < total; g += ngroups) {
-        int lo_s = 0, hi_s = nseg - 1;                              // the segment holding global entry g: last s with prefix[s] <= g
-        while (lo_s < hi_s) {
-            const int mid = (lo_s + hi_s + 1) >> 1;
-            if (prefix[mid] <= g) lo_s = mid; else hi_s = mid - 1;
-        }
+        int lo_s;                                                   // the segment holding global entry g, and g's place in it
+        uint32_t k;
+        queue_locate(a, nseg, cpre, g, sub, lo_s, k);
         const uint2* q = (const uint2*)a.bigq + (size_t)lo_s * (size_t)(4 * W);
-        const uint32_t k = g - prefix[lo_s];
 
         uint2 e = q[k];
         if (MODE == 1 && (e.y >> 31)) continue;                        // its row blocks are in the huge list (first pass, below)
@@ -534,9 +575,13 @@ __device__ __forceinline__ void mesh_queue_walk(const RenderArgs& a, int nseg)
         const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
         const int vf = a.frame0 + slot;
         const FrameDev& vfp = a.fp[vf];
-        const uint4 A = vertex_record_eye(a, vfp, vf, ci, cj, eye);
-        const uint4 v1 = vertex_record_eye(a, vfp, vf, ci + 1, pass == 0 ? cj : cj + 1, eye);
-        const uint4 v2 = vertex_record_eye(a, vfp, vf, pass == 0 ? ci + 1 : ci, cj + 1, eye);
+        // the triangle's three vertices: one each by the first three lanes of the group (the vertex programme is ~150 instructions a
+        // vertex whether one lane runs it or sixteen), handed round the group
+        const int vsel = sub < 3 ? sub : 0;
+        const uint4 rec = vertex_record_eye(a, vfp, vf, ci + (vsel == 1 || (vsel == 2 && pass == 0) ? 1 : 0),
+                                            cj + (vsel == 2 || (vsel == 1 && pass != 0) ? 1 : 0), eye);
+        const int gl0 = (int)(threadIdx.x & 63u) & ~15;
+        const uint4 A = shfl_u4(rec, gl0), v1 = shfl_u4(rec, gl0 + 1), v2 = shfl_u4(rec, gl0 + 2);
         TriSetup t;
         if (!tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
                                (int)v2.x, (int)v2.y, __uint_as_float(v2.z), a.cull))
@@ -632,9 +677,10 @@ __device__ __forceinline__ void mesh_huge_walk(const RenderArgs& a)
         const int pass = (int)(id >> 31), ci = (int)((id >> 16) & 0x7FFFu), cj = (int)(id & 0xFFFFu);
         const int vf = a.frame0 + slot;
         const FrameDev& vfp = a.fp[vf];
-        const uint4 A = vertex_record_eye(a, vfp, vf, ci, cj, eye);
-        const uint4 v1 = vertex_record_eye(a, vfp, vf, ci + 1, pass == 0 ? cj : cj + 1, eye);
-        const uint4 v2 = vertex_record_eye(a, vfp, vf, pass == 0 ? ci + 1 : ci, cj + 1, eye);
+        const int vsel = lane < 3 ? lane : 0;                       // (as the queue walk: a vertex each by the wave's first three lanes)
+        const uint4 rec = vertex_record_eye(a, vfp, vf, ci + (vsel == 1 || (vsel == 2 && pass == 0) ? 1 : 0),
+                                            cj + (vsel == 2 || (vsel == 1 && pass != 0) ? 1 : 0), eye);
+        const uint4 A = readlane_u4(rec, 0), v1 = readlane_u4(rec, 1), v2 = readlane_u4(rec, 2);
         TriSetup t;
         if (!tri_setup_snapped(t, (int)A.x, (int)A.y, __uint_as_float(A.z), (int)v1.x, (int)v1.y, __uint_as_float(v1.z),
                                (int)v2.x, (int)v2.y, __uint_as_float(v2.z), a.cull))
@@ -669,8 +715,10 @@ __device__ __forceinline__ void mesh_huge_walk(const RenderArgs& a)
 
 __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nseg)
 {
+    extern __shared__ uint32_t cpre[];                    // (blocks + 1 + threads words: launch_mesh_raster_general)
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
-    mesh_queue_walk<0>(a, nseg);
+    queue_prefix_lds(a, nseg, cpre);
+    mesh_queue_walk<0>(a, nseg, cpre);
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 __global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a) { mesh_huge_walk<0>(a); }
@@ -686,6 +734,7 @@ __global__ void __launch_bounds__(kCellTPB) k_mesh_tie_pass(RenderArgs a, int nf
     __shared__ uint4 sv[2][2][kCellTPB];
     __shared__ uint32_t glist[2 * kConvTPB];
     __shared__ uint32_t gcount;
+    extern __shared__ uint32_t cpre[];
     uint32_t any = 0;
     for (int fr = 0; fr < nframes; ++fr) any |= a.tie_flag[fr];
     if (!any) return;                                                          // (uniform)
@@ -701,7 +750,8 @@ __global__ void __launch_bounds__(kCellTPB) k_mesh_tie_pass(RenderArgs a, int nf
             __syncthreads();
         }
     }
-    mesh_queue_walk<1>(a, nseg);
+    queue_prefix_lds(a, nseg, cpre);
+    mesh_queue_walk<1>(a, nseg, cpre);
     mesh_huge_walk<1>(a);
 }
 
@@ -713,15 +763,20 @@ __global__ void __launch_bounds__(256) k_mesh_queue_reset(RenderArgs a, int n)
     const uint32_t nseg = (uint32_t)n * (uint32_t)a.H, ntile = (uint32_t)n * 2u * (uint32_t)a.tie_words;
     if (a.debug_skip & 256) { for (uint32_t k = t; k < nseg; k += nt) atomicExch(&a.bigq_count[k], 0u); }      // (r05 diagnosis, tuning build)
     else for (uint32_t k = t; k < nseg; k += nt) a.bigq_count[k] = 0u;
+    for (uint32_t k = t; k <= ((nseg + (1u << a.bigq_shift) - 1u) >> a.bigq_shift); k += nt) a.bigq_coarse[k] = 0u;
     for (uint32_t k = t; k < ntile; k += nt) a.tie_tiles[k] = 0u;
     if (t < (uint32_t)n) a.tie_flag[t] = 0u;
     if (t < 2u) a.hugeq[2 * (size_t)kHugeCap + t] = 0u;
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
-hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
+    RenderArgs a = a_in;
     const int nseg = plan.n * a.H;
+    a.bigq_coarse = a.bigq_count + nseg;                 // (nseg + 1 words follow the segment counters: mdvt_api.hip)
+    a.bigq_shift = queue_shift_for(nseg);
+    const int ncoarse = (nseg + (1 << a.bigq_shift) - 1) >> a.bigq_shift;
     const dim3 grid_c(cell_block_grid(a.W, a.H), 1, plan.n);
     hipError_t e;
     {
@@ -739,23 +794,25 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // (banks, mdvt_render_stereo_batch: the next launch set starts once this one's cell walk is through)
     if (plan.after_vertices && (e = hipEventRecord(plan.after_vertices, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_mesh_queue_scan, dim3(1), dim3(1024), 0, s, a.bigq_count, a.bigq_count + nseg, nseg, (a.debug_skip & 512) ? 1 : 0);
-    hipLaunchKernelGGL(k_mesh_raster_queue, dim3(2048), dim3(256), 0, s, a, nseg);
+    hipLaunchKernelGGL(k_mesh_raster_queue, dim3(2048), dim3(256), (size_t)(ncoarse + 1 + 256) * sizeof(uint32_t), s, a, nseg);
     hipLaunchKernelGGL(k_mesh_raster_huge, dim3(2048), dim3(256), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (tuning_env(TUNE_QUEUE_DUMP)) {       // tuning hook: queued (large) triangles and marked frames of this launch set on stderr
         uint32_t total = 0, marked = 0;
-        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&total, a.bigq_count + 2 * nseg, 4, hipMemcpyDeviceToHost) == hipSuccess) {
+        std::vector<uint32_t> coarse((size_t)ncoarse);
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(coarse.data(), a.bigq_coarse, coarse.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (uint32_t v : coarse) total += v;
             for (int f = 0; f < plan.n; ++f) { uint32_t v = 0; if (hipMemcpy(&v, a.tie_flag + f, 4, hipMemcpyDeviceToHost) == hipSuccess) marked += v; }
             fprintf(stderr, "queued triangles: %u in %d frames (%d x %d), %u frames with pixels marked as tied\n", total, plan.n, a.W, a.H, marked);
         }
     }
     // the frames in which a pixel was marked as an exact depth tie between colours: those pixels settled by draw id (mdvt_device.h)
+    const size_t tie_lds = (size_t)(ncoarse + 1 + kCellTPB) * sizeof(uint32_t);
     if (conv) {
-        if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_tie_pass<2, true>), dim3(2048), dim3(kCellTPB), 0, s, a, plan.n, nseg);
-        else hipLaunchKernelGGL((k_mesh_tie_pass<0, true>), dim3(2048), dim3(kCellTPB), 0, s, a, plan.n, nseg);
-    } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_tie_pass<2, false>), dim3(2048), dim3(kCellTPB), 0, s, a, plan.n, nseg);
-    else hipLaunchKernelGGL((k_mesh_tie_pass<0, false>), dim3(2048), dim3(kCellTPB), 0, s, a, plan.n, nseg);
+        if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_tie_pass<2, true>), dim3(2048), dim3(kCellTPB), tie_lds, s, a, plan.n, nseg);
+        else hipLaunchKernelGGL((k_mesh_tie_pass<0, true>), dim3(2048), dim3(kCellTPB), tie_lds, s, a, plan.n, nseg);
+    } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_tie_pass<2, false>), dim3(2048), dim3(kCellTPB), tie_lds, s, a, plan.n, nseg);
+    else hipLaunchKernelGGL((k_mesh_tie_pass<0, false>), dim3(2048), dim3(kCellTPB), tie_lds, s, a, plan.n, nseg);
     return hipGetLastError();
 }
 

@@ -32,12 +32,15 @@ def diagnose(r, bad_blk, info, render_again, tag):
     lines = [f"{tag}: second render on the same context {'matches the oracle' if ok else 'DIFFERS TOO'}; block {nbytes} B, "
              f"counters at dword {off_cnt}, huge list at {off_huge}, tie flags at {off_tie} (byte {4 * off_tie})"]
     cb, cg = bad_blk[off_cnt:off_cnt + nseg], good_blk[off_cnt:off_cnt + nseg]
-    pb, pg = bad_blk[off_cnt + nseg:off_cnt + 2 * nseg + 1], good_blk[off_cnt + nseg:off_cnt + 2 * nseg + 1]
-    lines.append(f"  queued triangles: bad {int(cb.sum())} (prefix total {int(pb[-1])}), good {int(cg.sum())} (prefix total {int(pg[-1])})")
+    sh = 4                                               # (queue_shift_for, mdvt_mesh_general.hip: blocks of 2^sh segments)
+    while ((nseg + (1 << sh) - 1) >> sh) > 4096: sh += 1
+    nc = (nseg + (1 << sh) - 1) >> sh
+    pb, pg = bad_blk[off_cnt + nseg:off_cnt + nseg + nc], good_blk[off_cnt + nseg:off_cnt + nseg + nc]
+    lines.append(f"  queued triangles: bad {int(cb.sum())} (block counters' total {int(pb.sum())}), good {int(cg.sum())} (block counters' total {int(pg.sum())})")
     for sgm in np.nonzero(cb != cg)[0]:
         lines.append(f"  segment {sgm}: counter bad {int(cb[sgm])} ({kind_of(int(cb[sgm]))}) good {int(cg[sgm])}")
-    if not np.array_equal(pb, np.concatenate([[0], np.cumsum(cb, dtype=np.uint64)]).astype(np.uint32)):
-        lines.append("  bad render: prefix sums are NOT the running sums of its counters")
+    if not np.array_equal(pb, np.add.reduceat(cb, np.arange(0, nseg, 1 << sh))):
+        lines.append("  bad render: the block counters are NOT the sums of their segments' counters")
     ent_b = bad_blk[:off_cnt].reshape(-1, 2); ent_g = good_blk[:off_cnt].reshape(-1, 2)
     for sgm in range(nseg):
         nb, ng = int(cb[sgm]), int(cg[sgm])
