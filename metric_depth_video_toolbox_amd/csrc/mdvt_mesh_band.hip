@@ -39,6 +39,14 @@ namespace mdvt {
 template <int FLAGS, int TPB, bool DBG>
 __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderArgs a, int rows_per_band, int nbands)
 {
+    // The launch arguments are read where they are used, through the kernarg segment (s_load: scalar memory, no VALU slot) -- taken
+    // by value they are all loaded at entry and live in ~60 scalar registers for the whole kernel, which has 102 and wants ~250: what
+    // did not fit was spilled to VGPR lanes and came back through v_readlane, one VALU instruction each, in every row's prologue.
+    // `a` is the kernel's first parameter: offset 0 of the segment.  KARGS(p) gives a pointer the compiler cannot see through, so the
+    // loads behind it stay where they are written.
+    typedef const __attribute__((address_space(4))) RenderArgs* KArgs;
+    const KArgs ka0 = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+#define KARGS(p) KArgs p = ka0; asm volatile("" : "+s"(p))
     const int dbg = DBG ? a.debug_skip : 0;
     const uint32_t cull = DBG ? (uint32_t)a.cull : 0u;
     constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4, SEED = FLAGS & 8;
@@ -82,14 +90,15 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
 
     auto fetch_row = [&](int r) {
         if (act4) {
-            const uint32_t* dp = (const uint32_t*)(dbase + (size_t)r * a.depth_pitch) + 3 * tid;
-            const uint32_t* cp = (const uint32_t*)(cbase + (size_t)r * a.color_pitch) + 3 * tid;
+            KARGS(kp);
+            const uint32_t* dp = (const uint32_t*)(kp->depth + (size_t)f * kp->depth_stride + (size_t)r * kp->depth_pitch) + 3 * tid;
+            const uint32_t* cp = (const uint32_t*)(kp->color + (size_t)f * kp->color_stride + (size_t)r * kp->color_pitch) + 3 * tid;
             pd0 = dp[0]; pd1 = dp[1]; pd2 = dp[2];
             pc0 = cp[0]; pc1 = cp[1]; pc2 = cp[2];
             if (EDGES) {
                 const size_t ncell_ = (size_t)(W - 1) * (H - 1);
-                const uint8_t* ti = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)r * (W - 1) + 4 * tid;
-                const uint8_t* ur = a.unused + (size_t)fr * a.ws_stride_px + (size_t)r * W + 4 * tid;
+                const uint8_t* ti = kp->tri_invalid + (size_t)fr * kp->ws_stride_tri + (size_t)r * (W - 1) + 4 * tid;
+                const uint8_t* ur = kp->unused + (size_t)fr * kp->ws_stride_px + (size_t)r * W + 4 * tid;
                 pfl = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -124,19 +133,23 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
     for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
     // The loop starts one row early: that prologue pass only stages the two vertex rows of scanline k0 (so that the
     // staging code exists once).
-    RowGeom g = row_geometry(k0, a.rowcell);
-    g.c = -1;
 #pragma unroll 1
     for (int k = k0 - 1; k < k1; ++k) {
+        // this scanline's row of cells, from the table every time (16 bytes of scalar memory): carried from the iteration before --
+        // and the next row's beside it -- the geometry was eighteen scalar registers of loop state
+        RowGeom g;
+        int gnc = -1;                           // the next scanline's row of cells
+        {
+            KARGS(kt);
+            g = row_geometry(k < k0 ? k0 : k, kt->rowcell);
+            if (k < k0) g.c = -1;
+            if (k + 1 < k1) gnc = kt->rowcell[k + 1].c;
+        }
         // the vertex row the next scanline may need, in flight while this one is rasterised
-        RowGeom gn = g;
-        if (k + 1 < k1) {
-            gn = row_geometry(k + 1, a.rowcell);
-            if (gn.c >= 0) {
-                const int need = ((gn.c & 1) ? have1 : have0) != gn.c ? gn.c : gn.c + 1;
-                const int held = (need & 1) ? have1 : have0;
-                if (held != need && pf_row != need) fetch_row(need);
-            }
+        if (gnc >= 0) {
+            const int need = ((gnc & 1) ? have1 : have0) != gnc ? gnc : gnc + 1;
+            const int held = (need & 1) ? have1 : have0;
+            if (held != need && pf_row != need) fetch_row(need);
         }
         // The row constants every lane computes with, in VECTOR registers (r04): the kernel needs ~250 scalar registers for its
         // arguments, loop state and lane masks and has 102; what did not fit was spilled to VGPR lanes and read back with
@@ -298,14 +311,15 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
             ties.mode = 0;
 
             // the next scanline's vertex row replaces the one no longer needed (its last reader was the raster above)
-            if (eye == 1 && k + 1 < k1 && gn.c >= 0) {
+            if (eye == 1 && gnc >= 0) {
 #pragma unroll 1
-                for (int r = gn.c; r <= gn.c + 1; ++r)
+                for (int r = gnc; r <= gnc + 1; ++r)
                     if (((r & 1) ? have1 : have0) != r) stage_row(r);
             }
 
             // ---- resolve this eye: LDS keys -> colour-key hole test -> coalesced stores; the keys are reset on the way ----
             const bool resolving = act4 && k >= k0 && !(dbg & 2);
+            KARGS(kr);
             uint4 k01 = make_uint4(~0u, ~0u, ~0u, ~0u), k23 = k01, ek4 = k01;
             if (resolving) {
                 uint4* zq = (uint4*)zb + 2 * tid;
@@ -333,44 +347,44 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                 uint32_t o[4], mw = 0, spx[4];
                 float oz[4];
                 const uint32_t ek[4] = {ek4.x, ek4.y, ek4.z, ek4.w};
-                const uint8_t* crow_k = cbase + (size_t)k * a.color_pitch;
+                const uint8_t* crow_k = kr->color + (size_t)f * kr->color_stride + (size_t)k * kr->color_pitch;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const bool covered = !(hi[q] == ~0u && lo[q] == ~0u);          // (a settled tie has the top bit of hi cleared)
                     const uint32_t rgb = lo[q] & 0xFFFFFFu;
-                    const bool hole = !covered || rgb == a.key_rgb;          // sr:740
+                    const bool hole = !covered || rgb == kr->key_rgb;          // sr:740
                     o[q] = hole ? 0u : rgb;                                  // sr:793
                     mw |= hole ? (0xFFu << (8 * q)) : 0u;
                     if (ZOUT) oz[q] = covered ? 1.0f / row_word_iz(hi[q]) : 0.0f;
                     uint32_t esrc = ~0u;
                     if (EDGEPTS && hole && ek[q] != kEmpty32) {              // sr:776, 813-814: only where the render left a hole
-                        if (a.edge_paint) o[q] = load_px_bytes(crow_k, (int)(ek[q] & 0xFFFFu));
+                        if (kr->edge_paint) o[q] = load_px_bytes(crow_k, (int)(ek[q] & 0xFFFFu));
                         esrc = ((uint32_t)k << 16) | (ek[q] & 0xFFFFu);
                     }
-                    if (SEED && a.seed[eye]) spx[q] = seed_pixel(a, fp, f, eye, 4 * tid + q, k, hole, esrc, 1);
+                    if (SEED && kr->seed[eye]) spx[q] = seed_pixel(a, fp, f, eye, 4 * tid + q, k, hole, esrc, 1);
                 }
-                if (SEED && a.seed[eye]) {
-                    uint32_t* sp = (uint32_t*)(a.seed[eye] + (size_t)f * a.seed_stride + (size_t)k * a.seed_pitch) + 3 * tid;
+                if (SEED && kr->seed[eye]) {
+                    uint32_t* sp = (uint32_t*)(kr->seed[eye] + (size_t)f * kr->seed_stride + (size_t)k * kr->seed_pitch) + 3 * tid;
                     sp[0] = __builtin_amdgcn_perm(spx[1], spx[0], 0x04020100u);
                     sp[1] = __builtin_amdgcn_perm(spx[2], spx[1], 0x05040201u);
                     sp[2] = __builtin_amdgcn_perm(spx[3], spx[2], 0x06050402u);
                 }
-                uint32_t* op = (uint32_t*)(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)k * a.rgb_pitch) + 3 * tid;
+                uint32_t* op = (uint32_t*)(kr->rgb[eye] + (size_t)f * kr->rgb_stride + (size_t)k * kr->rgb_pitch) + 3 * tid;
                 __builtin_nontemporal_store(__builtin_amdgcn_perm(o[1], o[0], 0x04020100u), op);
                 __builtin_nontemporal_store(__builtin_amdgcn_perm(o[2], o[1], 0x05040201u), op + 1);
                 __builtin_nontemporal_store(__builtin_amdgcn_perm(o[3], o[2], 0x06050402u), op + 2);
-                __builtin_nontemporal_store(mw, (uint32_t*)(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)k * a.mask_pitch) + tid);
-                if (ZOUT && a.zout[eye]) {
+                __builtin_nontemporal_store(mw, (uint32_t*)(kr->mask[eye] + (size_t)f * kr->mask_stride + (size_t)k * kr->mask_pitch) + tid);
+                if (ZOUT && kr->zout[eye]) {
                     typedef float f32x4 __attribute__((ext_vector_type(4)));
                     const f32x4 v = {oz[0], oz[1], oz[2], oz[3]};
-                    __builtin_nontemporal_store(v, (f32x4*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)k * a.zout_pitch) + tid);
+                    __builtin_nontemporal_store(v, (f32x4*)((uint8_t*)kr->zout[eye] + (size_t)f * kr->zout_stride + (size_t)k * kr->zout_pitch) + tid);
                 }
             }
             if (had_ties) for (int x = tid; x <= ties.nwords; x += TPB) ties.bits[x] = 0u;
             __syncthreads();
         }
-        g = gn;
     }
+#undef KARGS
 }
 
 size_t mesh_band_lds_bytes(int W, int tpb, bool, bool)
