@@ -77,8 +77,6 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
     uint32_t* wq = queue + wave * kQueueWave;
     const bool act4 = tid < W4;
 
-    const uint8_t* dbase = a.depth + (size_t)f * a.depth_stride;
-    const uint8_t* cbase = a.color + (size_t)f * a.color_stride;
 
     int have0 = -1, have1 = -1;                 // vertex row held by slot 0 / 1 (uniform)
     int pf_row = -1;                            // vertex row sitting in the prefetch registers (uniform)
@@ -278,7 +276,8 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
             //      memory once its words have been read out (below); here only position and key are worked out ----
             // (the edge points of scanlines erow_lo .. erow_hi are k_edge_rows_exact's: their row is not the source row)
             if (EDGEPTS && ties.mode == 0 && k >= k0 && !edge_row_deferred(fp, k)) {
-                const uint8_t* drow_k = dbase + (size_t)k * a.depth_pitch;
+                KARGS(ke);
+                const uint8_t* drow_k = ke->depth + (size_t)f * ke->depth_stride + (size_t)k * ke->depth_pitch;
                 const float guard = edge_col_guard(W);
                 // (source row k is one of the two staged vertex rows: c(k) is k or k - 1)
                 const int4* vk = ((k & 1) ? have1 : have0) == k ? verts + (size_t)(k & 1) * W : nullptr;
@@ -288,7 +287,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
                     ept[q] = 0u;
                     if (jj >= W) continue;
                     const bool un = vk ? (((uint32_t)vk[jj].w >> 26) & 1u) != 0u
-                                       : a.unused[(size_t)fr * a.ws_stride_px + (size_t)k * W + jj] != 0;
+                                       : ke->unused[(size_t)fr * ke->ws_stride_px + (size_t)k * W + jj] != 0;
                     if (!un) continue;
                     const uint32_t code = code16_of(load_px_bytes(drow_k, jj));
                     const float z = decode_z(code, fp.mult, fp.scale);

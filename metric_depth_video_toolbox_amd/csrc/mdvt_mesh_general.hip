@@ -142,30 +142,36 @@ template <typename T> __device__ __forceinline__ uint4 readlane_u4(const uint4& 
 
 constexpr int kCellTPB = 64;          // threads per workgroup of the cell walks = vertex columns it stages
 constexpr int kCellsWG = kCellTPB - 1;   // cells per workgroup: between its 64 columns
-// The two vertex rows (i, i + 1) of columns j0 .. j0 + 63 of both eyes into sv[eye][row][column].
-__device__ __forceinline__ void stage_vertex_rows(const RenderArgs& a, int fr, int i, int j0, uint4 (&sv)[2][2][kCellTPB])
+// Vertex row `row` of columns j0 .. j0 + 63, both eyes, into ring slot `slot`: sv[eye][slot][column].
+__device__ __forceinline__ void stage_vertex_row(const RenderArgs& a, int fr, int row, int j0, uint4 (&sv)[2][2][kCellTPB], int slot)
 {
     const int t = threadIdx.x, f = a.frame0 + fr;
     const FrameDev& fp = a.fp[f];
     const int jc = min(j0 + t, a.W - 1);                                   // (clamped: columns past the row end are never used)
-    uint4 r0, r1, r2, r3;
-    vertex_records(a, fp, f, i, jc, r0, r1);
-    vertex_records(a, fp, f, i + 1, jc, r2, r3);
-    sv[0][0][t] = r0; sv[1][0][t] = r1; sv[0][1][t] = r2; sv[1][1][t] = r3;
+    uint4 r0, r1;
+    vertex_records(a, fp, f, row, jc, r0, r1);
+    sv[0][slot][t] = r0; sv[1][slot][t] = r1;
 }
+// A workgroup of the cell walks takes kRowsWG rows of cells of its 63 columns, top to bottom, its vertex rows in a ring of two: the
+// row between two rows of cells is worked out once, not by the workgroup above it AND the one below (r05, second step: with the
+// vertex programme inside the walk every vertex was computed twice per eye, ~300 of the ~1 400 instructions a cell costs).
+#ifndef MDVT_ROWS_WG
+#define MDVT_ROWS_WG 4
+#endif
+constexpr int kRowsWG = MDVT_ROWS_WG;
 // The block of cells of a workgroup of the one-thread-per-cell kernels: row-major over the frame's cells, grid x = cell_block_grid.
 // (Measured and not kept, r04: an XCD-aware deal -- workgroup b runs on XCD b % 8, each XCD with its own L2, so each XCD took a
 // contiguous eighth of the blocks and the second reader of a vertex-record row found it in the L2 the first one had filled.  The
 // rasteriser's fetch traffic fell from 145 to 71 MB per 1080p frame and its time did not move, 6 % slower under a pose: these
 // kernels wait for their atomics, not for bytes.)
-__host__ __device__ __forceinline__ uint32_t cell_blocks(int W, int H) { return (uint32_t)((W - 1 + kCellsWG - 1) / kCellsWG) * (uint32_t)(H - 1); }
+__host__ __device__ __forceinline__ uint32_t cell_row_groups(int H) { return (uint32_t)((H - 1 + kRowsWG - 1) / kRowsWG); }
+__host__ __device__ __forceinline__ uint32_t cell_blocks(int W, int H) { return (uint32_t)((W - 1 + kCellsWG - 1) / kCellsWG) * cell_row_groups(H); }
 inline uint32_t cell_block_grid(int W, int H) { return cell_blocks(W, H); }
-__device__ __forceinline__ bool cell_block_of(int W, int H, int& bx, int& i)
+// block v of a frame -> its column block bx and its first row of cells i0
+__device__ __forceinline__ void cell_block_of(int W, uint32_t v, int& bx, int& i0)
 {
-    const uint32_t v = blockIdx.x, nbx = (uint32_t)((W - 1 + kCellsWG - 1) / kCellsWG);
-    if (v >= cell_blocks(W, H)) return false;
-    bx = (int)(v % nbx); i = (int)(v / nbx);
-    return true;
+    const uint32_t nbx = (uint32_t)((W - 1 + kCellsWG - 1) / kCellsWG);
+    bx = (int)(v % nbx); i0 = (int)(v / nbx) * kRowsWG;
 }
 
 // The queue's two levels of counters.  A wave that appends n triangles to a segment (one returning atomic on the segment's counter:
@@ -255,8 +261,9 @@ __device__ __forceinline__ bool tie_tiles_hit(const FragOut& f, int bx0, int by0
 
 // One thread per cell, both triangles, both eyes.  MODE as mesh_global_fragment's; the second pass runs for the frames with a marked
 // pixel only, and only the triangles whose pixel box touches a marked tile get as far as their set-up.
+// (the caller has staged the row's two vertex rows: sv[eye][top] above, sv[eye][top ^ 1] below, and synchronised)
 template <int FLAGS, int MODE>
-__device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kCellTPB], Pending (&pds)[2])
+__device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kCellTPB], int top, Pending (&pds)[2])
 {
     constexpr bool EDGES = FLAGS & 2;
     const int W = a.W, H = a.H;
@@ -266,12 +273,10 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     // the 2 x kCellTPB vertex records of both eyes, computed once per workgroup
     uint32_t inv0 = 0, inv1 = 0;
-    stage_vertex_rows(a, fr, i, bx * kCellsWG, sv);
     if (EDGES && act) {
         const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
         inv0 = tinv[0]; inv1 = tinv[ncell];
     }
-    __syncthreads();
     bool tq[2][2] = {{false, false}, {false, false}};          // [eye][triangle of the cell]: goes to the queue
     // (unrolled: each eye has its own pending word, so the left eye's last post is in flight while the right eye is rasterised)
 #pragma unroll
@@ -281,7 +286,7 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
         uint4 A = make_uint4(0, 0, 0, 0), B = A, Cv = A, D = A;
         if (act) {
             const int t = threadIdx.x;
-            A = sv[eye][0][t]; D = sv[eye][0][t + 1]; B = sv[eye][1][t]; Cv = sv[eye][1][t + 1];
+            A = sv[eye][top][t]; D = sv[eye][top][t + 1]; B = sv[eye][top ^ 1][t]; Cv = sv[eye][top ^ 1][t + 1];
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -349,16 +354,25 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
     }
 }
 
-// First pass: a workgroup per block of cells (grid: cell_block_grid x 1 x frames).
+// First pass: a workgroup per block of 63 x kRowsWG cells (grid: cell_block_grid x 1 x frames).
 template <int FLAGS>
 __global__ void __launch_bounds__(kCellTPB) k_mesh_raster_small(RenderArgs a)
 {
     __shared__ uint4 sv[2][2][kCellTPB];
     Pending pds[2] = {pending_none(), pending_none()};
-    int bx, i;
-    if (!cell_block_of(a.W, a.H, bx, i)) return;
+    if (blockIdx.x >= cell_blocks(a.W, a.H)) return;
+    int bx, i0;
+    cell_block_of(a.W, blockIdx.x, bx, i0);
+    const int fr = (int)blockIdx.z;
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
-    mesh_raster_small_block<FLAGS, 0>(a, (int)blockIdx.z, bx, i, sv, pds);
+    stage_vertex_row(a, fr, i0, bx * kCellsWG, sv, 0);
+#pragma unroll 1
+    for (int r = 0; r < kRowsWG && i0 + r < a.H - 1; ++r) {
+        stage_vertex_row(a, fr, i0 + r + 1, bx * kCellsWG, sv, (r + 1) & 1);
+        __syncthreads();
+        mesh_raster_small_block<FLAGS, 0>(a, fr, bx, i0 + r, sv, r & 1, pds);
+        __syncthreads();                                   // (the row above is replaced next: its last readers are through)
+    }
     pending_settle(a, pds[0]);
     pending_settle(a, pds[1]);
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -392,7 +406,7 @@ constexpr int kConvTPB = 64;          // cells (threads) per workgroup of k_mesh
 // MODE as mesh_global_fragment's (second pass: the same classification of the cells as in the first, so that every fragment of the
 // first pass is met again -- here, or in the first pass's lists of queued triangles, which this pass does not add to).
 template <int FLAGS, int MODE>
-__device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kConvTPB],
+__device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int fr, int bx, int i, uint4 (&sv)[2][2][kConvTPB], int top,
                                                        uint32_t (&glist)[2 * kConvTPB], uint32_t& gcount, Pending& pd)
 {
     constexpr bool EDGES = FLAGS & 2;
@@ -403,13 +417,12 @@ __device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int 
     const bool act = j < W - 1 && threadIdx.x < kCellsWG;
     const size_t ncell = (size_t)(W - 1) * (H - 1);
     uint32_t inv0 = 0, inv1 = 0;
-    stage_vertex_rows(a, fr, i, bx * kCellsWG, sv);
     if (EDGES && act) {
         const uint8_t* tinv = a.tri_invalid + (size_t)fr * a.ws_stride_tri + (size_t)i * (W - 1) + j;
         inv0 = tinv[0]; inv1 = tinv[ncell];
     }
     if (threadIdx.x == 0) gcount = 0u;
-    __syncthreads();
+    __syncthreads();                                       // (also: the caller's vertex rows are staged)
     const uint32_t cull = (uint32_t)a.cull;
     // (not unrolled with a pending word per eye, as k_mesh_raster_small is: measured, product default 2640 -> 2750 us per 32 frames)
 #pragma unroll 1
@@ -417,7 +430,7 @@ __device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int 
         if (!act || (inv0 && inv1)) continue;
         const FragOut fo = frag_out(a, fr, eye);
         const int t = threadIdx.x;
-        const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
+        const uint4 A = sv[eye][top][t], D = sv[eye][top][t + 1], B = sv[eye][top ^ 1][t], Cv = sv[eye][top ^ 1][t + 1];
         const int XA = (int)A.x, YA = (int)A.y, XB = (int)B.x, YB = (int)B.y, XC = (int)Cv.x, YC = (int)Cv.y, XD = (int)D.x, YD = (int)D.y;
         const float izA = __uint_as_float(A.z), izB = __uint_as_float(B.z), izC = __uint_as_float(Cv.z), izD = __uint_as_float(D.z);
         if (!(izA > 0.0f)) continue;                                   // A is a vertex of both triangles: near plane, both dropped
@@ -479,7 +492,7 @@ __device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int 
         const int t = (int)(ent & 0xFFu), eye = (int)(ent >> 8), pass = (int)(idx & 1u);
         const int cj = bx * kCellsWG + t;
         const FragOut fo = frag_out(a, fr, eye);
-        const uint4 A = sv[eye][0][t], D = sv[eye][0][t + 1], B = sv[eye][1][t], Cv = sv[eye][1][t + 1];
+        const uint4 A = sv[eye][top][t], D = sv[eye][top][t + 1], B = sv[eye][top ^ 1][t], Cv = sv[eye][top ^ 1][t + 1];
         const uint4 v1 = pass == 0 ? B : Cv, v2 = pass == 0 ? Cv : D;
         const uint32_t did = draw_id_global(pass, i, cj);
         bool removed = false;
@@ -540,11 +553,19 @@ __global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
     __shared__ uint4 sv[2][2][kConvTPB];
     __shared__ uint32_t glist[2 * kConvTPB];  // cells (thread | eye << 8) for the generic code
     __shared__ uint32_t gcount;
-    const uint32_t nbx = (uint32_t)((a.W - 1 + kCellsWG - 1) / kCellsWG);
-    if (blockIdx.x >= nbx * (uint32_t)(a.H - 1)) return;
+    if (blockIdx.x >= cell_blocks(a.W, a.H)) return;
+    int bx, i0;
+    cell_block_of(a.W, blockIdx.x, bx, i0);
+    const int fr = (int)blockIdx.z;
     Pending pd = pending_none();
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
-    mesh_raster_conv_block<FLAGS, 0>(a, (int)blockIdx.z, (int)(blockIdx.x % nbx), (int)(blockIdx.x / nbx), sv, glist, gcount, pd);
+    stage_vertex_row(a, fr, i0, bx * kCellsWG, sv, 0);
+#pragma unroll 1
+    for (int r = 0; r < kRowsWG && i0 + r < a.H - 1; ++r) {
+        stage_vertex_row(a, fr, i0 + r + 1, bx * kCellsWG, sv, (r + 1) & 1);
+        mesh_raster_conv_block<FLAGS, 0>(a, fr, bx, i0 + r, sv, r & 1, glist, gcount, pd);      // (synchronises before it reads the rows)
+        __syncthreads();                                   // (the row above and the list are replaced next)
+    }
     pending_settle(a, pd);
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
@@ -739,14 +760,18 @@ __global__ void __launch_bounds__(kCellTPB) k_mesh_tie_pass(RenderArgs a, int nf
     for (int fr = 0; fr < nframes; ++fr) any |= a.tie_flag[fr];
     if (!any) return;                                                          // (uniform)
     Pending pds[2] = {pending_none(), pending_none()};                         // (unused in this mode)
-    const uint32_t nblk = cell_blocks(a.W, a.H), nbx = (uint32_t)((a.W - 1 + kCellsWG - 1) / kCellsWG);
+    const uint32_t nbx = (uint32_t)((a.W - 1 + kCellsWG - 1) / kCellsWG), nblk = nbx * (uint32_t)(a.H - 1);      // (here: a row of cells each)
     for (int fr = 0; fr < nframes; ++fr) {
         if (a.tie_flag[fr] == 0u) continue;                                    // (workgroup uniform)
         for (uint32_t v = blockIdx.x; v < nblk; v += gridDim.x) {
+            const int bx = (int)(v % nbx), i = (int)(v / nbx);
+            stage_vertex_row(a, fr, i, bx * kCellsWG, sv, 0);
+            stage_vertex_row(a, fr, i + 1, bx * kCellsWG, sv, 1);
+            __syncthreads();
             // (the cells classified as the first pass classified them: k_mesh_raster_conv draws spans itself that k_mesh_raster_small
             //  would have queued)
-            if (CONV) mesh_raster_conv_block<FLAGS, 1>(a, fr, (int)(v % nbx), (int)(v / nbx), sv, glist, gcount, pds[0]);
-            else mesh_raster_small_block<FLAGS, 1>(a, fr, (int)(v % nbx), (int)(v / nbx), sv, pds);
+            if (CONV) mesh_raster_conv_block<FLAGS, 1>(a, fr, bx, i, sv, 0, glist, gcount, pds[0]);
+            else mesh_raster_small_block<FLAGS, 1>(a, fr, bx, i, sv, 0, pds);
             __syncthreads();
         }
     }
