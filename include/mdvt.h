@@ -67,8 +67,13 @@ typedef struct mdvt_config {
     double ipd_m;                /* --pupillary_distance / 1000 (sr:458-459)                         */
     double max_depth;            /* --max_depth (dfh:22)                                             */
     uint8_t key_rgb[4];          /* bg_color*255: (0,0,0), or (0,255,0) with --infill_mask (sr:555-558) */
-    uint32_t workspace_mib;      /* budget, in MiB, for the library-owned workspace of the posed / converged mesh path (about 100 B per
-                                    pixel and frame in flight: it sets how many frames one launch set takes, 1 ... 16); 0 = 4096 */
+    uint32_t workspace_mib;      /* budget, in MiB, for the slots of the posed / converged MESH path only (about 64-90 B per pixel and
+                                    frame in flight: it sets how many frames one launch set takes, 1 ... 16); 0 = 4096, more than
+                                    1048576 is refused.  Not covered: the four slots of the posed points path, the second huge-triangle
+                                    list, the infill-mask completion and normal-infill workspaces (mdvt_workspace_bytes reports all of
+                                    it).  Blocks already held are kept when the budget is lowered: they return to the process-wide pool
+                                    with the context (mdvt_release_cached_memory gives them back to the driver).  The field took over
+                                    `reserved1` of ABI 0.11: callers built against 0.11 must zero it.                              */
 } mdvt_config;
 
 /* Per-frame parameters: what sr:515-541, 563-566 and 707-721 compute before the render calls. */

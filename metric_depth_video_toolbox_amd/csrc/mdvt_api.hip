@@ -626,6 +626,9 @@ int mdvt_set_config(mdvt_ctx* c, const mdvt_config* cfg)
     if (cfg->edge_points < 0 || cfg->edge_points > 2) return fail(c, MDVT_ERR_INVALID_ARG, "edge_points must be 0, 1 or 2");
     if (cfg->edge_points && !cfg->remove_edges) return fail(c, MDVT_ERR_INVALID_ARG, "edge_points needs remove_edges (sr:589)");
     if (cfg->cull < 0 || cfg->cull > 2) return fail(c, MDVT_ERR_INVALID_ARG, "cull must be 0 (none), 1 (back) or 2 (front)");
+    // (advisor r04: the field took over a reserved one -- a caller built against 0.11 that left it uninitialised must not get an
+    //  arbitrary budget silently: anything above 1 TiB is refused, small values are honoured down to one slot)
+    if (cfg->workspace_mib > (1u << 20)) return fail(c, MDVT_ERR_INVALID_ARG, "workspace_mib %u out of range (0 = default 4096, at most 1048576)", cfg->workspace_mib);
     c->cfg = *cfg;
     c->cfg_set = true;
     return MDVT_OK;
@@ -838,9 +841,17 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
       // filter fill the rasteriser's waits: 32 frames of 1080p product default +3 %, mesh + convergence +4 %, mesh under a pose +7 %,
       // 8 frames of 4K pose + contention (C4) +10 %; a run that fits ONE launch set stays as it is (16 frames: two sets of 8 lose 1.5 %).
       // Points on the general path likewise (splat, then resolve: the next set's splat beside this set's resolve): C4 points +13 %.
-      const bool banks = r.general && !r.conv && chunk >= 2 && r.f1 - r.f0 > chunk && !want_bits &&
-                         !io->hole_counts && tuning_env(TUNE_WS_CHUNK) == nullptr;
-      const int bank_slots = chunk / 2;
+      const bool bankable = r.general && !r.conv && !want_bits && !io->hole_counts && tuning_env(TUNE_WS_CHUNK) == nullptr;
+      bool banks = bankable && chunk >= 2 && r.f1 - r.f0 > chunk;
+      int bank_slots = chunk / 2;
+      // r05: a posed mesh run that FITS one launch set is split into two sets on the two banks all the same when each half is large
+      // enough to fill the chip by itself (24 M pixels: 3 frames of 4K) -- since the vertex records went (64 B/px per slot, was 96) the
+      // 8 frames of C4 are one set of 8 slots, and its cell walk (VALU) and resolve (HBM) ran one after the other again
+      if (bankable && !banks && plan.mode == MDVT_MODE_MESH && r.f1 - r.f0 <= chunk && r.f1 - r.f0 >= 4 &&
+          (size_t)((r.f1 - r.f0) / 2) * (size_t)W * (size_t)H >= ((size_t)24 << 20)) {
+          banks = true;
+          bank_slots = (r.f1 - r.f0) / 2;
+      }
       hipStream_t const s_call = s;
       // (every way out of the bank loop joins the side stream back into the caller's: an error return must not leave the side
       //  stream working on its half of the workspace -- and on the caller's output buffers -- behind the caller's back; advisor, r04)

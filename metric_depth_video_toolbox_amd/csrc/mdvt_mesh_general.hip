@@ -158,20 +158,29 @@ __device__ __forceinline__ void stage_vertex_row(const RenderArgs& a, int fr, in
 #ifndef MDVT_ROWS_WG
 #define MDVT_ROWS_WG 4
 #endif
-constexpr int kRowsWG = MDVT_ROWS_WG;
-// The block of cells of a workgroup of the one-thread-per-cell kernels: row-major over the frame's cells, grid x = cell_block_grid.
+#ifndef MDVT_ROWS_WG_CONV_EDGES
+#define MDVT_ROWS_WG_CONV_EDGES 1
+#endif
+// Per kernel: four rows everywhere except the scanline walk with edge removal (k_mesh_raster_conv<2>, the product default's), which
+// is no faster for it (12.3 k frames/s against 12.45 k with one row: the row loop costs it 21 VGPRs -- 80 -> 101, six waves per SIMD
+// -> four -- where the others pay 15 and keep five).  Measured, same box: mesh + convergence 14.8 -> 16.3 k frames/s, mesh under a
+// pose 12.7 -> 13.8 k (13.1 k with edge removal, from 12.3 k), C4 mesh 2.29 -> 2.42 k; two rows give half of it, eight no more.
+__host__ __device__ constexpr int rows_wg(int flags, bool conv) { return (conv && (flags & 2)) ? MDVT_ROWS_WG_CONV_EDGES : MDVT_ROWS_WG; }
+// ... and the occupancy each is compiled for (waves per SIMD; 1 = whatever the registers come to).  The row loop takes 87-93 VGPRs
+// (five waves); held to 80 (six waves, a few dwords of scratch) the triangle walk without edge removal gains 2 % under a pose and the
+// one-row scanline walk with edge removal gets back to what it was (86 -> 80: 12.26 -> 12.5 k frames/s), the other two lose 3-5 %.
+__host__ __device__ constexpr int cell_waves(int flags, bool conv) { return conv == ((flags & 2) != 0) ? 6 : 1; }
+// The block of cells of a workgroup of the one-thread-per-cell kernels: row-major over the frame's cells, grid x = cell_blocks.
 // (Measured and not kept, r04: an XCD-aware deal -- workgroup b runs on XCD b % 8, each XCD with its own L2, so each XCD took a
 // contiguous eighth of the blocks and the second reader of a vertex-record row found it in the L2 the first one had filled.  The
 // rasteriser's fetch traffic fell from 145 to 71 MB per 1080p frame and its time did not move, 6 % slower under a pose: these
 // kernels wait for their atomics, not for bytes.)
-__host__ __device__ __forceinline__ uint32_t cell_row_groups(int H) { return (uint32_t)((H - 1 + kRowsWG - 1) / kRowsWG); }
-__host__ __device__ __forceinline__ uint32_t cell_blocks(int W, int H) { return (uint32_t)((W - 1 + kCellsWG - 1) / kCellsWG) * cell_row_groups(H); }
-inline uint32_t cell_block_grid(int W, int H) { return cell_blocks(W, H); }
+__host__ __device__ __forceinline__ uint32_t cell_blocks(int W, int H, int rows) { return (uint32_t)((W - 1 + kCellsWG - 1) / kCellsWG) * (uint32_t)((H - 1 + rows - 1) / rows); }
 // block v of a frame -> its column block bx and its first row of cells i0
-__device__ __forceinline__ void cell_block_of(int W, uint32_t v, int& bx, int& i0)
+__device__ __forceinline__ void cell_block_of(int W, uint32_t v, int rows, int& bx, int& i0)
 {
     const uint32_t nbx = (uint32_t)((W - 1 + kCellsWG - 1) / kCellsWG);
-    bx = (int)(v % nbx); i0 = (int)(v / nbx) * kRowsWG;
+    bx = (int)(v % nbx); i0 = (int)(v / nbx) * rows;
 }
 
 // The queue's two levels of counters.  A wave that appends n triangles to a segment (one returning atomic on the segment's counter:
@@ -354,15 +363,16 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
     }
 }
 
-// First pass: a workgroup per block of 63 x kRowsWG cells (grid: cell_block_grid x 1 x frames).
+// First pass: a workgroup per block of 63 x kRowsWG cells (grid: cell_blocks x 1 x frames).
 template <int FLAGS>
-__global__ void __launch_bounds__(kCellTPB) k_mesh_raster_small(RenderArgs a)
+__global__ void __launch_bounds__(kCellTPB, cell_waves(FLAGS, false)) k_mesh_raster_small(RenderArgs a)
 {
     __shared__ uint4 sv[2][2][kCellTPB];
     Pending pds[2] = {pending_none(), pending_none()};
-    if (blockIdx.x >= cell_blocks(a.W, a.H)) return;
+    constexpr int kRowsWG = rows_wg(FLAGS, false);
+    if (blockIdx.x >= cell_blocks(a.W, a.H, kRowsWG)) return;
     int bx, i0;
-    cell_block_of(a.W, blockIdx.x, bx, i0);
+    cell_block_of(a.W, blockIdx.x, kRowsWG, bx, i0);
     const int fr = (int)blockIdx.z;
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
     stage_vertex_row(a, fr, i0, bx * kCellsWG, sv, 0);
@@ -548,14 +558,15 @@ __device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int 
 }
 
 template <int FLAGS>
-__global__ void __launch_bounds__(kConvTPB) k_mesh_raster_conv(RenderArgs a)
+__global__ void __launch_bounds__(kConvTPB, cell_waves(FLAGS, true)) k_mesh_raster_conv(RenderArgs a)
 {
     __shared__ uint4 sv[2][2][kConvTPB];
     __shared__ uint32_t glist[2 * kConvTPB];  // cells (thread | eye << 8) for the generic code
     __shared__ uint32_t gcount;
-    if (blockIdx.x >= cell_blocks(a.W, a.H)) return;
+    constexpr int kRowsWG = rows_wg(FLAGS, true);
+    if (blockIdx.x >= cell_blocks(a.W, a.H, kRowsWG)) return;
     int bx, i0;
-    cell_block_of(a.W, blockIdx.x, bx, i0);
+    cell_block_of(a.W, blockIdx.x, kRowsWG, bx, i0);
     const int fr = (int)blockIdx.z;
     Pending pd = pending_none();
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
@@ -802,7 +813,7 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
     a.bigq_coarse = a.bigq_count + nseg;                 // (nseg + 1 words follow the segment counters: mdvt_api.hip)
     a.bigq_shift = queue_shift_for(nseg);
     const int ncoarse = (nseg + (1 << a.bigq_shift) - 1) >> a.bigq_shift;
-    const dim3 grid_c(cell_block_grid(a.W, a.H), 1, plan.n);
+    const dim3 grid_c(cell_blocks(a.W, a.H, rows_wg(plan.remove_edges ? 2 : 0, false)), 1, plan.n);
     hipError_t e;
     {
         const uint32_t words = (uint32_t)nseg + (uint32_t)plan.n * 2u * (uint32_t)a.tie_words;
@@ -811,7 +822,7 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
     const bool conv = plan.conv_raster && tuning_env(TUNE_RASTER_CONV_OFF) == nullptr;
     if (conv) {
         // frames with nothing but a toe-in (every frame of the launch: plan.conv_raster): scanline intervals instead of triangles
-        const dim3 grid_v(cell_block_grid(a.W, a.H), 1, plan.n);
+        const dim3 grid_v(cell_blocks(a.W, a.H, rows_wg(plan.remove_edges ? 2 : 0, true)), 1, plan.n);
         if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_conv<2>), grid_v, dim3(kConvTPB), 0, s, a);
         else hipLaunchKernelGGL((k_mesh_raster_conv<0>), grid_v, dim3(kConvTPB), 0, s, a);
     } else if (plan.remove_edges) hipLaunchKernelGGL((k_mesh_raster_small<2>), grid_c, dim3(kCellTPB), 0, s, a);

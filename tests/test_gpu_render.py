@@ -668,6 +668,11 @@ def test_invalid_arguments_return_codes(mods):
     assert L.mdvt_set_config(r.ctx.handle, C.byref(cfg)) == -1
     cfg = _lib.MdvtConfig(mode=0, edge_points=1, remove_edges=0, ipd_m=0.065, max_depth=100.0)
     assert L.mdvt_set_config(r.ctx.handle, C.byref(cfg)) == -1
+    # (advisor r04) workspace_mib took over a reserved field: garbage from a caller built against the older header is refused
+    cfg = _lib.MdvtConfig(mode=1, ipd_m=0.065, max_depth=100.0, workspace_mib=0xCDCDCDCD)
+    assert L.mdvt_set_config(r.ctx.handle, C.byref(cfg)) == -1 and b"workspace_mib" in L.mdvt_last_error(r.ctx.handle)
+    cfg = _lib.MdvtConfig(mode=1, ipd_m=0.065, max_depth=100.0, workspace_mib=1 << 20)
+    assert L.mdvt_set_config(r.ctx.handle, C.byref(cfg)) == 0
     r.close()
 
 
