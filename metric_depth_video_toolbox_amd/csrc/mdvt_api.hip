@@ -472,7 +472,8 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
             MDVT_HIP(c, ws_malloc(c, (void**)&c->ekeys[e], nf * npx * sizeof(unsigned long long), s));
             MDVT_HIP(c, hipMemsetAsync(c->ekeys[e], 0xFF, nf * npx * sizeof(unsigned long long), s));
         }
-        MDVT_HIP(c, ws_malloc(c, (void**)&c->elist, (nf * 2 * npx + nf * (size_t)c->H) * sizeof(uint32_t), s));
+        // (+ the vertex list of the mesh path's edge-point splat: npx entries and a counter per slot)
+        MDVT_HIP(c, ws_malloc(c, (void**)&c->elist, (nf * 2 * npx + nf * (size_t)c->H + nf * npx + nf) * sizeof(uint32_t), s));
         MDVT_HIP(c, hipMemsetAsync(c->elist + nf * 2 * npx, 0, nf * (size_t)c->H * sizeof(uint32_t), s));   // counters; the reset pass keeps them 0
         c->ws_ekeys = true;
     }
@@ -754,8 +755,8 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
             if ((size_t)ws_chunk > fit) ws_chunk = fit < 1 ? 1 : (int)fit;
             // ... and the slots have to fit the context's workspace budget (mdvt_config.workspace_mib, default 4 GiB: 16 slots at
             // 1080p, 8 at 3840 x 2160 -- where 16 would be 8.5 GB): per slot and pixel 16 B of z keys, 16 B of tie side words,
-            // 32 B of triangle queue, with edge points 24 B of edge keys and their list, 3 B of filter flags
-            const size_t per_slot = (size_t)W * (size_t)H * (16 + 16 + 32 + (plan.edge_points ? 24 : 0) + (plan.remove_edges ? 3 : 0));
+            // 32 B of triangle queue, with edge points 28 B of edge keys, their list and the vertex list, 3 B of filter flags
+            const size_t per_slot = (size_t)W * (size_t)H * (16 + 16 + 32 + (plan.edge_points ? 28 : 0) + (plan.remove_edges ? 3 : 0));
             const size_t budget = (size_t)(c->cfg.workspace_mib ? c->cfg.workspace_mib : 4096u) << 20;
             const size_t afford = budget / per_slot;
             if ((size_t)ws_chunk > afford) ws_chunk = afford < 1 ? 1 : (int)afford;
@@ -805,6 +806,8 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.keys[0] = c->keys[0]; a.keys[1] = c->keys[1];
     a.ekeys[0] = c->ekeys[0]; a.ekeys[1] = c->ekeys[1];
     a.elist = c->elist; a.elist_count = c->elist ? c->elist + (size_t)c->ws_frames * 2 * (size_t)W * H : nullptr;
+    a.vlist = c->elist ? a.elist_count + (size_t)c->ws_frames * H : nullptr;
+    a.vlist_count = c->elist ? a.vlist + (size_t)c->ws_frames * (size_t)W * H : nullptr;
     a.cbuf[0] = c->cbuf[0]; a.cbuf[1] = c->cbuf[1];
     a.tri_invalid = c->tri_invalid; a.unused = c->unused;
     if (c->bigq) {
@@ -886,7 +889,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                 if (a.cbuf[e]) a.cbuf[e] += px0;
                 if (a.ekeys[e]) a.ekeys[e] += px0;
             }
-            if (a.elist) { a.elist += (size_t)slot0 * 2 * (size_t)W * H; a.elist_count += (size_t)slot0 * H; }
+            if (a.elist) { a.elist += (size_t)slot0 * 2 * (size_t)W * H; a.elist_count += (size_t)slot0 * H; a.vlist += px0; a.vlist_count += slot0; }
             if (a.tri_invalid) a.tri_invalid += (size_t)slot0 * a.ws_stride_tri;
             if (a.unused) a.unused += px0;
             if (a.bigq) {

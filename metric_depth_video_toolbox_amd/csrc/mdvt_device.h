@@ -126,6 +126,23 @@ __device__ __forceinline__ Vert vertex_general(const FrameDev& f, const float* M
     return o;
 }
 
+// vertex_general for a frame with nothing but a toe-in (FrameDev.conv_band: fill_frame_dev has checked M[1] = M[4] = M[6] = M[7] = M[9] =
+// M[11] = 0 and M[5] = 1 EXACTLY): the products with those entries are +-0 and the sums with them change nothing, so X, Y = yc
+// and Z' come out bit for bit as vertex_general's with eleven operations fewer per eye -- except for the SIGN of a zero (x + 0 is +0
+// where x is -0), which no result depends on: a zero X or Y gives u = cxr, v = cyr either way, and Z' = +-0 is a vertex behind the
+// near plane whose record carries iz = 0 and is never looked at.
+__device__ __forceinline__ Vert vertex_conv_only(const FrameDev& f, const float* M, float xc, float yc, float z)
+{
+    Vert o;
+    const float X = (M[0] * xc + M[2] * z) + M[3];
+    const float Z = M[8] * xc + M[10] * z;
+    o.ok = (z > kNear) && (Z > kNear);
+    o.u = (f.fxr * X) / Z + f.cxr;
+    o.v = (f.fyr * yc) / Z + f.cyr;
+    o.z = Z;
+    return o;
+}
+
 // The frame's own arithmetic for kernels that serve both kinds of frame: the general 3x4 map, or
 // for a pure-shift frame u = gx +- dl/Z, v = gy exactly as the LDS row kernels evaluate it (frames too wide for
 // their LDS z-buffers are rendered by the global-key kernels and must not change a bit because of it).

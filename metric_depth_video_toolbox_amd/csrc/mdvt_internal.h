@@ -77,6 +77,8 @@ struct RenderArgs {
     unsigned long long* ekeys[2];// edge-point keys per eye
     uint32_t* elist;             // the edge-key words written since the last resolve, one segment of 2 W entries (eye << 31 | pixel) per
     uint32_t* elist_count;       //   (slot, source row) and its counter: k_edge_keys_reset empties exactly those words
+    uint32_t* vlist;             // mesh, general path: the vertices of removed triangles of a slot's frame as a list (source row << 16 | column),
+    uint32_t* vlist_count;       //   [slot][H*W] entries + [slot] counters: what k_edge_points_splat_list runs the f64 chain over
     unsigned long long* cbuf[2]; // general mesh path: per-eye side words of the pixels with an exact depth tie between colours (draw id << 32 | rgb,
                                  //   minimum over the fragments at the winning depth); touched at those pixels only
     uint32_t* tie_flag;          // [slot]: a pixel of the slot's frame was marked as tied in this use (zeroed per launch set)
@@ -136,7 +138,7 @@ hipError_t launch_mesh_band3(const RenderPlan& plan, const RenderArgs& a, hipStr
 bool mesh_conv_supported(const RenderPlan& plan, const RenderArgs& a);
 hipError_t launch_mesh_conv(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
 // the general paths' edge-point splat into the global edge keys, and the pass that empties the written words again
-hipError_t launch_edge_points_splat(const RenderArgs& a, int n, hipStream_t s);
+hipError_t launch_edge_points_splat(const RenderArgs& a, int n, bool as_list, bool counters_zeroed, hipStream_t s);
 hipError_t launch_edge_keys_reset(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_edge_point_pixels(const uint8_t* depth, size_t pitch, const FrameDev* fp, int W, int H, int of_by_one, int how,
                                     int32_t* out, hipStream_t s);

@@ -855,13 +855,28 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
 // point's source row: at most one word per vertex and eye, so 2 W entries hold them all): the resolve pass then reads the
 // edge keys only where the render left a hole, and k_edge_keys_reset empties exactly the written words -- instead of the
 // resolve rewriting the whole plane (8 B/px per eye) for the ~3 % of the words that were touched.
-__device__ __forceinline__ void post_edge_key(const RenderArgs& a, int eye, int fr, int src_row, size_t pix, u64 key)
+// The lanes of a wave that reach this together (`on`: this lane has a key to post) list their first writes with ONE atomic per
+// source row among them (r05): neighbouring lanes work on neighbouring vertices of one source row, and a returning atomic per lane on
+// that row's counter -- ~60 of them per row from all over the chip -- was most of the splat's time (96 us per 8 frames for 428
+// instructions a vertex).
+__device__ __forceinline__ void post_edge_key(const RenderArgs& a, int eye, int fr, int src_row, bool on, size_t pix, u64 key)
 {
-    const u64 old = atomicMin(&a.ekeys[eye][(size_t)fr * a.ws_stride_px + pix], key);
-    if (old == kEmpty64) {
-        const size_t seg = (size_t)fr * a.H + src_row;
-        const uint32_t k = atomicAdd(&a.elist_count[seg], 1u);
-        a.elist[seg * (size_t)(2 * a.W) + k] = ((uint32_t)eye << 31) | (uint32_t)pix;
+    u64 old = 0ull;
+    if (on) old = atomicMin(&a.ekeys[eye][(size_t)fr * a.ws_stride_px + pix], key);
+    const bool first = on && old == kEmpty64;
+    const int lane = (int)(threadIdx.x & 63u);
+    u64 m = __ballot(first);
+    while (m) {                                                     // (uniform over the lanes that are here)
+        const int l = __ffsll((long long)m) - 1;
+        const int row = __builtin_amdgcn_readlane(src_row, l);
+        const bool mine = first && src_row == row;
+        const u64 same = __ballot(mine);
+        const size_t seg = (size_t)fr * a.H + row;
+        uint32_t base = 0;
+        if (lane == l) base = atomicAdd(&a.elist_count[seg], (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, l);
+        if (mine) a.elist[seg * (size_t)(2 * a.W) + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = ((uint32_t)eye << 31) | (uint32_t)pix;
+        m &= ~same;
     }
 }
 
@@ -914,32 +929,87 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
         EdgePx ep;
         edge_point_pixels(fp, W, H, i, j, fp.sx != 1.0f, z, ep);          // the reference's f64 chain (mdvt_device.h)
 #pragma unroll
-        for (int eye = 0; eye < 2; ++eye) {
-            if (!ep.ok[eye]) continue;
-            post_edge_key(a, eye, fr, i, (size_t)ep.y[eye] * W + ep.x[eye], ((u64)ep.zkey[eye] << 32) | src);
-        }
+        for (int eye = 0; eye < 2; ++eye)
+            post_edge_key(a, eye, fr, i, ep.ok[eye], (size_t)ep.y[eye] * W + ep.x[eye], ((u64)ep.zkey[eye] << 32) | src);
     }
 }
 
-// Mesh mode only splats the removed vertices (~3 % of the grid).  The pass is a 1 B/px scan of the `unused` flags, four per thread as
-// one dword, and the vertex programme -- the reference's f64 chain, ~10^3 instructions -- for the few flagged vertices.  A workgroup
-// scans kSplatRows source rows and COMPACTS the flagged vertices of all of them into one list in LDS (r05), running the chain over
-// the list 256 vertices at a time: with the per-wave compaction of r03/r04 (a wave = 256 columns of one row) nearly every wave ran
-// the chain for the two or three vertices it had found, 12.7 us per 1080p frame for 3.8 MB of traffic.  W % 4 == 0 (launcher).
-constexpr int kSplatRows = 8;
-__device__ __forceinline__ void edge_point_splat_one(const RenderArgs& a, const FrameDev& fp, const uint8_t* dbase, int fr, uint32_t e)
+// Mesh mode only splats the removed vertices (~3 % of the grid): the reference's f64 chain, ~10^3 instructions a vertex.  Two launches
+// (r05): k_edge_vertices_list turns the 1 B/px plane of `unused` flags into a compact per-frame list of vertices (source row << 16 |
+// column; one atomic per workgroup of 16 K pixels), k_edge_points_splat_list runs the chain over the list with every lane busy.
+// Until r05 one kernel did both, a workgroup per 8 source rows compacting into LDS: 135 workgroups per 1080p frame, each a chain of
+// 15 load / append / barrier steps and two rounds of the chain -- 11.6 us per frame for 3.8 MB, latency all of it.  W % 4 == 0.
+// (`valid`: this lane has a vertex; every lane of the wave comes along for post_edge_key's sake)
+__device__ __forceinline__ void edge_point_splat_one(const RenderArgs& a, const FrameDev& fp, const uint8_t* dbase, int fr, uint32_t e, bool valid)
 {
     const int i = (int)(e >> 16), j = (int)(e & 0xFFFFu);
-    const float z = decode_z(code16_of(load_px_bytes(dbase + (size_t)i * a.depth_pitch, j)), fp.mult, fp.scale);
-    if (!(z > kNear)) return;
     EdgePx ep;
-    edge_point_pixels(fp, a.W, a.H, i, j, 1, z, ep);                      // the reference's f64 chain (mdvt_device.h)
+    ep.ok[0] = ep.ok[1] = false;
+    ep.x[0] = ep.x[1] = ep.y[0] = ep.y[1] = 0;
+    ep.zkey[0] = ep.zkey[1] = 0u;
+    if (valid) {
+        const float z = decode_z(code16_of(load_px_bytes(dbase + (size_t)i * a.depth_pitch, j)), fp.mult, fp.scale);
+        if (z > kNear) edge_point_pixels(fp, a.W, a.H, i, j, 1, z, ep);  // the reference's f64 chain (mdvt_device.h)
+    }
 #pragma unroll
-    for (int eye = 0; eye < 2; ++eye) {
-        if (!ep.ok[eye]) continue;
-        post_edge_key(a, eye, fr, i, (size_t)ep.y[eye] * a.W + ep.x[eye], ((u64)ep.zkey[eye] << 32) | e);
+    for (int eye = 0; eye < 2; ++eye)
+        post_edge_key(a, eye, fr, i, ep.ok[eye], (size_t)ep.y[eye] * a.W + ep.x[eye], ((u64)ep.zkey[eye] << 32) | e);
+}
+constexpr int kListTPB = 1024, kListDwords = 4;          // a workgroup of the list pass: 1024 threads x 4 dwords x 4 flags
+__global__ void __launch_bounds__(kListTPB) k_edge_vertices_list(RenderArgs a)
+{
+    __shared__ uint32_t wsum[kListTPB / 64];
+    __shared__ uint32_t wbase;
+    const int W = a.W, fr = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ndw = (uint32_t)W * (uint32_t)a.H / 4u;              // (W % 4 == 0: the plane is whole dwords, rows contiguous)
+    const uint32_t* flags = (const uint32_t*)(a.unused + (size_t)fr * a.ws_stride_px);
+    uint32_t fl[kListDwords], cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kListDwords; ++k) {
+        const uint32_t d = (blockIdx.x * kListDwords + k) * kListTPB + tid;
+        fl[k] = d < ndw ? flags[d] : 0u;
+        cnt += ((fl[k] & 0xFFu) != 0u) + ((fl[k] & 0xFF00u) != 0u) + ((fl[k] & 0xFF0000u) != 0u) + ((fl[k] >> 24) != 0u);
+    }
+    uint32_t inc = cnt;                                                   // inclusive sums along the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, off); if (lane >= off) inc += v; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < kListTPB / 64; ++k) { const uint32_t v = wsum[k]; wsum[k] = run; run += v; }
+        wbase = run ? atomicAdd(&a.vlist_count[fr], run) : 0u;
+    }
+    __syncthreads();
+    if (!cnt) return;
+    uint32_t* out = a.vlist + (size_t)fr * a.ws_stride_px + wbase + wsum[wave] + (inc - cnt);
+#pragma unroll
+    for (int k = 0; k < kListDwords; ++k) {
+        if (!fl[k]) continue;
+        const uint32_t o = ((blockIdx.x * kListDwords + k) * kListTPB + tid) * 4u;
+        const uint32_t i = o / (uint32_t)W, j = o - i * (uint32_t)W;      // (the dword's four pixels share a row)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if ((fl[k] >> (8 * q)) & 0xFFu) *out++ = (i << 16) | (j + (uint32_t)q);
     }
 }
+__global__ void __launch_bounds__(256) k_edge_points_splat_list(RenderArgs a)
+{
+    const int fr = blockIdx.y, f = a.frame0 + fr;
+    const FrameDev& fp = a.fp[f];
+    const uint8_t* dbase = a.depth + (size_t)f * a.depth_stride;
+    const uint32_t total = a.vlist_count[fr];
+    const uint32_t* list = a.vlist + (size_t)fr * a.ws_stride_px;
+    for (uint32_t k0 = blockIdx.x * 256u; k0 < total; k0 += gridDim.x * 256u) {          // (workgroup uniform)
+        const uint32_t k = k0 + threadIdx.x;
+        edge_point_splat_one(a, fp, dbase, fr, k < total ? list[k] : 0u, k < total);
+    }
+}
+
+// The one-kernel form (until r05 the only one; kept for launches under a POSE, where the list form measures 4.6 % slower -- 1080p x 32
+// with a pose and edge removal 13.0 -> 12.4 k frames/s, C4 mesh with edge removal 3.06 -> 2.92 k -- while convergence-only launches
+// gain from it: product default 12.5 -> 12.9 k, a single frame 163 -> 143 us).  A workgroup scans kSplatRows source rows of the flag
+// plane, compacts the flagged vertices of all of them into one list in LDS and runs the chain over it 256 vertices at a time.
+constexpr int kSplatRows = 8;
 __global__ void __launch_bounds__(256) k_edge_points_splat4(RenderArgs a)
 {
     const int W = a.W, H = a.H;
@@ -972,13 +1042,13 @@ __global__ void __launch_bounds__(256) k_edge_points_splat4(RenderArgs a)
         uint32_t n = cnt;
         while (n >= 256u) {
             n -= 256u;
-            edge_point_splat_one(a, fp, dbase, fr, list[n + tid]);
+            edge_point_splat_one(a, fp, dbase, fr, list[n + tid], true);
         }
         __syncthreads();
         if (tid == 0) cnt = n;
         __syncthreads();
     }
-    if ((uint32_t)tid < cnt) edge_point_splat_one(a, fp, dbase, fr, list[tid]);
+    if (cnt) edge_point_splat_one(a, fp, dbase, fr, (uint32_t)tid < cnt ? list[tid] : 0u, (uint32_t)tid < cnt);      // (uniform: cnt is the workgroup's)
 }
 
 // mdvt_edge_point_pixels: the pixel the edge point of EVERY vertex of one frame lands on, both eyes (INT32_MIN twice: outside
@@ -2733,9 +2803,17 @@ static hipError_t launch_mesh_rows(const RenderPlan& plan, const RenderArgs& a_i
 }
 
 // mesh mode: the vertices of removed triangles into the global edge keys (sr:589-606)
-hipError_t launch_edge_points_splat(const RenderArgs& a, int n, hipStream_t s)
+hipError_t launch_edge_points_splat(const RenderArgs& a, int n, bool as_list, bool counters_zeroed, hipStream_t s)
 {
-    if (a.W % 4 == 0) {
+    if (a.W % 4 == 0 && a.vlist && as_list) {
+        if (!counters_zeroed) {                              // (the general path's k_mesh_queue_reset has done it on its way)
+            hipError_t e = hipMemsetAsync(a.vlist_count, 0, (size_t)n * sizeof(uint32_t), s);
+            if (e != hipSuccess) return e;
+        }
+        const uint32_t ndw = (uint32_t)a.W * (uint32_t)a.H / 4u, per = (uint32_t)(kListTPB * kListDwords);
+        hipLaunchKernelGGL(k_edge_vertices_list, dim3((ndw + per - 1) / per, n), dim3(kListTPB), 0, s, a);
+        hipLaunchKernelGGL(k_edge_points_splat_list, dim3(256, n), dim3(256), 0, s, a);
+    } else if (a.W % 4 == 0) {
         const dim3 grid_s((a.H + kSplatRows - 1) / kSplatRows, n);
         hipLaunchKernelGGL(k_edge_points_splat4, grid_s, dim3(256), 0, s, a);
     } else {
@@ -2752,7 +2830,7 @@ static hipError_t launch_mesh_general(const RenderPlan& plan, const RenderArgs& 
     const bool edge = plan.remove_edges && plan.edge_points;
     hipError_t e;
     if ((e = launch_mesh_raster_general(plan, a, s)) != hipSuccess) return e;
-    if (edge && (e = launch_edge_points_splat(a, plan.n, s)) != hipSuccess) return e;
+    if (edge && (e = launch_edge_points_splat(a, plan.n, plan.conv_raster != 0, true, s)) != hipSuccess) return e;
     return launch_resolve_general<true>(plan, a, s);
 }
 

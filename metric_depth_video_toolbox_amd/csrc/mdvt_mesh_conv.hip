@@ -30,7 +30,7 @@
 //     depth edge -- a long triangle -- goes to the generic 64-bit path on the whole wave, like every other irregular cell:
 //     near plane, twisted, out of range).
 //   * edge points (sr:589-606) land up to a few rows away from their source row: they keep the general path's global
-//     64-bit edge keys (k_edge_points_splat4 before this kernel, read back here only where the render left a hole,
+//     64-bit edge keys (the edge-point splat before this kernel, read back here only where the render left a hole,
 //     k_edge_keys_reset after it).
 #include "mdvt_device.h"
 
@@ -157,7 +157,7 @@ __device__ __forceinline__ void conv_exotic_cell(int XA, int YA, float izA, uint
 }  // namespace
 
 // FLAGS bit 0: depth planes; bit 1: triangles removed by the 89-degree filter draw nothing; bit 2: edge points (global edge
-// keys, posted by k_edge_points_splat4 before this kernel); bit 3: the infill-mask seed image (sr:787-803).
+// keys, posted by the edge-point splat before this kernel); bit 3: the infill-mask seed image (sr:787-803).
 template <int FLAGS, int TPB>
 __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per_band, int nbands)
 {
@@ -667,7 +667,7 @@ hipError_t launch_mesh_conv(const RenderPlan& plan, const RenderArgs& a_in, hipS
     if (rows > a.H) rows = a.H;
     hipError_t e;
     const bool edge = plan.remove_edges && plan.edge_points;
-    if (edge && (e = launch_edge_points_splat(a, plan.n, s)) != hipSuccess) return e;     // the edge keys this kernel's resolve reads
+    if (edge && (e = launch_edge_points_splat(a, plan.n, true, false, s)) != hipSuccess) return e;     // the edge keys this kernel's resolve reads
     e = mesh_conv_tpb(a.W) == 512 ? launch_mesh_conv_tpb<512>(plan, a, rows, s) : launch_mesh_conv_tpb<1024>(plan, a, rows, s);
     if (e != hipSuccess) return e;
     if (edge) return launch_edge_keys_reset(a, plan.n, s);

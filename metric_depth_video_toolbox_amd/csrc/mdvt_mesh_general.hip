@@ -104,6 +104,8 @@ __device__ __forceinline__ void mesh_global_fragment(const RenderArgs& a, int sl
 // frame (6 B per vertex, read through the L2 by the row above and the row below) into LDS -- 64 threads, 64 columns, 63 cells, so no
 // second pass over a 65th column -- and the queue / huge walks recompute the three vertices of their triangle.  The same device
 // functions in the same order as the vertex pass ran them: the same bits.
+// (CONV: every frame of the launch is convergence-only -- k_mesh_raster_conv's launches: vertex_conv_only)
+template <bool CONV>
 __device__ __forceinline__ void vertex_records(const RenderArgs& a, const FrameDev& fp, int f, int i, int j, uint4& r0, uint4& r1)
 {
     const uint32_t dpx = load_px_bytes(a.depth + (size_t)f * a.depth_stride + (size_t)i * a.depth_pitch, j);
@@ -112,7 +114,8 @@ __device__ __forceinline__ void vertex_records(const RenderArgs& a, const FrameD
     const float gx = (float)j * fp.sx, gy = (float)i * fp.sy;
     float xc, yc;
     camera_point(fp, gx, gy, z, xc, yc);
-    const Vert v0 = vertex_for_eye(fp, 0, gx, gy, z, xc, yc), v1 = vertex_for_eye(fp, 1, gx, gy, z, xc, yc);
+    const Vert v0 = CONV ? vertex_conv_only(fp, fp.M[0], xc, yc, z) : vertex_for_eye(fp, 0, gx, gy, z, xc, yc);
+    const Vert v1 = CONV ? vertex_conv_only(fp, fp.M[1], xc, yc, z) : vertex_for_eye(fp, 1, gx, gy, z, xc, yc);
     const float iz0 = v0.ok ? rcp_exact(v0.z) : 0.0f, iz1 = v1.ok ? rcp_exact(v1.z) : 0.0f;      // 0 flags a vertex behind the near plane
     r0 = make_uint4((uint32_t)snap(v0.u), (uint32_t)snap(v0.v), __float_as_uint(iz0), rgb);
     r1 = make_uint4((uint32_t)snap(v1.u), (uint32_t)snap(v1.v), __float_as_uint(iz1), rgb);
@@ -143,13 +146,14 @@ template <typename T> __device__ __forceinline__ uint4 readlane_u4(const uint4& 
 constexpr int kCellTPB = 64;          // threads per workgroup of the cell walks = vertex columns it stages
 constexpr int kCellsWG = kCellTPB - 1;   // cells per workgroup: between its 64 columns
 // Vertex row `row` of columns j0 .. j0 + 63, both eyes, into ring slot `slot`: sv[eye][slot][column].
+template <bool CONV>
 __device__ __forceinline__ void stage_vertex_row(const RenderArgs& a, int fr, int row, int j0, uint4 (&sv)[2][2][kCellTPB], int slot)
 {
     const int t = threadIdx.x, f = a.frame0 + fr;
     const FrameDev& fp = a.fp[f];
     const int jc = min(j0 + t, a.W - 1);                                   // (clamped: columns past the row end are never used)
     uint4 r0, r1;
-    vertex_records(a, fp, f, row, jc, r0, r1);
+    vertex_records<CONV>(a, fp, f, row, jc, r0, r1);
     sv[0][slot][t] = r0; sv[1][slot][t] = r1;
 }
 // A workgroup of the cell walks takes kRowsWG rows of cells of its 63 columns, top to bottom, its vertex rows in a ring of two: the
@@ -375,10 +379,10 @@ __global__ void __launch_bounds__(kCellTPB, cell_waves(FLAGS, false)) k_mesh_ras
     cell_block_of(a.W, blockIdx.x, kRowsWG, bx, i0);
     const int fr = (int)blockIdx.z;
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
-    stage_vertex_row(a, fr, i0, bx * kCellsWG, sv, 0);
+    stage_vertex_row<false>(a, fr, i0, bx * kCellsWG, sv, 0);
 #pragma unroll 1
     for (int r = 0; r < kRowsWG && i0 + r < a.H - 1; ++r) {
-        stage_vertex_row(a, fr, i0 + r + 1, bx * kCellsWG, sv, (r + 1) & 1);
+        stage_vertex_row<false>(a, fr, i0 + r + 1, bx * kCellsWG, sv, (r + 1) & 1);
         __syncthreads();
         mesh_raster_small_block<FLAGS, 0>(a, fr, bx, i0 + r, sv, r & 1, pds);
         __syncthreads();                                   // (the row above is replaced next: its last readers are through)
@@ -570,10 +574,10 @@ __global__ void __launch_bounds__(kConvTPB, cell_waves(FLAGS, true)) k_mesh_rast
     const int fr = (int)blockIdx.z;
     Pending pd = pending_none();
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
-    stage_vertex_row(a, fr, i0, bx * kCellsWG, sv, 0);
+    stage_vertex_row<true>(a, fr, i0, bx * kCellsWG, sv, 0);
 #pragma unroll 1
     for (int r = 0; r < kRowsWG && i0 + r < a.H - 1; ++r) {
-        stage_vertex_row(a, fr, i0 + r + 1, bx * kCellsWG, sv, (r + 1) & 1);
+        stage_vertex_row<true>(a, fr, i0 + r + 1, bx * kCellsWG, sv, (r + 1) & 1);
         mesh_raster_conv_block<FLAGS, 0>(a, fr, bx, i0 + r, sv, r & 1, glist, gcount, pd);      // (synchronises before it reads the rows)
         __syncthreads();                                   // (the row above and the list are replaced next)
     }
@@ -776,8 +780,8 @@ __global__ void __launch_bounds__(kCellTPB) k_mesh_tie_pass(RenderArgs a, int nf
         if (a.tie_flag[fr] == 0u) continue;                                    // (workgroup uniform)
         for (uint32_t v = blockIdx.x; v < nblk; v += gridDim.x) {
             const int bx = (int)(v % nbx), i = (int)(v / nbx);
-            stage_vertex_row(a, fr, i, bx * kCellsWG, sv, 0);
-            stage_vertex_row(a, fr, i + 1, bx * kCellsWG, sv, 1);
+            stage_vertex_row<CONV>(a, fr, i, bx * kCellsWG, sv, 0);
+            stage_vertex_row<CONV>(a, fr, i + 1, bx * kCellsWG, sv, 1);
             __syncthreads();
             // (the cells classified as the first pass classified them: k_mesh_raster_conv draws spans itself that k_mesh_raster_small
             //  would have queued)
@@ -803,6 +807,7 @@ __global__ void __launch_bounds__(256) k_mesh_queue_reset(RenderArgs a, int n)
     for (uint32_t k = t; k < ntile; k += nt) a.tie_tiles[k] = 0u;
     if (t < (uint32_t)n) a.tie_flag[t] = 0u;
     if (t < 2u) a.hugeq[2 * (size_t)kHugeCap + t] = 0u;
+    if (a.vlist_count && t < (uint32_t)n) a.vlist_count[t] = 0u;             // (the edge-point splat's list counters: one launch fewer)
     if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 

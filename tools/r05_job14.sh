@@ -1,0 +1,17 @@
+#!/bin/bash
+# r05 GPU job 14: convergence-only vertex programme in k_mesh_raster_conv ("new") against the same library without it (libmdvt_hip_l1.so)
+# and the commit before (libmdvt_hip_d0.so: one-kernel splat everywhere); list splat for convergence-only launches only
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"
+OUT=gpurun_out/r05n; mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?"; tail -3 $OUT/pytest.log
+ab() {
+  tag=$1; shift
+  for v in d0 l1 "" d0 l1 ""; do
+    echo "== $tag on '${v:-new}': $(MDVT_LIB_VARIANT=$v python tools/kbench.py default --rounds 5 --calls 5 "$@" 2>&1 | tail -1)"
+  done
+}
+ab product_default --mesh --infill --conv 2.5 --frames 32 | tee $OUT/ab.log
+ab mesh_conv --mesh --conv 2.5 --frames 32 | tee -a $OUT/ab.log
+ab product_default_1 --mesh --infill --conv 2.5 --frames 1 | tee -a $OUT/ab.log
+ab mesh_pose_edges --mesh --pose --infill --frames 32 | tee -a $OUT/ab.log
