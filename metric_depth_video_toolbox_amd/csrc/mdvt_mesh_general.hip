@@ -163,17 +163,21 @@ __device__ __forceinline__ void stage_vertex_row(const RenderArgs& a, int fr, in
 #define MDVT_ROWS_WG 4
 #endif
 #ifndef MDVT_ROWS_WG_CONV_EDGES
-#define MDVT_ROWS_WG_CONV_EDGES 1
+#define MDVT_ROWS_WG_CONV_EDGES MDVT_ROWS_WG
 #endif
-// Per kernel: four rows everywhere except the scanline walk with edge removal (k_mesh_raster_conv<2>, the product default's), which
-// is no faster for it (12.3 k frames/s against 12.45 k with one row: the row loop costs it 21 VGPRs -- 80 -> 101, six waves per SIMD
-// -> four -- where the others pay 15 and keep five).  Measured, same box: mesh + convergence 14.8 -> 16.3 k frames/s, mesh under a
-// pose 12.7 -> 13.8 k (13.1 k with edge removal, from 12.3 k), C4 mesh 2.29 -> 2.42 k; two rows give half of it, eight no more.
 __host__ __device__ constexpr int rows_wg(int flags, bool conv) { return (conv && (flags & 2)) ? MDVT_ROWS_WG_CONV_EDGES : MDVT_ROWS_WG; }
-// ... and the occupancy each is compiled for (waves per SIMD; 1 = whatever the registers come to).  The row loop takes 87-93 VGPRs
-// (five waves); held to 80 (six waves, a few dwords of scratch) the triangle walk without edge removal gains 2 % under a pose and the
-// one-row scanline walk with edge removal gets back to what it was (86 -> 80: 12.26 -> 12.5 k frames/s), the other two lose 3-5 %.
-__host__ __device__ constexpr int cell_waves(int flags, bool conv) { return conv == ((flags & 2) != 0) ? 6 : 1; }
+// ... and the occupancy each is compiled for (waves per SIMD; 1 = whatever the registers come to).  What the row loop costs is
+// registers: the per-lane addresses its body leads to (source pixels, filter flags, key planes) are hoisted out of it and live across
+// the whole walk -- 80 VGPRs (six waves per SIMD) became 87-101 (five, four), which ate the gain and more for the scanline walk with
+// edge removal.  With the block's column and frame made opaque per row (an empty asm: the addresses are worked out again, a few
+// integer operations) the scanline walks fit 80 (20 bytes of scratch with edge removal) and the triangle walks take 80 / 83.  Measured, same box each:
+// mesh + convergence 14.8 (one row) -> 16.3 (four rows) -> 18.0 k frames/s (80 VGPRs, convergence-only vertex programme); product
+// default (scanline walk with edge removal) 14.27 k at one row -> 14.70 k at four rows and 80 VGPRs (two rows: 14.43 k); mesh under a
+// pose 12.7 -> 13.8 k; C4 mesh 2.29 -> 2.42 k; eight rows give no more.
+#ifndef MDVT_SMALL2_WAVES
+#define MDVT_SMALL2_WAVES 1
+#endif
+__host__ __device__ constexpr int cell_waves(int flags, bool conv) { return conv ? 6 : ((flags & 2) ? MDVT_SMALL2_WAVES : 6); }
 // The block of cells of a workgroup of the one-thread-per-cell kernels: row-major over the frame's cells, grid x = cell_blocks.
 // (Measured and not kept, r04: an XCD-aware deal -- workgroup b runs on XCD b % 8, each XCD with its own L2, so each XCD took a
 // contiguous eighth of the blocks and the second reader of a vertex-record row found it in the L2 the first one had filled.  The
@@ -382,9 +386,11 @@ __global__ void __launch_bounds__(kCellTPB, cell_waves(FLAGS, false)) k_mesh_ras
     stage_vertex_row<false>(a, fr, i0, bx * kCellsWG, sv, 0);
 #pragma unroll 1
     for (int r = 0; r < kRowsWG && i0 + r < a.H - 1; ++r) {
-        stage_vertex_row<false>(a, fr, i0 + r + 1, bx * kCellsWG, sv, (r + 1) & 1);
+        int bxr = bx, frr = fr;                            // (opaque per row: see k_mesh_raster_conv)
+        asm volatile("" : "+s"(bxr), "+s"(frr));
+        stage_vertex_row<false>(a, frr, i0 + r + 1, bxr * kCellsWG, sv, (r + 1) & 1);
         __syncthreads();
-        mesh_raster_small_block<FLAGS, 0>(a, fr, bx, i0 + r, sv, r & 1, pds);
+        mesh_raster_small_block<FLAGS, 0>(a, frr, bxr, i0 + r, sv, r & 1, pds);
         __syncthreads();                                   // (the row above is replaced next: its last readers are through)
     }
     pending_settle(a, pds[0]);
@@ -577,8 +583,12 @@ __global__ void __launch_bounds__(kConvTPB, cell_waves(FLAGS, true)) k_mesh_rast
     stage_vertex_row<true>(a, fr, i0, bx * kCellsWG, sv, 0);
 #pragma unroll 1
     for (int r = 0; r < kRowsWG && i0 + r < a.H - 1; ++r) {
-        stage_vertex_row<true>(a, fr, i0 + r + 1, bx * kCellsWG, sv, (r + 1) & 1);
-        mesh_raster_conv_block<FLAGS, 0>(a, fr, bx, i0 + r, sv, r & 1, glist, gcount, pd);      // (synchronises before it reads the rows)
+        // (the block's column and frame made opaque per row: hoisted out of the loop, the per-lane addresses they lead to -- source
+        //  pixels, filter flags, key planes -- live in ~15 VGPRs across the whole walk and cost the kernel a wave per SIMD)
+        int bxr = bx, frr = fr;
+        asm volatile("" : "+s"(bxr), "+s"(frr));
+        stage_vertex_row<true>(a, frr, i0 + r + 1, bxr * kCellsWG, sv, (r + 1) & 1);
+        mesh_raster_conv_block<FLAGS, 0>(a, frr, bxr, i0 + r, sv, r & 1, glist, gcount, pd);      // (synchronises before it reads the rows)
         __syncthreads();                                   // (the row above and the list are replaced next)
     }
     pending_settle(a, pd);
