@@ -582,8 +582,9 @@ def open_output(path: str, mmap_mode: Optional[str] = "r"):
     return SegmentedFrames(parts, bounds)
 
 
-def _remove_segments(path: str):
-    """Remove `<path>.index.json` and the segment files it names (an earlier multi-rank run's form of the output)."""
+def _remove_segments(path: str, keep=()):
+    """Remove `<path>.index.json` and the segment files it names (an earlier multi-rank run's form of the output), except the
+    files named in `keep` (base names: the segments the run that calls this has just written)."""
     ip = path + ".index.json"
     if not os.path.exists(ip):
         return
@@ -591,6 +592,8 @@ def _remove_segments(path: str):
         with open(ip) as fh:
             idx = json.load(fh)
         for s in idx.get("segments", []):
+            if s["file"] in keep:
+                continue
             f = os.path.join(os.path.dirname(path), s["file"])
             if os.path.exists(f):
                 os.remove(f)
@@ -713,6 +716,9 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
             idx = {"frames": N, "world": world, "frame_shape": list(pl["frame_shape"]), "dtype": "uint8",
                    "segments": [{"rank": r, "lo": a, "hi": b, "file": os.path.basename(segment_path(pl["final"], r, world))}
                                 for r, a, b in pl["segments"]]}
+            # (advisor r04) the segments of an earlier run with ANOTHER world size (`<final>.rankXofY.npy`) are named by the old index
+            # only: they go with it, before the new index takes its place -- multi-GB files nobody would find again
+            _remove_segments(pl["final"], keep={sg["file"] for sg in idx["segments"]})
             with open(pl["final"] + ".index.json.tmp", "w") as fh:
                 json.dump(idx, fh)
             os.replace(pl["final"] + ".index.json.tmp", pl["final"] + ".index.json")

@@ -321,6 +321,15 @@ def test_outputs_of_an_earlier_run_do_not_shadow_the_fresh_ones(tmp_path):
     os.utime(base, (1, 1))                                   # the single file is the OLD one
     got = clip.open_output(base)
     assert got.ndim == 4 and int(np.asarray(got[3]).max()) == 2
-    clip._remove_segments(base)
-    assert not os.path.exists(seg0) and not os.path.exists(base + ".index.json")
+    # (advisor r04) a run with another world size keeps the segments it has just written (`keep`) and removes the old index's others
+    seg3 = base + ".rank0of3.npy"
+    np.save(seg3, np.zeros((1, 2, 4, 3), np.uint8))
+    with open(base + ".index.json") as fh:
+        idx = json.load(fh)
+    idx["segments"].append({"rank": 0, "lo": 0, "hi": 1, "file": os.path.basename(seg3)})
+    with open(base + ".index.json", "w") as fh:
+        json.dump(idx, fh)
+    clip._remove_segments(base, keep={os.path.basename(seg3)})
+    assert not os.path.exists(seg0) and not os.path.exists(seg1) and os.path.exists(seg3) and not os.path.exists(base + ".index.json")
+    os.remove(seg3)
     assert int(np.asarray(clip.open_output(base)).max()) == 0
