@@ -86,6 +86,9 @@ __device__ __forceinline__ void mesh_global_fragment(const RenderArgs& a, int sl
     const uint32_t rgb = shade_px(q0, q1, q2, rcp_exact(iz), c0, c1, c2);
     const u64 mine = zkey_word<true>(f.parity, __float_as_uint(iz), kNoTie | rgb);      // iz > 0: its bits are a 31-bit order key
     if (MODE == 0) {
+#ifdef MDVT_ABLATE_POST           // (a build of its own, timing ablation: the fragment without its post -- as a run-time hook it cost the walks registers)
+        if (MDVT_ABLATE_POST) { asm volatile("" :: "v"(mine)); return; }
+#endif
         pending_settle(a, pd);            // (before the post: the pending word's registers are then free to take the next return)
         pd.old = zkey_post_word(&f.keys[o], f.parity, mine);
         pd.mine = mine; pd.o = o; pd.se = (uint32_t)slot * 2u + (uint32_t)eye;
