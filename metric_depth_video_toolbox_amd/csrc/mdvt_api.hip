@@ -910,7 +910,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         }
         a.frame0 = f0;
         if (plan.remove_edges) {
-            MDVT_HIP(c, hipMemsetAsync(a.unused, 0, (size_t)plan.n * a.ws_stride_px, s));
+            MDVT_HIP(c, launch_zero_bytes(a.unused, (size_t)plan.n * a.ws_stride_px, s));
             MDVT_HIP(c, launch_edge_filter(a.depth, a.depth_pitch, a.depth_stride, dfp, f0, plan.n, W, H,
                                            plan.mode == MDVT_MODE_MESH, a.tri_invalid, a.ws_stride_tri,
                                            a.unused, a.ws_stride_px, s));

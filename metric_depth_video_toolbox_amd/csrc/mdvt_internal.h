@@ -104,6 +104,7 @@ hipError_t launch_decode_depth(const uint8_t* rgb, size_t rgb_pitch, float* out,
                                float mult, float scale, hipStream_t s);
 hipError_t launch_encode_depth(const float* depth, size_t depth_pitch, uint8_t* rgb, size_t rgb_pitch, int W, int H,
                                double max_depth, int bgr, hipStream_t s);
+hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s);
 hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t stride, const FrameDev* fp, int frame0,
                               int n, int W, int H, int of_by_one, uint8_t* tri_invalid, size_t tri_stride,
                               uint8_t* unused, size_t unused_stride, hipStream_t s);

@@ -373,6 +373,27 @@ __global__ void __launch_bounds__(128) k_edge_filter4(const uint8_t* __restrict_
     }
 }
 
+// Zero `bytes` bytes at `p` (any alignment): 16-byte stores over the aligned body, byte stores at its two ends.  Replaces the per-set
+// hipMemsetAsync of the 89-degree filter's flag plane (two runtime fill launches, 13 us per 16 MB): one launch; measured, a single
+// product-default frame per call 148.9 -> 146.7 us, 32 frames per call unchanged (the fills hid behind the other bank's walk).
+__global__ void __launch_bounds__(256) k_zero_bytes(uint8_t* p, size_t bytes)
+{
+    const size_t head = min(bytes, (size_t)((16u - (uint32_t)((uintptr_t)p & 15u)) & 15u));
+    const size_t body = (bytes - head) >> 4, tail0 = head + (body << 4);
+    uint4* q = reinterpret_cast<uint4*>(p + head);
+    const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x, nt = (size_t)gridDim.x * 256u;
+    for (size_t k = t; k < body; k += nt) q[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < head) p[t] = 0;
+    if (t < bytes - tail0) p[tail0 + t] = 0;
+}
+hipError_t launch_zero_bytes(void* p, size_t bytes, hipStream_t s)
+{
+    if (!bytes) return hipSuccess;
+    const size_t blocks = (bytes / 16 + 255) / 256;
+    hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks))), dim3(256), 0, s, (uint8_t*)p, bytes);
+    return hipGetLastError();
+}
+
 hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t stride, const FrameDev* fp, int frame0,
                               int n, int W, int H, int of_by_one, uint8_t* tri_invalid, size_t tri_stride,
                               uint8_t* unused, size_t unused_stride, hipStream_t s)
