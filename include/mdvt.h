@@ -164,7 +164,10 @@ int mdvt_release_cached_memory(int device);
 int mdvt_cached_memory(int device, uint64_t* idle_bytes, uint64_t* idle_blocks);
 /* libmdvt_hip_tuning.so only (MDVT_ERR_UNSUPPORTED in the product library): what = 0 copies the general mesh path's triangle-queue
  * block to h_dst (host, `capacity` bytes; NULL: sizes only) after a device synchronisation.  info: bytes of the block; dword offsets
- * of the segment counters / the huge list / the tie flags; segments; W; H; frame slots.  tests/dbg_stress_case.py's diagnosis. */
+ * of the segment counters / the huge list / the tie flags; segments; W; H; frame slots.  tests/dbg_stress_case.py's diagnosis.
+ * what = 1: the cross-XCD coherence test on that block (h_dst: 80 dwords; overwrites the block).  what = 2: a census of the two
+ * process-wide pools as this context's GPU sees them -- info[0..3] = idle parameter blocks of this / of another GPU, idle workspace
+ * blocks of this / of another GPU; info[4] = the context's pool tag (tests/test_gpu_fresh_context.py). */
 int mdvt_debug_read(mdvt_ctx* ctx, int what, void* h_dst, uint64_t capacity, uint64_t info[8]);
 
 /* Diagnostic: where the edge point of EVERY vertex of one frame lands (sr:589-606, 615-619, 727-735, 745-750, 838-858: the
