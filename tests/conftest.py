@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Soaks only (MDVT_SEGV_TRACE=1): a native backtrace if the process dies of a signal (tools/probe/segv_trace.c) -- installed
+    after pytest's faulthandler, which it hands the signal on to."""
+    if os.environ.get("MDVT_SEGV_TRACE") != "1":
+        return
+    import ctypes
+    import subprocess
+    so = f"/tmp/libsegv_trace_{os.getpid()}.so"
+    subprocess.check_call(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", so, os.path.join(REPO, "tools", "probe", "segv_trace.c")])
+    out = os.path.join(os.environ.get("MDVT_SEGV_TRACE_DIR", "/tmp"), f"segv_trace_{os.getpid()}.log")      # (pytest captures fd 2)
+    ctypes.CDLL(so).segv_trace_install(out.encode())
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
