@@ -582,6 +582,45 @@ int mdvt_create(mdvt_ctx** out, int device, int width, int height, uint32_t flag
     return MDVT_OK;
 }
 
+// ---- The banks' side stream and events: process-wide, never destroyed ------------------------------------------------------
+// r05: three soak processes in ~3 000 multi-frame sweep jobs (300 k contexts that had used banks) died of a signal -- never one of
+// 3 500 single-frame jobs (1.4 M contexts) -- and the native backtrace of the third (tools/probe/segv_trace.c) is the HSA runtime's
+// own callback thread faulting inside libamdhip64, not a frame of this library.  What only the bank path has is a stream and four
+// events created by a context and destroyed with it; whatever the runtime's handler still holds of them after the
+// hipDeviceSynchronize of mdvt_destroy, the library no longer destroys them: they wait here for the next context of the same GPU
+// that uses banks (the treatment the pinned parameter blocks and the workspace blocks got for their own reasons).
+struct BankRes { hipStream_t side; hipEvent_t ev[4]; int device; };
+static std::mutex g_bank_mutex;
+static std::vector<BankRes>& bank_pool() { static std::vector<BankRes>* p = new std::vector<BankRes>(); return *p; }      // (leaked on purpose)
+
+static hipError_t bank_res_take(mdvt_ctx* c)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_bank_mutex);
+        auto& pool = bank_pool();
+        for (size_t k = pool.size(); k-- > 0;)
+            if (pool[k].device == c->device) {
+                c->side = pool[k].side; c->ev_start = pool[k].ev[0]; c->ev_join = pool[k].ev[1]; c->ev_vert[0] = pool[k].ev[2]; c->ev_vert[1] = pool[k].ev[3];
+                pool.erase(pool.begin() + (long)k);
+                return hipSuccess;
+            }
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    for (hipEvent_t* ev : {&c->ev_start, &c->ev_join, &c->ev_vert[0], &c->ev_vert[1]})
+        if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    return e;
+}
+// (the caller has synchronised the device: nothing submitted still uses them)
+static void bank_res_give(mdvt_ctx* c)
+{
+    if (!c->side) return;
+    if (c->ev_start && c->ev_join && c->ev_vert[0] && c->ev_vert[1]) {
+        std::lock_guard<std::mutex> lock(g_bank_mutex);
+        bank_pool().push_back({c->side, {c->ev_start, c->ev_join, c->ev_vert[0], c->ev_vert[1]}, c->device});
+    }       // (a half-created set -- an error in bank_res_take -- is abandoned, not destroyed)
+    c->side = nullptr; c->ev_start = c->ev_join = c->ev_vert[0] = c->ev_vert[1] = nullptr;
+}
+
 static void free_telea(mdvt_ctx* c)
 {
     mdvt::TeleaWorkspace& w = c->telea;
@@ -596,9 +635,8 @@ int mdvt_destroy(mdvt_ctx* c)
     if (!c) return MDVT_OK;
     DeviceGuard g(c->device);
     (void)hipDeviceSynchronize();
-    if (c->side) (void)hipStreamDestroy(c->side);
+    bank_res_give(c);
     if (c->hugeq2) ws_free(c, c->hugeq2);
-    for (hipEvent_t ev : {c->ev_start, c->ev_join, c->ev_vert[0], c->ev_vert[1]}) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : c->slots) {
         pool_give(sl.host, sl.dev, sl.capacity * sizeof(FrameDev), c->pool_tag);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -867,10 +905,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
       } bank_join{c, s_call, false};
       if (banks) {
           chunk = bank_slots;
-          if (!c->side) {
-              MDVT_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-              for (hipEvent_t* ev : {&c->ev_start, &c->ev_join, &c->ev_vert[0], &c->ev_vert[1]}) MDVT_HIP(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
-          }
+          if (!c->side) MDVT_HIP(c, bank_res_take(c));        // (process-wide: see bank_res_take)
           MDVT_HIP(c, hipEventRecord(c->ev_start, s_call));            // (the inputs, the parameter block, the runs before this one)
           MDVT_HIP(c, hipStreamWaitEvent(c->side, c->ev_start, 0));
           bank_join.armed = true;

@@ -6,7 +6,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"
 OUT=gpurun_out/r05w; mkdir -p $OUT/traces
 MDVT_SEGV_TRACE=1 MDVT_SEGV_TRACE_DIR=$ROOT/$OUT/traces python tools/soak.py --tag r05d --commit ${SOAK_COMMIT:-unknown} --seed0 564000 --seeds 0 --cases 0 --full 0 --finish 0 \
-     --aux-seeds 0 --batch-seeds 2600 --batch-cases 100 --procs 14 --budget-min ${BUDGET_MIN:-19} > $OUT/soak.log 2>&1
+     --aux-seeds 0 --batch-seeds 2400 --batch-cases 100 --procs 14 --budget-min ${BUDGET_MIN:-19} > $OUT/soak.log 2>&1
 tail -8 gpurun_out/soak_r05d/summary.md | cut -c1-300
 find gpurun_out/soak_r05d -name "batch_*.log" -size -3k -delete
 find $OUT/traces -size 0 -delete
