@@ -519,8 +519,9 @@ int host_snap(float x)
     return (int)rintf(x * (float)kSubpix);
 }
 
-// Scanline k (centre 256 k + 128) is covered by the cell row c = largest i with snap(f32(i) * sy) <= centre, if that is
-// not the last vertex row (k_mesh_rows derives the same per workgroup).
+// Scanline k (centre S k + S/2) is covered by the cell row c = largest i with snap(f32(i) * sy) < centre (a centre ON a vertex
+// row belongs to the cells above it: bottom edges own their centres, mdvt_device.h edge_in), if that is not the last vertex
+// row (k_mesh_rows derives the same per workgroup).
 int ensure_rowcell(mdvt_ctx* c, hipStream_t s)
 {
     if (c->rowcell) return MDVT_OK;
@@ -531,8 +532,8 @@ int ensure_rowcell(mdvt_ctx* c, hipStream_t s)
         const int Yc = k * kSubpix + kSubpix / 2;
         int ilo = (int)(((float)k + 0.5f) / sy);
         ilo = ilo < 0 ? 0 : (ilo > H - 1 ? H - 1 : ilo);
-        while (ilo > 0 && host_snap((float)ilo * sy) > Yc) --ilo;
-        while (ilo + 1 <= H - 1 && host_snap((float)(ilo + 1) * sy) <= Yc) ++ilo;
+        while (ilo > 0 && host_snap((float)ilo * sy) >= Yc) --ilo;
+        while (ilo + 1 <= H - 1 && host_snap((float)(ilo + 1) * sy) < Yc) ++ilo;
         mdvt::RowCell r{};
         r.c = (ilo <= H - 2) ? ilo : -1;
         r.Yt = r.c >= 0 ? host_snap((float)r.c * sy) : 0;

@@ -168,14 +168,33 @@ __device__ __forceinline__ int snap(float x)
 }
 
 // floor division by the sub-pixel grid (power of two): arithmetic shift.
-__device__ __forceinline__ int floordiv_subpix(int a) { return a >> 8; }
-static_assert(kSubpix == 256, "floordiv_subpix assumes a 1/256 grid");
+__device__ __forceinline__ int floordiv_subpix(int a) { return a >> kSubpixBits; }
 
+// GL_POINTS of size 1 (dmt:1510): the unit square around the SNAPPED vertex, rasterised with the fill rule below -- the
+// pixel whose centre lies inside it, a centre on the square's left or bottom edge belongs to it:
+//   column = ceil(X / S) - 1,  row = floor(Y / S)        (X, Y snapped, S = kSubpix)
+// -1 / out of range = not drawn.  Pinned by tests/golden/render_gl_points_*.npz.
+__device__ __forceinline__ int point_col(float u) { return floordiv_subpix(snap(u) - 1); }
+__device__ __forceinline__ int point_row(float v) { return floordiv_subpix(snap(v)); }
+// point_col in three instructions, for the LDS row kernels: the bits of fma(u, S, 1.5 * 2^23) are 0x4B400000 + rint(u S) while
+// |u S| < 2^22 (a single rounding of an exact product: round-half-even, like snap's rintf), and outside that range they still
+// lie on the same side of every column of a row that fits the LDS (W <= 10240 << 2^22 / S): "not drawn" either way.
+__device__ __forceinline__ int point_col_row_kernel(float u)
+{
+    const int X1 = __float_as_int(__builtin_fmaf(u, (float)kSubpix, 12582912.0f)) - 0x4B400001;     // rint(u S) - 1
+    return X1 >> kSubpixBits;
+}
+
+// Fill rule: a pixel centre exactly on an edge belongs to the triangle if the edge is a LEFT edge or a horizontal BOTTOM
+// edge (image space, y down; deltas orientation-normalised to clockwise).  This is OpenGL's convention -- the rasteriser's
+// "top-left" rule acts towards window y = 0, the bottom of the picture -- as observed on the pinned GL
+// (tests/golden/render_gl_*.npz); until r06 the decree had Direct3D's (top edges).
+__device__ __forceinline__ bool edge_owns_centre(int dx, int dy) { return (dy < 0) || (dy == 0 && dx < 0); }
 __device__ __forceinline__ bool edge_in(i64 w, int dx, int dy)
 {
     if (w > 0) return true;
     if (w < 0) return false;
-    return (dy < 0) || (dy == 0 && dx > 0);     // top-left rule, clockwise (y down)
+    return edge_owns_centre(dx, dy);
 }
 
 // One triangle prepared for point-in-triangle queries on the sub-pixel grid.  The three edge
@@ -366,10 +385,10 @@ __device__ __forceinline__ bool tri_small_setup(TriSmall& t, int X0, int Y0, flo
     return true;
 }
 
-// The walk carries BIASED edge values: w_k + 1 where the top-left rule admits w_k == 0 (edge_in), w_k otherwise, so
+// The walk carries BIASED edge values: w_k + 1 where the fill rule admits w_k == 0 (edge_in), w_k otherwise, so
 // "inside" is min(w0, w1, w2) > 0 -- two instructions per pixel centre instead of a dozen compares.
 struct TriWalk32 { int w0, w1, w2; };
-__device__ __forceinline__ int edge_bias(int dx, int dy) { return ((dy < 0) || (dy == 0 && dx > 0)) ? 1 : 0; }
+__device__ __forceinline__ int edge_bias(int dx, int dy) { return edge_owns_centre(dx, dy) ? 1 : 0; }
 __device__ __forceinline__ TriWalk32 tri_small_start(const TriSmall& t, int px, int py)
 {
     const int Xc = px * kSubpix + kSubpix / 2, Yc = py * kSubpix + kSubpix / 2;
@@ -468,7 +487,8 @@ __device__ __forceinline__ bool tri_row_range(const TriSetup& t, int py, int px0
         const float x = (float)A / (float)dys[k];
         if (dys[k] > 0) fhi = fminf(fhi, x); else flo = fmaxf(flo, x);
     }
-    const float l = floorf((flo - 128.0f) * (1.0f / 256.0f)) - 1.0f, h = floorf((fhi - 128.0f) * (1.0f / 256.0f)) + 1.0f;
+    constexpr float kHalf = (float)(kSubpix / 2), kInv = 1.0f / (float)kSubpix;
+    const float l = floorf((flo - kHalf) * kInv) - 1.0f, h = floorf((fhi - kHalf) * kInv) + 1.0f;
     lo = l < (float)px0 ? px0 : (l > (float)px1 ? px1 + 1 : (int)l);
     hi = h > (float)px1 ? px1 : (h < (float)px0 ? px0 - 1 : (int)h);
     return lo <= hi;

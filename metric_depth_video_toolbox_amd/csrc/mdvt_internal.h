@@ -21,8 +21,22 @@ bool tuning_build();
 
 // Near plane of the reference's render call: ctr.set_constant_z_near(0.0001) (dmt:1520).
 constexpr float kNear = 1e-4f;
-// Rasteriser sub-pixel grid and the clamp applied before snapping (DESIGN.md "Arithmetic decree").
-constexpr int kSubpix = 256;
+// Rasteriser sub-pixel grid (GL_SUBPIXEL_BITS) and the clamp applied before snapping (DESIGN.md "Arithmetic decree").
+// The rasterising translation units are compiled once per supported grid (Makefile): 8 bits, what desktop GPUs report
+// and the default of mdvt_config.subpixel_bits, and 4 bits, the grid of the GL the fixtures of tests/golden/render_gl_*.npz
+// were rendered with.  Everything they define lives in namespace mdvt::MDVT_GRID; mdvt_api.hip picks per context.
+#ifndef MDVT_SUBPIX_BITS
+#define MDVT_SUBPIX_BITS 8
+#endif
+#if MDVT_SUBPIX_BITS == 8
+#define MDVT_GRID grid8
+#elif MDVT_SUBPIX_BITS == 4
+#define MDVT_GRID grid4
+#else
+#error "MDVT_SUBPIX_BITS must be 4 or 8"
+#endif
+constexpr int kSubpixBits = MDVT_SUBPIX_BITS;
+constexpr int kSubpix = 1 << kSubpixBits;
 constexpr float kSnapLimit = 2097152.0f;   // 2^21 px: snapped coordinates fit int32, differences too
 
 // Per-frame constants, derived on the host in f64 and rounded once (see fill_frame_dev()).

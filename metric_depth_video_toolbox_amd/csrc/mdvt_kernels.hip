@@ -488,7 +488,6 @@ __device__ __forceinline__ uint32_t points_splat_group(int g, const uint32_t (&d
 {
     uint32_t need = 0;
     constexpr bool UNUSED = FLAGS & 2, EDGE = FLAGS & 4;
-    const float fW = (float)W;
 #pragma unroll
     for (int q = 0; q < PX; ++q) {
         const int j = g * PX + q;
@@ -499,9 +498,9 @@ __device__ __forceinline__ uint32_t points_splat_group(int g, const uint32_t (&d
         const float fj = (float)j;
         if (!(UNUSED && un[q])) {
             const u64 key = ((u64)code << 40) | ((u64)(uint32_t)j << 24) | (u64)cpx[q];
-            const float uL = fj + d, uR = fj - d;
-            if (uL >= 0.0f && uL < fW) atomicMin(&zb[(int)floorf(uL)], key);
-            if (uR >= 0.0f && uR < fW) atomicMin(&zb[W + (int)floorf(uR)], key);
+            const int xL = point_col_row_kernel(fj + d), xR = point_col_row_kernel(fj - d);        // (the row: point_row(f32(i)) == i)
+            if ((uint32_t)xL < (uint32_t)W) atomicMin(&zb[xL], key);
+            if ((uint32_t)xR < (uint32_t)W) atomicMin(&zb[W + xR], key);
         } else if (EDGE && edge_on) {
             // sr:599-600, 746: the column the reference's f64 chain rounds to (mdvt_device.h "edge points")
             const uint32_t ekey = (code << 16) | (uint32_t)j;
@@ -733,8 +732,7 @@ hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s)
 // -------------------------------------------------------------------------------------------------
 // Hand-scheduled variant of the row kernel for the headline case (4 px/lane, one group per thread, no
 // edge filter): byte shuffles are single v_perm_b32 ops, out-of-range fragments are steered to a trash
-// LDS word instead of branching (no exec-mask traffic), float->int uses truncation (== floor for the
-// non-negative values that pass the range test).  Same arithmetic, same results as k_points_rows.
+// LDS word instead of branching (no exec-mask traffic).  Same arithmetic, same results as k_points_rows.
 // -------------------------------------------------------------------------------------------------
 template <int TPB, bool ZOUT, bool BITS, int NT = 3>
 __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
@@ -779,7 +777,6 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
         cpx[1] = __builtin_amdgcn_perm(c1, c0, 0x0c050403u);
         cpx[2] = __builtin_amdgcn_perm(c2, c1, 0x0c040302u);
         cpx[3] = c2 >> 8;
-        const float fW = (float)W;
         const float fj0 = (float)(g << 2);
         const uint32_t jhi = (uint32_t)g >> 6, jlo = ((uint32_t)g << 2) & 0xFFu;
         const int trash = 2 * W;
@@ -789,11 +786,11 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
             const bool ok = z > kNear;
             const float d = dl / z;
             const float fj = fj0 + (float)q;
-            const float uL = fj + d, uR = fj - d;
-            const bool okL = ok && (uL < fW);
-            const bool okR = ok && (uR >= 0.0f);
-            const int sL = okL ? (int)uL : trash;
-            const int sR = okR ? W + (int)uR : trash;
+            const int xL = point_col_row_kernel(fj + d), xR = point_col_row_kernel(fj - d);
+            const bool okL = ok && (uint32_t)xL < (uint32_t)W;
+            const bool okR = ok && (uint32_t)xR < (uint32_t)W;
+            const int sL = okL ? xL : trash;
+            const int sR = okR ? W + xR : trash;
             const uint32_t hi = __builtin_amdgcn_perm(c32[q], jhi, 0x0c070600u);      // code16 << 8 | j >> 8
             const uint32_t lo = __builtin_amdgcn_perm(jlo + (uint32_t)q, cpx[q], 0x04020100u);   // (j & 255) << 24 | rgb
             const u64 key = ((u64)hi << 32) | lo;
@@ -942,8 +939,8 @@ __global__ void __launch_bounds__(256) k_points_splat_general(RenderArgs a)
         for (int eye = 0; eye < 2; ++eye) {
             const Vert v = vertex_for_eye(fp, eye, gx, gy, z, xc, yc);
             if (!v.ok) continue;
-            if (!(v.u >= 0.0f && v.u < (float)W && v.v >= 0.0f && v.v < (float)H)) continue;
-            const int px = (int)floorf(v.u), py = (int)floorf(v.v);
+            const int px = point_col(v.u), py = point_row(v.v);
+            if (!((uint32_t)px < (uint32_t)W && (uint32_t)py < (uint32_t)H)) continue;
             zkey_post<false>(&a.keys[eye][(size_t)fr * a.ws_stride_px + (size_t)py * W + px], (a.key_parity >> fr) & 1u, __float_as_uint(v.z), src);   // v.z > 0
         }
     } else if (EDGE) {
@@ -1211,10 +1208,11 @@ static hipError_t launch_resolve_general(const RenderPlan& plan, const RenderArg
 // =================================================================================================
 //
 // With v = grid_y (depth independent) every vertex row is a horizontal line on screen, so an output
-// scanline k is covered by exactly ONE row of grid cells: the row c whose snapped span [Yt, Yb)
-// contains the scanline (a scanline lying exactly on a vertex row belongs to the cells below it: the
-// row above touches it only with bottom edges / a bottom vertex, which the top-left rule excludes
-// for either orientation).  The 2-D rasterisation collapses to interval coverage along x.
+// scanline k is covered by exactly ONE row of grid cells: the row c whose snapped span (Yt, Yb]
+// contains the scanline (a scanline lying exactly on a vertex row belongs to the cells ABOVE it: the
+// row below touches it only with top edges / a top vertex, which the fill rule -- left and bottom edges
+// own their pixel centres, edge_in -- excludes for either orientation).  The 2-D rasterisation
+// collapses to interval coverage along x.
 //
 //   stage    the two vertex rows c, c+1 once per workgroup: decode, d = dl/Z, 1/Z, snapped x for BOTH
 //            eyes, packed colour -> 16 B per vertex in LDS (coalesced 12 B/lane HBM reads)
@@ -1294,7 +1292,7 @@ struct VertStore {
 // Regular cell (both triangles in the grid's own orientation): on the scanline the cell is the interval
 // between its two column edges, split by the diagonal A-C.  With
 //   E_col_j(X) = h (X - XA) - (XB - XA) t,   E_diag(X) = h (X - XA) - (XC - XA) t
-// tri1 = {E_col_j >= 0, E_diag < 0}, tri2 = {E_diag >= 0, E_col_j+1 < 0} (top-left rule), and the integer
+// tri1 = {E_col_j >= 0, E_diag < 0}, tri2 = {E_diag >= 0, E_col_j+1 < 0} (left edges own their centres), and the integer
 // barycentric weights are these same edge values -- identical to the generic edge functions, three 64-bit
 // subtractions per pixel instead of two triangle set-ups.
 struct RegularCell {
@@ -1352,9 +1350,9 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
     const int Yc = k * kSubpix + kSubpix / 2;
     int ilo = (int)(((float)k + 0.5f) / fp.sy);
     ilo = ilo < 0 ? 0 : (ilo > H - 1 ? H - 1 : ilo);
-    while (ilo > 0 && snap((float)ilo * fp.sy) > Yc) --ilo;
-    while (ilo + 1 <= H - 1 && snap((float)(ilo + 1) * fp.sy) <= Yc) ++ilo;
-    const int c = (ilo <= H - 2) ? ilo : -1;           // largest i with Ys(i) <= Yc; -1: below the last vertex row
+    while (ilo > 0 && snap((float)ilo * fp.sy) >= Yc) --ilo;
+    while (ilo + 1 <= H - 1 && snap((float)(ilo + 1) * fp.sy) < Yc) ++ilo;
+    const int c = (ilo <= H - 2) ? ilo : -1;           // largest i with Ys(i) < Yc (fill rule: bottom edges own their centres); -1: below the last vertex row
     const int Yt = c >= 0 ? snap((float)c * fp.sy) : 0;
     const int Yb = c >= 0 ? snap((float)(c + 1) * fp.sy) : 0;
     const int tt = Yc - Yt, bb = Yb - Yc, hh = Yb - Yt;     // scanline position inside the cell row (sub-pixels)
@@ -1450,8 +1448,9 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                             // exact integer tests in regular_cell_pixel decide.
                             // crossings XA + (XB-XA) t/h and XD + (XC-XD) t/h from 32-bit conversions (the 64-bit kcol values
                             // would cost ~10 instructions each to convert); only the estimate, the integer tests decide
-                            int q0 = (int)floorf((((float)XA + (float)(XB - XA) * tf) - 128.0f) * (1.0f / 256.0f));
-                            int q1 = (int)floorf((((float)XD + (float)(XC - XD) * tf) - 128.0f) * (1.0f / 256.0f)) + 1;
+                            constexpr float kHalf = (float)(kSubpix / 2), kInv = 1.0f / (float)kSubpix;
+                            int q0 = (int)floorf((((float)XA + (float)(XB - XA) * tf) - kHalf) * kInv);
+                            int q1 = (int)floorf((((float)XD + (float)(XC - XD) * tf) - kHalf) * kInv) + 1;
                             if (q0 < p0) q0 = p0;
                             if (q1 > p1) q1 = p1;
                             rp0 = q0; rp1 = q1;

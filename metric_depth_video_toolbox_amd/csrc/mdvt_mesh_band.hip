@@ -9,7 +9,7 @@
 //     diagonal A-C.  With tt = Yc - Yt, hh = Yb - Yt (uniform for the row) and
 //         kcol0 = (XB-XA) tt + hh XA,   kdiag = (XC-XA) tt + hh XA,   kcol1 = (XC-XD) tt + hh XD
 //     pixel centre Xc lies in tri1 = (A,B,C) iff kcol0 <= hh Xc < kdiag and in tri2 = (A,C,D) iff kdiag <= hh Xc < kcol1
-//     (a cell mirrored by a fold: the same with the bounds swapped) -- the top-left rule of the generic edge functions
+//     (a cell mirrored by a fold: the same with the bounds swapped) -- the fill rule of the generic edge functions
 //     written out for edges that start and end on the two vertex rows.  The covered pixel columns of a cell are
 //     therefore [P(klo), P(khi)) with P(k) = ceil((k - 128 hh) / (256 hh)): an exact integer division by a
 //     row-uniform constant instead of candidate pixels tested one by one, and the integer barycentric weights are

@@ -12,7 +12,7 @@
 //     v = (gy - cy) / (m10 + m8 (gx - cx) / fx) + cy of a vertex does not depend on its depth, only on its grid
 //     position.  A vertex row is therefore still (almost) a horizontal line on screen -- tilted by a few rows across
 //     the frame, in opposite directions for the two eyes -- and an output scanline is covered, column by column, by ONE
-//     row of cells: the row i(j) with Y[i][j] <= Yc < Y[i+1][j] ("the bracket of column j").  Depth only enters the
+//     row of cells: the row i(j) with Y[i][j] < Yc <= Y[i+1][j] ("the bracket of column j": bottom edges own their centres).  Depth only enters the
 //     snapped Y through f32 rounding, so the brackets are found from the staged vertices themselves, never assumed.
 //   * one workgroup renders (frame, band of scanlines, EYE) -- an eye's vertices are 16 bytes {X, Y, 1/Z', rgb} and two
 //     rows of them plus the scanline's z keys fit 2 workgroups per CU, exactly like k_mesh_band.  The "two rows" are
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
         const int e = min(est_row(fp, Yc, rzL), est_row(fp, Yc, rzR)) - 4;
         return e < 0 ? 0 : e;
     };
-    // Every column's ring is advanced until it brackets the scanline centre Ycn: Y[a] <= Ycn < Y[a + 1] (or the grid ends).
+    // Every column's ring is advanced until it brackets the scanline centre Ycn: Y[a] < Ycn <= Y[a + 1] (or the grid ends).
     auto stage_to = [&](int Ycn, int ib, bool init) {
         for (int col = tid; col < W; col += TPB) {
             int arow, Ybot = 0, pending = 0;
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
                 arow = ib + (int)(((tw >> 27) - (uint32_t)ib) & 31u);
                 Ybot = t0 ? r1.y : r0.y;
             }
-            while (pending > 0 || (Ybot <= Ycn && arow + 2 <= H - 1)) {
+            while (pending > 0 || (Ybot < Ycn && arow + 2 <= H - 1)) {
                 const int row = arow + 2;
                 const int4 rec = vertex_at(row, col);
                 ring[(size_t)(row & 1) * W + col] = rec;
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
             if (col >= W) continue;
             int arow, Ybot;
             column_state(col, ib, arow, Ybot);
-            if (!(Ybot <= Ycn && arow + 2 <= H - 1)) continue;
+            if (!(Ybot < Ycn && arow + 2 <= H - 1)) continue;
             const int row = arow + 2;
             pdx[q] = load_px_bytes(dbase + (size_t)row * a.depth_pitch, col) | 0x80000000u;
             uint32_t cw = load_px_bytes(cbase + (size_t)row * a.color_pitch, col) | (((uint32_t)row & 31u) << 27);
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
             const int col = tid + q * TPB;
             const int4 rec = conv_vertex(dpx, cw, row, col, fp, M);
             ring[(size_t)(row & 1) * W + col] = rec;
-            more |= rec.y <= Ycn && row + 1 <= H - 1;
+            more |= rec.y < Ycn && row + 1 <= H - 1;
         }
         return more;
     };
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
         for (int col = tid; col < W; col += TPB) {
             int arow, Ybot;
             column_state(col, ib, arow, Ybot);
-            while (Ybot <= Ycn && arow + 2 <= H - 1) {
+            while (Ybot < Ycn && arow + 2 <= H - 1) {
                 const int row = arow + 2;
                 const int4 rec = vertex_at(row, col);
                 ring[(size_t)(row & 1) * W + col] = rec;
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
                     const uint32_t cA = wA & 0xFFFFFFu, cB = wB & 0xFFFFFFu;
                     const int rowA = (int)(wA >> 27);
                     const int hAB = YB - YA;
-                    const int brk = (YA <= Yc && Yc < YB) ? 1 : 0;                 // this column's bracket holds
+                    const int brk = (YA < Yc && Yc <= YB) ? 1 : 0;                 // this column's bracket holds
                     const int colok = (izA > 0.0f && izB > 0.0f && hAB < kConvMaxH &&
                                        (((uint32_t)(XA + kConvCoord) | (uint32_t)(XB + kConvCoord)) >> 20) == 0u) ? 1 : 0;
                     const int tA = Yc - YA;
@@ -406,8 +406,8 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
                     const bool regular = pAB <= pDC;
                     const bool mono = regular ? (pAB <= pAC && pAC <= pDC) : (pAC <= pAB && pDC <= pAC);
                     const bool fast = cell && same_row && brk && brkD && colok && okD && hok && mono;
-                    // a cell both of whose columns put the scanline above its top or at / below its bottom holds no pixel centre of it
-                    const bool outside = (Yc < YA && Yc < YD) || (YB <= Yc && YC <= Yc);
+                    // a cell both of whose columns put the scanline at / above its top or below its bottom holds no pixel centre of it
+                    const bool outside = (Yc <= YA && Yc <= YD) || (YB < Yc && YC < Yc);
                     const bool exotic = cell && same_row && !fast && !outside;
                     const bool step = cell && !same_row;                    // the staircase steps between these two columns
                     const uint32_t skip = EDGES ? (wA >> 24) & 3u : 0u;                                   // dmt:1372

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(kCellTPB, cell_waves(FLAGS, false)) k_mesh_ras
 // nearly every scanline that meets it enters through its left column edge and leaves through its right one, crossing the
 // diagonal in between -- never its top or bottom edge.  On such a scanline the covered pixels are
 //     [P(left crossing), P(right crossing))  split at P(diagonal crossing),   P(k, h) = ceil((k - 128 h) / (256 h))
-// (the top-left rule of the generic edge functions written out for edges that start above the scanline and end below it; h =
+// (the fill rule of the generic edge functions written out for edges that start above the scanline and end at or below it; h =
 // the edge's own height), and a fragment's three edge functions are 32-bit values from 24-bit multiplies.  That is ~150
 // instructions per cell and eye where the triangle-by-triangle set-up and walk of k_mesh_raster_small needs 2 x 211.  Whatever
 // does not fit -- a scanline through a cell's top or bottom edge (a few per thousand cells), twisted or folded cells, cells
@@ -462,15 +462,15 @@ __device__ __forceinline__ void mesh_raster_conv_block(const RenderArgs& a, int 
         const uint32_t inr = (uint32_t)(XA + kCoord) | (uint32_t)(XB + kCoord) | (uint32_t)(XC + kCoord) | (uint32_t)(XD + kCoord);
         generic |= (inr >> 20) != 0u || hAB <= 0 || hAB >= kMaxH || hAC <= 0 || hAC >= kMaxH || hDC <= 0 || hDC >= kMaxH;
         if (!generic) {
-            int k_lo = floordiv_subpix(min(YA, YD) - kSubpix / 2 + kSubpix - 1), k_hi = floordiv_subpix(max(YB, YC) - kSubpix / 2 - 1);
+            int k_lo = floordiv_subpix(min(YA, YD) - kSubpix / 2 + kSubpix), k_hi = floordiv_subpix(max(YB, YC) - kSubpix / 2);      // centres in (top, bottom]
             k_lo = max(k_lo, 0); k_hi = min(k_hi, H - 1);
             if (k_hi - k_lo > 2) generic = true;
             else {
                 for (int k = k_lo; k <= k_hi; ++k) {
                     const int Yc = k * kSubpix + kSubpix / 2;
-                    if (!(YA <= Yc && YD <= Yc && Yc < YB && Yc < YC)) {
+                    if (!(YA < Yc && YD < Yc && Yc <= YB && Yc <= YC)) {
                         // the scanline passes through the cell's top or bottom edge -- unless it misses the cell altogether
-                        if (!((Yc < YA && Yc < YD) || (YB <= Yc && YC <= Yc))) generic = true;
+                        if (!((Yc <= YA && Yc <= YD) || (YB < Yc && YC < Yc))) generic = true;
                         continue;
                     }
                     const int tA = Yc - YA, tD = Yc - YD;

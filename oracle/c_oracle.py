@@ -24,6 +24,7 @@ class OrcParams(C.Structure):
         ("conv_angle", C.c_double),
         ("T", C.c_double * 16),
         ("key_rgb", C.c_uint8 * 4),
+        ("subpixel_bits", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -163,12 +164,13 @@ def convergence_angle(distance: float, ipd_m: float) -> float:
 
 def make_params(W, H, K, *, Kr=None, ipd_m=0.065, max_depth=100.0, depth_scale=1.0, mode=MODE_POINTS,
                 remove_edges=False, edge_points=False, conv_angle=0.0, T=None, key_rgb=(0, 0, 0),
-                force_general=False, cull=0) -> OrcParams:
+                force_general=False, cull=0, subpixel_bits=0) -> OrcParams:
     p = OrcParams()
     p.W, p.H = int(W), int(H)
     p.mode = int(mode)
     p.remove_edges = int(bool(remove_edges))
     p.cull = int(cull)
+    p.subpixel_bits = int(subpixel_bits)
     p.edge_points = int(edge_points)
     kk = k4(K)
     kr = kk if Kr is None else k4(Kr)

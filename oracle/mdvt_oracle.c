@@ -16,7 +16,15 @@
 #include <string.h>
 
 #define ORC_NEAR 1e-4f            /* ctr.set_constant_z_near(0.0001), dmt:1520 */
-#define ORC_SUBPIX 256            /* raster sub-pixel grid (decree)            */
+/* Raster sub-pixel grid: 2^subpixel_bits positions per pixel (GL_SUBPIXEL_BITS).  8 is the decree's default (what desktop
+ * GPUs report); orc_params.subpixel_bits selects another grid so that the oracle can be held to a GL whose grid differs
+ * (SwiftShader: 4, tests/golden/render_gl_*.npz).  The library is single threaded; the entry points set it per call. */
+static int ORC_SUBPIX = 256;
+static void orc_set_subpix(const orc_params* p)
+{
+    const int bits = (p->subpixel_bits >= 1 && p->subpixel_bits <= 8) ? p->subpixel_bits : 8;
+    ORC_SUBPIX = 1 << bits;
+}
 #define ORC_SNAP_LIMIT 2097152.0f /* |u|,|v| clamp before snapping (2^21 px)   */
 
 /* ------------------------------------------------------------------------------------------ */
@@ -385,7 +393,11 @@ static inline int orc_edge_in(int64_t w, int64_t dx, int64_t dy)
 {
     if (w > 0) return 1;
     if (w < 0) return 0;
-    return (dy < 0) || (dy == 0 && dx > 0);    /* top-left rule, clockwise (y down) orientation */
+    /* A pixel centre exactly on an edge belongs to the triangle if the edge is a LEFT edge or a horizontal BOTTOM edge (image
+     * space, y down; orientation normalised to clockwise).  This is OpenGL's fill convention: the hardware's "top-left" rule
+     * acts towards window y = 0, which is the BOTTOM of the picture (observed on the pinned GL: tests/golden/render_gl_*.npz;
+     * Direct3D, whose y = 0 is the top, gives the same edges the name top-left). */
+    return (dy < 0) || (dy == 0 && dx < 0);
 }
 
 static int64_t g_stats[5];
@@ -516,8 +528,15 @@ static void orc_render_eye(const orc_params* p, int eye, const float* depth, con
             const orc_vert* v = &V[k];
             if (!v->ok) continue;
             if (unused && unused[k]) continue;
-            if (!(v->u >= 0.0f && v->u < (float)W && v->v >= 0.0f && v->v < (float)H)) continue;
-            const int px = (int)floorf(v->u), py = (int)floorf(v->v);
+            /* A size-1 point is the unit square around the SNAPPED vertex, rasterised like any polygon with the fill rule of
+             * orc_edge_in: the pixel whose centre lies inside it, a centre on the square's left or bottom edge belongs to it,
+             * on its right or top edge not:  px = ceil(X/S) - 1, py = floor(Y/S), with X, Y the snapped position in 1/S
+             * pixels.  (Observed on the pinned GL, tests/golden/render_gl_*.npz: a point at u in [j, j + 1/(2S)] lands in
+             * column j - 1.) */
+            const int64_t X = orc_snap(v->u), Y = orc_snap(v->v);
+            const int64_t px64 = orc_floordiv(X - 1, ORC_SUBPIX), py64 = orc_floordiv(Y, ORC_SUBPIX);
+            if (px64 < 0 || px64 >= W || py64 < 0 || py64 >= H) continue;
+            const int px = (int)px64, py = (int)py64;
             const size_t o = (size_t)py * W + px;
             if (!(v->z < t.zbuf[o])) continue;
             t.zbuf[o] = v->z;
@@ -602,6 +621,7 @@ int orc_render_stereo_seed(const orc_params* p, const uint8_t* depth_rgb, const 
     const int W = p->W, H = p->H;
     const size_t n = (size_t)W * H;
     const int want_seed = left_seed || right_seed;
+    orc_set_subpix(p);
     float* depth = (float*)malloc(n * sizeof(float));
     orc_decode_depth(depth_rgb, W, H, p->max_depth, p->depth_scale, depth);
 
