@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 13
+#define MDVT_VERSION_MINOR 14
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -74,6 +74,14 @@ typedef struct mdvt_config {
                                     it).  Blocks already held are kept when the budget is lowered: they return to the process-wide pool
                                     with the context (mdvt_release_cached_memory gives them back to the driver).  The field took over
                                     `reserved1` of ABI 0.11: callers built against 0.11 must zero it.                              */
+    int32_t subpixel_bits;       /* the rasteriser's sub-pixel grid, log2 of the positions per pixel a vertex is snapped to before
+                                    coverage is decided -- OpenGL's GL_SUBPIXEL_BITS, an implementation constant of whatever GL
+                                    ran the reference (dmt:1422-1572).  0 = 8 (what desktop GPUs report); 4 = the grid of the
+                                    conformant GL the fixtures tests/golden/render_gl_*.npz were rendered with (SwiftShader), so
+                                    that the path can be held to them; other values are refused.  Applies to the mesh AND to
+                                    points (a size-1 point is the unit square around the snapped vertex).  New in ABI 0.14
+                                    together with reserved2: the struct grew from 40 to 48 bytes                                */
+    int32_t reserved2;           /* must be 0 */
 } mdvt_config;
 
 /* Per-frame parameters: what sr:515-541, 563-566 and 707-721 compute before the render calls. */

@@ -36,7 +36,8 @@ class MdvtError(RuntimeError):
 
 class MdvtConfig(C.Structure):
     _fields_ = [("mode", C.c_int32), ("remove_edges", C.c_int32), ("edge_points", C.c_int32), ("cull", C.c_int32),
-                ("ipd_m", C.c_double), ("max_depth", C.c_double), ("key_rgb", C.c_uint8 * 4), ("workspace_mib", C.c_uint32)]
+                ("ipd_m", C.c_double), ("max_depth", C.c_double), ("key_rgb", C.c_uint8 * 4), ("workspace_mib", C.c_uint32),
+                ("subpixel_bits", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class MdvtFrameParams(C.Structure):

@@ -17,6 +17,9 @@
 #include <vector>
 
 using namespace mdvt;
+using namespace mdvt::grid8;          // grid-independent launchers of the rasterising translation units; the renders are dispatched:
+// The render launchers exist once per sub-pixel grid (mdvt_internal.h); a context uses the set of its mdvt_config.subpixel_bits.
+#define MDVT_GRID_CALL(c, fn, ...) (grid_bits(c) == 4 ? mdvt::grid4::fn(__VA_ARGS__) : mdvt::grid8::fn(__VA_ARGS__))
 
 namespace {
 
@@ -65,6 +68,7 @@ struct mdvt_ctx {
     size_t bigq_bytes = 0;            // the queue block as laid out (without tuning padding)
     int huge_lists = 1;               // huge lists inside the queue block (2: tuning layout "joint")
     mdvt::RowCell* rowcell = nullptr; // [H] scanline -> cell row table of the mesh grid (pure-shift band kernel)
+    int rowcell_bits = 0;             // the sub-pixel grid that table was built for
     uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
     int row_counts_frames = 0;
     // infill-mask completion: per image stamp u16 + T f32 + work image u8x3, and the per-image counters
@@ -513,34 +517,39 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
 bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
 // The decree's snap (mdvt_device.h) on the host: same IEEE operations (this file is compiled with -ffp-contract=off).
-int host_snap(float x)
+int host_snap(float x, int subpix)
 {
     x = fminf(fmaxf(x, -kSnapLimit), kSnapLimit);
-    return (int)rintf(x * (float)kSubpix);
+    return (int)rintf(x * (float)subpix);
 }
+
+int grid_bits(const mdvt_ctx* c) { return c->cfg.subpixel_bits == 4 ? 4 : 8; }
 
 // Scanline k (centre S k + S/2) is covered by the cell row c = largest i with snap(f32(i) * sy) < centre (a centre ON a vertex
 // row belongs to the cells above it: bottom edges own their centres, mdvt_device.h edge_in), if that is not the last vertex
 // row (k_mesh_rows derives the same per workgroup).
 int ensure_rowcell(mdvt_ctx* c, hipStream_t s)
 {
-    if (c->rowcell) return MDVT_OK;
+    if (c->rowcell && c->rowcell_bits == grid_bits(c)) return MDVT_OK;
     const int H = c->H;
+    const int kSubpix = 1 << grid_bits(c);        // (shadows the compile-time grid of this translation unit on purpose)
     const float sy = (float)(((double)H + 1.0) / (double)H);
     std::vector<mdvt::RowCell> t((size_t)H);
     for (int k = 0; k < H; ++k) {
         const int Yc = k * kSubpix + kSubpix / 2;
         int ilo = (int)(((float)k + 0.5f) / sy);
         ilo = ilo < 0 ? 0 : (ilo > H - 1 ? H - 1 : ilo);
-        while (ilo > 0 && host_snap((float)ilo * sy) >= Yc) --ilo;
-        while (ilo + 1 <= H - 1 && host_snap((float)(ilo + 1) * sy) < Yc) ++ilo;
+        while (ilo > 0 && host_snap((float)ilo * sy, kSubpix) >= Yc) --ilo;
+        while (ilo + 1 <= H - 1 && host_snap((float)(ilo + 1) * sy, kSubpix) < Yc) ++ilo;
         mdvt::RowCell r{};
         r.c = (ilo <= H - 2) ? ilo : -1;
-        r.Yt = r.c >= 0 ? host_snap((float)r.c * sy) : 0;
-        r.Yb = r.c >= 0 ? host_snap((float)(r.c + 1) * sy) : 1;
+        r.Yt = r.c >= 0 ? host_snap((float)r.c * sy, kSubpix) : 0;
+        r.Yb = r.c >= 0 ? host_snap((float)(r.c + 1) * sy, kSubpix) : 1;
         t[(size_t)k] = r;
     }
-    MDVT_HIP(c, ws_malloc(c, (void**)&c->rowcell, (size_t)H * sizeof(mdvt::RowCell), s));
+    if (!c->rowcell) MDVT_HIP(c, ws_malloc(c, (void**)&c->rowcell, (size_t)H * sizeof(mdvt::RowCell), s));
+    else MDVT_HIP(c, hipDeviceSynchronize());     // a render of the other grid may still read the table
+    c->rowcell_bits = grid_bits(c);
     MDVT_HIP(c, hipMemcpyAsync(c->rowcell, t.data(), (size_t)H * sizeof(mdvt::RowCell), hipMemcpyHostToDevice, s));
     MDVT_HIP(c, hipStreamSynchronize(s));      // `t` is pageable host memory
     return MDVT_OK;
@@ -666,6 +675,9 @@ int mdvt_set_config(mdvt_ctx* c, const mdvt_config* cfg)
     if (cfg->edge_points < 0 || cfg->edge_points > 2) return fail(c, MDVT_ERR_INVALID_ARG, "edge_points must be 0, 1 or 2");
     if (cfg->edge_points && !cfg->remove_edges) return fail(c, MDVT_ERR_INVALID_ARG, "edge_points needs remove_edges (sr:589)");
     if (cfg->cull < 0 || cfg->cull > 2) return fail(c, MDVT_ERR_INVALID_ARG, "cull must be 0 (none), 1 (back) or 2 (front)");
+    if (cfg->subpixel_bits != 0 && cfg->subpixel_bits != 4 && cfg->subpixel_bits != 8)
+        return fail(c, MDVT_ERR_INVALID_ARG, "subpixel_bits must be 0 (default: 8), 4 or 8 -- the grids this build's rasterisers are compiled for");
+    if (cfg->reserved2 != 0) return fail(c, MDVT_ERR_INVALID_ARG, "reserved2 must be 0");
     // (advisor r04: the field took over a reserved one -- a caller built against 0.11 that left it uninitialised must not get an
     //  arbitrary budget silently: anything above 1 TiB is refused, small values are honoured down to one slot)
     if (cfg->workspace_mib > (1u << 20)) return fail(c, MDVT_ERR_INVALID_ARG, "workspace_mib %u out of range (0 = default 4096, at most 1048576)", cfg->workspace_mib);
@@ -754,13 +766,13 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     // A pure-shift frame wider than the LDS row kernels can hold (10 240 px for points, ~4 300 for the mesh with edge
     // points) is rendered by the global-key kernels instead -- with its own pure-shift arithmetic (FrameDev.general
     // stays 0), so the pixels do not depend on which kernels ran.  MDVT_FORCE_GLOBAL=1 sends every frame that way (tests).
-    const bool wide = !mdvt::render_fits_lds(plan, W) || tuning_env(TUNE_FORCE_GLOBAL) != nullptr;
+    const bool wide = !MDVT_GRID_CALL(c, render_fits_lds, plan, W) || tuning_env(TUNE_FORCE_GLOBAL) != nullptr;
     if (wide) general = 1;
     bool conv_kernel = false;
     if (plan.mode == MDVT_MODE_MESH && !wide) {
         RenderArgs probe{};
         probe.W = W; probe.H = H;
-        conv_kernel = mdvt::mesh_conv_supported(plan, probe);
+        conv_kernel = MDVT_GRID_CALL(c, mesh_conv_supported, plan, probe);
     }
     bool any_global = false, any_conv = false;
     for (int k = 0; k < n_frames; ++k) {
@@ -957,7 +969,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
             for (int k = f0; k < f0 + plan.n; ++k)
                 if (fd[(size_t)k].erow_lo < fd[(size_t)k].erow_hi)
                     plan.edge_rows_max = std::max(plan.edge_rows_max, fd[(size_t)k].erow_hi - fd[(size_t)k].erow_lo + 1);
-        hipError_t e = launch_render(plan, a, s);
+        hipError_t e = MDVT_GRID_CALL(c, launch_render, plan, a, s);
         plan.after_vertices = nullptr;
         if (r.general && e == hipSuccess) c->key_parity ^= (plan.n >= 32 ? 0xFFFFFFFFu : ((1u << plan.n) - 1u)) << slot0;   // these slots' next use has the other parity
         if (e == hipErrorNotSupported) return fail(c, MDVT_ERR_UNSUPPORTED, "render mode %d is not built yet", plan.mode);

@@ -18,6 +18,13 @@ namespace mdvt {
 enum TuneKey { TUNE_BLUR_ONE_PASS, TUNE_DEBUG_SKIP, TUNE_EDGE_INBAND, TUNE_FORCE_GLOBAL, TUNE_LDS_PAD, TUNE_MESH_BAND, TUNE_MESH_BAND3, TUNE_MESH_CONV, TUNE_MESH_OLD, TUNE_MESH_TPB, TUNE_NI_DUMP, TUNE_NI_SKIP, TUNE_PARAM_UPLOAD, TUNE_POINTS_CFG, TUNE_POINTS_NT, TUNE_POOL_TAG, TUNE_QUEUE_DUMP, TUNE_RASTER_CONV_OFF, TUNE_TELEA_BLOCKS, TUNE_TELEA_DUMP, TUNE_WS_CHUNK, TUNE_WS_FRESH, TUNE_WS_LAYOUT, TUNE_WS_PAD, TUNE_WS_POOL, TUNE_COUNT };
 const char* tuning_env(TuneKey k);
 bool tuning_build();
+// The ablation hooks inside the kernels (RenderArgs.debug_skip, NormalInfillArgs.debug_skip) exist in the objects of the tuning
+// library only (-DMDVT_TUNING, Makefile): the product kernels are compiled with the constant 0 and carry no such test.
+#ifdef MDVT_TUNING
+#define MDVT_DEBUG_SKIP(a) ((a).debug_skip)
+#else
+#define MDVT_DEBUG_SKIP(a) 0
+#endif
 
 // Near plane of the reference's render call: ctr.set_constant_z_near(0.0001) (dmt:1520).
 constexpr float kNear = 1e-4f;
@@ -142,23 +149,8 @@ struct RenderPlan {
     int edge_rows_max;   // pure-shift launches with edge points: the most scanlines any frame leaves to k_edge_rows_exact (0: none)
     hipEvent_t after_vertices;   // general paths: recorded on the launch's stream behind the first pass (the mesh's cell walk, the points' splat; nullptr: none)
 };
-hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s);
-// mdvt_mesh_band.hip: the pure-shift mesh rows as bands (no edge removal)
-bool mesh_band_supported(const RenderPlan& plan, const RenderArgs& a);
-hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
-// mdvt_mesh_band3.hip: the same rows with no vertex records in LDS, both eyes per pass, three workgroups per CU
-bool mesh_band3_supported(const RenderPlan& plan, const RenderArgs& a);
-hipError_t launch_mesh_band3(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
-// mdvt_mesh_conv.hip: mesh + convergence only, z-buffer in LDS (the product default of movie_2_3D.py:433-445)
-bool mesh_conv_supported(const RenderPlan& plan, const RenderArgs& a);
-hipError_t launch_mesh_conv(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
-// the general paths' edge-point splat into the global edge keys, and the pass that empties the written words again
-hipError_t launch_edge_points_splat(const RenderArgs& a, int n, bool as_list, bool counters_zeroed, hipStream_t s);
-hipError_t launch_edge_keys_reset(const RenderArgs& a, int n, hipStream_t s);
-hipError_t launch_edge_point_pixels(const uint8_t* depth, size_t pitch, const FrameDev* fp, int W, int H, int of_by_one, int how,
-                                    int32_t* out, hipStream_t s);
-// mdvt_mesh_general.hip: the rasteriser of the general mesh path (between the vertex pass and the resolve pass)
-hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a, hipStream_t s);
+// The rasterising translation units (mdvt_kernels.hip's render sections, mdvt_mesh_*.hip) are compiled once per sub-pixel grid;
+// what they define is declared in mdvt_grid_decls.h, once per grid namespace (below, after the shared declarations).
 // (mdvt_normal_infill.hip; workspace: normal_infill_workspace_bytes(1, W, H))
 hipError_t launch_infill_normals(const uint8_t* color, size_t color_pitch, const uint8_t* hole, size_t hole_pitch,
                                  const float* normal, size_t normal_pitch, uint8_t* out, size_t out_pitch, int W, int H,
@@ -198,11 +190,14 @@ hipError_t launch_normal_infill(const ImageSet& img, const ImageSet& mask, const
                                 const BlurKernel& K, hipStream_t s);
 hipError_t launch_infill_mask_normals(const ImageSet& img, const ImageSet& hole, const ImageSet& mask, uint8_t* workspace, int n, int W, int H,
                                       int max_steps, hipStream_t s);
-hipError_t launch_pack_mask(const RenderArgs& a, int n, hipStream_t s);
-hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 hipError_t launch_selftest(int which, unsigned long long seed, unsigned long long* d_mism, hipStream_t s);
 hipError_t launch_coherence_test(uint32_t* blk, size_t dwords, uint32_t tag, uint32_t* d_xcc, uint32_t* d_out, hipStream_t s);     // (mdvt_selftest.hip; r05 diagnosis)
-size_t render_lds_bytes(const RenderPlan& plan, int W);
-bool render_fits_lds(const RenderPlan& plan, int W);      // can the pure-shift row kernels hold a row of this width in LDS?
+
+namespace grid8 {
+#include "mdvt_grid_decls.h"
+}
+namespace grid4 {
+#include "mdvt_grid_decls.h"
+}
 
 }  // namespace mdvt

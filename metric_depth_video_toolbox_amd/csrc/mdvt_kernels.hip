@@ -20,6 +20,9 @@
 
 namespace mdvt {
 
+// Sections that do not depend on the sub-pixel grid are compiled once, with the default grid (-DMDVT_SUBPIX_BITS=8), into
+// namespace mdvt; the rasterising sections once per grid into mdvt::MDVT_GRID (mdvt_internal.h).
+#if MDVT_SUBPIX_BITS == 8
 // =================================================================================================
 // depth codec (dfh)
 // =================================================================================================
@@ -413,6 +416,9 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
     return hipGetLastError();
 }
 
+#endif  // grid-independent sections
+
+namespace MDVT_GRID {
 // =================================================================================================
 // POINT MODE, pure stereo shift: one workgroup per (frame,row), z-buffer in LDS
 // =================================================================================================
@@ -1125,7 +1131,7 @@ __global__ void __launch_bounds__(256) k_resolve_general(RenderArgs a)
     const int y = blockIdx.y;
     const int fr = blockIdx.z >> 1, eye = blockIdx.z & 1;
     if (g >= W / PX) return;
-    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
+    if (MDVT_DEBUG_SKIP(a) & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
     const int f = a.frame0 + fr;
     const uint8_t* cbase = a.color + (size_t)f * a.color_stride;
     u64* krow = a.keys[eye] + (size_t)fr * a.ws_stride_px + (size_t)y * W + (size_t)g * PX;
@@ -1337,7 +1343,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
     ties.bits = (uint32_t*)(((uintptr_t)(kcode + (EDGEPTS ? W : 0)) + 15) & ~(uintptr_t)15);
     ties.nwords = (W + 31) / 32;
     ties.mode = 0;
-    ties.force = (a.debug_skip & 32) != 0;
+    ties.force = (MDVT_DEBUG_SKIP(a) & 32) != 0;
 
     const int fr = blockIdx.x / H;
     const int k = blockIdx.x - fr * H;                 // output row
@@ -1359,7 +1365,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
     const float tf = c >= 0 ? (float)tt / (float)hh : 0.0f; // scanline height inside the cell row, for the candidate estimate only
 
     // ---- stage the two vertex rows, clear the z-buffer ----
-    if (c >= 0 && !(a.debug_skip & 4)) {
+    if (c >= 0 && !(MDVT_DEBUG_SKIP(a) & 4)) {
         const int ngroups = W / PX;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -1401,7 +1407,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
         // ---- rasterise this eye (passes 1 and 2 only for a row with exact depth ties, see RowTies) ----
 #pragma unroll 1
         for (ties.mode = 0; ties.mode < 3; ++ties.mode) {
-        if (c >= 0 && !(a.debug_skip & 1)) {
+        if (c >= 0 && !(MDVT_DEBUG_SKIP(a) & 1)) {
             for (int j0 = 0; j0 < W - 1; j0 += TPB) {
                 const int j = j0 + tid;
                 TriSetup t[2];
@@ -1456,7 +1462,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                             rp0 = q0; rp1 = q1;
                             if (q1 - q0 >= kShortSpan) {
                                 lngcell = true;           // rubber-sheet cell across a vertical depth edge: whole-wave path below
-                            } else if (!(a.debug_skip & 16)) {
+                            } else if (!(MDVT_DEBUG_SKIP(a) & 16)) {
                                 const i64 kdiag = mul64(XC - XA, tt) + mul64(hh, XA);
                                 for (int px = q0; px <= q1; ++px) regular_cell_pixel(rc, px, tt, bb, hh, kcol0, kcol1, kdiag, zb, ties);
                             }
@@ -1483,7 +1489,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                 }
                 // long regular cells: the whole wave works on one lane's cell at a time (64 pixel centres per step)
                 {
-                    u64 m = (a.debug_skip & 8) ? 0ull : __ballot(lngcell);
+                    u64 m = (MDVT_DEBUG_SKIP(a) & 8) ? 0ull : __ballot(lngcell);
                     while (m) {
                         const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
                         m &= m - 1;
@@ -1507,7 +1513,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
                 // long spans of irregular cells: the whole wave works on one lane's triangle at a time
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
-                    u64 m = (a.debug_skip & 8) ? 0ull : __ballot(lng[pass]);
+                    u64 m = (MDVT_DEBUG_SKIP(a) & 8) ? 0ull : __ballot(lng[pass]);
                     while (m) {
                         const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
                         m &= m - 1;
@@ -1540,7 +1546,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
         // ---- edge points of source row k (sr:589-606, 745-781): vertices of removed triangles ----
         if (EDGEPTS && !edge_row_deferred(fp, k)) {        // (scanlines erow_lo .. erow_hi: k_edge_rows_exact)
             const uint8_t* drow_k = a.depth + (size_t)f * a.depth_stride + (size_t)k * a.depth_pitch;
-            const bool k_staged = c >= 0 && (k == c || k == c + 1) && !(a.debug_skip & 4);
+            const bool k_staged = c >= 0 && (k == c || k == c + 1) && !(MDVT_DEBUG_SKIP(a) & 4);
             const float guard = edge_col_guard(W);
             for (int j = tid; j < W; j += TPB) {
                 if (!(cfl[j] & 4u)) continue;
@@ -1568,7 +1574,7 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
         float* zrow = ZOUT && a.zout[eye]
                           ? (float*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)k * a.zout_pitch)
                           : nullptr;
-        for (int g = tid; g < W / PX && !(a.debug_skip & 2); g += TPB) {
+        for (int g = tid; g < W / PX && !(MDVT_DEBUG_SKIP(a) & 2); g += TPB) {
             uint32_t opx[PX], om[PX], spx[PX];
             float oz[PX];
 #pragma unroll
@@ -1603,6 +1609,10 @@ __global__ void __launch_bounds__(TPB) k_mesh_rows(RenderArgs a)
     }
 }
 
+}  // namespace MDVT_GRID
+
+#if MDVT_SUBPIX_BITS == 8
+using MDVT_GRID::RowIO;      // (the row loads / stores of the points section: plain memory access, nothing of the grid in them)
 // =================================================================================================
 // MESH MODE, general (pose / convergence): triangles rasterised into global 64-bit z keys
 // =================================================================================================
@@ -2639,6 +2649,9 @@ hipError_t launch_swap_rb(const ImageSet& src, const ImageSet& dst, int n, int W
     return hipGetLastError();
 }
 
+#endif  // grid-independent sections
+
+namespace MDVT_GRID {
 // =================================================================================================
 // launch plumbing
 // =================================================================================================
@@ -3121,4 +3134,5 @@ hipError_t launch_render(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
     return e != hipSuccess ? e : launch_edge_rows_exact(plan, a, s);
 }
 
+}  // namespace MDVT_GRID
 }  // namespace mdvt

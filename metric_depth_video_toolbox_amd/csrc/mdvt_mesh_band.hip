@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 namespace mdvt {
+namespace MDVT_GRID {      // one copy per sub-pixel grid (mdvt_internal.h)
 
 // FLAGS bit 0: depth planes; bit 1: triangles removed by the 89-degree filter draw nothing (remove_edges; tri_invalid /
 // unused come from k_edge_filter); bit 2: the vertices of removed triangles are splatted into the holes (sr:589-606,
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderAr
     typedef const __attribute__((address_space(4))) RenderArgs* KArgs;
     const KArgs ka0 = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
 #define KARGS(p) KArgs p = ka0; asm volatile("" : "+s"(p))
-    const int dbg = DBG ? a.debug_skip : 0;
+    const int dbg = DBG ? MDVT_DEBUG_SKIP(a) : 0;
     const uint32_t cull = DBG ? (uint32_t)a.cull : 0u;
     constexpr bool ZOUT = FLAGS & 1, EDGES = FLAGS & 2, EDGEPTS = FLAGS & 4, SEED = FLAGS & 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -418,7 +419,7 @@ static hipError_t launch_mesh_band_tpb(const RenderPlan& plan, const RenderArgs&
                       (plan.remove_edges && a.seed[0] ? 8 : 0);
 #define MDVT_CASE(F)                                                                                                        \
     case F:                                                                                                                 \
-        if (a.debug_skip || a.cull) {                                                                                       \
+        if (MDVT_DEBUG_SKIP(a) || a.cull) {                                                                                       \
             (void)hipFuncSetAttribute((const void*)k_mesh_band<F, TPB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             hipLaunchKernelGGL((k_mesh_band<F, TPB, true>), grid, block, lds, s, a, rows, nbands);                               \
         } else {                                                                                                            \
@@ -450,4 +451,5 @@ hipError_t launch_mesh_band(const RenderPlan& plan, const RenderArgs& a_in, hipS
     return launch_mesh_band_tpb<1024>(plan, a, rows, s);
 }
 
+}  // namespace MDVT_GRID
 }  // namespace mdvt

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 namespace mdvt {
+namespace MDVT_GRID {      // one copy per sub-pixel grid (mdvt_internal.h)
 
 namespace {
 
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 6) k_mesh_band3(RenderA
     uint32_t* queue = (uint32_t*)(zb2 + 2 * (size_t)W);     // [TPB/64][kQueueWave]
     const int nwords = (W + 31) / 32;
     uint32_t* tbits = queue + (TPB / 64) * kQueueWave;      // per eye [W/32 + 1] exact-depth-tie bits + flag (RowTies, mdvt_device.h)
-    const bool tforce = (a.debug_skip & 32) != 0;
+    const bool tforce = (MDVT_DEBUG_SKIP(a) & 32) != 0;
     // (built where it is used: an array of RowTies indexed by the eye would live in scratch memory)
     auto ties_of = [&](int eye, int mode) { RowTies t; t.bits = tbits + eye * (nwords + 1); t.nwords = nwords; t.mode = mode; t.force = tforce; return t; };
 
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 6) k_mesh_band3(RenderA
 
 #pragma unroll 1
         for (int mode = 0; mode < 3; ++mode) {
-            if (g.c >= 0 && !(a.debug_skip & 1)) {
+            if (g.c >= 0 && !(MDVT_DEBUG_SKIP(a) & 1)) {
                 int qn = 0;                                          // items on this wave's stack (uniform)
                 // the first pass's source pixels
                 int jn = wave * 63 + lane;
@@ -138,12 +139,12 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 6) k_mesh_band3(RenderA
                         const bool drawn = fast && skip != 3u && !(cull && (cull == 1u) != regular);
                         const int plo = regular ? pA : pD;
                         int n = drawn ? (regular ? pD - pA : pA - pD) : 0;
-                        if (n > 0 && !(a.debug_skip & 16))
+                        if (n > 0 && !(MDVT_DEBUG_SKIP(a) & 16))
                             cell_pixel(XA, XB, XC, XD, izA, izB, izC, izD, cAc, cBc, cC, cD, kcol0, kcol1, plo, j, skip, g, zb, tie);
                         // Further pixels of the cell become (eye, cell, pixel) items on the wave's stack, shaded 64 at a time: first
                         // one item per lane and round (spans of up to 4 px), then the long spans (rubber sheet across a depth
                         // edge), one cell at a time written by the whole wave.  One loop, so that the shading code exists once.
-                        if (a.debug_skip & 8) n = 0;
+                        if (MDVT_DEBUG_SKIP(a) & 8) n = 0;
                         u64 lm = __ballot(n > 4);
                         const bool last = final_pass && eye == (serve1 ? 1 : 0);        // the last eye this pass serves: the stack is emptied
                         if (__ballot(n > 1) != 0ull || last) {
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 6) k_mesh_band3(RenderA
                         }
                         if (final_pass) continue;
                         // exotic cells (near plane, out of the 24-bit range, twisted, zero width): generic path, whole wave
-                        u64 em = (a.debug_skip & 8) ? 0ull : __ballot(exotic);
+                        u64 em = (MDVT_DEBUG_SKIP(a) & 8) ? 0ull : __ballot(exotic);
                         while (em) {
                             const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)em) - 1);
                             em &= em - 1;
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 6) k_mesh_band3(RenderA
         }
 
         // ---- resolve both eyes: LDS keys -> colour-key hole test -> coalesced stores; the keys are reset on the way ----
-        const bool resolving = act4 && !(a.debug_skip & 2);
+        const bool resolving = act4 && !(MDVT_DEBUG_SKIP(a) & 2);
         const bool edge_row = EDGEPTS && !edge_row_deferred(fp, k);     // (scanlines erow_lo .. erow_hi: k_edge_rows_exact)
 #pragma unroll 1
         for (int eye = 0; eye < 2; ++eye) {
@@ -369,4 +370,5 @@ hipError_t launch_mesh_band3(const RenderPlan& plan, const RenderArgs& a_in, hip
     return launch_mesh_band3_tpb<1024>(plan, a, rows, s);
 }
 
+}  // namespace MDVT_GRID
 }  // namespace mdvt

@@ -37,6 +37,7 @@
 #include <stdlib.h>
 
 namespace mdvt {
+namespace MDVT_GRID {      // one copy per sub-pixel grid (mdvt_internal.h)
 
 namespace {
 
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
     ties.bits = queue + (TPB / 64) * kQueueWave;
     ties.nwords = (W + 31) / 32;
     ties.mode = 0;
-    ties.force = (a.debug_skip & 32) != 0;
+    ties.force = (MDVT_DEBUG_SKIP(a) & 32) != 0;
     uint32_t* steps = ties.bits + ties.nwords + 1;          // [kStepCap] listed staircase steps, then [0] their count, [1] waves done
     uint32_t* steps_n = steps + kStepCap;
 
@@ -367,11 +368,11 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
         const int ib = ibase_of(Yc);
         const int4* r0p = ring;
         const int4* r1p = ring + W;
-        if (k + 1 < k1 && !(a.debug_skip & 128)) prefetch_next(Yc + kSubpix, ib);          // in flight while the scanline is rasterised
+        if (k + 1 < k1 && !(MDVT_DEBUG_SKIP(a) & 128)) prefetch_next(Yc + kSubpix, ib);          // in flight while the scanline is rasterised
         // (passes 1 and 2 only for a row with exact depth ties between different colours: RowTies in mdvt_device.h)
 #pragma unroll 1
         for (ties.mode = 0; ties.mode < 3; ++ties.mode) {
-            if (!(a.debug_skip & 1)) {
+            if (!(MDVT_DEBUG_SKIP(a) & 1)) {
                 int qn = 0;                                          // items on this wave's stack (uniform)
                 constexpr int kCellsPerPass = 63 * (TPB / 64);
 #pragma unroll 1
@@ -414,11 +415,11 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
                     const uint32_t rowcol = ((uint32_t)(ib + (int)(((uint32_t)rowA - (uint32_t)ib) & 31u)) << 16) | (uint32_t)j;
                     const int plo = regular ? pAB : pDC;
                     int n = (fast && skip != 3u) ? (regular ? pDC - pAB : pAB - pDC) : 0;
-                    if (n > 0 && !(a.debug_skip & 16))
+                    if (n > 0 && !(MDVT_DEBUG_SKIP(a) & 16))
                         conv_cell_pixel(XA, YA, XB, YB, XC, YC, XD, YD, izA, izB, izC, izD, cA, cB, cC, cD, plo,
                                         (mul24(hAC, plo * kSubpix + kSubpix / 2) < kAC) == regular, skip, cull, Yc, rowcol, zb, ties);
                     // Further pixels of the cell become (cell, pixel) items on the wave's stack, shaded 64 at a time (as k_mesh_band)
-                    if (a.debug_skip & 8) n = 0;
+                    if (MDVT_DEBUG_SKIP(a) & 8) n = 0;
                     u64 lm = __ballot(n > 4);
                     if (__ballot(n > 1) != 0ull || final_pass) {
                         int round = 1, lcell = 0, lpix = 0, lrem = 0;
@@ -473,7 +474,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
 #define MDVT_BF(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l))
 #define MDVT_BU(v) (uint32_t)__builtin_amdgcn_readlane((int)(v), l)
                     // irregular cells whose four vertices are in the ring (near plane, out of range, twisted, grid border)
-                    u64 em = (a.debug_skip & 8) ? 0ull : __ballot(exotic);
+                    u64 em = (MDVT_DEBUG_SKIP(a) & 8) ? 0ull : __ballot(exotic);
                     while (em) {
                         const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)em) - 1);
                         em &= em - 1;
@@ -482,7 +483,7 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
                                          MDVT_BU(skip), (int)cull, k, W, lane, MDVT_BU(rowcol), zb, ties);
                     }
                     // steps of the staircase: listed for the last wave out (below); a full list: here and now, on this wave
-                    if (__ballot(step) != 0ull && !(a.debug_skip & 8)) {
+                    if (__ballot(step) != 0ull && !(MDVT_DEBUG_SKIP(a) & 8)) {
                         uint32_t slot = kStepCap;
                         if (step) {
                             const int ra = ib + (int)(((uint32_t)rowA - (uint32_t)ib) & 31u), rd = ib + (int)(((uint32_t)rowD - (uint32_t)ib) & 31u);
@@ -558,10 +559,10 @@ __global__ void __launch_bounds__(TPB, 4) k_mesh_conv(RenderArgs a, int rows_per
         ties.mode = 0;
 
         // the brackets of the next scanline (the ring's last readers were the raster passes above)
-        if (k + 1 < k1 && stage_prefetched(Yc + kSubpix, ib) && !(a.debug_skip & 4)) stage_rest(Yc + kSubpix, ib);
+        if (k + 1 < k1 && stage_prefetched(Yc + kSubpix, ib) && !(MDVT_DEBUG_SKIP(a) & 4)) stage_rest(Yc + kSubpix, ib);
 
         // ---- resolve: LDS keys -> colour-key hole test -> coalesced stores; the keys are reset on the way ----
-        if (act4 && !(a.debug_skip & 2)) {
+        if (act4 && !(MDVT_DEBUG_SKIP(a) & 2)) {
             uint4* zq = (uint4*)zb + 2 * tid;
             const uint4 k01 = zq[0], k23 = zq[1];
             zq[0] = make_uint4(~0u, ~0u, ~0u, ~0u); zq[1] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -674,4 +675,5 @@ hipError_t launch_mesh_conv(const RenderPlan& plan, const RenderArgs& a_in, hipS
     return hipSuccess;
 }
 
+}  // namespace MDVT_GRID
 }  // namespace mdvt

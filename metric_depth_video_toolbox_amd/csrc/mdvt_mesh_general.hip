@@ -19,6 +19,7 @@
 #include <vector>
 
 namespace mdvt {
+namespace MDVT_GRID {      // one copy per sub-pixel grid (mdvt_internal.h)
 
 namespace {
 
@@ -61,7 +62,7 @@ __device__ __forceinline__ void pending_settle(const RenderArgs& a, const Pendin
     if (p.o == ~0u) return;
     const int slot = (int)(p.se >> 1);
     const uint32_t parity = (a.key_parity >> slot) & 1u;
-    if (zkey_colour_conflict(p.old, p.mine, parity) || ((a.debug_skip & 32) && zkey_covered(p.old, parity))) {   // (bit 5: test hook,
+    if (zkey_colour_conflict(p.old, p.mine, parity) || ((MDVT_DEBUG_SKIP(a) & 32) && zkey_covered(p.old, parity))) {   // (bit 5: test hook,
         const FragOut f = frag_out(a, slot, (int)(p.se & 1u));                                                         //  tuning build)
         zkey_mark_tied(&f.keys[p.o], parity);
         f.cbuf[p.o] = ~0ull;                                // (every marker stores the same value; the second pass is a later kernel)
@@ -328,7 +329,7 @@ __device__ __forceinline__ void mesh_raster_small_block(const RenderArgs& a, int
                             toq = MODE == 0;             // (second pass: nothing is queued -- the first pass's lists are walked again)
                         } else if (MODE == 0 || tie_tiles_hit(fo, bx0, by0, bx1, by1)) {
                             TriSmall ts;
-                            if (tri_small_setup(ts, X0, Y0, iz0, X1, Y1, iz1, X2, Y2, iz2, a.cull) && !(a.debug_skip & 16)) {
+                            if (tri_small_setup(ts, X0, Y0, iz0, X1, Y1, iz1, X2, Y2, iz2, a.cull) && !(MDVT_DEBUG_SKIP(a) & 16)) {
                                 TriWalk32 row = tri_small_start(ts, bx0, by0);
                                 for (int py = by0; py <= by1; ++py) {
                                     TriWalk32 w = row;
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(kCellTPB, cell_waves(FLAGS, false)) k_mesh_ras
     int bx, i0;
     cell_block_of(a.W, blockIdx.x, kRowsWG, bx, i0);
     const int fr = (int)blockIdx.z;
-    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
+    if (MDVT_DEBUG_SKIP(a) & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
     stage_vertex_row<false>(a, fr, i0, bx * kCellsWG, sv, 0);
 #pragma unroll 1
     for (int r = 0; r < kRowsWG && i0 + r < a.H - 1; ++r) {
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(kCellTPB, cell_waves(FLAGS, false)) k_mesh_ras
     }
     pending_settle(a, pds[0]);
     pending_settle(a, pds[1]);
-    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (MDVT_DEBUG_SKIP(a) & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 // ---- The same stage for frames whose vertex rows stay (almost) horizontal on screen: convergence only ---------------------
@@ -582,7 +583,7 @@ __global__ void __launch_bounds__(kConvTPB, cell_waves(FLAGS, true)) k_mesh_rast
     cell_block_of(a.W, blockIdx.x, kRowsWG, bx, i0);
     const int fr = (int)blockIdx.z;
     Pending pd = pending_none();
-    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
+    if (MDVT_DEBUG_SKIP(a) & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
     stage_vertex_row<true>(a, fr, i0, bx * kCellsWG, sv, 0);
 #pragma unroll 1
     for (int r = 0; r < kRowsWG && i0 + r < a.H - 1; ++r) {
@@ -595,7 +596,7 @@ __global__ void __launch_bounds__(kConvTPB, cell_waves(FLAGS, true)) k_mesh_rast
         __syncthreads();                                   // (the row above and the list are replaced next)
     }
     pending_settle(a, pd);
-    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (MDVT_DEBUG_SKIP(a) & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 // The queued triangles, dealt over the whole chip (a horizontal depth edge under vertical parallax turns an entire row
@@ -765,10 +766,10 @@ __device__ __forceinline__ void mesh_huge_walk(const RenderArgs& a)
 __global__ void __launch_bounds__(256) k_mesh_raster_queue(RenderArgs a, int nseg)
 {
     extern __shared__ uint32_t cpre[];                    // (blocks + 1 + threads words: launch_mesh_raster_general)
-    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
+    if (MDVT_DEBUG_SKIP(a) & 512) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (r05 diagnosis, tuning build)
     queue_prefix_lds(a, nseg, cpre);
     mesh_queue_walk<0>(a, nseg, cpre);
-    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (MDVT_DEBUG_SKIP(a) & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 __global__ void __launch_bounds__(256) k_mesh_raster_huge(RenderArgs a) { mesh_huge_walk<0>(a); }
 
@@ -814,14 +815,14 @@ __global__ void __launch_bounds__(256) k_mesh_queue_reset(RenderArgs a, int n)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x, nt = gridDim.x * 256u;
     const uint32_t nseg = (uint32_t)n * (uint32_t)a.H, ntile = (uint32_t)n * 2u * (uint32_t)a.tie_words;
-    if (a.debug_skip & 256) { for (uint32_t k = t; k < nseg; k += nt) atomicExch(&a.bigq_count[k], 0u); }      // (r05 diagnosis, tuning build)
+    if (MDVT_DEBUG_SKIP(a) & 256) { for (uint32_t k = t; k < nseg; k += nt) atomicExch(&a.bigq_count[k], 0u); }      // (r05 diagnosis, tuning build)
     else for (uint32_t k = t; k < nseg; k += nt) a.bigq_count[k] = 0u;
     for (uint32_t k = t; k <= ((nseg + (1u << a.bigq_shift) - 1u) >> a.bigq_shift); k += nt) a.bigq_coarse[k] = 0u;
     for (uint32_t k = t; k < ntile; k += nt) a.tie_tiles[k] = 0u;
     if (t < (uint32_t)n) a.tie_flag[t] = 0u;
     if (t < 2u) a.hugeq[2 * (size_t)kHugeCap + t] = 0u;
     if (a.vlist_count && t < (uint32_t)n) a.vlist_count[t] = 0u;             // (the edge-point splat's list counters: one launch fewer)
-    if (a.debug_skip & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (MDVT_DEBUG_SKIP(a) & 512) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
@@ -870,4 +871,5 @@ hipError_t launch_mesh_raster_general(const RenderPlan& plan, const RenderArgs& 
     return hipGetLastError();
 }
 
+}  // namespace MDVT_GRID
 }  // namespace mdvt

@@ -275,7 +275,7 @@ __device__ __forceinline__ void ni_stage_requests_and_marks(const NiArgs& a, int
     const int W = a.W, H = a.H;
     const size_t ib = (size_t)im * H * W;
     const uint8_t* mimg = a.mask.image(im);
-    if (a.bg[ib + (size_t)y * W + x] && !(a.debug_skip & 2)) {
+    if (a.bg[ib + (size_t)y * W + x] && !(MDVT_DEBUG_SKIP(a) & 2)) {
         uint8_t* need = a.need + ib;
         if (x >= 2 && x + 1 < W && y >= 2 && y + 1 < H) {                 // (no reflection: 4 bytes per row)
 #pragma unroll
@@ -290,7 +290,7 @@ __device__ __forceinline__ void ni_stage_requests_and_marks(const NiArgs& a, int
             }
         }
     }
-    if (a.debug_skip & 1) return;
+    if (MDVT_DEBUG_SKIP(a) & 1) return;
     const int mark = ni_march_lower_side(mimg, a.mask.pitch, load_px_bytes(mimg + (size_t)y * a.mask.pitch, x), x, y, W, H);
     if (mark < 0) return;
     a.marks[ib + (size_t)mark] = 1;
@@ -333,7 +333,7 @@ __device__ __forceinline__ void ni_stage_filled(const NiArgs& a, int im, int x, 
         const float nz = (((float)((m >> 16) & 0xFFu) / 255.0f) * 2.0f) - 1.0f;
         const float len = sqrtf(nx * nx + ny * ny);                               // sr:177
         const bool green = nx == 0.0f && ny == 1.0f && nz == 0.0f;               // sr:182
-        if (len > 1e-6f && !green && !(a.debug_skip & 4)) {
+        if (len > 1e-6f && !green && !(MDVT_DEBUG_SKIP(a) & 4)) {
             const float dx = nx / len, dy = ny / len;
             const float fx = (float)x, fy = (float)y;
             bool done = false;
@@ -365,7 +365,7 @@ __device__ __forceinline__ void ni_stage_filled(const NiArgs& a, int im, int x, 
             }
         }
     }
-    const uint32_t v = (have && !(a.debug_skip & 8)) ? ni_masked_blur_px(a.out.image(im), a.out.pitch, sx, sy, W, H, a.K) : 0u;
+    const uint32_t v = (have && !(MDVT_DEBUG_SKIP(a) & 8)) ? ni_masked_blur_px(a.out.image(im), a.out.pitch, sx, sy, W, H, a.K) : 0u;
     store_px_bytes(a.filled + 3 * (ib + (size_t)y * W), x, v);
 }
 

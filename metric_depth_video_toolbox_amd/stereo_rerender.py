@@ -287,6 +287,9 @@ class StereoRerenderer:
       workspace_mib                                  budget for the posed / converged mesh path's workspace (mdvt.h; 0 = 4096 MiB)
       cull                                           0 draw both faces of the mesh (default), 1 cull back faces, 2 front faces
                                                      (dmt:1507-1556 leaves Open3D's mesh_show_back_face at its default)
+      subpixel_bits                                  the rasteriser's sub-pixel grid (GL_SUBPIXEL_BITS of the GL that ran the
+                                                     reference): 0 = 8, the default; 4 = the grid of the GL the fixtures
+                                                     tests/golden/render_gl_*.npz were rendered with (mdvt.h)
     """
 
     FINISH_SPLIT_FRAMES = 32         # finish_infill_mask_sbs: from this many frames per call, two concurrent half passes
@@ -295,7 +298,7 @@ class StereoRerenderer:
                  max_depth=100, master_xfov: float = 45.0, render_as_pointcloud: bool = False,
                  remove_edges: bool = False, infill_mask: bool = False, do_basic_infill: bool = False,
                  dont_remove_edges: bool = False, dont_place_points_in_edges: bool = False, cull: int = 0,
-                 workspace_mib: int = 0):
+                 workspace_mib: int = 0, subpixel_bits: int = 0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no ROCm GPU visible: the stereo-rerender path has no CPU fallback")
@@ -321,6 +324,8 @@ class StereoRerenderer:
         cfg.cull = int(cull)
         cfg.workspace_mib = int(workspace_mib)                             # 0: the library's default (4096)
         self.cull = int(cull)
+        cfg.subpixel_bits = int(subpixel_bits)
+        self.subpixel_bits = int(subpixel_bits)
         cfg.ipd_m = self.pupillary_distance / 1000                         # sr:458-459
         cfg.max_depth = float(self.max_depth)
         for k in range(3):

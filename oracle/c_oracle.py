@@ -164,13 +164,14 @@ def convergence_angle(distance: float, ipd_m: float) -> float:
 
 def make_params(W, H, K, *, Kr=None, ipd_m=0.065, max_depth=100.0, depth_scale=1.0, mode=MODE_POINTS,
                 remove_edges=False, edge_points=False, conv_angle=0.0, T=None, key_rgb=(0, 0, 0),
-                force_general=False, cull=0, subpixel_bits=0) -> OrcParams:
+                force_general=False, cull=0, subpixel_bits=None) -> OrcParams:
     p = OrcParams()
     p.W, p.H = int(W), int(H)
     p.mode = int(mode)
     p.remove_edges = int(bool(remove_edges))
     p.cull = int(cull)
-    p.subpixel_bits = int(subpixel_bits)
+    # (MDVT_TEST_SUBPIXEL_BITS: the whole GPU suite on another sub-pixel grid, tests/conftest.py -- the renderers AND this checker)
+    p.subpixel_bits = int(os.environ.get("MDVT_TEST_SUBPIXEL_BITS", 0)) if subpixel_bits is None else int(subpixel_bits)
     p.edge_points = int(edge_points)
     kk = k4(K)
     kr = kk if Kr is None else k4(Kr)
@@ -231,6 +232,42 @@ def render_stereo(p: OrcParams, depth_rgb: np.ndarray, color_rgb: np.ndarray, wa
                                       _p(out["left_mask"], C.c_uint8), _p(out["right_mask"], C.c_uint8), ld, rd, ls, rs)
     if rc != 0:
         raise ValueError(f"orc_render_stereo failed: {rc}")
+    return out
+
+
+class OrcGlOpts(C.Structure):
+    _fields_ = [("near_clip", C.c_int32), ("samples", C.c_int32), ("pattern", C.c_int32), ("resolve", C.c_int32),
+                ("depth_tie_tol", C.c_double)]
+
+
+# |1/Z - 1/Z'| below which a GL's depth buffer cannot tell two fragments apart: window depth is 1 - near/Z to 24 bits (or an
+# f32 just below 1.0: the same 2^-24 spacing) with near = 1e-4 (dmt:1520), and its interpolation is good to a few of those
+# steps -- 4 * 2^-24 / 1e-4.
+GL_DEPTH_TIE_TOL = 4.0 * 2.0 ** -24 / 1e-4
+
+
+def render_stereo_gl(p: OrcParams, depth_rgb: np.ndarray, color_rgb: np.ndarray, *, near_clip=False, samples=0, pattern=0, resolve=0,
+                     depth_tie_tol=0.0):
+    """The GL candidates of mdvt_oracle.c (diagnostics) -> dict(left_rgb, right_rgb, left_mask, right_mask[, left_ambiguous,
+    right_ambiguous] when depth_tie_tol > 0)."""
+    depth_rgb = np.ascontiguousarray(depth_rgb, np.uint8)
+    color_rgb = np.ascontiguousarray(color_rgb, np.uint8)
+    H, W = p.H, p.W
+    assert depth_rgb.shape == (H, W, 3) and color_rgb.shape == (H, W, 3)
+    g = OrcGlOpts(int(bool(near_clip)), int(samples), int(pattern), int(resolve), float(depth_tie_tol))
+    out = {"left_rgb": np.empty((H, W, 3), np.uint8), "right_rgb": np.empty((H, W, 3), np.uint8),
+           "left_mask": np.empty((H, W), np.uint8), "right_mask": np.empty((H, W), np.uint8)}
+    la = ra = None
+    if depth_tie_tol > 0:
+        out["left_ambiguous"], out["right_ambiguous"] = np.empty((H, W), np.uint8), np.empty((H, W), np.uint8)
+        la, ra = _p(out["left_ambiguous"], C.c_uint8), _p(out["right_ambiguous"], C.c_uint8)
+    L = lib()
+    L.orc_render_stereo_gl.restype = C.c_int
+    rc = L.orc_render_stereo_gl(C.byref(p), C.byref(g), _p(depth_rgb, C.c_uint8), _p(color_rgb, C.c_uint8),
+                                _p(out["left_rgb"], C.c_uint8), _p(out["right_rgb"], C.c_uint8),
+                                _p(out["left_mask"], C.c_uint8), _p(out["right_mask"], C.c_uint8), la, ra)
+    if rc != 0:
+        raise ValueError(f"orc_render_stereo_gl failed: {rc}")
     return out
 
 

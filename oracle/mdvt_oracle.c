@@ -643,6 +643,292 @@ int orc_render_stereo_seed(const orc_params* p, const uint8_t* depth_rgb, const 
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* GL candidates (diagnostics): what the states dmt.render leaves to the GL would change        */
+/* ------------------------------------------------------------------------------------------ */
+/* The decree above fixes three things a real OpenGL does differently or leaves to the implementation:
+ *   near_clip      GL CLIPS a triangle that straddles the near plane (dmt:1520: 1e-4); the decree drops it whole.
+ *   samples = 4    Open3D's legacy window asks for a 4x multisampled framebuffer; the decree samples once, at the centre.
+ *   depth_tie_tol  GL compares WINDOW depth, 24 bits (or an f32 just below 1.0) of 1 - near/Z: with near = 1e-4 two
+ *                  fragments closer than ~6e-4 Z^2 metres are the same depth (GL_LESS: the first drawn stays) or differ by
+ *                  the implementation's rounding noise; the decree compares f32 1/Z exactly.
+ * orc_render_stereo_gl renders with any of them switched on, with the SAME vertex programme, snap, fill rule, draw order
+ * and shading arithmetic as the decree (with every option off it is held bit for bit to orc_render_stereo by
+ * tests/test_oracle_golden.py), so that each difference between the decree and the GL fixtures (tests/golden/
+ * render_gl_*.npz) can be attributed, and so that the candidates are in place should a render of the reference show that
+ * one of them is what it does.  The HIP path implements none of them.
+ *   Clipping: in eye space against z = near, attributes (colour as float, 1/Z) interpolated linearly along the clipped edge
+ *   as GL does in clip space; the polygon is fanned from its first vertex.
+ *   Multisampling: coverage and depth per sample, colour once per pixel at the pixel centre (GL's default, no centroid),
+ *   written to the covered samples that pass the depth test; resolve = mean of the four samples, uncovered ones holding the
+ *   clear colour (= the key colour).  `pattern` 0: the Direct3D / Vulkan standard 4x positions (6,2) (14,6) (2,10) (10,14)/16
+ *   that desktop GPUs use; 1: SwiftShader's (3,10) (10,13) (13,6) (6,3)/16 in image space (y down), as measured on the pinned GL.
+ *   `resolve` 0: (sum + 2) >> 2; 1: SwiftShader's avg(avg(s0,s1), avg(s2,s3)) with avg = (a + b + 1) >> 1.
+ *   Ambiguity plane: bit 0 where a fragment that did not win lies within depth_tie_tol (in units of 1/Z) of the winner and
+ *   carries another colour -- the pixels whose outcome a GL decides by its depth buffer's resolution; bit 1 where the winning
+ *   fragment's triangle spans more than a factor 2 in 1/Z (a rubber-sheet triangle across a depth edge: the perspective-
+ *   correct colour there amplifies every rounding of the interpolation, and GLs interpolate differently). */
+typedef struct { double X, Y, Z; float c[3]; } orc_glv;     /* eye space + colour */
+
+typedef struct {
+    int W, H, ns;
+    int ox[4], oy[4];           /* sample offsets inside the pixel, sub-pixel units */
+    float* zbuf;                /* [ns][H*W] interpolated 1/Z, 0 = empty */
+    uint8_t* rgb;               /* [ns][H*W][3] */
+    uint8_t* covered;           /* [ns][H*W] */
+    uint8_t* ambiguous;         /* [H*W] or NULL: bit 0 depth near-tie, bit 1 the winner's triangle is steep in 1/Z */
+    uint8_t* steep;             /* [ns][H*W] work plane */
+    int pass2;                  /* 1: fill `ambiguous` only */
+    float tol;
+    int cull;
+} orc_gl_target;
+
+static void orc_gl_raster(orc_gl_target* t, const float u[3], const float v[3], const float izv[3], const float col[3][3])
+{
+    const int64_t X0 = orc_snap(u[0]), Y0 = orc_snap(v[0]);
+    const int64_t X1 = orc_snap(u[1]), Y1 = orc_snap(v[1]);
+    const int64_t X2 = orc_snap(u[2]), Y2 = orc_snap(v[2]);
+    int64_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
+    if (area2 == 0) return;
+    if ((t->cull == 1 && area2 > 0) || (t->cull == 2 && area2 < 0)) return;
+    const int64_t s = area2 > 0 ? 1 : -1;
+    area2 *= s;
+    int64_t minX = X0 < X1 ? X0 : X1; if (X2 < minX) minX = X2;
+    int64_t maxX = X0 > X1 ? X0 : X1; if (X2 > maxX) maxX = X2;
+    int64_t minY = Y0 < Y1 ? Y0 : Y1; if (Y2 < minY) minY = Y2;
+    int64_t maxY = Y0 > Y1 ? Y0 : Y1; if (Y2 > maxY) maxY = Y2;
+    int64_t px0 = orc_floordiv(minX, ORC_SUBPIX) - 1, px1 = orc_floordiv(maxX, ORC_SUBPIX) + 1;
+    int64_t py0 = orc_floordiv(minY, ORC_SUBPIX) - 1, py1 = orc_floordiv(maxY, ORC_SUBPIX) + 1;
+    if (px0 < 0) px0 = 0;
+    if (py0 < 0) py0 = 0;
+    if (px1 > t->W - 1) px1 = t->W - 1;
+    if (py1 > t->H - 1) py1 = t->H - 1;
+    const int64_t dx0 = s * (X2 - X1), dy0 = s * (Y2 - Y1);
+    const int64_t dx1 = s * (X0 - X2), dy1 = s * (Y0 - Y2);
+    const int64_t dx2 = s * (X1 - X0), dy2 = s * (Y1 - Y0);
+    const float ra = 1.0f / (float)area2;
+    const size_t n = (size_t)t->W * t->H;
+    const int64_t half = ORC_SUBPIX / 2;
+    float izmin = izv[0] < izv[1] ? izv[0] : izv[1], izmax = izv[0] > izv[1] ? izv[0] : izv[1];
+    if (izv[2] < izmin) izmin = izv[2];
+    if (izv[2] > izmax) izmax = izv[2];
+    const uint8_t steep = izmax > 2.0f * izmin;
+    for (int64_t py = py0; py <= py1; ++py)
+        for (int64_t px = px0; px <= px1; ++px) {
+            int hit[4], any = 0;
+            float izs[4];
+            for (int k = 0; k < t->ns; ++k) {
+                const int64_t Xs = px * ORC_SUBPIX + t->ox[k], Ys = py * ORC_SUBPIX + t->oy[k];
+                const int64_t w0 = s * ((X2 - X1) * (Ys - Y1) - (Y2 - Y1) * (Xs - X1));
+                const int64_t w1 = s * ((X0 - X2) * (Ys - Y2) - (Y0 - Y2) * (Xs - X2));
+                const int64_t w2 = s * ((X1 - X0) * (Ys - Y0) - (Y1 - Y0) * (Xs - X0));
+                hit[k] = orc_edge_in(w0, dx0, dy0) && orc_edge_in(w1, dx1, dy1) && orc_edge_in(w2, dx2, dy2);
+                if (!hit[k]) continue;
+                any = 1;
+                const float q0 = ((float)w0 * ra) * izv[0], q1 = ((float)w1 * ra) * izv[1], q2 = ((float)w2 * ra) * izv[2];
+                izs[k] = (q0 + q1) + q2;
+            }
+            if (!any) continue;
+            /* colour: once per pixel, at the pixel centre (== the sample for ns == 1) */
+            const int64_t Xc = px * ORC_SUBPIX + half, Yc = py * ORC_SUBPIX + half;
+            const int64_t c0 = s * ((X2 - X1) * (Yc - Y1) - (Y2 - Y1) * (Xc - X1));
+            const int64_t c1 = s * ((X0 - X2) * (Yc - Y2) - (Y0 - Y2) * (Xc - X2));
+            const int64_t c2 = s * ((X1 - X0) * (Yc - Y0) - (Y1 - Y0) * (Xc - X0));
+            const float q0 = ((float)c0 * ra) * izv[0], q1 = ((float)c1 * ra) * izv[1], q2 = ((float)c2 * ra) * izv[2];
+            const float izc = (q0 + q1) + q2;
+            uint8_t frag[3];
+            for (int ch = 0; ch < 3; ++ch) {
+                float val;
+                if (izc > 0.0f) val = rintf(((q0 * col[0][ch] + q1 * col[1][ch]) + q2 * col[2][ch]) * (1.0f / izc));
+                else val = rintf((((float)c0 * ra) * col[0][ch] + ((float)c1 * ra) * col[1][ch]) + ((float)c2 * ra) * col[2][ch]);
+                if (!(val >= 0.0f)) val = 0.0f;
+                if (val > 255.0f) val = 255.0f;
+                frag[ch] = (uint8_t)val;
+            }
+            const size_t o = (size_t)py * t->W + (size_t)px;
+            for (int k = 0; k < t->ns; ++k) {
+                if (!hit[k]) continue;
+                float* zb = t->zbuf + (size_t)k * n; uint8_t* cv = t->covered + (size_t)k * n; uint8_t* rg = t->rgb + 3 * (size_t)k * n;
+                if (t->pass2) {
+                    if (cv[o] && fabsf(izs[k] - zb[o]) <= t->tol && memcmp(frag, rg + 3 * o, 3) != 0) t->ambiguous[o] |= 1;
+                    continue;
+                }
+                if (cv[o] && !(izs[k] > zb[o])) continue;
+                zb[o] = izs[k]; cv[o] = 1; memcpy(rg + 3 * o, frag, 3);
+                if (t->steep) t->steep[(size_t)k * n + o] = steep;
+            }
+        }
+}
+
+/* one triangle given in eye space: clip against the near plane (or drop it whole), project with the render camera, raster */
+static void orc_gl_tri(orc_gl_target* t, const orc_eye* e, const orc_glv* a, const orc_glv* b, const orc_glv* c,
+                       const orc_vert* va, const orc_vert* vb, const orc_vert* vc, int near_clip)
+{
+    const orc_glv* in[3] = { a, b, c };
+    const orc_vert* vv[3] = { va, vb, vc };
+    const int ok[3] = { va->ok, vb->ok, vc->ok };
+    if (ok[0] && ok[1] && ok[2]) {
+        const float u[3] = { va->u, vb->u, vc->u }, v[3] = { va->v, vb->v, vc->v };
+        const float iz[3] = { 1.0f / va->z, 1.0f / vb->z, 1.0f / vc->z };
+        const float col[3][3] = { { a->c[0], a->c[1], a->c[2] }, { b->c[0], b->c[1], b->c[2] }, { c->c[0], c->c[1], c->c[2] } };
+        orc_gl_raster(t, u, v, iz, col);
+        return;
+    }
+    if (!near_clip || !(ok[0] || ok[1] || ok[2])) return;
+    /* Sutherland-Hodgman against Z = near */
+    float pu[4], pv[4], piz[4], pc[4][3];
+    int np = 0;
+    const double zn = (double)ORC_NEAR;
+    for (int k = 0; k < 3; ++k) {
+        const int k1 = (k + 1) % 3;
+        const orc_glv* P = in[k]; const orc_glv* Q = in[k1];
+        if (ok[k]) {
+            pu[np] = vv[k]->u; pv[np] = vv[k]->v; piz[np] = 1.0f / vv[k]->z;
+            for (int ch = 0; ch < 3; ++ch) pc[np][ch] = P->c[ch];
+            ++np;
+        }
+        if (ok[k] != ok[k1]) {
+            const double tt = (zn - P->Z) / (Q->Z - P->Z);
+            const double X = P->X + tt * (Q->X - P->X), Y = P->Y + tt * (Q->Y - P->Y);
+            pu[np] = (float)((double)e->fxr * X / zn + (double)e->cxr);
+            pv[np] = (float)((double)e->fyr * Y / zn + (double)e->cyr);
+            piz[np] = (float)(1.0 / zn);
+            for (int ch = 0; ch < 3; ++ch) pc[np][ch] = (float)((double)P->c[ch] + tt * ((double)Q->c[ch] - (double)P->c[ch]));
+            ++np;
+        }
+    }
+    for (int k = 1; k + 1 < np; ++k) {
+        const float u[3] = { pu[0], pu[k], pu[k + 1] }, v[3] = { pv[0], pv[k], pv[k + 1] }, iz[3] = { piz[0], piz[k], piz[k + 1] };
+        float col[3][3];
+        for (int ch = 0; ch < 3; ++ch) { col[0][ch] = pc[0][ch]; col[1][ch] = pc[k][ch]; col[2][ch] = pc[k + 1][ch]; }
+        orc_gl_raster(t, u, v, iz, col);
+    }
+}
+
+/* eye-space position of grid vertex (i, j) (f64; only the clipper reads it) */
+static void orc_gl_eye_space(const orc_eye* e, int i, int j, float zsrc, orc_glv* o)
+{
+    const double gx = (double)((float)j * e->sx), gy = (double)((float)i * e->sy), z = (double)zsrc;
+    const double xc = (gx - (double)e->cx) * z / (double)e->fx, yc = (gy - (double)e->cy) * z / (double)e->fy;
+    if (!e->general) {
+        o->X = xc + (double)e->sign * ((double)e->dl / (double)e->fxr); o->Y = yc; o->Z = z;
+        return;
+    }
+    const float* M = e->M;
+    o->X = (M[0] * xc + M[1] * yc) + M[2] * z + M[3];
+    o->Y = (M[4] * xc + M[5] * yc) + M[6] * z + M[7];
+    o->Z = (M[8] * xc + M[9] * yc) + M[10] * z + M[11];
+}
+
+static void orc_gl_render_eye(const orc_params* p, const orc_gl_opts* g, int eye, const float* depth, const uint8_t* color,
+                              const uint8_t* tri_invalid, const uint8_t* unused, uint8_t* out_rgb, uint8_t* out_mask, uint8_t* out_amb)
+{
+    const int W = p->W, H = p->H;
+    const size_t n = (size_t)W * H;
+    orc_eye e;
+    orc_eye_setup(p, eye, &e);
+    orc_gl_target t;
+    memset(&t, 0, sizeof t);
+    t.W = W; t.H = H; t.cull = p->cull;
+    t.ns = g->samples == 4 ? 4 : 1;
+    if (t.ns == 1) { t.ox[0] = t.oy[0] = ORC_SUBPIX / 2; }
+    else {
+        static const int pat[2][4][2] = { { { 6, 2 }, { 14, 6 }, { 2, 10 }, { 10, 14 } }, { { 3, 10 }, { 10, 13 }, { 13, 6 }, { 6, 3 } } };
+        for (int k = 0; k < 4; ++k) { t.ox[k] = pat[g->pattern ? 1 : 0][k][0] * ORC_SUBPIX / 16; t.oy[k] = pat[g->pattern ? 1 : 0][k][1] * ORC_SUBPIX / 16; }
+    }
+    t.zbuf = (float*)calloc(n * t.ns, sizeof(float));
+    t.rgb = (uint8_t*)calloc(n * t.ns, 3);
+    t.covered = (uint8_t*)calloc(n * t.ns, 1);
+    t.ambiguous = out_amb;
+    t.tol = (float)g->depth_tie_tol;
+    if (out_amb) { memset(out_amb, 0, n); t.steep = (uint8_t*)calloc(n * t.ns, 1); }
+
+    orc_vert* V = (orc_vert*)malloc(n * sizeof(orc_vert));
+    orc_glv* G = (orc_glv*)malloc(n * sizeof(orc_glv));
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            const size_t k = (size_t)i * W + j;
+            V[k] = orc_vertex(&e, i, j, depth[k]);
+            orc_gl_eye_space(&e, i, j, depth[k], &G[k]);
+            for (int ch = 0; ch < 3; ++ch) G[k].c[ch] = (float)color[3 * k + ch];
+        }
+    for (t.pass2 = 0; t.pass2 < ((out_amb && g->depth_tie_tol > 0.0) ? 2 : 1); ++t.pass2) {
+        if (p->mode == ORC_MODE_POINTS) {
+            /* the unit square around the snapped vertex, as two triangles at the vertex's own depth (orc_render_eye's rule
+             * is what this gives for one sample at the centre) */
+            for (size_t k = 0; k < n; ++k) {
+                if (!V[k].ok || (unused && unused[k])) continue;
+                const float hs = 0.5f;
+                const float cu = (float)orc_snap(V[k].u) / (float)ORC_SUBPIX, cv = (float)orc_snap(V[k].v) / (float)ORC_SUBPIX;
+                const float iz[3] = { 1.0f / V[k].z, 1.0f / V[k].z, 1.0f / V[k].z };
+                const float col[3][3] = { { G[k].c[0], G[k].c[1], G[k].c[2] }, { G[k].c[0], G[k].c[1], G[k].c[2] }, { G[k].c[0], G[k].c[1], G[k].c[2] } };
+                const float u1[3] = { cu - hs, cu - hs, cu + hs }, v1[3] = { cv - hs, cv + hs, cv + hs };
+                const float u2[3] = { cu - hs, cu + hs, cu + hs }, v2[3] = { cv - hs, cv + hs, cv - hs };
+                const int keep = t.cull; t.cull = 0;
+                orc_gl_raster(&t, u1, v1, iz, col);
+                orc_gl_raster(&t, u2, v2, iz, col);
+                t.cull = keep;
+            }
+        } else {
+            const size_t ncell = (size_t)(W - 1) * (H - 1);
+            for (int pass = 0; pass < 2; ++pass)
+                for (int i = 0; i < H - 1; ++i)
+                    for (int j = 0; j < W - 1; ++j) {
+                        if (tri_invalid && tri_invalid[(size_t)pass * ncell + (size_t)i * (W - 1) + j]) continue;
+                        const size_t i1 = (size_t)i * W + j, i2 = (size_t)(i + 1) * W + j;
+                        const size_t i3 = (size_t)(i + 1) * W + j + 1, i4 = (size_t)i * W + j + 1;
+                        const size_t v0 = i1, v1 = pass == 0 ? i2 : i3, v2 = pass == 0 ? i3 : i4;
+                        orc_gl_tri(&t, &e, &G[v0], &G[v1], &G[v2], &V[v0], &V[v1], &V[v2], g->near_clip);
+                    }
+        }
+    }
+    /* resolve + colour-key hole mask (sr:740, 793) */
+    for (size_t k = 0; k < n; ++k) {
+        uint8_t c[3];
+        if (t.ns == 1) {
+            if (t.covered[k]) memcpy(c, t.rgb + 3 * k, 3); else memcpy(c, p->key_rgb, 3);
+        } else {
+            for (int ch = 0; ch < 3; ++ch) {
+                int sv[4];
+                for (int q = 0; q < 4; ++q) sv[q] = t.covered[(size_t)q * n + k] ? t.rgb[3 * ((size_t)q * n + k) + ch] : p->key_rgb[ch];
+                c[ch] = g->resolve ? (uint8_t)((((sv[0] + sv[1] + 1) >> 1) + ((sv[2] + sv[3] + 1) >> 1) + 1) >> 1)
+                                   : (uint8_t)((sv[0] + sv[1] + sv[2] + sv[3] + 2) >> 2);
+            }
+        }
+        const int hole = c[0] == p->key_rgb[0] && c[1] == p->key_rgb[1] && c[2] == p->key_rgb[2];
+        out_mask[k] = hole ? 255 : 0;
+        if (hole) { out_rgb[3 * k] = out_rgb[3 * k + 1] = out_rgb[3 * k + 2] = 0; }
+        else memcpy(out_rgb + 3 * k, c, 3);
+    }
+    if (t.steep) { for (size_t k = 0; k < n * t.ns; ++k) if (t.steep[k]) out_amb[k % n] |= 2; free(t.steep); }
+    free(V); free(G); free(t.zbuf); free(t.rgb); free(t.covered);
+}
+
+int orc_render_stereo_gl(const orc_params* p, const orc_gl_opts* g, const uint8_t* depth_rgb, const uint8_t* color_rgb,
+                         uint8_t* left_rgb, uint8_t* right_rgb, uint8_t* left_mask, uint8_t* right_mask,
+                         uint8_t* left_ambiguous, uint8_t* right_ambiguous)
+{
+    if (!p || !g || p->W < 2 || p->H < 2) return -1;
+    if (p->mode != ORC_MODE_POINTS && p->mode != ORC_MODE_MESH) return -1;
+    if (g->samples != 0 && g->samples != 1 && g->samples != 4) return -1;
+    orc_set_subpix(p);
+    if (g->samples == 4 && ORC_SUBPIX < 16) return -1;
+    const int W = p->W, H = p->H;
+    const size_t n = (size_t)W * H;
+    float* depth = (float*)malloc(n * sizeof(float));
+    orc_decode_depth(depth_rgb, W, H, p->max_depth, p->depth_scale, depth);
+    uint8_t* tri_invalid = NULL; uint8_t* unused = NULL;
+    if (p->remove_edges) {
+        tri_invalid = (uint8_t*)malloc(2 * (size_t)(W - 1) * (H - 1));
+        unused = (uint8_t*)malloc(n);
+        orc_edge_filter(depth, W, H, p->K, p->mode == ORC_MODE_MESH, tri_invalid, unused, NULL);
+    }
+    orc_gl_render_eye(p, g, 0, depth, color_rgb, tri_invalid, unused, left_rgb, left_mask, left_ambiguous);
+    orc_gl_render_eye(p, g, 1, depth, color_rgb, tri_invalid, unused, right_rgb, right_mask, right_ambiguous);
+    free(tri_invalid); free(unused); free(depth);
+    return 0;
+}
+
 int orc_render_stereo(const orc_params* p, const uint8_t* depth_rgb, const uint8_t* color_rgb,
                       uint8_t* left_rgb, uint8_t* right_rgb, uint8_t* left_mask, uint8_t* right_mask,
                       float* left_depth, float* right_depth)

@@ -42,3 +42,24 @@ def orc():
     from oracle import c_oracle
     c_oracle.build()
     return c_oracle
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _whole_suite_on_another_grid():
+    """MDVT_TEST_SUBPIXEL_BITS=4 python -m pytest tests -m gpu: every StereoRerenderer the GPU tests make renders on the 4-bit
+    sub-pixel grid (mdvt_config.subpixel_bits) unless the test chose one itself, and -- because the tests hand the renderer's
+    grid to the oracle -- is compared with the oracle on that grid.  That is how the second copy of the rasterising kernels
+    (csrc/Makefile: *_g4.o) is held to everything the default grid is held to."""
+    bits = os.environ.get("MDVT_TEST_SUBPIXEL_BITS")
+    if not bits:
+        yield
+        return
+    from metric_depth_video_toolbox_amd import stereo_rerender
+    orig = stereo_rerender.StereoRerenderer.__init__
+
+    def init(self, *a, **kw):
+        kw.setdefault("subpixel_bits", int(bits))
+        orig(self, *a, **kw)
+    stereo_rerender.StereoRerenderer.__init__ = init
+    yield
+    stereo_rerender.StereoRerenderer.__init__ = orig

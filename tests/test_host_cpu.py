@@ -24,12 +24,12 @@ def test_library_exports_every_declared_symbol(lib):
     declared = sorted(set(re.findall(r"\b(mdvt_[a-z_]+)\s*\(", hdr)))
     assert declared == sorted(lib.SYMBOLS), "keep _lib.SYMBOLS in step with include/mdvt.h"
     assert lib.exported_symbols() == list(lib.SYMBOLS)
-    assert lib.load().mdvt_version() == (0 << 16) | 13
+    assert lib.load().mdvt_version() == (0 << 16) | 14
 
 
 def test_struct_layouts_match_the_header(lib):
     import ctypes as C
-    assert C.sizeof(lib.MdvtConfig) == 40
+    assert C.sizeof(lib.MdvtConfig) == 48          # ABI 0.14: + subpixel_bits, reserved2
     assert C.sizeof(lib.MdvtFrameParams) == 8 * (9 + 9 + 2 + 16) + 8
     assert C.sizeof(lib.MdvtIO) == 8 * 27
 
@@ -302,6 +302,24 @@ def test_the_product_library_has_no_tuning_hooks():
     L = ctypes.CDLL(_lib.lib_path("tuning"))
     for sym in _lib.SYMBOLS:
         assert hasattr(L, sym)
+    # the product KERNELS carry no ablation test either.  Every read of RenderArgs.debug_skip /
+    # NormalInfillArgs.debug_skip in csrc/ goes through MDVT_DEBUG_SKIP(a), which is the constant 0 unless the object is compiled
+    # with -DMDVT_TUNING, and the Makefile gives that flag to the *_t.o objects of libmdvt_hip_tuning.so only.
+    csrc = os.path.join(REPO, "metric_depth_video_toolbox_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        for ln, line in enumerate(open(os.path.join(csrc, f)).read().split("\n"), 1):
+            code = line.split("//")[0]
+            for m in re.finditer(r"\bdebug_skip\b", code):
+                before, after = code[:m.start()], code[m.end():]
+                ok = (re.search(r"=[^=]", after.lstrip()[:2] + " ") and not after.lstrip().startswith("==")) or "int debug_skip" in code or \
+                     "int32_t debug_skip" in code or "define MDVT_DEBUG_SKIP" in code or before.rstrip().endswith("((a)")
+                assert ok, f"{f}:{ln}: debug_skip read outside MDVT_DEBUG_SKIP(): {line.strip()}"
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    rules = re.findall(r"^\$\(OBJDIR\)/(%[^:]*): .*\n\t@mkdir[^\n]*\n\t([^\n]*)", mk, re.M)
+    assert {t: ("-DMDVT_TUNING" in cmd) for t, cmd in rules} == {"%.o": False, "%_g4.o": False, "%_t.o": True}
+    assert "_t.o" not in re.search(r"^OBJS_PRODUCT := (.*)$", mk, re.M).group(1)
 
 
 def test_outputs_of_an_earlier_run_do_not_shadow_the_fresh_ones(tmp_path):
