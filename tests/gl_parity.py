@@ -1,6 +1,6 @@
 """How a render is held to the GL fixtures tests/golden/render_gl_*.npz (made by tests/golden/gen_gl_golden.py with a
 conformant OpenGL, SwiftShader) -- shared by tests/test_oracle_golden.py (the oracle), tests/test_gpu_render.py (the HIP path)
-and tools/report_gl_parity.py.
+and tests/report_gl_parity.py.
 
 What can be asked of two correct rasterisers that do not share their float arithmetic:
 
