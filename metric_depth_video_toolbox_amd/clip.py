@@ -1,8 +1,12 @@
 """Clip-level driver: the counterpart of the reference's whole `stereo_rerender.py` run (sr:318-968)
 for frame dumps, with frames streamed through the GPU in batches and sharded over ranks.
 
-On-disk formats.  The reference reads/writes FFV1-in-MKV through OpenCV (sr:327-341, 435-444, 941);
-a device-side FFV1 codec is out of scope, so this driver works on raw frame dumps:
+On-disk formats.  The reference reads/writes FFV1-in-MKV through OpenCV (sr:327-341, 435-444, 941).  This driver does the
+same when --depth_video is a Matroska file (video_io.py / libmdvt_video.so: a host-side FFV1 + Matroska reader and writer written
+from the RFCs; a device-side FFV1 codec is out of scope): `x.mkv` [+ `y.mkv`] in, `x.mkv_stereo.mkv`, `x.mkv_stereo.mkv_infillmask.mkv`,
+`x.mkv_stereo.mkv_depth.mkv` (the reference's names, sr:411-444) and `x.mkv_stereo.mkv_holemask.mkv` (this build's extra, grey) out,
+each written as `x.mkv_tmp_...` and renamed once its frame count is right (dfh:163-179).  A colour video in another codec
+(H.264 ...) cannot be decoded here.  Otherwise it works on raw frame dumps, the format for benchmarking:
 
   <name>.npy            uint8 [N, H, W, 3]  RGB frames (np.load(..., mmap_mode="r") compatible)
   depth dump            the same layout holding the 16-bit RGB depth code of dfh:48-61 (RGB order)
@@ -197,6 +201,10 @@ class _RawFrames:
     def __init__(self, arr, writable: bool):
         self.arr = arr
         self.fd = -1
+        if isinstance(arr, (VideoFrames, VideoSink)):           # a video file: its own decode / encode-and-append
+            self.read_into = arr.read_into if isinstance(arr, VideoFrames) else None
+            self.write_from = arr.write_from if isinstance(arr, VideoSink) else None
+            return
         if isinstance(arr, np.memmap) and arr.flags["C_CONTIGUOUS"] and getattr(arr, "filename", None) and arr.ndim >= 2:
             # A slice of a memmap (depth[k:]) is still an np.memmap with the parent's filename AND the parent's `offset`:
             # the file position of its first byte is the root mapping's offset plus the distance of the data pointers.
@@ -238,6 +246,119 @@ class _RawFrames:
         if self.fd >= 0:
             os.close(self.fd)
             self.fd = -1
+
+
+class VideoFrames:
+    """An FFV1-in-Matroska file as the read-only [N, H, W, 3] uint8 frame array render_clip / open_output expect (RGB order).
+    Reads go through a small pool of decoders: a sequential reader continues where its decoder stands, anything else is a
+    seek (free in an intra-only stream; an inter-coded one -- FFmpeg's default, a key frame every 12 -- decodes forward from the
+    last key frame, so it gets ONE decoder and all the slice threads instead of several decoders leap-frogging)."""
+
+    def __init__(self, path: str, readers: int = 2):
+        import threading
+        from . import video_io
+        first = video_io.VideoReader(path)
+        self.path, self.fps, self.info = path, first.fps, first.info
+        self.shape = (first.frames, first.height, first.width, 3)
+        self.dtype, self.ndim = np.dtype(np.uint8), 4
+        n = max(1, int(readers)) if first.info.intra else 1
+        cores = _usable_cores()
+        first.threads = max(1, cores // (2 * n)) if n > 1 else 0
+        self._readers = [first] + [video_io.VideoReader(path, threads=first.threads) for _ in range(n - 1)]
+        self._pos = [0] * n
+        self._busy = [False] * n
+        self._cv = threading.Condition()
+
+    def __len__(self):
+        return self.shape[0]
+
+    def read_into(self, dst: np.ndarray, a: int, n: int):
+        with self._cv:
+            while True:
+                free = [k for k in range(len(self._readers)) if not self._busy[k]]
+                if free:
+                    k = next((k for k in free if self._pos[k] == a), None)
+                    if k is None:
+                        behind = [k for k in free if self._pos[k] <= a]
+                        k = max(behind, key=lambda q: self._pos[q]) if behind else free[0]
+                    self._busy[k] = True
+                    break
+                self._cv.wait()
+        try:
+            r = self._readers[k]
+            if self._pos[k] != a:
+                r.seek(a)
+            for i in range(n):
+                if not r.read_into(dst[i]):
+                    raise IOError(f"{self.path}: ends at frame {a + i}")
+            self._pos[k] = a + n
+        except BaseException:
+            self._pos[k] = -1 << 60         # unknown position: the next use seeks
+            raise
+        finally:
+            with self._cv:
+                self._busy[k] = False
+                self._cv.notify()
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            lo, hi, step = idx.indices(len(self))
+            if step != 1:
+                return np.stack([self[t] for t in range(lo, hi, step)]) if hi > lo else np.empty((0,) + self.shape[1:], np.uint8)
+            out = np.empty((max(0, hi - lo),) + self.shape[1:], np.uint8)
+            if hi > lo:
+                self.read_into(out, lo, hi - lo)
+            return out
+        t = int(idx)
+        if t < 0:
+            t += len(self)
+        out = np.empty((1,) + self.shape[1:], np.uint8)
+        self.read_into(out, t, 1)
+        return out[0]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self[0:len(self)]
+        return a if dtype is None else a.astype(dtype)
+
+    def close(self):
+        for r in self._readers:
+            r.close()
+
+
+class VideoSink:
+    """An output video being written: render_clip's store threads hand it frame sub-ranges in any order (write_from), each
+    thread encodes its frames itself (one FFV1 packet per frame, slices on one thread: the parallelism is across frames) and
+    the packets are appended in frame order.  Grey frames (the hole mask) are written as R = G = B."""
+
+    def __init__(self, path: str, width: int, height: int, fps: float, grey: bool = False, slices=(4, 4), bgr: bool = False):
+        import threading
+        from . import video_io
+        self._vio, self.bgr = video_io, bgr
+        self.slices = (min(slices[0], width), min(slices[1], height))
+        self._w = video_io.VideoWriter(path, width, height, fps, slices=self.slices)
+        self.path, self.grey, self.shape_hw = path, grey, (height, width)
+        self._pending, self._next, self._lock = {}, 0, threading.Lock()
+
+    def write_from(self, src: np.ndarray, a: int, n: int):
+        for i in range(n):
+            f = src[i]
+            if self.grey:
+                f = np.repeat(f[..., None], 3, axis=-1)
+            pkt, _ = self._vio.encode_frame(f, slices=self.slices, threads=1, bgr=self.bgr)
+            with self._lock:
+                self._pending[a + i] = pkt
+                while self._next in self._pending:
+                    self._w.write_packet(self._pending.pop(self._next))
+                    self._next += 1
+
+    def close(self) -> int:
+        with self._lock:
+            if self._pending:
+                missing = self._next
+                self._pending.clear()
+                self._w.close()
+                raise RuntimeError(f"{self.path}: frame {missing} was never written")
+            return self._w.close()
 
 
 def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParameters, *, lo: int = 0,
@@ -335,7 +456,13 @@ def render_clip(depth_frames, color_frames, out_sbs, out_mask, clip: D.ClipParam
         t_l = time.perf_counter()
         st["in_done"].synchronize()                 # the H2D copies that last read these pinned buffers are done
         t_l1 = time.perf_counter()
-        jobs = fan(f_color.read_into, st["h_c"][:n].numpy(), a, n, 2) + fan(f_depth.read_into, st["h_d"][:n].numpy(), a, n, 2)
+        if color_frames is depth_frames and isinstance(depth_frames, VideoFrames):      # sr:508-509 on one video: decode it once
+            for j in fan(f_depth.read_into, st["h_d"][:n].numpy(), a, n, 2):
+                j.result()
+            np.copyto(st["h_c"][:n].numpy(), st["h_d"][:n].numpy())
+            jobs = []
+        else:
+            jobs = fan(f_color.read_into, st["h_c"][:n].numpy(), a, n, 2) + fan(f_depth.read_into, st["h_d"][:n].numpy(), a, n, 2)
         for j in jobs:
             j.result()
         if trace is not None:
@@ -492,24 +619,34 @@ def npy_shape(path: str):
     return shape
 
 
+def frames_in(path: str) -> int:
+    """Frames in an output file of either kind (a .npy header, or the frames indexed in a Matroska file: what the reference asks
+    cv2.CAP_PROP_FRAME_COUNT for, dfh:169)."""
+    from . import video_io
+    if video_io.is_matroska(path):
+        with video_io.VideoReader(path) as r:
+            return r.frames
+    return npy_shape(path)[0]
+
+
 def verify_and_move(tmp_path: str, expected_frames: int, final_path: str):
     """The reference's tmp -> final protocol (dfh:163-179): rename only if the frame count matches."""
-    got = npy_shape(tmp_path)[0]
+    got = frames_in(tmp_path)
     if got != expected_frames:
         raise RuntimeError(f"{tmp_path}: {got} frames written, expected {expected_frames}; left in place")
     os.replace(tmp_path, final_path)
 
 
-OUTPUT_KINDS = {"sbs": "", "mask": "_holemask.npy", "depth": "_depth.npy", "infill": "_infillmask.npy", "infilled": "_infilled.npy"}
+OUTPUT_KINDS = {"sbs": "", "mask": "_holemask", "depth": "_depth", "infill": "_infillmask", "infilled": "_infilled"}
 
 
 def segment_path(path: str, rank: int, world: int) -> str:
-    """File of rank `rank`'s output segment: `<path>` itself for a single rank, else `<path>.rank<r>of<R>.npy`."""
-    return path if world == 1 else f"{path}.rank{rank}of{world}.npy"
+    """File of rank `rank`'s output segment: `<path>` itself for a single rank, else `<path>.rank<r>of<R><ext of path>`."""
+    return path if world == 1 else f"{path}.rank{rank}of{world}{os.path.splitext(path)[1] or '.npy'}"
 
 
 def plan_outputs(depth_path: str, clip: D.ClipParameters, world: int, *, create_sbs_depth_video: bool = False,
-                 infill_mask: bool = False, normal_infill: bool = False):
+                 infill_mask: bool = False, normal_infill: bool = False, ext: str = ".npy"):
     """Names and shapes of everything a run writes (pure host logic).  With one rank every output is one `.npy` dump, as the
     reference writes one file per output (sr:411-444).  With R ranks every rank owns the SEGMENT of each output that holds
     its contiguous frame range -- its own file `<output>.rank<r>of<R>.npy`, written as `<tmp>.rank<r>of<R>.npy` and renamed
@@ -519,8 +656,8 @@ def plan_outputs(depth_path: str, clip: D.ClipParameters, world: int, *, create_
     read either form.  Returns {kind: dict(final, tmp, frame_shape, segments=[(rank, lo, hi)])} ."""
     N, W, H = clip.n_frames, clip.W, clip.H
     kind = "Touchly1" if clip.mode_flags & 64 else ("Touchly0" if clip.mode_flags & 32 else "stereo")     # sr:411-422
-    final = depth_path + f"_{kind}.npy"
-    tmp = depth_path + f"_tmp_{kind}.npy"
+    final = depth_path + f"_{kind}{ext}"              # ext ".mkv": the reference's own names (sr:411-444)
+    tmp = depth_path + f"_tmp_{kind}{ext}"
     oH, oW = output_shape(clip)
     shapes = {"sbs": (oH, oW, 3), "mask": (H, 2 * W)}
     if create_sbs_depth_video:
@@ -530,7 +667,8 @@ def plan_outputs(depth_path: str, clip: D.ClipParameters, world: int, *, create_
     if normal_infill:
         shapes["infilled"] = (H, 2 * W, 3)
     segs = [(r,) + tuple(D.frame_range(r, world, N)) for r in range(world)]
-    return {k: dict(final=final + OUTPUT_KINDS[k], tmp=tmp + OUTPUT_KINDS[k], frame_shape=shp, segments=segs, frames=N)
+    return {k: dict(final=final + (OUTPUT_KINDS[k] + ext if OUTPUT_KINDS[k] else ""), tmp=tmp + (OUTPUT_KINDS[k] + ext if OUTPUT_KINDS[k] else ""),
+                    frame_shape=shp, segments=segs, frames=N)
             for k, shp in shapes.items()}
 
 
@@ -568,13 +706,17 @@ class SegmentedFrames:
 def open_output(path: str, mmap_mode: Optional[str] = "r"):
     """An output of run(): the single dump `<path>` or the per-rank segments named by `<path>.index.json` (run() leaves only the
     form it wrote; should both exist -- files copied together by hand -- the newer one is taken)."""
+    from . import video_io
+
+    def one(f, mapped=True):
+        return VideoFrames(f, readers=1) if video_io.is_matroska(f) else np.load(f, mmap_mode=mmap_mode if mapped else None)
     ip = path + ".index.json"
     if os.path.exists(path) and not (os.path.exists(ip) and os.path.getmtime(ip) > os.path.getmtime(path)):
-        return np.load(path, mmap_mode=mmap_mode)
+        return one(path)
     with open(path + ".index.json") as fh:
         idx = json.load(fh)
     here = os.path.dirname(path)
-    parts = [np.load(os.path.join(here, s["file"]), mmap_mode=mmap_mode if s["hi"] > s["lo"] else None) for s in idx["segments"]]
+    parts = [one(os.path.join(here, s["file"]), s["hi"] > s["lo"]) for s in idx["segments"]]
     bounds = [s["lo"] for s in idx["segments"]] + [idx["frames"]]
     for p, s in zip(parts, idx["segments"]):
         if p.shape[0] != s["hi"] - s["lo"]:
@@ -604,14 +746,35 @@ def _remove_segments(path: str, keep=()):
 def merge_output(path: str, remove_segments: bool = True) -> str:
     """Concatenate the segments of `<path>.index.json` into the single dump `<path>` (tmp -> final rename)."""
     seg = open_output(path)
-    if isinstance(seg, np.ndarray):
+    if not isinstance(seg, SegmentedFrames):
         return path
-    tmp = path + ".merge_tmp.npy"
-    out = np.lib.format.open_memmap(tmp, mode="w+", dtype=seg.dtype, shape=seg.shape)
-    for p, b0 in zip(seg.parts, seg.bounds[:-1]):
-        out[b0:b0 + p.shape[0]] = p
-    out.flush()
-    del out
+    if isinstance(seg.parts[0], VideoFrames):
+        # video segments: the packets are copied as they are (every segment was written with the same size and slice counts)
+        from . import video_io
+        tmp = path + ".merge_tmp.mkv"
+        first = video_io.VideoReader(seg.parts[0].path)
+        H, W = first.height, first.width
+        sl = (min(4, W), min(4, H))                    # VideoSink's slice grid
+        if first.info.slices != sl[0] * sl[1]:
+            raise RuntimeError(f"{seg.parts[0].path}: {first.info.slices} slices per frame, not one of this driver's segments")
+        first.close()
+        with video_io.VideoWriter(tmp, W, H, seg.parts[0].fps, slices=sl) as w:
+            for part in seg.parts:
+                with video_io.VideoReader(part.path) as r:
+                    while True:
+                        pkt = r.next_packet()
+                        if pkt is None:
+                            break
+                        w.write_packet(pkt)
+        for part in seg.parts:
+            part.close()
+    else:
+        tmp = path + ".merge_tmp.npy"
+        out = np.lib.format.open_memmap(tmp, mode="w+", dtype=seg.dtype, shape=seg.shape)
+        for p, b0 in zip(seg.parts, seg.bounds[:-1]):
+            out[b0:b0 + p.shape[0]] = p
+        out.flush()
+        del out
     os.replace(tmp, path)
     if remove_segments:
         with open(path + ".index.json") as fh:
@@ -668,9 +831,14 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     Multi-process aware: under torchrun every rank renders its own contiguous frame range into its own output segment
     files (plan_outputs); rank 0 adds the index.  `backend`: torch.distributed backend (default: RCCL when a GPU is
     visible; MDVT_DIST_BACKEND overrides -- the two-ranks-on-one-GPU tests use gloo)."""
+    from . import video_io
     rank, world = D.init_process_group(backend or os.environ.get("MDVT_DIST_BACKEND"))
-    depth = np.load(depth_path, mmap_mode="r")
-    color = depth if color_path is None else np.load(color_path, mmap_mode="r")                        # sr:508-509
+    video = video_io.is_matroska(depth_path)                 # the reference's own format (sr:326-341): outputs follow it
+    depth = VideoFrames(depth_path) if video else np.load(depth_path, mmap_mode="r")
+    if color_path is None:
+        color = depth                                                                                  # sr:508-509
+    else:
+        color = VideoFrames(color_path) if video_io.is_matroska(color_path) else np.load(color_path, mmap_mode="r")
     if depth.ndim != 4 or depth.shape[3] != 3 or depth.dtype != np.uint8:
         raise ValueError("depth dump must be uint8 [N, H, W, 3]")
     if color.shape != depth.shape:
@@ -683,7 +851,7 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     clip = load_clip_parameters(n_total, W, H, n_use=N, **clip_kwargs) if rank == 0 else None
     clip = D.broadcast_clip_parameters(clip, src=0)
     plan = plan_outputs(depth_path, clip, world, create_sbs_depth_video=create_sbs_depth_video,
-                        infill_mask=bool(clip_kwargs.get("infill_mask")), normal_infill=normal_infill)
+                        infill_mask=bool(clip_kwargs.get("infill_mask")), normal_infill=normal_infill, ext=".mkv" if video else ".npy")
     final = plan["sbs"]["final"]
     lo, hi = D.frame_range(rank, world, N)
     io_threads = 12
@@ -696,7 +864,11 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
     outs = {}
     for k, pl in plan.items():
         t = segment_path(pl["tmp"], rank, world)
-        if hi > lo:
+        if video:                                   # cv2.VideoWriter(tmp, 'FFV1', frame_rate, out_size) (sr:435-444)
+            shp = pl["frame_shape"]
+            # (the depth-code frames are B, G, R arrays -- what sr:930-939 hands cv2 --, everything else is RGB)
+            outs[k] = VideoSink(t, shp[1], shp[0], depth.fps or 30.0, grey=len(shp) == 2, bgr=k == "depth")
+        elif hi > lo:
             outs[k] = np.lib.format.open_memmap(t, mode="w+", dtype=np.uint8, shape=(hi - lo,) + pl["frame_shape"])
         else:                                   # more ranks than frames: an empty segment (cannot be mapped)
             outs[k] = np.empty((0,) + pl["frame_shape"], np.uint8)
@@ -707,6 +879,9 @@ def run(depth_path: str, color_path: Optional[str], *, batch: int = 16, create_s
                                       out_infilled=outs.get("infilled"))
     # (no msync: the dumps were written through the page cache, which every later reader shares; forcing 6 GB of dirty pages
     #  to the disk before the rename is what the reference's writers do not do either, and costs seconds on a container fs)
+    if video:
+        for o in outs.values():
+            o.close()                               # out.release() (sr:950)
     del outs
     for k, pl in plan.items():
         verify_and_move(segment_path(pl["tmp"], rank, world), hi - lo, segment_path(pl["final"], rank, world))

@@ -143,6 +143,49 @@ def test_cli_end_to_end(mods, orc, tmp_path, capsys):
     r.close()
 
 
+def test_cli_end_to_end_on_matroska_files(mods, orc, tmp_path, capsys):
+    """The reference's real interface: `--depth_video x.mkv --color_video y.mkv` in, FFV1-in-Matroska out
+    under the reference's names -- x.mkv_stereo.mkv, ..._infillmask.mkv, ..._depth.mkv (sr:411-444) -- through the tmp -> final
+    protocol (dfh:163-179), every frame equal to the oracle's render of the decoded inputs; the 16-bit depth code survives both
+    files (lossless)."""
+    from metric_depth_video_toolbox_amd import video_io
+    clip, sr, synthetic = mods
+    W, H, N = 160, 90, 7
+    d, c = synthetic.SyntheticScene(W, H, config_id=3, n_fg=5).clip(N)
+    dp, cp = str(tmp_path / "v_depth.mkv"), str(tmp_path / "v.mkv")
+    for path, frames in ((dp, d), (cp, c)):
+        with video_io.VideoWriter(path, W, H, 24000 / 1001, bgr=True) as w:          # as cv2.VideoWriter receives them: BGR
+            for f in frames:
+                w.write(np.ascontiguousarray(f[..., ::-1]))
+    rc = sr.main(["--depth_video", dp, "--color_video", cp, "--xfov", "50", "--pupillary_distance", "65", "--infill_mask",
+                  "--create_sbs_depth_video", "--max_frames", "5", "--batch", "3"])
+    assert rc == 0 and "Processing complete" in capsys.readouterr().out
+    final = dp + "_stereo.mkv"
+    for f in (final, final + "_infillmask.mkv", final + "_depth.mkv", final + "_holemask.mkv"):
+        assert os.path.exists(f) and video_io.is_matroska(f), f
+    assert not [f for f in os.listdir(tmp_path) if "_tmp_" in f]
+    with video_io.VideoReader(final) as r:
+        assert (r.width, r.height, r.frames) == (2 * W, H, 5) and abs(r.fps - 24000 / 1001) < 1e-3
+        sbs = np.stack(list(r))
+    mask = np.stack(list(video_io.VideoReader(final + "_holemask.mkv")))
+    im = np.stack(list(video_io.VideoReader(final + "_infillmask.mkv")))
+    zrgb = np.stack(list(video_io.VideoReader(final + "_depth.mkv")))
+    assert np.array_equal(mask[..., 0], mask[..., 1]) and np.array_equal(mask[..., 0], mask[..., 2])
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
+    p = r.frame_params(xfov=50.0)
+    K = np.array([p.K[k] for k in range(9)]).reshape(3, 3)
+    op = orc.make_params(W, H, K, ipd_m=0.065, max_depth=100, depth_scale=p.depth_scale, mode=orc.MODE_MESH,
+                         remove_edges=True, edge_points=True, key_rgb=(0, 255, 0))
+    for t in range(5):
+        want = orc.render_stereo(op, d[t], c[t], want_depth=True, want_seed=True)
+        assert np.array_equal(sbs[t][:, :W], want["left_rgb"]) and np.array_equal(sbs[t][:, W:], want["right_rgb"])
+        assert np.array_equal(mask[t][:, :W, 0], want["left_mask"]) and np.array_equal(mask[t][:, W:, 0], want["right_mask"])
+        assert np.array_equal(im[t][:, :W], orc.finish_infill_mask(want["left_seed"])[0])
+        for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):          # sr:930-939: the depth code of both eyes, B, G, R
+            assert np.array_equal(zrgb[t][:, sl], orc.encode_depth(want[eye + "_depth"], 100.0))          # (read back as RGB: R = high byte)
+    r.close()
+
+
 def _touchly_np(depth, tmax, tmin, zero_is_far):
     """sr:549-551 / 687-691 literally."""
     d8 = np.rint(np.maximum(0, np.minimum(depth, tmax) - tmin) * (255 / (tmax - tmin))).astype(np.uint8)
