@@ -12,7 +12,7 @@
  *   writer  cv2.VideoWriter(path, fourcc('F','F','V','1'), fps, (w, h)) + .write()   stereo_rerender.py:426-444, 941;
  *                                                                              depth_frames_helper.py:125-161
  * INTEROPERABILITY UNPINNED: no FFmpeg exists here to read these files or to produce files for the reader.  The encoder is
- * checked by an independent decoder restated from the RFC's pseudo-code (oracle/ffv1_ref.py), the container by structural
+ * checked by an independent decoder restated from the RFC's pseudo-code (test infrastructure: ffv1_ref.py next to the C oracle), the container by structural
  * tests (EBML sizes, CRCs); tests/golden/gen_ffv1_golden.py produces cross-check vectors on a machine that has ffmpeg.
  */
 #ifndef MDVT_VIDEO_H

@@ -10,7 +10,7 @@ the algorithmic read bytes to 4 digits, which is itself the calibration the guid
 import csv, glob, json, os, sys, statistics
 
 src, tag = sys.argv[1], sys.argv[2]
-needle = sys.argv[3] if len(sys.argv) > 3 else "mdvt::k_"
+needle = sys.argv[3] if len(sys.argv) > 3 else "::k_"
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"tag": tag, "kernels": {}}
 
