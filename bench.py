@@ -193,7 +193,9 @@ def pmc_traffic(kernel_substr, frames, W, H):
             continue
         for k, e in d.get("kernels", {}).items():
             if kernel_substr in k and "hbm_bytes_per_launch" in e:
-                best = {"bytes": e["hbm_bytes_per_launch"], "source": os.path.relpath(f, REPO)}
+                best = {"bytes": e["hbm_bytes_per_launch"], "source": os.path.relpath(f, REPO),
+                        "box": (cfg.get("device_uuids") or [None])[0], "commit": d.get("commit"),
+                        "kernel_avg_us": round(e["avg_ns_timed_region"] / 1e3, 1) if "avg_ns_timed_region" in e else None}
     return best
 
 
@@ -401,12 +403,25 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
                          "traffic_source": tr["source"] if tr else None,
+                         # the counters come from the committed PMC passes of ANOTHER run (rocprofv3 cannot ride along in this one):
+                         # evidence for the byte ratio only -- which box and tree they were taken on, and that run's own kernel time
+                         "traffic_source_box_uuid": tr["box"] if tr else None, "traffic_source_commit": tr["commit"] if tr else None,
+                         "traffic_source_kernel_avg_us": tr["kernel_avg_us"] if tr else None,
+                         "traffic_source_is_this_box": bool(tr and tr["box"] in uuids),
                          "kernel": kname.rstrip(", "),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms},
             "extra": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.mode, args.remove_edges, args.cpu_seconds)
+            # BASELINE.md section 3's other CPU figures, same port, same cores, shorter samples: C1 (640x480, the reference's own
+            # CPU-runnable case) in both draw modes, and 1080p in the reference's default draw mode (mesh)
+            also = {}
+            for tag, (w, h, mode) in {"c1_640x480_points": (640, 480, "points"), "c1_640x480_mesh": (640, 480, "mesh"),
+                                       f"{W}x{H}_mesh": (W, H, "mesh")}.items():
+                if (w, h, mode) != (W, H, args.mode):
+                    also[tag] = cpu_baseline(w, h, mode, False, max(2.0, args.cpu_seconds / 3))
+            out["cpu_baseline"]["also"] = also
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
@@ -487,11 +502,24 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
             sweep[str(nf)] = measure_variant(lambda: r.prepare(depth_rgb[:nf], color_rgb[:nf], pp, out_sbs=sbs[:nf], out_mask=mask[:nf]),
                                              nf, W, H, dev, torch)
         out["points_batch_sweep"] = sweep
-        nf = min(32, n_have)
-        pp = [r.frame_params(xfov=45.0) for _ in range(nf)]
-        out["points_fused_maskbits_and_counts"] = measure_variant(
-            lambda: r.prepare(depth_rgb[:nf], color_rgb[:nf], pp, out_sbs=sbs[:nf], out_mask=mask[:nf], want_maskbits=True, want_hole_counts=True),
-            nf, W, H, dev, torch)
+        # the north star's fused variant: packed 1 bit/px hole mask (DPP-combined nibbles) + per-eye hole counts out of the same kernel.
+        # With the byte mask as well the algorithmic bytes are the headline's 14 B/px plus the packed mask's 0.25; without it (the
+        # packed mask IS the hole mask) 6 in + 6 rgb + 0.25 = 12.25 B/px leave and enter the chip, and that is what is credited.
+        fused = {}
+        for nf in (32, 128):
+            if nf > n_have:
+                continue
+            pp = [r.frame_params(xfov=45.0) for _ in range(nf)]
+            fused[str(nf)] = measure_variant(
+                lambda: r.prepare(depth_rgb[:nf], color_rgb[:nf], pp, out_sbs=sbs[:nf], out_mask=mask[:nf], want_maskbits=True, want_hole_counts=True),
+                nf, W, H, dev, torch)
+            fused[str(nf) + "_no_byte_mask"] = measure_variant(
+                lambda: r.prepare(depth_rgb[:nf], color_rgb[:nf], pp, out_sbs=sbs[:nf], want_maskbits=True, want_hole_counts=True, want_mask=False),
+                nf, W, H, dev, torch, bytes_per_px=12.25)
+            fused[str(nf) + "_no_byte_mask"]["bytes_per_px_credited"] = 12.25
+        out["points_fused_maskbits_and_counts"] = dict(fused.get("32", {}), by_frames=fused,
+                                                        what="k_points_rows_fast<.., BITS>: headline kernel + packed hole mask + hole counts in ONE launch "
+                                                             "(no reduce launch); *_no_byte_mask: the byte mask left out, 12.25 B/px credited")
     nf = min(32, n_have)
     rm = StereoRerenderer(W, H, device=dev.index, pupillary_distance=65)
     pm = [rm.frame_params(xfov=45.0) for _ in range(nf)]

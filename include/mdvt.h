@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define MDVT_VERSION_MAJOR 0
-#define MDVT_VERSION_MINOR 14
+#define MDVT_VERSION_MINOR 15
 #define MDVT_VERSION ((MDVT_VERSION_MAJOR << 16) | MDVT_VERSION_MINOR)
 
 typedef struct mdvt_ctx mdvt_ctx;
@@ -104,6 +104,9 @@ typedef struct mdvt_io {
     const uint8_t* color_rgb;  size_t color_pitch;  size_t color_stride;   /* colour frame                       */
     uint8_t* left_rgb; uint8_t* right_rgb; size_t rgb_pitch;  size_t rgb_stride;    /* sr:819, 907           */
     uint8_t* left_mask; uint8_t* right_mask; size_t mask_pitch; size_t mask_stride; /* 255 = hole (sr:740, 854) */
+    /* (ABI 0.15: both byte masks may be NULL when the packed mask below is requested and the frames are rendered by the kernel
+     *  that compacts the mask itself -- points mode, pure stereo shift, no edge removal, W % 4 == 0, W <= 4096 --: 12.25
+     *  instead of 14 bytes per pixel leave the chip.  Every other path answers MDVT_ERR_INVALID_ARG.) */
     float* left_depth; float* right_depth; size_t zout_pitch; size_t zout_stride;   /* optional; 0 = background (dmt:1563) */
     /* optional compacted hole mask: 1 bit per pixel, bit k of byte b = pixel 8b+k (np.packbits(mask > 0,
      * bitorder="little")), rows padded to whole dwords: maskbits_pitch >= 4*ceil(W/32) */

@@ -70,6 +70,7 @@ struct mdvt_ctx {
     mdvt::RowCell* rowcell = nullptr; // [H] scanline -> cell row table of the mesh grid (pure-shift band kernel)
     int rowcell_bits = 0;             // the sub-pixel grid that table was built for
     uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
+    unsigned long long* count_acc = nullptr;   // [row_counts_frames][17], zero between launches (RenderArgs.count_acc)
     int row_counts_frames = 0;
     // infill-mask completion: per image stamp u16 + T f32 + work image u8x3, and the per-image counters
     int telea_images = 0, telea_rounds = 0;
@@ -657,6 +658,7 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->unused) ws_free(c, c->unused);
     if (c->elist) ws_free(c, c->elist);
     if (c->row_counts) ws_free(c, c->row_counts);
+    if (c->count_acc) ws_free(c, c->count_acc);
     if (c->rowcell) ws_free(c, c->rowcell);
     pool_give(c->telea_levels_host, nullptr, 64, -1);
     free_telea(c);
@@ -706,12 +708,17 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
 {
     if (!c) return MDVT_ERR_INVALID_ARG;
     if (n_frames <= 0 || !params || !io) return fail(c, MDVT_ERR_INVALID_ARG, "n_frames/params/io invalid");
-    if (!io->depth_rgb || !io->color_rgb || !io->left_rgb || !io->right_rgb || !io->left_mask || !io->right_mask)
-        return fail(c, MDVT_ERR_INVALID_ARG, "depth_rgb, color_rgb, left/right rgb and mask buffers are required");
+    if (!io->depth_rgb || !io->color_rgb || !io->left_rgb || !io->right_rgb)
+        return fail(c, MDVT_ERR_INVALID_ARG, "depth_rgb, color_rgb and left/right rgb buffers are required");
+    // The byte masks may be left out (both NULL) by a caller that takes the packed mask instead -- where the compaction is fused
+    // into the render kernel (pure-shift point frames: checked per run below); everywhere else they are required.
+    const bool no_byte_mask = !io->left_mask && !io->right_mask && io->left_maskbits && io->right_maskbits;
+    if (!no_byte_mask && (!io->left_mask || !io->right_mask))
+        return fail(c, MDVT_ERR_INVALID_ARG, "left/right mask buffers are required (both may be NULL only when maskbits are given)");
     const int W = c->W, H = c->H;
     if (W < 2 || H < 2) return fail(c, MDVT_ERR_INVALID_ARG, "rendering needs at least a 2x2 frame");
     if (io->depth_pitch < (size_t)3 * W || io->color_pitch < (size_t)3 * W || io->rgb_pitch < (size_t)3 * W ||
-        io->mask_pitch < (size_t)W)
+        (!no_byte_mask && io->mask_pitch < (size_t)W))
         return fail(c, MDVT_ERR_INVALID_ARG, "a pitch is smaller than one row");   // sr:507 shape assert
     const bool zout = io->left_depth || io->right_depth;
     if (zout && io->zout_pitch < (size_t)4 * W) return fail(c, MDVT_ERR_INVALID_ARG, "zout_pitch smaller than one row");
@@ -841,12 +848,15 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.seed[0] = io->left_seed; a.seed[1] = io->right_seed; a.seed_pitch = io->seed_pitch; a.seed_stride = io->seed_stride;
     if (io->hole_counts) {
         if (c->row_counts_frames < count_frames) {
-            if (c->row_counts) { MDVT_HIP(c, hipDeviceSynchronize()); ws_free(c, c->row_counts); }     // (earlier submissions may still count into it)
-            c->row_counts = nullptr; c->row_counts_frames = 0;
+            if (c->row_counts) { MDVT_HIP(c, hipDeviceSynchronize()); ws_free(c, c->row_counts); ws_free(c, c->count_acc); }     // (earlier submissions may still count into it)
+            c->row_counts = nullptr; c->count_acc = nullptr; c->row_counts_frames = 0;
             MDVT_HIP(c, ws_malloc(c, (void**)&c->row_counts, (size_t)count_frames * 2 * H * sizeof(uint32_t), s));
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->count_acc, (size_t)count_frames * 17 * sizeof(unsigned long long), s));
+            MDVT_HIP(c, hipMemsetAsync(c->count_acc, 0, (size_t)count_frames * 17 * sizeof(unsigned long long), s));     // (a recycled block holds old data)
             c->row_counts_frames = count_frames;
         }
         a.row_counts = c->row_counts;
+        a.count_acc = c->count_acc;
     }
     a.fp = dfp;
     a.edge_paint = c->cfg.edge_points != 2;
@@ -963,6 +973,9 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
                                            plan.mode == MDVT_MODE_MESH, a.tri_invalid, a.ws_stride_tri,
                                            a.unused, a.ws_stride_px, s));
         }
+        if (no_byte_mask && !MDVT_GRID_CALL(c, points_fused_bits_applies, plan, a))
+            return fail(c, MDVT_ERR_INVALID_ARG, "the byte masks may be NULL only where the mask compaction is fused into the render "
+                        "(points mode, pure stereo shift, no edge removal, W %% 4 == 0, W <= 4096, W * H < 2^24 with hole_counts)");
         a.key_parity = c->key_parity >> slot0;
         plan.edge_rows_max = 0;
         if (!r.general && !r.conv && plan.edge_points)
@@ -975,7 +988,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         if (e == hipErrorNotSupported) return fail(c, MDVT_ERR_UNSUPPORTED, "render mode %d is not built yet", plan.mode);
         if (e != hipSuccess) return fail(c, MDVT_ERR_HIP, "render launch failed: %s", hipGetErrorString(e));
         if ((want_bits || io->hole_counts) && !plan.fused_bits) MDVT_HIP(c, launch_pack_mask(a, plan.n, s));
-        if (io->hole_counts) MDVT_HIP(c, launch_reduce_counts(a, plan.n, s));
+        if (io->hole_counts && !plan.fused_bits) MDVT_HIP(c, launch_reduce_counts(a, plan.n, s));
       }
       if (banks) {
           a = a_all;

@@ -88,6 +88,9 @@ struct RenderArgs {
     uint32_t* hole_counts;       // optional [n_frames][2]
     uint8_t* seed[2]; size_t seed_pitch, seed_stride;            // optional infill-mask seed images
     uint32_t* row_counts;        // workspace [frames in launch][2][H], zeroed per launch (when hole_counts)
+    unsigned long long* count_acc; // workspace [frames in launch][17]: the fused points kernel's hole-count accumulators (16 row classes +
+                                 //   the frame's total; left | right << 24 | arrivals << 48), all zero between launches: whoever completes
+                                 //   a word resets it
     const FrameDev* fp;          // device array, one per frame of the batch
     int32_t W, H;
     int32_t frame0;              // first frame of this launch within the batch

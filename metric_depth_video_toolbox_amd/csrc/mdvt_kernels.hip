@@ -665,19 +665,58 @@ __global__ void __launch_bounds__(TPB, ((FLAGS & 5) == 4) ? 6 : 1) k_points_rows
 }
 
 // Wavefront hole-mask compaction.  Each lane holds the hole flags of 4 consecutive pixels (nib, LSB = lowest
-// x).  Eight lanes' nibbles are OR-combined with three cross-lane exchanges into one dword of the packed
-// 1-bit/px mask; the per-(frame,eye) hole count is the popcount of four 64-lane ballots, one atomic per wave.
+// x; lane & 7 == g & 7).  Eight lanes' nibbles are OR-combined into one dword of the packed 1-bit/px mask with three DPP
+// operands on the VALU (two quad permutes and a row shift: no LDS round trip -- __shfl_xor compiles to ds_bpermute_b32 here,
+// three of them per eye behind the row's 8-byte LDS atomics were most of what the fused variant cost in r05); the hole count
+// of the wave is the popcount of four 64-lane ballots (scalar unit).  The dword is valid in the lanes with g & 7 == 0.
+template <int CTRL>
+__device__ __forceinline__ uint32_t or_dpp(uint32_t v)
+{
+    return v | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ uint32_t mask_dword_of_8_lanes(uint32_t nib, int g)
+{
+    uint32_t v = nib << (4 * (g & 7));
+    v = or_dpp<0xB1>(v);          // quad_perm [1,0,3,2]: lane ^ 1
+    v = or_dpp<0x4E>(v);          // quad_perm [2,3,0,1]: lane ^ 2
+    return or_dpp<0x104>(v);      // row_shl:4: lane i takes lane i + 4 (of its row of 16)
+}
+
+__device__ __forceinline__ int wave_hole_count(uint32_t nib)
+{
+    return __popcll(__ballot(nib & 1)) + __popcll(__ballot(nib & 2)) + __popcll(__ballot(nib & 4)) + __popcll(__ballot(nib & 8));
+}
+
 __device__ __forceinline__ int compact_hole_nibble(uint32_t nib, int g, bool act, uint8_t* bits_row, bool want_count)
 {
     if (bits_row) {
-        uint32_t v = nib << (4 * (g & 7));
-        v |= __shfl_xor((int)v, 1);
-        v |= __shfl_xor((int)v, 2);
-        v |= __shfl_xor((int)v, 4);
+        const uint32_t v = mask_dword_of_8_lanes(nib, g);
         if (act && (g & 7) == 0) ((uint32_t*)bits_row)[g >> 3] = v;
     }
-    if (!want_count) return 0;
-    return __popcll(__ballot(nib & 1)) + __popcll(__ballot(nib & 2)) + __popcll(__ballot(nib & 4)) + __popcll(__ballot(nib & 8));
+    return want_count ? wave_hole_count(nib) : 0;
+}
+
+// A row's hole counts (left, right) into the frame's total without a second launch: the rows of a frame fall into 16 classes
+// (row & 15: a frame's ~H workgroups finish within microseconds of each other, and returning atomics on ONE address take
+// ~4 ns each), each with an accumulator word  left | right << 24 | arrivals << 48;  whoever brings a class to its last
+// arrival adds the class total to the frame's word, and whoever completes that writes hole_counts and leaves the words zero
+// for the next launch.  (W * H < 2^24: the caller's condition for this path.)
+__device__ __forceinline__ void post_row_hole_counts(const RenderArgs& a, int fr, int f, int i, uint32_t left, uint32_t right)
+{
+    u64* acc = a.count_acc + (size_t)fr * 17;
+    const int k = i & 15;
+    const u64 one = 1ull << 48;
+    u64 add = (u64)left | ((u64)right << 24) | one;
+    u64 now = atomicAdd(&acc[k], add) + add;
+    if ((uint32_t)(now >> 48) != (uint32_t)((a.H - k + 15) >> 4)) return;
+    (void)atomicExch(&acc[k], 0ull);
+    add = (now & (one - 1ull)) | one;
+    now = atomicAdd(&acc[16], add) + add;
+    if ((uint32_t)(now >> 48) != (uint32_t)min(16, a.H)) return;
+    (void)atomicExch(&acc[16], 0ull);
+    a.hole_counts[2 * (size_t)f] = (uint32_t)now & 0xFFFFFFu;
+    a.hole_counts[2 * (size_t)f + 1] = (uint32_t)(now >> 24) & 0xFFFFFFu;
 }
 
 // row_counts[(2*frame + eye)*H + row] -> hole_counts[2*frame + eye]
@@ -769,6 +808,7 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
     {
         uint4* z4 = (uint4*)zb;
         for (int x = g; x < W; x += TPB) z4[x] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (BITS && g < 3) ((uint32_t*)(zb + 2 * (size_t)W + 1))[g] = 0u;      // hole counts of the row (left, right), waves done
     }
     __syncthreads();
 
@@ -806,6 +846,7 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
     }
     __syncthreads();
 
+    int cnt[2] = {0, 0};
     if (act || BITS) {
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
@@ -829,16 +870,18 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
             }
             if (act) {
                 uint32_t* op = (uint32_t*)(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)i * a.rgb_pitch) + 3 * g;
+                uint8_t* mbase = a.mask[eye];                      // (NULL with BITS: the caller takes the packed mask only)
+                uint32_t* mp = (uint32_t*)(mbase + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch) + g;
                 if (NT & 2) {                          // ... and every output byte written once
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(o[1], o[0], 0x04020100u), op);
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(o[2], o[1], 0x05040201u), op + 1);
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(o[3], o[2], 0x06050402u), op + 2);
-                    __builtin_nontemporal_store(mw, (uint32_t*)(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch) + g);
+                    if (!BITS || mbase) __builtin_nontemporal_store(mw, mp);
                 } else {
                 op[0] = __builtin_amdgcn_perm(o[1], o[0], 0x04020100u);
                 op[1] = __builtin_amdgcn_perm(o[2], o[1], 0x05040201u);
                 op[2] = __builtin_amdgcn_perm(o[3], o[2], 0x06050402u);
-                ((uint32_t*)(a.mask[eye] + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch))[g] = mw;
+                if (!BITS || mbase) *mp = mw;
                 }
                 if (ZOUT && a.zout[eye]) {
                     float4* zp = (float4*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)i * a.zout_pitch) + g;
@@ -851,22 +894,20 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
             if (BITS) {
                 const uint32_t nib = act ? ((mw & 1u) | ((mw >> 7) & 2u) | ((mw >> 14) & 4u) | ((mw >> 21) & 8u)) : 0u;
                 uint8_t* brow = a.maskbits[eye] ? a.maskbits[eye] + (size_t)f * a.maskbits_stride + (size_t)i * a.maskbits_pitch : nullptr;
-                const int c = compact_hole_nibble(nib, g, act, brow, a.hole_counts != nullptr);
-                // the z keys of this eye have been consumed by every wave only after the barrier below;
-                // wave totals go to a few LDS words past the trash slot
-                if (a.hole_counts && (g & 63) == 0) ((uint32_t*)(zb + 2 * (size_t)W + 1))[eye * (TPB / 64) + (g >> 6)] = (uint32_t)c;
+                cnt[eye] = compact_hole_nibble(nib, g, act, brow, a.hole_counts != nullptr);
             }
         }
     }
-    if (BITS && a.hole_counts) {
-        __syncthreads();
-        if (g < 2) {
-            const uint32_t* wc = (const uint32_t*)(zb + 2 * (size_t)W + 1) + g * (TPB / 64);
-            uint32_t tot = 0;
-#pragma unroll
-            for (int w = 0; w < TPB / 64; ++w) tot += wc[w];
-            a.row_counts[(2 * (size_t)fr + g) * a.H + i] = tot;
-        }
+    if (BITS && a.hole_counts && (g & 63) == 0) {
+        // No barrier: a wave adds its two counts to the row's LDS words and then counts itself in; the wave that arrives last
+        // (its own adds and everyone else's precede its arrival in the LDS queue) posts the row.
+        uint32_t* wc = (uint32_t*)(zb + 2 * (size_t)W + 1);
+        __hip_atomic_fetch_add(&wc[0], (uint32_t)cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&wc[1], (uint32_t)cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t k = __hip_atomic_fetch_add(&wc[2], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == (uint32_t)(TPB / 64 - 1))
+            post_row_hole_counts(a, fr, f, i, __hip_atomic_load(&wc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                                 __hip_atomic_load(&wc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     }
 }
 
@@ -2740,10 +2781,19 @@ template <int TPB>
 static hipError_t launch_points_rows_fast(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const bool zout = a.zout[0] || a.zout[1];
-    const bool bits = a.maskbits[0] || a.maskbits[1] || a.hole_counts;
+    // (hole counts ride in 24-bit fields of the accumulator words: larger frames take the byte mask through k_pack_mask)
+    const bool bits = (a.maskbits[0] || a.maskbits[1] || a.hole_counts) && (!a.hole_counts || (size_t)a.W * a.H < ((size_t)1 << 24));
     plan.fused_bits = bits;
     if (zout) return bits ? launch_points_rows_fast_cfg<TPB, true, true>(plan, a, s) : launch_points_rows_fast_cfg<TPB, true, false>(plan, a, s);
     return bits ? launch_points_rows_fast_cfg<TPB, false, true>(plan, a, s) : launch_points_rows_fast_cfg<TPB, false, false>(plan, a, s);
+}
+
+// Will this launch be rendered by k_points_rows_fast with the mask compaction fused in (the one kernel that can leave the byte
+// mask out)?  The same conditions as the dispatch below.
+bool points_fused_bits_applies(const RenderPlan& plan, const RenderArgs& a)
+{
+    return plan.mode == MDVT_MODE_POINTS && !plan.general && plan.vec4 && !plan.remove_edges && points_cfg_override() == 0 &&
+           a.W / 4 <= 1024 && (a.maskbits[0] || a.maskbits[1]) && (!a.hole_counts || (size_t)a.W * a.H < ((size_t)1 << 24));
 }
 
 static hipError_t launch_points_rows_vec4(RenderPlan& plan, const RenderArgs& a, hipStream_t s)

@@ -345,10 +345,13 @@ class StereoRerenderer:
 
     # -- the per-frame loop body, batched -----------------------------------------------------
     def prepare(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
-                out_depth=None, want_maskbits: bool = False, want_hole_counts: bool = False, want_seed: bool = False):
+                out_depth=None, want_maskbits: bool = False, want_hole_counts: bool = False, want_seed: bool = False,
+                want_mask: bool = True):
         """Validate once and pack everything one submission needs (buffer table, parameter records).
         Returns a PreparedRender whose launch() is a single C-ABI call -- use it when the same buffers
-        are rendered into repeatedly (streaming loops, benchmarks)."""
+        are rendered into repeatedly (streaming loops, benchmarks).
+        want_mask=False (with want_maskbits): no byte mask is written, the packed 1 bit/px mask is the hole mask -- where the
+        compaction is fused into the render kernel (pure-shift point frames; the library refuses elsewhere)."""
         torch = self.torch
         single = depth_rgb.dim() == 3
         if single:
@@ -361,8 +364,11 @@ class StereoRerenderer:
         arr = self.pack_params(params, N)
         dev = depth_rgb.device
         sbs = out_sbs if out_sbs is not None else torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=dev)
-        mask = out_mask if out_mask is not None else torch.empty((N, H, 2 * W), dtype=torch.uint8, device=dev)
-        assert tuple(sbs.shape[-3:]) == (H, 2 * W, 3) and tuple(mask.shape[-2:]) == (H, 2 * W)
+        assert want_mask or want_maskbits, "want_mask=False needs want_maskbits"
+        mask = None
+        if want_mask:
+            mask = out_mask if out_mask is not None else torch.empty((N, H, 2 * W), dtype=torch.uint8, device=dev)
+        assert tuple(sbs.shape[-3:]) == (H, 2 * W, 3) and (mask is None or tuple(mask.shape[-2:]) == (H, 2 * W))
         zout = None
         if want_depth:
             zout = out_depth if out_depth is not None else torch.empty((N, H, 2 * W), dtype=torch.float32, device=dev)
@@ -372,12 +378,15 @@ class StereoRerenderer:
         io.color_rgb, io.color_pitch, io.color_stride = color_rgb.data_ptr(), 3 * W, 3 * W * H
         io.left_rgb, io.right_rgb = sbs.data_ptr(), sbs.data_ptr() + 3 * W
         io.rgb_pitch, io.rgb_stride = 6 * W, 6 * W * H
-        io.left_mask, io.right_mask = mask.data_ptr(), mask.data_ptr() + W
-        io.mask_pitch, io.mask_stride = 2 * W, 2 * W * H
+        if mask is not None:
+            io.left_mask, io.right_mask = mask.data_ptr(), mask.data_ptr() + W
+            io.mask_pitch, io.mask_stride = 2 * W, 2 * W * H
         if zout is not None:
             io.left_depth, io.right_depth = zout.data_ptr(), zout.data_ptr() + 4 * W
             io.zout_pitch, io.zout_stride = 8 * W, 8 * W * H
-        res = {"sbs": sbs[0] if single else sbs, "mask": mask[0] if single else mask}
+        res = {"sbs": sbs[0] if single else sbs}
+        if mask is not None:
+            res["mask"] = mask[0] if single else mask
         if zout is not None:
             res["depth"] = zout[0] if single else zout
         bits = counts = None
@@ -400,14 +409,14 @@ class StereoRerenderer:
         return PreparedRender(self, N, arr, io, res, (depth_rgb, color_rgb, sbs, mask, zout, bits, counts, seed), dev)
 
     def render(self, depth_rgb, color_rgb, params, *, out_sbs=None, out_mask=None, want_depth: bool = False,
-               out_depth=None, stream=None, want_maskbits: bool = False, want_hole_counts: bool = False,
+               out_depth=None, stream=None, want_maskbits: bool = False, want_hole_counts: bool = False, want_mask: bool = True,
                want_seed: bool = False):
         """depth_rgb, color_rgb: uint8 device tensors [N,H,W,3] (or [H,W,3]); params: one
         MdvtFrameParams or a sequence of N.  Returns dict(sbs=[N,H,2W,3] u8 (left | right, sr:918),
         mask=[N,H,2W] u8 (255 = hole), depth=[N,H,2W] f32 (optional; 0 = background))."""
         return self.prepare(depth_rgb, color_rgb, params, out_sbs=out_sbs, out_mask=out_mask,
                             want_depth=want_depth, out_depth=out_depth, want_maskbits=want_maskbits,
-                            want_hole_counts=want_hole_counts, want_seed=want_seed).launch(stream)
+                            want_hole_counts=want_hole_counts, want_seed=want_seed, want_mask=want_mask).launch(stream)
 
     def finish_infill_mask_sbs(self, seed_sbs, out=None, max_rounds: int = 0, want_remaining: bool = False):
         """finish_infill_mask for side-by-side seed buffers [N,H,2W,3] (render(want_seed=True)["seed"]): both eyes of

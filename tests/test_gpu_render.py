@@ -559,6 +559,39 @@ def test_compacted_hole_mask_and_counts(mods, orc, kind):
     r.close()
 
 
+@pytest.mark.parametrize("shape", [(192, 108, 3), (1920, 21, 5), (1028, 7, 2), (2568, 33, 2)])
+def test_fused_mask_compaction_without_byte_mask(mods, shape):
+    """The headline kernel with the compaction fused in and NO byte mask (want_mask=False): packed mask and counts equal those of a
+    plain render's byte mask; the frame totals come out of the kernel's own accumulators (16 row classes + the frame word, left zero
+    for the next launch: rendered three times, with a different clip the second time); every other path refuses NULL byte masks."""
+    _lib, sr, synthetic = mods
+    W, H, N = shape
+    r = sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=True)
+    p = r.frame_params(xfov=45.0)
+    clips = [synthetic.SyntheticScene(W, H, seed=s, n_fg=6).clip(N) for s in (17, 18, 17)]
+    for d, c in clips:
+        dd, cc = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+        plain = r.render(dd, cc, p)
+        got = r.render(dd, cc, p, want_maskbits=True, want_hole_counts=True, want_mask=False)
+        assert "mask" not in got
+        mask = plain["mask"].cpu().numpy() > 0
+        bits, counts = got["maskbits"].cpu().numpy(), got["hole_counts"].cpu().numpy()
+        assert np.array_equal(got["sbs"].cpu().numpy(), plain["sbs"].cpu().numpy())
+        for k in range(N):
+            for eye, sl in ((0, slice(0, W)), (1, slice(W, 2 * W))):
+                want = np.packbits(mask[k][:, sl], axis=1, bitorder="little")
+                assert np.array_equal(bits[k, :, eye, :want.shape[1]], want), (shape, k, eye)
+                assert counts[k, eye] == mask[k][:, sl].sum(), (shape, k, eye)
+    r.close()
+    d, c = clips[0]
+    for kw in (dict(render_as_pointcloud=False), dict(render_as_pointcloud=True, infill_mask=True)):
+        r = sr.StereoRerenderer(W, H, pupillary_distance=65, **kw)
+        with pytest.raises(_lib.MdvtError) as e:
+            r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), r.frame_params(xfov=45.0), want_maskbits=True, want_mask=False)
+        assert e.value.code == -1 and "byte masks may be NULL only" in str(e.value)
+        r.close()
+
+
 def test_infill_using_normals_on_device(mods, orc, golden):
     """The HIP kernel against the reference's own outputs (golden) and against the oracle on a big case."""
     _lib, sr, synthetic = mods

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(lib):
     declared = sorted(set(re.findall(r"\b(mdvt_[a-z_]+)\s*\(", hdr)))
     assert declared == sorted(lib.SYMBOLS), "keep _lib.SYMBOLS in step with include/mdvt.h"
     assert lib.exported_symbols() == list(lib.SYMBOLS)
-    assert lib.load().mdvt_version() == (0 << 16) | 14
+    assert lib.load().mdvt_version() == (0 << 16) | 15
 
 
 def test_struct_layouts_match_the_header(lib):

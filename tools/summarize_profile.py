@@ -13,6 +13,11 @@ src, tag = sys.argv[1], sys.argv[2]
 needle = sys.argv[3] if len(sys.argv) > 3 else "::k_"
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"tag": tag, "kernels": {}}
+try:        # the tree the summary is written in (the GPU box has no .git: the profile ran on a snapshot of this tree or an older one)
+    import subprocess
+    out["commit"] = subprocess.check_output(["git", "-C", repo, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    out["commit"] = None
 
 def rows(pattern):
     for f in glob.glob(os.path.join(src, pattern), recursive=True):
