@@ -168,11 +168,16 @@ int mdvt_workspace_bytes(mdvt_ctx* ctx, uint64_t* bytes);
 
 /* Workspace blocks of destroyed (or grown) contexts are kept by the process for the next context on the same GPU instead of going
  * back to the driver (a block fresh from the driver is filled and synchronised once before its first use; see DESIGN.md section 9
- * for the r04 finding behind this); beyond 8 GiB of idle blocks the oldest are released.  mdvt_release_cached_memory returns the
+ * for the r04 finding behind this); beyond 4 GiB of idle blocks per GPU (mdvt_set_cached_memory_limit) that GPU's oldest are released.  mdvt_release_cached_memory returns the
  * idle blocks of GPU `device` (-1: of every GPU) to the driver -- torch.cuda.empty_cache()'s role; it synchronises the device.
  * mdvt_cached_memory reports them (either pointer may be NULL).  No reference counterpart: Open3D / NumPy own their memory. */
 int mdvt_release_cached_memory(int device);
 int mdvt_cached_memory(int device, uint64_t* idle_bytes, uint64_t* idle_blocks);
+/* The most idle bytes kept PER GPU (accounted per GPU; default 4 GiB = the default workspace_mib budget); whatever a GPU holds
+ * beyond the new limit goes back to the driver at once, oldest first (synchronises those GPUs).  0 = keep nothing: every
+ * context's blocks return to the driver when it goes (the pre-r05 behaviour, with the fresh-block treatment still applied).
+ * Process-wide, thread-safe.  ABI 0.15. */
+int mdvt_set_cached_memory_limit(uint64_t bytes_per_gpu);
 /* libmdvt_hip_tuning.so only (MDVT_ERR_UNSUPPORTED in the product library): what = 0 copies the general mesh path's triangle-queue
  * block to h_dst (host, `capacity` bytes; NULL: sizes only) after a device synchronisation.  info: bytes of the block; dword offsets
  * of the segment counters / the huge list / the tie flags; segments; W; H; frame slots.  tests/dbg_stress_case.py's diagnosis.

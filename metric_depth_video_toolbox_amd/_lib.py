@@ -25,7 +25,8 @@ SYMBOLS = ("mdvt_version", "mdvt_create", "mdvt_destroy", "mdvt_last_error", "md
            "mdvt_edge_filter", "mdvt_infill_using_normals", "mdvt_mark_lower_side", "mdvt_touchly_depth",
            "mdvt_equirect_tables", "mdvt_equirect_remap", "mdvt_masked_blur", "mdvt_finish_infill_mask",
            "mdvt_finish_infill_mask_stereo", "mdvt_swap_rb", "mdvt_selftest", "mdvt_normal_infill", "mdvt_infill_using_mask_normals",
-           "mdvt_edge_point_pixels", "mdvt_workspace_bytes", "mdvt_release_cached_memory", "mdvt_cached_memory", "mdvt_debug_read")
+           "mdvt_edge_point_pixels", "mdvt_workspace_bytes", "mdvt_release_cached_memory", "mdvt_cached_memory", "mdvt_set_cached_memory_limit",
+           "mdvt_debug_read")
 
 
 class MdvtError(RuntimeError):
@@ -133,6 +134,8 @@ def load():
     L.mdvt_release_cached_memory.argtypes = [C.c_int]
     L.mdvt_cached_memory.restype = C.c_int
     L.mdvt_cached_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mdvt_set_cached_memory_limit.restype = C.c_int
+    L.mdvt_set_cached_memory_limit.argtypes = [C.c_uint64]
     L.mdvt_debug_read.restype = C.c_int
     L.mdvt_debug_read.argtypes = [vp, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     _libs[variant] = L
@@ -150,6 +153,23 @@ def cached_memory(device: int = -1):
 def release_cached_memory(device: int = -1) -> None:
     """Return the pool's idle workspace blocks to the driver (mdvt_release_cached_memory)."""
     load().mdvt_release_cached_memory(int(device))
+
+
+def set_cached_memory_limit(bytes_per_gpu: int) -> None:
+    """Idle workspace bytes the process keeps per GPU for the next context (mdvt_set_cached_memory_limit; default 4 GiB)."""
+    load().mdvt_set_cached_memory_limit(int(bytes_per_gpu))
+
+
+def retry_after_release(alloc):
+    """Run `alloc()` (a torch allocation); on torch's out-of-memory error hand the library's idle workspace blocks back to the
+    driver (torch's allocator cannot see them) and try once more."""
+    import torch
+    try:
+        return alloc()
+    except torch.cuda.OutOfMemoryError:
+        release_cached_memory(-1)
+        torch.cuda.empty_cache()
+        return alloc()
 
 
 def exported_symbols():

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <string>
 #include <unordered_map>
+#include <map>
 #include <vector>
 
 using namespace mdvt;
@@ -139,9 +140,11 @@ struct DeviceGuard {
 struct DevBlock { void* p; size_t bytes; int tag; unsigned long long stamp; };
 std::mutex g_dev_pool_mutex;
 std::vector<DevBlock>& dev_pool() { static std::vector<DevBlock> p; return p; }
-size_t g_dev_pool_idle = 0;
+std::map<int, size_t>& dev_pool_idle() { static std::map<int, size_t> m; return m; }      // idle bytes per pool tag (= per GPU)
 unsigned long long g_dev_pool_stamp = 0;
-constexpr size_t kDevPoolIdleCap = (size_t)8 << 30;      // idle bytes kept per process before the oldest blocks go back to the driver
+// Idle bytes kept PER GPU before that GPU's oldest blocks go back to the driver (mdvt_set_cached_memory_limit; default 4 GiB = the
+// default workspace_mib budget, i.e. one context's worth of the largest workspace the library allocates by default).
+size_t g_dev_pool_idle_cap = (size_t)4 << 30;
 
 // Size classes: 4 KiB steps up to 64 KiB, 16 steps per power of two up to 1 MiB (at most 6.25 % over the request), 64 KiB steps
 // above (the large blocks are what mdvt_config.workspace_mib budgets: they stay what was asked for; a clip's contexts share
@@ -168,7 +171,7 @@ hipError_t ws_malloc(mdvt_ctx* c, void** p, size_t bytes, hipStream_t s)
         for (size_t k = pool.size(); k-- > 0;)            // newest first
             if (pool[k].bytes == want && pool[k].tag == c->pool_tag) {
                 *p = pool[k].p;
-                g_dev_pool_idle -= want;
+                dev_pool_idle()[c->pool_tag] -= want;
                 pool.erase(pool.begin() + (long)k);
                 break;
             }
@@ -222,11 +225,12 @@ void ws_free(mdvt_ctx* c, void* p)
         std::lock_guard<std::mutex> lock(g_dev_pool_mutex);
         auto& pool = dev_pool();
         pool.push_back({p, bytes, c->pool_tag, ++g_dev_pool_stamp});
-        g_dev_pool_idle += bytes;
-        for (size_t k = 0; g_dev_pool_idle > kDevPoolIdleCap && k < pool.size();) {     // oldest first (the vector is in stamp order)
+        size_t& idle = dev_pool_idle()[c->pool_tag];                                     // (accounted and capped per GPU)
+        idle += bytes;
+        for (size_t k = 0; idle > g_dev_pool_idle_cap && k < pool.size();) {             // oldest first (the vector is in stamp order)
             if (pool[k].tag != c->pool_tag) { ++k; continue; }                           // (this GPU's only: the device guard is the caller's)
             out.push_back(pool[k].p);
-            g_dev_pool_idle -= pool[k].bytes;
+            idle -= pool[k].bytes;
             pool.erase(pool.begin() + (long)k);
         }
     }
@@ -616,10 +620,15 @@ static hipError_t bank_res_take(mdvt_ctx* c)
                 return hipSuccess;
             }
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-    for (hipEvent_t* ev : {&c->ev_start, &c->ev_join, &c->ev_vert[0], &c->ev_vert[1]})
-        if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
-    return e;
+    // built in locals, handed to the context only when complete: a half-made set must not leave c->side set (every later banked
+    // render would skip this function and record a null event); what was made of it is abandoned, like everything of this kind
+    BankRes r{};
+    hipError_t e = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking);
+    for (hipEvent_t& ev : r.ev)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    c->side = r.side; c->ev_start = r.ev[0]; c->ev_join = r.ev[1]; c->ev_vert[0] = r.ev[2]; c->ev_vert[1] = r.ev[3];
+    return hipSuccess;
 }
 // (the caller has synchronised the device: nothing submitted still uses them)
 static void bank_res_give(mdvt_ctx* c)
@@ -909,10 +918,10 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
       bool banks = bankable && chunk >= 2 && r.f1 - r.f0 > chunk;
       int bank_slots = chunk / 2;
       // r05: a posed mesh run that FITS one launch set is split into two sets on the two banks all the same when each half is large
-      // enough to fill the chip by itself (24 M pixels: 3 frames of 4K) -- since the vertex records went (64 B/px per slot, was 96) the
+      // enough to fill the chip by itself (3 frames of 4K = 24.9 M pixels: 6 to 8 frames of C4's shape) -- since the vertex records went (64 B/px per slot, was 96) the
       // 8 frames of C4 are one set of 8 slots, and its cell walk (VALU) and resolve (HBM) ran one after the other again
       if (bankable && !banks && plan.mode == MDVT_MODE_MESH && r.f1 - r.f0 <= chunk && r.f1 - r.f0 >= 4 &&
-          (size_t)((r.f1 - r.f0) / 2) * (size_t)W * (size_t)H >= ((size_t)24 << 20)) {
+          (size_t)((r.f1 - r.f0) / 2) * (size_t)W * (size_t)H >= (size_t)3 * 3840 * 2160) {
           banks = true;
           bank_slots = (r.f1 - r.f0) / 2;
       }
@@ -1041,7 +1050,7 @@ int mdvt_release_cached_memory(int device)
         for (size_t k = 0; k < pool.size();) {
             if (device >= 0 && pool[k].tag != device) { ++k; continue; }
             out.push_back(pool[k]);
-            g_dev_pool_idle -= pool[k].bytes;
+            dev_pool_idle()[pool[k].tag] -= pool[k].bytes;
             pool.erase(pool.begin() + (long)k);
         }
     }
@@ -1049,6 +1058,31 @@ int mdvt_release_cached_memory(int device)
     if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
     for (const DevBlock& b : out) {
         // (a block tagged for a GPU this process does not have -- the tuning build's MDVT_POOL_TAG -- lives on the current one)
+        DeviceGuard g(b.tag >= 0 && b.tag < count ? b.tag : 0);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(b.p);
+    }
+    return MDVT_OK;
+}
+
+int mdvt_set_cached_memory_limit(uint64_t bytes_per_gpu)
+{
+    std::vector<DevBlock> out;
+    {
+        std::lock_guard<std::mutex> lock(g_dev_pool_mutex);
+        g_dev_pool_idle_cap = (size_t)bytes_per_gpu;
+        auto& pool = dev_pool();
+        for (size_t k = 0; k < pool.size();) {                                           // oldest first, per GPU
+            size_t& idle = dev_pool_idle()[pool[k].tag];
+            if (idle <= g_dev_pool_idle_cap) { ++k; continue; }
+            out.push_back(pool[k]);
+            idle -= pool[k].bytes;
+            pool.erase(pool.begin() + (long)k);
+        }
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
+    for (const DevBlock& b : out) {
         DeviceGuard g(b.tag >= 0 && b.tag < count ? b.tag : 0);
         (void)hipDeviceSynchronize();
         (void)hipFree(b.p);

@@ -891,21 +891,21 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
                     else *zp = make_float4(oz[0], oz[1], oz[2], oz[3]);
                 }
             }
-            if (BITS) {
+            if (BITS && !(MDVT_DEBUG_SKIP(a) & 64)) {
                 const uint32_t nib = act ? ((mw & 1u) | ((mw >> 7) & 2u) | ((mw >> 14) & 4u) | ((mw >> 21) & 8u)) : 0u;
                 uint8_t* brow = a.maskbits[eye] ? a.maskbits[eye] + (size_t)f * a.maskbits_stride + (size_t)i * a.maskbits_pitch : nullptr;
-                cnt[eye] = compact_hole_nibble(nib, g, act, brow, a.hole_counts != nullptr);
+                cnt[eye] = compact_hole_nibble(nib, g, act && !(MDVT_DEBUG_SKIP(a) & 8), brow, a.hole_counts != nullptr);      // (tuning build: ablations)
             }
         }
     }
-    if (BITS && a.hole_counts && (g & 63) == 0) {
+    if (BITS && a.hole_counts && (g & 63) == 0 && !(MDVT_DEBUG_SKIP(a) & 32)) {
         // No barrier: a wave adds its two counts to the row's LDS words and then counts itself in; the wave that arrives last
         // (its own adds and everyone else's precede its arrival in the LDS queue) posts the row.
         uint32_t* wc = (uint32_t*)(zb + 2 * (size_t)W + 1);
         __hip_atomic_fetch_add(&wc[0], (uint32_t)cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&wc[1], (uint32_t)cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t k = __hip_atomic_fetch_add(&wc[2], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k == (uint32_t)(TPB / 64 - 1))
+        if (k == (uint32_t)(TPB / 64 - 1) && !(MDVT_DEBUG_SKIP(a) & 16))
             post_row_hole_counts(a, fr, f, i, __hip_atomic_load(&wc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
                                  __hip_atomic_load(&wc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     }
@@ -2758,8 +2758,10 @@ static int points_cfg_override()
 }
 
 template <int TPB, bool ZOUT, bool BITS>
-static hipError_t launch_points_rows_fast_cfg(const RenderPlan& plan, const RenderArgs& a, hipStream_t s)
+static hipError_t launch_points_rows_fast_cfg(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
+    RenderArgs a = a_in;
+    if (const char* e = tuning_env(TUNE_DEBUG_SKIP)) a.debug_skip = atoi(e);      // (tuning build: the BITS tail's ablations, 8 / 16 / 32 / 64)
     const size_t lds = (2 * (size_t)a.W + 2) * sizeof(u64) + (BITS ? 2 * (TPB / 64) * sizeof(uint32_t) + 8 : 0);
     const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
     if (lds > 48 * 1024)

@@ -363,15 +363,15 @@ class StereoRerenderer:
         assert depth_rgb.is_cuda and color_rgb.is_cuda and depth_rgb.is_contiguous() and color_rgb.is_contiguous()
         arr = self.pack_params(params, N)
         dev = depth_rgb.device
-        sbs = out_sbs if out_sbs is not None else torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=dev)
+        sbs = out_sbs if out_sbs is not None else _lib.retry_after_release(lambda: torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=dev))
         assert want_mask or want_maskbits, "want_mask=False needs want_maskbits"
         mask = None
         if want_mask:
-            mask = out_mask if out_mask is not None else torch.empty((N, H, 2 * W), dtype=torch.uint8, device=dev)
+            mask = out_mask if out_mask is not None else _lib.retry_after_release(lambda: torch.empty((N, H, 2 * W), dtype=torch.uint8, device=dev))
         assert tuple(sbs.shape[-3:]) == (H, 2 * W, 3) and (mask is None or tuple(mask.shape[-2:]) == (H, 2 * W))
         zout = None
         if want_depth:
-            zout = out_depth if out_depth is not None else torch.empty((N, H, 2 * W), dtype=torch.float32, device=dev)
+            zout = out_depth if out_depth is not None else _lib.retry_after_release(lambda: torch.empty((N, H, 2 * W), dtype=torch.float32, device=dev))
 
         io = _lib.MdvtIO()
         io.depth_rgb, io.depth_pitch, io.depth_stride = depth_rgb.data_ptr(), 3 * W, 3 * W * H
@@ -402,7 +402,7 @@ class StereoRerenderer:
             res["hole_counts"] = counts[0] if single else counts
         seed = None
         if want_seed:           # [N, H, 2W, 3] u8: the infill-mask seed images, left | right (sr:787-803, 921-928)
-            seed = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=dev)
+            seed = _lib.retry_after_release(lambda: torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device=dev))
             io.left_seed, io.right_seed = seed.data_ptr(), seed.data_ptr() + 3 * W
             io.seed_pitch, io.seed_stride = 6 * W, 6 * W * H
             res["seed"] = seed[0] if single else seed
@@ -541,11 +541,16 @@ class StereoRerenderer:
                                                       px.data_ptr(), C.c_void_p(s.cuda_stream)))
         return px
 
-    def close(self):
+    def close(self, release_cached_memory: bool = False):
+        """Destroy the context(s).  Their workspace blocks stay in the library's process-wide pool for the next context of this GPU
+        (up to mdvt_set_cached_memory_limit, 4 GiB per GPU by default); release_cached_memory=True hands them back to the driver
+        now -- what a long-lived process that is done rendering should do (torch's allocator cannot reclaim them)."""
         if getattr(self, "_ctx2", None) is not None:
             self._ctx2.close()
             self._ctx2 = None
         self.ctx.close()
+        if release_cached_memory:
+            _lib.release_cached_memory(self.device)
 
 
 # ------------------------------------------------------------------------------------------------

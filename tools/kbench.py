@@ -30,6 +30,7 @@ ap.add_argument("--pose", action="store_true")
 ap.add_argument("--c4", action="store_true", help="BASELINE configs[3] as bench.py's extra.c4_* runs it: scene 4 + contention band + frames 40, 70, ... of the pose track (use with --width 3840 --height 2160 --frames 8)")
 ap.add_argument("--bits", action="store_true")
 ap.add_argument("--counts", action="store_true")
+ap.add_argument("--nomask", action="store_true", help="with --bits: no byte mask (want_mask=False)")
 ap.add_argument("--edges", action="store_true", help="remove_edges without --infill_mask (edge points painted, no seed image)")
 ap.add_argument("--split", type=int, default=1, help="the batch as this many sub-batches, each with its own context on its own stream")
 ap.add_argument("--stagger-us", type=float, default=0.0, help="with --split: sub-batch k starts k x this late and the streams free-run (joined once per timing)")
@@ -54,7 +55,7 @@ p = [r.frame_params(xfov=45.0, convergence_distance=a.conv, transformation=Ts[k]
 sbs = torch.empty((N, H, 2 * W, 3), dtype=torch.uint8, device="cuda")
 mask = torch.empty((N, H, 2 * W), dtype=torch.uint8, device="cuda")
 zo = torch.empty((N, H, 2 * W), dtype=torch.float32, device="cuda") if a.zout else None
-job = r.prepare(d, c, p, out_sbs=sbs, out_mask=mask, want_depth=a.zout, out_depth=zo, want_maskbits=a.bits, want_hole_counts=a.counts)
+job = r.prepare(d, c, p, out_sbs=sbs, out_mask=mask, want_depth=a.zout, out_depth=zo, want_maskbits=a.bits, want_hole_counts=a.counts, want_mask=not a.nomask)
 stream = torch.cuda.current_stream()
 if a.split > 1:
     per = (N + a.split - 1) // a.split
@@ -63,7 +64,7 @@ if a.split > 1:
     streams = [torch.cuda.Stream() for _ in range(a.split)]
     jobs = [rs[k].prepare(d[k * per:(k + 1) * per], c[k * per:(k + 1) * per], p[k * per:(k + 1) * per], out_sbs=sbs[k * per:(k + 1) * per],
                           out_mask=mask[k * per:(k + 1) * per], want_depth=a.zout, out_depth=None if zo is None else zo[k * per:(k + 1) * per],
-                          want_maskbits=a.bits, want_hole_counts=a.counts) for k in range(a.split)]
+                          want_maskbits=a.bits, want_hole_counts=a.counts, want_mask=not a.nomask) for k in range(a.split)]
 def run():
     if a.split > 1:
         for k in range(a.split):
