@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <string>
 #include <unordered_map>
+#include <array>
 #include <map>
 #include <vector>
 
@@ -71,7 +72,9 @@ struct mdvt_ctx {
     mdvt::RowCell* rowcell = nullptr; // [H] scanline -> cell row table of the mesh grid (pure-shift band kernel)
     int rowcell_bits = 0;             // the sub-pixel grid that table was built for
     uint32_t* row_counts = nullptr;   // [row_counts_frames][2][H]
-    unsigned long long* count_acc = nullptr;   // [row_counts_frames][17], zero between launches (RenderArgs.count_acc)
+    uint32_t* wave_counts = nullptr;  // [row_counts_frames][H][16] (RenderArgs.wave_counts)
+    uint32_t* divcheck = nullptr;     // [kDivSlots] (RenderArgs.divcheck), zeroed when allocated; slot k belongs to div_keys[k]
+    std::vector<std::array<uint32_t, 3>> div_keys;      // bits of (mult, scale, dl) of the parameter sets checked so far
     int row_counts_frames = 0;
     // infill-mask completion: per image stamp u16 + T f32 + work image u8x3, and the per-image counters
     int telea_images = 0, telea_rounds = 0;
@@ -667,7 +670,8 @@ int mdvt_destroy(mdvt_ctx* c)
     if (c->unused) ws_free(c, c->unused);
     if (c->elist) ws_free(c, c->elist);
     if (c->row_counts) ws_free(c, c->row_counts);
-    if (c->count_acc) ws_free(c, c->count_acc);
+    if (c->wave_counts) ws_free(c, c->wave_counts);
+    if (c->divcheck) ws_free(c, c->divcheck);
     if (c->rowcell) ws_free(c, c->rowcell);
     pool_give(c->telea_levels_host, nullptr, 64, -1);
     free_telea(c);
@@ -752,6 +756,29 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         const int rc = fill_frame_dev(c, params[k], fd[(size_t)k]);
         if (rc != MDVT_OK) return rc;
         general |= fd[(size_t)k].general;
+        fd[(size_t)k].div_slot = -1;
+    }
+    // Pure-shift point frames: the disparity's division proven short per parameter set (FrameDev.div_slot).  A new set costs one
+    // launch of 65536 threads on this stream, once per context; clips have one set, or one per distinct field of view.
+    if (c->cfg.mode == MDVT_MODE_POINTS) {
+        for (int k = 0; k < n_frames; ++k) {
+            FrameDev& f = fd[(size_t)k];
+            if (f.general) continue;
+            std::array<uint32_t, 3> key;
+            memcpy(&key[0], &f.mult, 4); memcpy(&key[1], &f.scale, 4); memcpy(&key[2], &f.dl, 4);
+            int slot = -1;
+            for (size_t q = c->div_keys.size(); q-- > 0;) if (c->div_keys[q] == key) { slot = (int)q; break; }
+            if (slot < 0 && c->div_keys.size() < (size_t)mdvt::kDivSlots) {
+                if (!c->divcheck) {
+                    MDVT_HIP(c, ws_malloc(c, (void**)&c->divcheck, mdvt::kDivSlots * sizeof(uint32_t), s));
+                    MDVT_HIP(c, hipMemsetAsync(c->divcheck, 0, mdvt::kDivSlots * sizeof(uint32_t), s));
+                }
+                slot = (int)c->div_keys.size();
+                MDVT_HIP(c, MDVT_GRID_CALL(c, launch_divcheck, f.mult, f.scale, f.dl, c->divcheck + slot, s));
+                c->div_keys.push_back(key);
+            }
+            f.div_slot = slot;
+        }
     }
     // The arithmetic of a frame (pure shift or general) is its own property, never its batch
     // neighbours': consecutive frames of one kind form a run, every run gets its own launches.
@@ -857,17 +884,17 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
     a.seed[0] = io->left_seed; a.seed[1] = io->right_seed; a.seed_pitch = io->seed_pitch; a.seed_stride = io->seed_stride;
     if (io->hole_counts) {
         if (c->row_counts_frames < count_frames) {
-            if (c->row_counts) { MDVT_HIP(c, hipDeviceSynchronize()); ws_free(c, c->row_counts); ws_free(c, c->count_acc); }     // (earlier submissions may still count into it)
-            c->row_counts = nullptr; c->count_acc = nullptr; c->row_counts_frames = 0;
+            if (c->row_counts) { MDVT_HIP(c, hipDeviceSynchronize()); ws_free(c, c->row_counts); ws_free(c, c->wave_counts); }     // (earlier submissions may still count into it)
+            c->row_counts = nullptr; c->wave_counts = nullptr; c->row_counts_frames = 0;
             MDVT_HIP(c, ws_malloc(c, (void**)&c->row_counts, (size_t)count_frames * 2 * H * sizeof(uint32_t), s));
-            MDVT_HIP(c, ws_malloc(c, (void**)&c->count_acc, (size_t)count_frames * 17 * sizeof(unsigned long long), s));
-            MDVT_HIP(c, hipMemsetAsync(c->count_acc, 0, (size_t)count_frames * 17 * sizeof(unsigned long long), s));     // (a recycled block holds old data)
+            MDVT_HIP(c, ws_malloc(c, (void**)&c->wave_counts, (size_t)count_frames * H * 16 * sizeof(uint32_t), s));
             c->row_counts_frames = count_frames;
         }
         a.row_counts = c->row_counts;
-        a.count_acc = c->count_acc;
+        a.wave_counts = c->wave_counts;
     }
     a.fp = dfp;
+    a.divcheck = c->divcheck;
     a.edge_paint = c->cfg.edge_points != 2;
     a.cull = c->cfg.cull;
     if (c->cfg.mode == MDVT_MODE_MESH) { if ((rc = ensure_rowcell(c, s)) != MDVT_OK) return rc; a.rowcell = c->rowcell; }
@@ -984,7 +1011,7 @@ int mdvt_render_stereo_batch(mdvt_ctx* c, int n_frames, const mdvt_frame_params*
         }
         if (no_byte_mask && !MDVT_GRID_CALL(c, points_fused_bits_applies, plan, a))
             return fail(c, MDVT_ERR_INVALID_ARG, "the byte masks may be NULL only where the mask compaction is fused into the render "
-                        "(points mode, pure stereo shift, no edge removal, W %% 4 == 0, W <= 4096, W * H < 2^24 with hole_counts)");
+                        "(points mode, pure stereo shift, no edge removal, W %% 4 == 0, W <= 4096)");
         a.key_parity = c->key_parity >> slot0;
         plan.edge_rows_max = 0;
         if (!r.general && !r.conv && plan.edge_points)

@@ -23,3 +23,4 @@ hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s);
 size_t render_lds_bytes(const RenderPlan& plan, int W);
 bool render_fits_lds(const RenderPlan& plan, int W);      // can the pure-shift row kernels hold a row of this width in LDS?
 bool points_fused_bits_applies(const RenderPlan& plan, const RenderArgs& a);      // k_points_rows_fast with the mask compaction fused in (byte masks optional)
+hipError_t launch_divcheck(float mult, float scale, float dl, uint32_t* bad, hipStream_t s);      // FrameDev.div_slot: the short division tried on every depth code

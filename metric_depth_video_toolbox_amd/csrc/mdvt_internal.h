@@ -71,7 +71,12 @@ struct FrameDev {
     // i or i + 1 (which of the two the chain decides per point); the LDS row kernels leave the edge points of scanlines
     // erow_lo .. erow_hi to k_edge_rows_exact.  erow_wild: some row's offset is neither (a camera matrix with cy far
     // from H/2): the frame is rendered by the global-key kernels, whose edge points take the whole chain.
-    int32_t erow_lo, erow_hi, erow_wild, pad_;
+    int32_t erow_lo, erow_hi, erow_wild;
+    // pure-shift point frames: index of this frame's (mult, scale, dl) in the context's table of division checks (RenderArgs.divcheck), -1:
+    // none.  The disparity dl / z of a frame has 65535 possible operands z -- the depth codes --: k_divcheck has tried all of them, and
+    // where the 4-instruction sequence (v_rcp_f32, one multiply, two fma) gave the bits of the IEEE division every time the counter is 0
+    // and the row kernel takes it instead of the 10-instruction expansion.
+    int32_t div_slot;
 };
 
 // Which row of grid cells covers output scanline k of a pure-shift mesh frame, and that row's snapped extent (depends on
@@ -88,9 +93,8 @@ struct RenderArgs {
     uint32_t* hole_counts;       // optional [n_frames][2]
     uint8_t* seed[2]; size_t seed_pitch, seed_stride;            // optional infill-mask seed images
     uint32_t* row_counts;        // workspace [frames in launch][2][H], zeroed per launch (when hole_counts)
-    unsigned long long* count_acc; // workspace [frames in launch][17]: the fused points kernel's hole-count accumulators (16 row classes +
-                                 //   the frame's total; left | right << 24 | arrivals << 48), all zero between launches: whoever completes
-                                 //   a word resets it
+    const uint32_t* divcheck;    // [kDivSlots] mismatches of the short division per parameter set (FrameDev.div_slot); 0 = proven
+    uint32_t* wave_counts;       // workspace [frames in launch][H][16]: the fused points kernel's hole counts per wave (left | right << 16)
     const FrameDev* fp;          // device array, one per frame of the batch
     int32_t W, H;
     int32_t frame0;              // first frame of this launch within the batch
@@ -133,6 +137,7 @@ hipError_t launch_edge_filter(const uint8_t* depth_rgb, size_t pitch, size_t str
                               int n, int W, int H, int of_by_one, uint8_t* tri_invalid, size_t tri_stride,
                               uint8_t* unused, size_t unused_stride, hipStream_t s);
 
+constexpr int kDivSlots = 256;        // parameter sets (mult, scale, dl) a context keeps division checks for; later ones take the IEEE division
 constexpr int kTieTile = 32;          // pixels: side of the tiles whose "holds a pixel marked as tied" bits gate the second rasteriser pass of the general mesh path
 inline size_t tie_words_of(int W, int H) { return ((size_t)((W + kTieTile - 1) / kTieTile) * (size_t)((H + kTieTile - 1) / kTieTile) + 31) / 32; }
 constexpr int kHugeCap = 1 << 17;     // row-block entries of huge triangles per launch set (overflow: the queue kernel keeps the triangle)

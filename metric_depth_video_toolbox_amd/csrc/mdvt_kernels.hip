@@ -12,6 +12,7 @@
 //
 // Compiled with -ffp-contract=off: see the arithmetic decree in mdvt_device.h / DESIGN.md.
 #include "mdvt_device.h"
+#include <type_traits>
 
 #include <vector>
 #include <stdio.h>
@@ -697,26 +698,31 @@ __device__ __forceinline__ int compact_hole_nibble(uint32_t nib, int g, bool act
     return want_count ? wave_hole_count(nib) : 0;
 }
 
-// A row's hole counts (left, right) into the frame's total without a second launch: the rows of a frame fall into 16 classes
-// (row & 15: a frame's ~H workgroups finish within microseconds of each other, and returning atomics on ONE address take
-// ~4 ns each), each with an accumulator word  left | right << 24 | arrivals << 48;  whoever brings a class to its last
-// arrival adds the class total to the frame's word, and whoever completes that writes hole_counts and leaves the words zero
-// for the next launch.  (W * H < 2^24: the caller's condition for this path.)
-__device__ __forceinline__ void post_row_hole_counts(const RenderArgs& a, int fr, int f, int i, uint32_t left, uint32_t right)
+// The fused points kernel's hole counts: every WAVE stores its two counts as one dword (left | right << 16: at most 256 each) to
+// wave_counts[(frame * H + row) * 16 + wave] -- a plain fire-and-forget store, no LDS total, no barrier, no atomic -- and
+// k_reduce_wave_counts adds them up per frame.  r06 measured the alternatives on 128 frames of 1080p (595 us without counts):
+// LDS totals + barrier + row store + reduce launch 664; LDS totals without a barrier + one RETURNING atomic per workgroup into
+// per-frame accumulators that the last arrival finishes (no second launch) 664 -> 639 without the atomics; fire-and-forget atomics per
+// wave with the frame's last workgroup waiting for the arrivals: dropped -- its wait has to read with read-modify-write atomics (a
+// load may be served from the XCD's own L2, which is not coherent with the other XCDs' atomics within a kernel: the first version hung
+// at 1080p on stale values) and with 128 frames in flight the waiting workgroups' polling stalled the launch.
+constexpr int kWaveCountStride = 16;      // dwords per row (workgroups of at most 1024 threads)
+
+__global__ void __launch_bounds__(256) k_reduce_wave_counts(const uint32_t* __restrict__ wave_counts, uint32_t* __restrict__ hole_counts,
+                                                            int H, int waves, int frame0)
 {
-    u64* acc = a.count_acc + (size_t)fr * 17;
-    const int k = i & 15;
-    const u64 one = 1ull << 48;
-    u64 add = (u64)left | ((u64)right << 24) | one;
-    u64 now = atomicAdd(&acc[k], add) + add;
-    if ((uint32_t)(now >> 48) != (uint32_t)((a.H - k + 15) >> 4)) return;
-    (void)atomicExch(&acc[k], 0ull);
-    add = (now & (one - 1ull)) | one;
-    now = atomicAdd(&acc[16], add) + add;
-    if ((uint32_t)(now >> 48) != (uint32_t)min(16, a.H)) return;
-    (void)atomicExch(&acc[16], 0ull);
-    a.hole_counts[2 * (size_t)f] = (uint32_t)now & 0xFFFFFFu;
-    a.hole_counts[2 * (size_t)f + 1] = (uint32_t)(now >> 24) & 0xFFFFFFu;
+    __shared__ uint32_t part[2][4];
+    const int fr = blockIdx.x;
+    const uint32_t* src = wave_counts + (size_t)fr * H * kWaveCountStride;
+    uint32_t l = 0, r = 0;
+    // (thread t reads dword t & 15 of rows t >> 4, t >> 4 + 16, ...: 64-byte runs per row, only the waves that exist)
+    const int w = threadIdx.x & 15;
+    if (w < waves)
+        for (int i = threadIdx.x >> 4; i < H; i += 16) { const uint32_t v = src[(size_t)i * kWaveCountStride + w]; l += v & 0xFFFFu; r += v >> 16; }
+    for (int off = 32; off > 0; off >>= 1) { l += __shfl_down((int)l, off); r += __shfl_down((int)r, off); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = l; part[1][threadIdx.x >> 6] = r; }
+    __syncthreads();
+    if (threadIdx.x < 2) hole_counts[2 * (size_t)(frame0 + fr) + threadIdx.x] = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
 }
 
 // row_counts[(2*frame + eye)*H + row] -> hole_counts[2*frame + eye]
@@ -774,6 +780,35 @@ hipError_t launch_reduce_counts(const RenderArgs& a, int n, hipStream_t s)
     return hipGetLastError();
 }
 
+// The headline kernel's division, proven per parameter set.  d = dl / z is IEEE-correctly rounded by decree, and hipcc's expansion of it
+// is 10 VALU instructions of the ~220 a lane spends on its four pixels -- with the kernel at ~80 % of the VALU issue rate next to
+// ~78 % of HBM peak (r06: every instruction added to it shows up in its time).  But a frame's z has only 65535 values:
+// z = (f32(code << 16) * mult) * scale.  points_div_short is v_rcp_f32, one multiply and two fma -- Markstein's correction step from the
+// raw reciprocal, faithful in general and correctly rounded unless the quotient sits within ~2^-23 ulp of a rounding boundary --
+// and k_divcheck compares it with the IEEE division for every code of one (mult, scale, dl): a counter of 0 is a proof for that frame's
+// operands, anything else leaves the frame on the expansion.  (tools/probe/div_probe.hip: 0 mismatches in 336 parameter sets.)
+__device__ __forceinline__ float points_div_short(float dl, float z)
+{
+    const float y = __builtin_amdgcn_rcpf(z);
+    const float q = dl * y;
+    return __builtin_fmaf(__builtin_fmaf(-z, q, dl), y, q);
+}
+
+__global__ void __launch_bounds__(256) k_divcheck(float mult, float scale, float dl, uint32_t* __restrict__ bad)
+{
+    const uint32_t code = blockIdx.x * 256u + threadIdx.x;           // 0 .. 65535
+    const float z = ((float)(code << 16) * mult) * scale;
+    bool differs = false;
+    if (z > kNear) differs = __float_as_uint(points_div_short(dl, z)) != __float_as_uint(dl / z);
+    if (__ballot(differs) && (threadIdx.x & 63) == 0) atomicAdd(bad, (uint32_t)__popcll(__ballot(differs)));
+}
+
+hipError_t launch_divcheck(float mult, float scale, float dl, uint32_t* bad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_divcheck, dim3(256), dim3(256), 0, s, mult, scale, dl, bad);
+    return hipGetLastError();
+}
+
 // -------------------------------------------------------------------------------------------------
 // Hand-scheduled variant of the row kernel for the headline case (4 px/lane, one group per thread, no
 // edge filter): byte shuffles are single v_perm_b32 ops, out-of-range fragments are steered to a trash
@@ -808,7 +843,6 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
     {
         uint4* z4 = (uint4*)zb;
         for (int x = g; x < W; x += TPB) z4[x] = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (BITS && g < 3) ((uint32_t*)(zb + 2 * (size_t)W + 1))[g] = 0u;      // hole counts of the row (left, right), waves done
     }
     __syncthreads();
 
@@ -826,38 +860,44 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
         const float fj0 = (float)(g << 2);
         const uint32_t jhi = (uint32_t)g >> 6, jlo = ((uint32_t)g << 2) & 0xFFu;
         const int trash = 2 * W;
+        auto splat = [&](auto short_div) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float z = ((float)c32[q] * mult) * scale;
-            const bool ok = z > kNear;
-            const float d = dl / z;
-            const float fj = fj0 + (float)q;
-            const int xL = point_col_row_kernel(fj + d), xR = point_col_row_kernel(fj - d);
-            const bool okL = ok && (uint32_t)xL < (uint32_t)W;
-            const bool okR = ok && (uint32_t)xR < (uint32_t)W;
-            const int sL = okL ? xL : trash;
-            const int sR = okR ? W + xR : trash;
-            const uint32_t hi = __builtin_amdgcn_perm(c32[q], jhi, 0x0c070600u);      // code16 << 8 | j >> 8
-            const uint32_t lo = __builtin_amdgcn_perm(jlo + (uint32_t)q, cpx[q], 0x04020100u);   // (j & 255) << 24 | rgb
-            const u64 key = ((u64)hi << 32) | lo;
-            atomicMin(&zb[sL], key);
-            atomicMin(&zb[sR], key);
-        }
+            for (int q = 0; q < 4; ++q) {
+                const float z = ((float)c32[q] * mult) * scale;
+                const bool ok = z > kNear;
+                const float d = decltype(short_div)::value ? points_div_short(dl, z) : dl / z;
+                const float fj = fj0 + (float)q;
+                const int xL = point_col_row_kernel(fj + d), xR = point_col_row_kernel(fj - d);
+                const bool okL = ok && (uint32_t)xL < (uint32_t)W;
+                const bool okR = ok && (uint32_t)xR < (uint32_t)W;
+                const int sL = okL ? xL : trash;
+                const int sR = okR ? W + xR : trash;
+                const uint32_t hi = __builtin_amdgcn_perm(c32[q], jhi, 0x0c070600u);      // code16 << 8 | j >> 8
+                const uint32_t lo = __builtin_amdgcn_perm(jlo + (uint32_t)q, cpx[q], 0x04020100u);   // (j & 255) << 24 | rgb
+                const u64 key = ((u64)hi << 32) | lo;
+                atomicMin(&zb[sL], key);
+                atomicMin(&zb[sR], key);
+            }
+        };
+        // (wave-uniform: the frame's parameter set has been proven, or it has not)
+        if (fp.div_slot >= 0 && a.divcheck[fp.div_slot] == 0u && !(MDVT_DEBUG_SKIP(a) & 128)) splat(std::true_type{});      // (128: tuning build's A/B)
+        else splat(std::false_type{});
     }
     __syncthreads();
 
-    int cnt[2] = {0, 0};
+    const bool counting = BITS && a.hole_counts && !(MDVT_DEBUG_SKIP(a) & 32);
+    uint32_t cnt[2] = {0u, 0u};
     if (act || BITS) {
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
-            uint4 k01 = make_uint4(0, 0, 0, 0), k23 = make_uint4(0, 0, 0, 0);     // inactive lanes: "covered, not key"
+            uint4 k01 = make_uint4(0, 0, 0, 0), k23 = make_uint4(0, 0, 0, 0);
             if (act) {
                 const uint4* zq = (const uint4*)(zb + (size_t)eye * W) + 2 * g;
                 k01 = zq[0]; k23 = zq[1];
             }
             const uint32_t hi[4] = {k01.y, k01.w, k23.y, k23.w};
             const uint32_t lo[4] = {k01.x, k01.z, k23.x, k23.z};
-            uint32_t o[4], mw = 0;
+            uint32_t o[4], mw = 0, nib = 0;
             float oz[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -865,12 +905,22 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
                 const uint32_t rgb = lo[q] & 0xFFFFFFu;
                 const bool hole = !covered || rgb == a.key_rgb;    // sr:740
                 o[q] = hole ? 0u : rgb;                            // sr:793
-                mw |= hole ? (0xFFu << (8 * q)) : 0u;
+                if (BITS) {
+                    nib |= hole ? (1u << q) : 0u;
+                    // the compare's lane mask IS the ballot: the wave's count costs scalar instructions only
+                    if (counting && !(MDVT_DEBUG_SKIP(a) & 64)) cnt[eye] += (uint32_t)__popcll(__ballot(hole && act));
+                } else {
+                    mw |= hole ? (0xFFu << (8 * q)) : 0u;
+                }
                 if (ZOUT) oz[q] = covered ? decode_z(hi[q] >> 8, mult, scale) : 0.0f;
+            }
+            uint8_t* mbase = a.mask[eye];                          // (NULL with BITS: the caller takes the packed mask only)
+            if (BITS && mbase) {                                   // nibble -> four bytes of 0 / 255
+                const uint32_t b = __umul24(nib, 0x204081u) & 0x01010101u;
+                mw = (b << 8) - b;
             }
             if (act) {
                 uint32_t* op = (uint32_t*)(a.rgb[eye] + (size_t)f * a.rgb_stride + (size_t)i * a.rgb_pitch) + 3 * g;
-                uint8_t* mbase = a.mask[eye];                      // (NULL with BITS: the caller takes the packed mask only)
                 uint32_t* mp = (uint32_t*)(mbase + (size_t)f * a.mask_stride + (size_t)i * a.mask_pitch) + g;
                 if (NT & 2) {                          // ... and every output byte written once
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(o[1], o[0], 0x04020100u), op);
@@ -891,24 +941,16 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
                     else *zp = make_float4(oz[0], oz[1], oz[2], oz[3]);
                 }
             }
-            if (BITS && !(MDVT_DEBUG_SKIP(a) & 64)) {
-                const uint32_t nib = act ? ((mw & 1u) | ((mw >> 7) & 2u) | ((mw >> 14) & 4u) | ((mw >> 21) & 8u)) : 0u;
-                uint8_t* brow = a.maskbits[eye] ? a.maskbits[eye] + (size_t)f * a.maskbits_stride + (size_t)i * a.maskbits_pitch : nullptr;
-                cnt[eye] = compact_hole_nibble(nib, g, act && !(MDVT_DEBUG_SKIP(a) & 8), brow, a.hole_counts != nullptr);      // (tuning build: ablations)
+            if (BITS && a.maskbits[eye] && !(MDVT_DEBUG_SKIP(a) & 64)) {
+                if (!act) nib = 0u;
+                const uint32_t v = mask_dword_of_8_lanes(nib, g);
+                if (act && (g & 7) == 0 && !(MDVT_DEBUG_SKIP(a) & 8))
+                    ((uint32_t*)(a.maskbits[eye] + (size_t)f * a.maskbits_stride + (size_t)i * a.maskbits_pitch))[g >> 3] = v;
             }
         }
     }
-    if (BITS && a.hole_counts && (g & 63) == 0 && !(MDVT_DEBUG_SKIP(a) & 32)) {
-        // No barrier: a wave adds its two counts to the row's LDS words and then counts itself in; the wave that arrives last
-        // (its own adds and everyone else's precede its arrival in the LDS queue) posts the row.
-        uint32_t* wc = (uint32_t*)(zb + 2 * (size_t)W + 1);
-        __hip_atomic_fetch_add(&wc[0], (uint32_t)cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&wc[1], (uint32_t)cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t k = __hip_atomic_fetch_add(&wc[2], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k == (uint32_t)(TPB / 64 - 1) && !(MDVT_DEBUG_SKIP(a) & 16))
-            post_row_hole_counts(a, fr, f, i, __hip_atomic_load(&wc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
-                                 __hip_atomic_load(&wc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    }
+    if (counting && (g & 63) == 0)
+        a.wave_counts[((size_t)fr * a.H + i) * kWaveCountStride + (g >> 6)] = cnt[0] | (cnt[1] << 16);
 }
 
 // =================================================================================================
@@ -2776,6 +2818,8 @@ static hipError_t launch_points_rows_fast_cfg(const RenderPlan& plan, const Rend
         }
     }
     hipLaunchKernelGGL((k_points_rows_fast<TPB, ZOUT, BITS>), grid, block, lds, s, a);
+    if (BITS && a.hole_counts && !(MDVT_DEBUG_SKIP(a) & 16))
+        hipLaunchKernelGGL(k_reduce_wave_counts, dim3(plan.n), dim3(256), 0, s, a.wave_counts, a.hole_counts, a.H, TPB / 64, a.frame0);
     return hipGetLastError();
 }
 
@@ -2783,8 +2827,7 @@ template <int TPB>
 static hipError_t launch_points_rows_fast(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const bool zout = a.zout[0] || a.zout[1];
-    // (hole counts ride in 24-bit fields of the accumulator words: larger frames take the byte mask through k_pack_mask)
-    const bool bits = (a.maskbits[0] || a.maskbits[1] || a.hole_counts) && (!a.hole_counts || (size_t)a.W * a.H < ((size_t)1 << 24));
+    const bool bits = a.maskbits[0] || a.maskbits[1] || a.hole_counts;
     plan.fused_bits = bits;
     if (zout) return bits ? launch_points_rows_fast_cfg<TPB, true, true>(plan, a, s) : launch_points_rows_fast_cfg<TPB, true, false>(plan, a, s);
     return bits ? launch_points_rows_fast_cfg<TPB, false, true>(plan, a, s) : launch_points_rows_fast_cfg<TPB, false, false>(plan, a, s);
@@ -2795,7 +2838,7 @@ static hipError_t launch_points_rows_fast(RenderPlan& plan, const RenderArgs& a,
 bool points_fused_bits_applies(const RenderPlan& plan, const RenderArgs& a)
 {
     return plan.mode == MDVT_MODE_POINTS && !plan.general && plan.vec4 && !plan.remove_edges && points_cfg_override() == 0 &&
-           a.W / 4 <= 1024 && (a.maskbits[0] || a.maskbits[1]) && (!a.hole_counts || (size_t)a.W * a.H < ((size_t)1 << 24));
+           a.W / 4 <= 1024 && (a.maskbits[0] || a.maskbits[1]);
 }
 
 static hipError_t launch_points_rows_vec4(RenderPlan& plan, const RenderArgs& a, hipStream_t s)

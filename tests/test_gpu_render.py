@@ -559,7 +559,7 @@ def test_compacted_hole_mask_and_counts(mods, orc, kind):
     r.close()
 
 
-@pytest.mark.parametrize("shape", [(192, 108, 3), (1920, 21, 5), (1028, 7, 2), (2568, 33, 2)])
+@pytest.mark.parametrize("shape", [(192, 108, 3), (1920, 21, 5), (1028, 7, 2), (2568, 33, 2), (1920, 1080, 3)])
 def test_fused_mask_compaction_without_byte_mask(mods, shape):
     """The headline kernel with the compaction fused in and NO byte mask (want_mask=False): packed mask and counts equal those of a
     plain render's byte mask; the frame totals come out of the kernel's own accumulators (16 row classes + the frame word, left zero
