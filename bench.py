@@ -559,6 +559,26 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
     out["infill_mask_completion"] = {"frames_per_call": nf, "ms_per_call_median_of_5": ms[2], "ms_per_frame": ms[2] / nf,
                                      "what": "mdvt_finish_infill_mask_stereo on the product-default seed images of both eyes "
                                              "(level-synchronous Telea inpaint + masked blur, one host read-back per pass)"}
+    # the asynchronous form (no host read-back: the call only enqueues): with the default bound of 256 levels (these frames have ~131:
+    # ~250 launches find empty lists) and with a bound a caller that has seen the clip's earlier frames would pass
+    def timed_finish(**kw):
+        rp.finish_infill_mask_sbs(seed, out=fin, **kw)
+        t = []
+        for _ in range(5):
+            torch.cuda.synchronize(dev)
+            ev[0].record()
+            rp.finish_infill_mask_sbs(seed, out=fin, **kw)
+            ev[1].record()
+            torch.cuda.synchronize(dev)
+            t.append(ev[0].elapsed_time(ev[1]))
+        return sorted(t)[2]
+    ms_nw = timed_finish(no_host_wait=True)
+    rem = rp.finish_infill_mask_sbs(seed, out=fin, max_rounds=144, want_remaining=True, no_host_wait=True)[1]
+    ms_nw_tight = timed_finish(no_host_wait=True, max_rounds=144)
+    out["infill_mask_completion"].update({
+        "no_host_wait_ms_per_frame_bound_256": ms_nw / nf, "no_host_wait_ms_per_frame_bound_144": ms_nw_tight / nf,
+        "no_host_wait_bound_144_key_pixels_left": int(rem.sum()),
+        "no_host_wait": "max_rounds < 0 at the C-ABI: every level up to the bound is launched, nothing waits on the stream"})
     if n_have >= 32:       # a caller that holds 32 frames: the completion splits them over two contexts / streams (stereo_rerender.py)
         nf2 = 32
         pd2 = [rp.frame_params(xfov=45.0, convergence_distance=2.5) for _ in range(nf2)]

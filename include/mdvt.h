@@ -256,10 +256,13 @@ int mdvt_masked_blur(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, uint
  * max_rounds (<= 0: 256, at most 32766) bounds the front's travel, in pixels of 4-neighbour distance from the nearest
  * seed; the rounds stop at the level of the deepest key-coloured pixel, and d_remaining (optional, n_images x uint32)
  * receives the number of key-coloured pixels beyond max_rounds.  Up to 32 images share one pass (14 B/px of workspace
- * each).  Unlike the other entry points this one WAITS on the stream once per pass: the levels come from a distance
- * transform, and the host reads the deepest level back so that exactly that many level launches follow -- a caller that
- * pipelines batches should issue it from the thread / stream that can afford the wait (the read-back word is per-ctx state:
- * like every entry point, not to be called on one ctx from two threads at once).
+ * each).  With max_rounds >= 0 this entry point -- unlike the others -- WAITS on the stream once per pass: the levels come from a
+ * distance transform, and the host reads the deepest level back so that exactly that many level launches follow (the read-back
+ * word is per-ctx state: like every entry point, not to be called on one ctx from two threads at once).
+ * max_rounds < 0 (ABI 0.15) is the ASYNCHRONOUS form: |max_rounds| levels are launched without asking the device how many exist
+ * (two launches per level; a level that does not exist finds an empty list and returns, ~3 us of device time each), nothing waits
+ * on the stream and the call can be captured or pipelined like a render.  Same bytes as the waiting form with the same bound; a
+ * caller that knows its clips (d_remaining of earlier frames tells whether a bound was enough) passes a tight one.
  * The key colour is the ctx's cfg.key_rgb.  d_out may not alias d_seed. */
 int mdvt_finish_infill_mask(mdvt_ctx* ctx, const uint8_t* d_seed, size_t seed_pitch, size_t seed_stride, uint8_t* d_out,
                             size_t out_pitch, size_t out_stride, int n_images, int max_rounds, uint32_t* d_remaining,

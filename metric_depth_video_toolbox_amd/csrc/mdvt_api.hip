@@ -1452,7 +1452,10 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
     if (n_frames < 1) return fail(c, MDVT_ERR_INVALID_ARG, "n_images must be >= 1");
     if (seed_pitch < (size_t)3 * c->W || out_pitch < (size_t)3 * c->W) return fail(c, MDVT_ERR_INVALID_ARG, "pitch smaller than one row");
     if (d_seed == d_out || (d_seed_right && d_seed_right == d_out_right)) return fail(c, MDVT_ERR_INVALID_ARG, "d_out may not alias d_seed");
-    if (max_rounds <= 0) max_rounds = 256;
+    // max_rounds < 0: |max_rounds| levels, every one of them launched without asking the device how many exist (no wait on the stream)
+    const bool no_wait = max_rounds < 0;
+    if (no_wait) max_rounds = -max_rounds;
+    if (max_rounds == 0) max_rounds = 256;
     if (max_rounds > 32766) return fail(c, MDVT_ERR_INVALID_ARG, "max_rounds must be <= 32766");
     DeviceGuard g(c->device);
     hipStream_t s = (hipStream_t)stream;
@@ -1496,8 +1499,8 @@ static int finish_infill_mask(mdvt_ctx* c, const uint8_t* d_seed, const uint8_t*
                                   d_seed_right ? d_seed_right - d_seed : 0, nf};
         const mdvt::ImageSet out{d_out + (size_t)f0 * out_stride, out_pitch, out_stride, d_out_right ? d_out_right - d_out : 0, nf};
         const mdvt::ImageSet work{c->telea.img, (size_t)3 * W, 3 * npx, 0, n};
-        MDVT_HIP(c, launch_telea_init(seed, c->telea, n, W, H, max_rounds, key, c->telea_levels_host, s));
-        MDVT_HIP(c, launch_telea_rounds(c->telea, W, H, (int)*c->telea_levels_host, key, s));               // sr:806, inpaintRadius = 3
+        MDVT_HIP(c, launch_telea_init(seed, c->telea, n, W, H, max_rounds, key, no_wait ? nullptr : c->telea_levels_host, s));
+        MDVT_HIP(c, launch_telea_rounds(c->telea, W, H, no_wait ? max_rounds : (int)*c->telea_levels_host, key, s));               // sr:806, inpaintRadius = 3
         // (the level lists and T are done with: their storage serves the blur's per-row pixel lists and row counters)
         MDVT_HIP(c, launch_masked_blur(work, &seed, out, n, W, H, K, key, s, c->telea.nlist, reinterpret_cast<uint32_t*>(c->telea.T)));   // sr:807-808
         if (d_remaining) {      // image order of the result: left eyes of all frames, then right eyes

@@ -2656,10 +2656,13 @@ hipError_t launch_telea_init(const ImageSet& seed, const TeleaWorkspace& ws, int
     else hipLaunchKernelGGL(k_telea_dt_cols, dim3((W + 63) / 64, n), dim3(1024), 0, s, a, (uint32_t)max_rounds);
     hipLaunchKernelGGL(k_telea_rmax, dim3(1), dim3(1), 0, s, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(h_levels, ws.counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-    const int R = (int)*h_levels;
-    if (R == 0) return hipSuccess;
+    int R = max_rounds;
+    if (h_levels) {       // (NULL: the asynchronous form -- every level up to max_rounds gets its launches; the ones that do not exist have empty lists)
+        if ((e = hipMemcpyAsync(h_levels, ws.counts, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        R = (int)*h_levels;
+        if (R == 0) return hipSuccess;
+    }
     if ((e = hipMemsetAsync(ws.counts, 0, sizeof(uint32_t), s)) != hipSuccess) return e;         // counts[0] carried R; level 0 is empty
     const dim3 grid_s((unsigned)(((W + kSortTile - 1) / kSortTile) * ((H + kSortTile - 1) / kSortTile)), n);
     hipLaunchKernelGGL(k_telea_scan, dim3(1), dim3(1024), 0, s, a, R);

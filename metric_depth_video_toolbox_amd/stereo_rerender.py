@@ -418,10 +418,13 @@ class StereoRerenderer:
                             want_depth=want_depth, out_depth=out_depth, want_maskbits=want_maskbits,
                             want_hole_counts=want_hole_counts, want_seed=want_seed, want_mask=want_mask).launch(stream)
 
-    def finish_infill_mask_sbs(self, seed_sbs, out=None, max_rounds: int = 0, want_remaining: bool = False):
+    def finish_infill_mask_sbs(self, seed_sbs, out=None, max_rounds: int = 0, want_remaining: bool = False, no_host_wait: bool = False):
         """finish_infill_mask for side-by-side seed buffers [N,H,2W,3] (render(want_seed=True)["seed"]): both eyes of
         all frames in one pass (mdvt_finish_infill_mask_stereo).  Returns [N,H,2W,3] (and, with want_remaining, an
-        int32 tensor [2,N]: left eyes, right eyes)."""
+        int32 tensor [2,N]: left eyes, right eyes).  no_host_wait: the asynchronous form (max_rounds, default 256, levels are
+        launched without reading the deepest level back: nothing waits on the stream)."""
+        if no_host_wait:
+            max_rounds = -(int(max_rounds) if max_rounds > 0 else 256)
         torch = self.torch
         W, H = self.W, self.H
         single = seed_sbs.dim() == 3

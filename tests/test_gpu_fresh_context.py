@@ -106,3 +106,30 @@ def test_pool_blocks_go_back_to_contexts_of_their_own_gpu_only(monkeypatch):
     r2.close()
     probe.close()
     _lib.release_cached_memory(-1)
+
+
+def test_bank_resources_crowd(tmp_path):
+    """The crowd that found both runtime bugs, on the path the r05 fix protects: 8 processes share the GPU, each
+    makes 300 multi-frame calls that take the two-bank path (side stream + four events from the process-wide pool of
+    `bank_res_take`), a context per call, native backtraces armed.  Every process must exit 0 with every call's bytes equal to its
+    first call's, and the first calls must agree across processes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import numpy as np
+    procs, calls = 8, 300
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MDVT_")}
+    env.update(CALLS=str(calls), MDVT_SEGV_TRACE_DIR=str(tmp_path), OMP_NUM_THREADS="1")
+    ps = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dbg_bank_crowd.py")], cwd=REPO, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(procs)]
+    outs = [p.communicate(timeout=1200)[0] for p in ps]
+    traces = "\n".join(open(os.path.join(tmp_path, f)).read()[-3000:] for f in sorted(os.listdir(tmp_path)) if f.endswith(".log"))
+    tail = "\n".join(o[-800:] for o in outs) + "\n" + traces
+    for p, o in zip(ps, outs):
+        assert p.returncode == 0, f"a process died (rc {p.returncode}):\n{tail}"
+        m = re.search(r"^bank crowd calls (\d+) bad (\d+)$", o, re.M)
+        assert m and int(m.group(1)) == calls and int(m.group(2)) == 0, tail
+    for mesh in (0, 1):
+        firsts = [np.load(os.path.join(tmp_path, f)) for f in sorted(os.listdir(tmp_path)) if f.startswith(f"bank_crowd_first_{mesh}_")]
+        assert len(firsts) == procs
+        for f in firsts[1:]:
+            assert np.array_equal(f["sbs"], firsts[0]["sbs"]) and np.array_equal(f["mask"], firsts[0]["mask"])

@@ -1341,6 +1341,25 @@ def test_finish_infill_mask_matches_the_oracle(mods, orc, W, H):
     rb.close()
 
 
+def test_finish_infill_mask_without_host_wait(mods):
+    """The asynchronous form (max_rounds < 0 at the C-ABI: every level up to the bound gets its launches, none waits for the level
+    count): the bytes and the `remaining` counts of the waiting form -- with the default bound, with a tight one, and with one
+    that is too small (the same pixels stay unfilled)."""
+    _lib, sr, synthetic = mods
+    W, H = 250, 61
+    rng = np.random.default_rng(77)
+    seeds = np.stack([_synthetic_seed(rng, W, H) for _ in range(4)])
+    sbs = torch.from_numpy(np.concatenate([seeds[:2], seeds[2:]], axis=2)).cuda()      # [2, H, 2W, 3]
+    r = sr.StereoRerenderer(W, H, infill_mask=True)
+    for bound in (0, 40, 3):
+        want, wrem = r.finish_infill_mask_sbs(sbs, max_rounds=bound, want_remaining=True)
+        got, grem = r.finish_infill_mask_sbs(sbs, max_rounds=bound, want_remaining=True, no_host_wait=True)
+        assert np.array_equal(got.cpu().numpy(), want.cpu().numpy()), bound
+        assert np.array_equal(grem.cpu().numpy(), wrem.cpu().numpy()), bound
+        assert (int(wrem.sum()) > 0) == (bound == 3)
+    r.close()
+
+
 def test_finish_infill_mask_wide_and_tall_images(mods, orc):
     """Rows beyond 2048 pixels take the two-vector row pass of the distance transform, images taller than 1088 rows the
     column pass that does not keep its segment in registers: one image that needs both, and an odd width beside it."""
