@@ -87,6 +87,8 @@ def lib():
         L.orc_telea_fmm.restype = None
         L.orc_telea_bands.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_float, u8p]
         L.orc_telea_bands.restype = C.c_int
+        L.orc_telea_windows.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, u8p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+        L.orc_telea_windows.restype = None
         L.orc_finish_infill_mask.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, u8p, u8p]
         L.orc_finish_infill_mask.restype = C.c_int
         L.orc_box_blur4.argtypes = [u8p, C.c_int, C.c_int, u8p]
@@ -438,3 +440,18 @@ def normal_infill(img: np.ndarray, infill_mask: np.ndarray, want_stages: bool = 
     return out, {"blur": st[:3 * n].reshape(H, W, 3), "filled": st[3 * n:6 * n].reshape(H, W, 3),
                  "merged": st[6 * n:9 * n].reshape(H, W, 3), "bg": st[9 * n:10 * n].reshape(H, W).astype(bool),
                  "grown": st[10 * n:11 * n].reshape(H, W).astype(bool)}
+
+
+def telea_windows(img: np.ndarray, mask: np.ndarray, radius: int = 3):
+    """telea_fmm's heap order from order-free steps (orc_telea_windows: windows of 0.70 in T, sorted pops, order-free activation,
+    dependency-ordered estimates) -> (image, T field, stats dict).  Must equal telea_fmm bit for bit."""
+    img = np.ascontiguousarray(img, np.uint8)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    H, W = mask.shape
+    out = np.empty_like(img)
+    T = np.empty((H, W), np.float32)
+    st = (C.c_uint64 * 8)()
+    lib().orc_telea_windows(_p(img, C.c_uint8), _p(mask, C.c_uint8), W, H, int(radius), _p(out, C.c_uint8), _p(T, C.c_float), st)
+    names = ("windows", "max_pops_per_window", "pops", "sum_T_chain", "sum_colour_chain", "max_colour_chain_in_a_window",
+             "lookahead_violations", "max_activations_per_window")
+    return out, T, dict(zip(names, (int(v) for v in st)))

@@ -1421,6 +1421,133 @@ int orc_telea_bands(const uint8_t* img, const uint8_t* mask, int W, int H, int r
     return steps;
 }
 
+/* The heap order of orc_telea_fmm as a CONSERVATIVE PARALLEL SIMULATION (r06, verdict r05 item 3): the same result, bit for bit,
+ * from steps whose parts are order-free, and the numbers that say what a device version of it would cost.
+ *
+ * Look-ahead.  A pixel q is estimated once, when the first of its 4-neighbours is popped (its "parent" p, the heap's minimum at that
+ * moment).  Every other non-INSIDE 4-neighbour of q is then either still in the band (T >= T(p)) or original (T = 0: then q's
+ * parent is an original pixel and T(p) = 0).  FastMarching_solve gives min + 1/sqrt(2) at the least, so T(q) >= T(p) + 0.7071: a
+ * pixel activated by a pop of the window [k d, (k+1) d), d = 0.70, is itself popped in a LATER window.  Hence one window at a time:
+ *   1. the window's pops = the band pixels with T < (k+1) d, SORTED by (T, S) -- S = the activation order, below;
+ *   2. every INSIDE pixel next to a pop is activated; its order key A = 4 rank(parent) + d, parent = the adjacent pop of least rank,
+ *      d = OpenCV's neighbour index of q as seen from the parent (up, left, down, right): per pixel, order-free;
+ *   3. T and colour of the activated pixels, each reading the pixels activated BEFORE it (earlier windows: all; this window:
+ *      smaller A): a dependency graph whose edges join pixels at most 4 apart (the radius-3 disc and the 4-neighbours its image
+ *      gradients read).  Here it is walked in A order; a device walks it by readiness.  S = window << 32 | A.
+ * stats[0] windows, [1] most pops in a window, [2] all pops, [3] sum over the windows of the longest T-dependency chain inside the
+ * window (4-neighbours), [4] the same for the colour estimate (distance <= 4), [5] longest single-window colour chain, [6] pixels
+ * whose T fell inside their own window (must be 0: the look-ahead), [7] most activations in a window. */
+typedef struct { float t; uint64_t s; uint32_t idx; } orc_win_item;
+static int orc_win_cmp(const void* a, const void* b)
+{
+    const orc_win_item* x = (const orc_win_item*)a; const orc_win_item* y = (const orc_win_item*)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->s < y->s ? -1 : (x->s > y->s ? 1 : 0);
+}
+typedef struct { uint32_t a; uint32_t idx; } orc_act_item;
+static int orc_act_cmp(const void* a, const void* b)
+{
+    const orc_act_item* x = (const orc_act_item*)a; const orc_act_item* y = (const orc_act_item*)b;
+    return x->a < y->a ? -1 : (x->a > y->a ? 1 : 0);
+}
+
+void orc_telea_windows(const uint8_t* img, const uint8_t* mask, int W, int H, int radius, uint8_t* out, float* T_out, uint64_t stats[8])
+{
+    const size_t n = (size_t)W * H;
+    const double delta = 0.70;
+    uint16_t* stamp = (uint16_t*)malloc(n * sizeof(uint16_t));           /* 0 = not INSIDE, 0xFFFF = INSIDE */
+    float* T = (float*)calloc(n, sizeof(float));
+    uint64_t* S = (uint64_t*)calloc(n, sizeof(uint64_t));
+    uint32_t* akey = (uint32_t*)malloc(n * sizeof(uint32_t));            /* activation key in the current window, ~0 = none */
+    uint32_t* awin = (uint32_t*)calloc(n, sizeof(uint32_t));             /* window (1-based) in which the pixel was activated */
+    uint32_t* dT = (uint32_t*)calloc(n, sizeof(uint32_t));               /* chain depths inside the activation window */
+    uint32_t* dC = (uint32_t*)calloc(n, sizeof(uint32_t));
+    uint32_t* band = (uint32_t*)malloc(n * sizeof(uint32_t));
+    orc_win_item* pops = (orc_win_item*)malloc(n * sizeof(orc_win_item));
+    orc_act_item* acts = (orc_act_item*)malloc(n * sizeof(orc_act_item));
+    size_t nb = 0;
+    memset(stats, 0, 8 * sizeof(uint64_t));
+    memset(akey, 0xFF, n * sizeof(uint32_t));
+    memcpy(out, img, n * 3);
+    for (size_t k = 0; k < n; ++k) stamp[k] = mask[k] ? ORC_T_UNKNOWN : 0;
+    orc_telea_state st = { W, H, stamp, T, out };
+    const int dx[4] = { 0, -1, 0, 1 }, dy[4] = { -1, 0, 1, 0 };
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (stamp[(size_t)y * W + x]) continue;
+            int b = 0;
+            for (int d = 0; d < 4; ++d) {
+                const int xx = x + dx[d], yy = y + dy[d];
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H && stamp[(size_t)yy * W + xx]) b = 1;
+            }
+            if (b) { const size_t k = (size_t)y * W + x; S[k] = (uint64_t)k; band[nb++] = (uint32_t)k; }
+        }
+    uint32_t win = 0;
+    while (nb) {
+        float tmin = 1.0e30f;
+        for (size_t q = 0; q < nb; ++q) if (T[band[q]] < tmin) tmin = T[band[q]];
+        const double hi = (floor((double)tmin / delta) + 1.0) * delta;
+        ++win;
+        /* 1. the window's pops, sorted */
+        size_t np = 0, keep = 0;
+        for (size_t q = 0; q < nb; ++q) {
+            const uint32_t k = band[q];
+            if ((double)T[k] < hi) { pops[np].t = T[k]; pops[np].s = S[k]; pops[np].idx = k; ++np; }
+            else band[keep++] = k;
+        }
+        nb = keep;
+        qsort(pops, np, sizeof(orc_win_item), orc_win_cmp);
+        /* 2. activation: per INSIDE neighbour the least 4 rank + d (the loop order is irrelevant: a minimum) */
+        size_t na = 0;
+        for (size_t r = 0; r < np; ++r) {
+            const int y = (int)(pops[r].idx / (uint32_t)W), x = (int)(pops[r].idx % (uint32_t)W);
+            for (int d = 0; d < 4; ++d) {
+                const int xx = x + dx[d], yy = y + dy[d];
+                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                const size_t k = (size_t)yy * W + xx;
+                if (stamp[k] != ORC_T_UNKNOWN) continue;
+                const uint32_t a = (uint32_t)(4 * r + (size_t)d);
+                if (akey[k] == 0xFFFFFFFFu) acts[na++].idx = (uint32_t)k;
+                if (a < akey[k]) akey[k] = a;
+            }
+        }
+        for (size_t q = 0; q < na; ++q) acts[q].a = akey[acts[q].idx];
+        qsort(acts, na, sizeof(orc_act_item), orc_act_cmp);
+        /* 3. the estimates, in activation order (every read is of a pixel activated before) */
+        uint32_t maxT = 0, maxC = 0;
+        for (size_t q = 0; q < na; ++q) {
+            const size_t k = acts[q].idx;
+            const int y = (int)(k / (size_t)W), x = (int)(k % (size_t)W);
+            float t; uint8_t rgb[3];
+            orc_telea_pixel(&st, x, y, 1, radius, &t, rgb);
+            uint32_t depT = 0, depC = 0;
+            for (int yy = y - 4; yy <= y + 4; ++yy)
+                for (int xx = x - 4; xx <= x + 4; ++xx) {
+                    if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                    const size_t m = (size_t)yy * W + xx;
+                    if (awin[m] != win || stamp[m] != 0) continue;                      /* activated in this window, before q */
+                    if ((xx - x) * (xx - x) + (yy - y) * (yy - y) <= 16 && dC[m] > depC) depC = dC[m];
+                    if (abs(xx - x) + abs(yy - y) == 1 && dT[m] > depT) depT = dT[m];
+                }
+            dT[k] = depT + 1; dC[k] = depC + 1; awin[k] = win;
+            if (dT[k] > maxT) maxT = dT[k];
+            if (dC[k] > maxC) maxC = dC[k];
+            T[k] = t; memcpy(out + 3 * k, rgb, 3); stamp[k] = 0;
+            S[k] = ((uint64_t)win << 32) | acts[q].a;
+            akey[k] = 0xFFFFFFFFu;
+            if ((double)t < hi) ++stats[6];
+            band[nb++] = (uint32_t)k;
+        }
+        ++stats[0];
+        if (np > stats[1]) stats[1] = np;
+        stats[2] += np; stats[3] += maxT; stats[4] += maxC;
+        if (maxC > stats[5]) stats[5] = maxC;
+        if (na > stats[7]) stats[7] = na;
+    }
+    if (T_out) memcpy(T_out, T, n * sizeof(float));
+    free(stamp); free(T); free(S); free(akey); free(awin); free(dT); free(dC); free(band); free(pops); free(acts);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* basic_nomal_infill.normal_infill (bni:87-119) and the helpers it is made of                 */
 /* ------------------------------------------------------------------------------------------ */

@@ -429,6 +429,36 @@ def test_level_synchronous_order_vs_sequential_fast_marching(orc):
     assert not np.all(fmm[green] == (0, 255, 0), -1).any()
 
 
+def test_heap_order_as_a_conservative_parallel_simulation(orc):
+    """cv2.inpaint's heap order (orc_telea_fmm) is reproduced BIT FOR BIT by orc_telea_windows: windows of 0.70 in T (FastMarching_solve
+    adds at least 1/sqrt(2), so nothing activated inside a window pops inside it), the window's pops sorted by (T, activation order),
+    every neighbour's activation key a minimum over its adjacent pops, the estimates in key order.  The steps inside a window are
+    order-free except the last, whose dependency chains -- the part a device cannot overlap -- are counted: on a rendered seed image
+    they are tens of pixels per window (a front is estimated along itself, Gauss-Seidel fashion), thousands per image."""
+    from metric_depth_video_toolbox_amd.synthetic import SyntheticScene
+    from metric_depth_video_toolbox_amd.depth_map_tools import compute_camera_matrix
+    rng = np.random.default_rng(3)
+    for W, H, dens in ((96, 64, 0.02), (250, 61, 0.01), (64, 200, 0.0005)):
+        img = rng.integers(1, 255, (H, W, 3), dtype=np.uint8)
+        known = rng.uniform(size=(H, W)) < dens
+        known[H // 3:H // 3 + 5, W // 4:W // 4 + 9] = True          # a block of known pixels: straight rims
+        known[:, 0] = True                                           # and a known border column, like the seed image's fixed normals
+        mask = (~known).astype(np.uint8)
+        img[mask > 0] = 0
+        got, T, st = orc.telea_windows(img, mask)
+        assert np.array_equal(got, orc.telea_fmm(img, mask)), (W, H)
+        assert st["lookahead_violations"] == 0 and st["pops"] >= int(mask.sum())
+    W, H = 240, 136
+    d, c = SyntheticScene(W, H, config_id=3).frame(0)
+    p = orc.make_params(W, H, compute_camera_matrix(45.0, None, W, H), ipd_m=0.065, mode=orc.MODE_MESH, remove_edges=True,
+                        edge_points=1, key_rgb=(0, 255, 0))
+    seed = orc.render_stereo(p, d, c, want_seed=True)["right_seed"]
+    mask = (np.all(seed == (0, 255, 0), -1) | np.all(seed == 0, -1)).astype(np.uint8)
+    got, T, st = orc.telea_windows(seed, mask)
+    assert np.array_equal(got, orc.telea_fmm(seed, mask)) and st["lookahead_violations"] == 0
+    assert st["windows"] > 20 and st["sum_colour_chain"] > 10 * st["windows"]      # (measured: ~55 dependent estimates per window)
+
+
 def test_rasteriser_statistics_near_plane_ties_and_culling(orc):
     """What the decree's known deviations from OpenGL amount to on the benchmark content:
     * near plane: OpenGL clips a triangle that crosses z = 1e-4 (dmt:1520), the decree drops it whole.  Config C4's
