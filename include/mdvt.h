@@ -261,7 +261,7 @@ int mdvt_masked_blur(mdvt_ctx* ctx, const uint8_t* d_img, size_t img_pitch, uint
  * word is per-ctx state: like every entry point, not to be called on one ctx from two threads at once).
  * max_rounds < 0 (ABI 0.15) is the ASYNCHRONOUS form: |max_rounds| levels are launched without asking the device how many exist
  * (two launches per level; a level that does not exist finds an empty list and returns, ~3 us of device time each), nothing waits
- * on the stream and the call can be captured or pipelined like a render.  Same bytes as the waiting form with the same bound; a
+ * on the stream: the call only enqueues work, like a render, and the caller's thread is free to stage the next batch.  Same bytes as the waiting form with the same bound; a
  * caller that knows its clips (d_remaining of earlier frames tells whether a bound was enough) passes a tight one.
  * The key colour is the ctx's cfg.key_rgb.  d_out may not alias d_seed. */
 int mdvt_finish_infill_mask(mdvt_ctx* ctx, const uint8_t* d_seed, size_t seed_pitch, size_t seed_stride, uint8_t* d_out,

@@ -699,26 +699,27 @@ __device__ __forceinline__ int compact_hole_nibble(uint32_t nib, int g, bool act
 }
 
 // The fused points kernel's hole counts: every WAVE stores its two counts as one dword (left | right << 16: at most 256 each) to
-// wave_counts[(frame * H + row) * 16 + wave] -- a plain fire-and-forget store, no LDS total, no barrier, no atomic -- and
+// wave_counts[(frame * H + row) * waves + wave] -- a plain fire-and-forget store, no LDS total, no barrier, no atomic -- and
 // k_reduce_wave_counts adds them up per frame.  r06 measured the alternatives on 128 frames of 1080p (595 us without counts):
 // LDS totals + barrier + row store + reduce launch 664; LDS totals without a barrier + one RETURNING atomic per workgroup into
 // per-frame accumulators that the last arrival finishes (no second launch) 664 -> 639 without the atomics; fire-and-forget atomics per
 // wave with the frame's last workgroup waiting for the arrivals: dropped -- its wait has to read with read-modify-write atomics (a
 // load may be served from the XCD's own L2, which is not coherent with the other XCDs' atomics within a kernel: the first version hung
 // at 1080p on stale values) and with 128 frames in flight the waiting workgroups' polling stalled the launch.
-constexpr int kWaveCountStride = 16;      // dwords per row (workgroups of at most 1024 threads)
-
+// wave_counts[(frame * H + row) * waves + wave], waves = threads per workgroup / 64: a frame's counts are H * waves consecutive dwords
 __global__ void __launch_bounds__(256) k_reduce_wave_counts(const uint32_t* __restrict__ wave_counts, uint32_t* __restrict__ hole_counts,
                                                             int H, int waves, int frame0)
 {
     __shared__ uint32_t part[2][4];
     const int fr = blockIdx.x;
-    const uint32_t* src = wave_counts + (size_t)fr * H * kWaveCountStride;
+    const int n = H * waves;                                       // (a multiple of 4: waves is 4, 8 or 16)
+    const uint4* src = reinterpret_cast<const uint4*>(wave_counts + (size_t)fr * n);
     uint32_t l = 0, r = 0;
-    // (thread t reads dword t & 15 of rows t >> 4, t >> 4 + 16, ...: 64-byte runs per row, only the waves that exist)
-    const int w = threadIdx.x & 15;
-    if (w < waves)
-        for (int i = threadIdx.x >> 4; i < H; i += 16) { const uint32_t v = src[(size_t)i * kWaveCountStride + w]; l += v & 0xFFFFu; r += v >> 16; }
+    for (int k = threadIdx.x; k < n / 4; k += 256) {
+        const uint4 v = src[k];
+        l += (v.x & 0xFFFFu) + (v.y & 0xFFFFu) + (v.z & 0xFFFFu) + (v.w & 0xFFFFu);
+        r += (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
+    }
     for (int off = 32; off > 0; off >>= 1) { l += __shfl_down((int)l, off); r += __shfl_down((int)r, off); }
     if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = l; part[1][threadIdx.x >> 6] = r; }
     __syncthreads();
@@ -950,7 +951,7 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
         }
     }
     if (counting && (g & 63) == 0)
-        a.wave_counts[((size_t)fr * a.H + i) * kWaveCountStride + (g >> 6)] = cnt[0] | (cnt[1] << 16);
+        a.wave_counts[((size_t)fr * a.H + i) * (TPB / 64) + (g >> 6)] = cnt[0] | (cnt[1] << 16);
 }
 
 // =================================================================================================

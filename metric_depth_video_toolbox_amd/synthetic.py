@@ -128,5 +128,5 @@ def c4_clip(n_frames: int = 8, W: int = 3840, H: int = 2160, host_frames: int = 
         sh = (16 * (k // nh), 24 * (k // nh))
         d[k] = np.roll(d[k % nh], shift=sh, axis=(0, 1))
         c[k] = np.roll(c[k % nh], shift=sh, axis=(0, 1))
-    Ts = synthetic_pose_track(300)[40:40 + n_frames * 30:30]
+    Ts = synthetic_pose_track(max(300, 40 + 30 * n_frames))[40:40 + n_frames * 30:30]      # one pose per frame (frames 40, 70, ... of the track)
     return d, c, Ts

@@ -78,14 +78,16 @@ def test_bench_launch_sets_at_full_hd(mods, orc, variant):
                  None, (0, 7, 8, 15, 16, 31), variant == "product_default", f"{variant} 1080p x {N}")
 
 
-@pytest.mark.parametrize("mode", ["points", "mesh"])
-def test_bench_c4_launch_sets_at_4k(mods, orc, mode):
+@pytest.mark.parametrize("mode,N", [("points", 8), ("mesh", 8), ("mesh", 7)])
+def test_bench_c4_launch_sets_at_4k(mods, orc, mode, N):
     """bench.py `extra.c4_4k_pose_points` / `c4_4k_pose_mesh`: 8 frames of 3840 x 2160 under the pose track with the contention band
-    (in mesh mode: the queued and the huge triangles) in one call -- banks of 2 (mesh: 4 slots by the 4 GiB budget; points: 4 slots)."""
+    (in mesh mode: the queued and the huge triangles) in one call -- banks of 2 (mesh: 4 slots by the 4 GiB budget; points: 4 slots).
+    7 frames: the odd split of a run that fits one launch set into two banks (halves of 3 frames of 4K and more are split: sets of
+    3, 3 and 1)."""
     _lib, sr, synthetic = mods
-    W, H, N = 3840, 2160, 8
+    W, H = 3840, 2160
     d, c, Ts = synthetic.c4_clip(N, W, H)
     _check_batch(sr, orc, W, H, d, c,
                  lambda: sr.StereoRerenderer(W, H, pupillary_distance=65, render_as_pointcloud=(mode == "points")),
                  lambda r: [r.frame_params(xfov=45.0, transformation=Ts[k]) for k in range(N)],
-                 Ts, (0, 3, 7), False, f"C4 {mode} 4K x {N}")
+                 Ts, (0, 3, N - 1), False, f"C4 {mode} 4K x {N}")
