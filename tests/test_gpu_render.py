@@ -829,13 +829,19 @@ def test_randomised_parity_sweep(mods, orc):
                                 render_as_pointcloud=not mesh, infill_mask=infill, dont_place_points_in_edges=no_pts)
         p = r.frame_params(xfov=xfov, convergence_distance=cs["conv_d"], transformation=T)
         want_seed = infill and H >= 3 and W >= 3
-        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True, want_seed=want_seed)
+        got = r.render(torch.from_numpy(depth_rgb).cuda(), torch.from_numpy(color).cuda(), p, want_depth=True, want_seed=want_seed,
+                       want_maskbits=True, want_hole_counts=True)
         tag = f"sweep#{cs['case']} {W}x{H} mesh={mesh} infill={infill} no_pts={no_pts} ipd={ipd} xfov={xfov} md={max_depth} kind={cs['kind']} style={cs['style']}"
         op = orc.make_params(W, H, _K(p), ipd_m=ipd / 1000, max_depth=max_depth, depth_scale=p.depth_scale,
                              mode=orc.MODE_MESH if mesh else orc.MODE_POINTS, remove_edges=r.remove_edges, edge_points=int(r.edge_points),
                              conv_angle=p.convergence_angle, T=T, key_rgb=r.key_rgb)
         want = orc.render_stereo(op, depth_rgb, color, want_depth=True, want_seed=want_seed)
         _compare({k: got[k] for k in ("sbs", "mask", "depth")}, want, W, tag)
+        # the packed mask and the hole counts (fused into the headline kernel, a post-pass everywhere else) say what the byte mask says
+        mk, bits, counts = got["mask"].cpu().numpy() > 0, got["maskbits"].cpu().numpy(), got["hole_counts"].cpu().numpy()
+        for eye, sl in ((0, slice(0, W)), (1, slice(W, 2 * W))):
+            pk = np.packbits(mk[:, sl], axis=1, bitorder="little")
+            assert np.array_equal(bits[:, eye, :pk.shape[1]], pk) and int(counts[eye]) == int(mk[:, sl].sum()), tag + " packed mask / counts"
         if want_seed:            # the infill-mask chain on whatever seeds this case produced
             fin = r.finish_infill_mask_sbs(got["seed"]).cpu().numpy()
             for eye, sl in (("left", slice(0, W)), ("right", slice(W, 2 * W))):
