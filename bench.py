@@ -503,7 +503,7 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
                                              nf, W, H, dev, torch)
         out["points_batch_sweep"] = sweep
         # the north star's fused variant: packed 1 bit/px hole mask (DPP-combined nibbles) + per-eye hole counts out of the same kernel.
-        # With the byte mask as well the algorithmic bytes are the headline's 14 B/px plus the packed mask's 0.25; without it (the
+        # With the byte mask as well the bytes moved are the headline's 14 B/px plus the packed mask's 0.25 (credited: 14.25); without it (the
         # packed mask IS the hole mask) 6 in + 6 rgb + 0.25 = 12.25 B/px leave and enter the chip, and that is what is credited.
         fused = {}
         for nf in (32, 128):
@@ -512,7 +512,8 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
             pp = [r.frame_params(xfov=45.0) for _ in range(nf)]
             fused[str(nf)] = measure_variant(
                 lambda: r.prepare(depth_rgb[:nf], color_rgb[:nf], pp, out_sbs=sbs[:nf], out_mask=mask[:nf], want_maskbits=True, want_hole_counts=True),
-                nf, W, H, dev, torch)
+                nf, W, H, dev, torch, bytes_per_px=14.25)
+            fused[str(nf)]["bytes_per_px_credited"] = 14.25
             fused[str(nf) + "_no_byte_mask"] = measure_variant(
                 lambda: r.prepare(depth_rgb[:nf], color_rgb[:nf], pp, out_sbs=sbs[:nf], want_maskbits=True, want_hole_counts=True, want_mask=False),
                 nf, W, H, dev, torch, bytes_per_px=12.25)

@@ -815,7 +815,12 @@ hipError_t launch_divcheck(float mult, float scale, float dl, uint32_t* bad, hip
 // edge filter): byte shuffles are single v_perm_b32 ops, out-of-range fragments are steered to a trash
 // LDS word instead of branching (no exec-mask traffic).  Same arithmetic, same results as k_points_rows.
 // -------------------------------------------------------------------------------------------------
-template <int TPB, bool ZOUT, bool BITS, int NT = 3>
+// BITS: 0 = byte mask only (the headline); 1 = packed mask and / or hole counts, whichever of the optional buffers are there (run-time
+// tests; the wave counts its holes by ballots); 8 | mask | 2 pack | 4 count = the same with the set of outputs fixed at compile time
+// (r06: the generic form ran the CU's scalar unit at ~70 % -- null tests, branches and exec masks around the optional stores: 267 SALU
+// instructions per wave against the headline's 161; counting from the packed mask in a kernel afterwards instead of by ballots here
+// was measured too: 37 us per 128 frames against 6).
+template <int TPB, bool ZOUT, int BITS, int NT = 3>
 __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -886,7 +891,8 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
     }
     __syncthreads();
 
-    const bool counting = BITS && a.hole_counts && !(MDVT_DEBUG_SKIP(a) & 32);
+    constexpr bool kSpec = (BITS & 8) != 0;
+    const bool counting = kSpec ? (BITS & 4) != 0 : (BITS && a.hole_counts && !(MDVT_DEBUG_SKIP(a) & 32));
     uint32_t cnt[2] = {0u, 0u};
     if (act || BITS) {
 #pragma unroll
@@ -916,7 +922,9 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
                 if (ZOUT) oz[q] = covered ? decode_z(hi[q] >> 8, mult, scale) : 0.0f;
             }
             uint8_t* mbase = a.mask[eye];                          // (NULL with BITS: the caller takes the packed mask only)
-            if (BITS && mbase) {                                   // nibble -> four bytes of 0 / 255
+            const bool has_mask = kSpec ? (BITS & 1) != 0 : (!BITS || mbase != nullptr);
+            const bool has_pack = kSpec ? (BITS & 2) != 0 : (BITS && a.maskbits[eye] != nullptr && !(MDVT_DEBUG_SKIP(a) & 64));
+            if (BITS && has_mask) {                                // nibble -> four bytes of 0 / 255
                 const uint32_t b = __umul24(nib, 0x204081u) & 0x01010101u;
                 mw = (b << 8) - b;
             }
@@ -927,12 +935,12 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(o[1], o[0], 0x04020100u), op);
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(o[2], o[1], 0x05040201u), op + 1);
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(o[3], o[2], 0x06050402u), op + 2);
-                    if (!BITS || mbase) __builtin_nontemporal_store(mw, mp);
+                    if (has_mask) __builtin_nontemporal_store(mw, mp);
                 } else {
                 op[0] = __builtin_amdgcn_perm(o[1], o[0], 0x04020100u);
                 op[1] = __builtin_amdgcn_perm(o[2], o[1], 0x05040201u);
                 op[2] = __builtin_amdgcn_perm(o[3], o[2], 0x06050402u);
-                if (!BITS || mbase) *mp = mw;
+                if (has_mask) *mp = mw;
                 }
                 if (ZOUT && a.zout[eye]) {
                     float4* zp = (float4*)((uint8_t*)a.zout[eye] + (size_t)f * a.zout_stride + (size_t)i * a.zout_pitch) + g;
@@ -942,7 +950,7 @@ __global__ void __launch_bounds__(TPB) k_points_rows_fast(RenderArgs a)
                     else *zp = make_float4(oz[0], oz[1], oz[2], oz[3]);
                 }
             }
-            if (BITS && a.maskbits[eye] && !(MDVT_DEBUG_SKIP(a) & 64)) {
+            if (BITS && has_pack) {
                 if (!act) nib = 0u;
                 const uint32_t v = mask_dword_of_8_lanes(nib, g);
                 if (act && (g & 7) == 0 && !(MDVT_DEBUG_SKIP(a) & 8))
@@ -2803,12 +2811,12 @@ static int points_cfg_override()
     return 0;
 }
 
-template <int TPB, bool ZOUT, bool BITS>
+template <int TPB, bool ZOUT, int BITS>
 static hipError_t launch_points_rows_fast_cfg(const RenderPlan& plan, const RenderArgs& a_in, hipStream_t s)
 {
     RenderArgs a = a_in;
     if (const char* e = tuning_env(TUNE_DEBUG_SKIP)) a.debug_skip = atoi(e);      // (tuning build: the BITS tail's ablations, 8 / 16 / 32 / 64)
-    const size_t lds = (2 * (size_t)a.W + 2) * sizeof(u64) + (BITS ? 2 * (TPB / 64) * sizeof(uint32_t) + 8 : 0);
+    const size_t lds = (2 * (size_t)a.W + 2) * sizeof(u64);
     const dim3 grid((unsigned)(plan.n * a.H)), block(TPB);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)k_points_rows_fast<TPB, ZOUT, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2816,14 +2824,15 @@ static hipError_t launch_points_rows_fast_cfg(const RenderPlan& plan, const Rend
         const char* e = tuning_env(TUNE_POINTS_NT);
         if (e && *e) {
             const int nt = atoi(e);
-            if (nt == 0) { hipLaunchKernelGGL((k_points_rows_fast<TPB, false, false, 0>), grid, block, lds, s, a); return hipGetLastError(); }
-            if (nt == 1) { hipLaunchKernelGGL((k_points_rows_fast<TPB, false, false, 1>), grid, block, lds, s, a); return hipGetLastError(); }
-            if (nt == 2) { hipLaunchKernelGGL((k_points_rows_fast<TPB, false, false, 2>), grid, block, lds, s, a); return hipGetLastError(); }
+            if (nt == 0) { hipLaunchKernelGGL((k_points_rows_fast<TPB, false, 0, 0>), grid, block, lds, s, a); return hipGetLastError(); }
+            if (nt == 1) { hipLaunchKernelGGL((k_points_rows_fast<TPB, false, 0, 1>), grid, block, lds, s, a); return hipGetLastError(); }
+            if (nt == 2) { hipLaunchKernelGGL((k_points_rows_fast<TPB, false, 0, 2>), grid, block, lds, s, a); return hipGetLastError(); }
         }
     }
     hipLaunchKernelGGL((k_points_rows_fast<TPB, ZOUT, BITS>), grid, block, lds, s, a);
-    if (BITS && a.hole_counts && !(MDVT_DEBUG_SKIP(a) & 16))
+    if (BITS && a.hole_counts && !(MDVT_DEBUG_SKIP(a) & 16)) {
         hipLaunchKernelGGL(k_reduce_wave_counts, dim3(plan.n), dim3(256), 0, s, a.wave_counts, a.hole_counts, a.H, TPB / 64, a.frame0);
+    }
     return hipGetLastError();
 }
 
@@ -2831,10 +2840,20 @@ template <int TPB>
 static hipError_t launch_points_rows_fast(RenderPlan& plan, const RenderArgs& a, hipStream_t s)
 {
     const bool zout = a.zout[0] || a.zout[1];
-    const bool bits = a.maskbits[0] || a.maskbits[1] || a.hole_counts;
+    const bool pack = a.maskbits[0] != nullptr, count = a.hole_counts != nullptr, mask = a.mask[0] != nullptr;
+    const bool bits = pack || count;
     plan.fused_bits = bits;
-    if (zout) return bits ? launch_points_rows_fast_cfg<TPB, true, true>(plan, a, s) : launch_points_rows_fast_cfg<TPB, true, false>(plan, a, s);
-    return bits ? launch_points_rows_fast_cfg<TPB, false, true>(plan, a, s) : launch_points_rows_fast_cfg<TPB, false, false>(plan, a, s);
+    if (zout) return bits ? launch_points_rows_fast_cfg<TPB, true, 1>(plan, a, s) : launch_points_rows_fast_cfg<TPB, true, 0>(plan, a, s);
+    if (!bits) return launch_points_rows_fast_cfg<TPB, false, 0>(plan, a, s);
+    if (tuning_env(TUNE_DEBUG_SKIP)) return launch_points_rows_fast_cfg<TPB, false, 1>(plan, a, s);      // (the ablations live in the generic form)
+    switch ((mask ? 1 : 0) | (pack ? 2 : 0) | (count ? 4 : 0)) {           // the set of outputs fixed at compile time
+        case 2: return launch_points_rows_fast_cfg<TPB, false, 8 | 2>(plan, a, s);
+        case 3: return launch_points_rows_fast_cfg<TPB, false, 8 | 3>(plan, a, s);
+        case 6: return launch_points_rows_fast_cfg<TPB, false, 8 | 6>(plan, a, s);
+        case 7: return launch_points_rows_fast_cfg<TPB, false, 8 | 7>(plan, a, s);
+        case 5: return launch_points_rows_fast_cfg<TPB, false, 8 | 5>(plan, a, s);
+        default: return launch_points_rows_fast_cfg<TPB, false, 1>(plan, a, s);
+    }
 }
 
 // Will this launch be rendered by k_points_rows_fast with the mask compaction fused in (the one kernel that can leave the byte
