@@ -137,8 +137,14 @@ __device__ __forceinline__ Vert vertex_conv_only(const FrameDev& f, const float*
     const float X = (M[0] * xc + M[2] * z) + M[3];
     const float Z = M[8] * xc + M[10] * z;
     o.ok = (z > kNear) && (Z > kNear);
+#ifdef MDVT_EXP_RCP_VERTEX      // timing experiment only (r06, verdict r05 item 4): ONE reciprocal per vertex and eye, as GL hardware divides -- other bits
+    const float r = rcp_exact(Z);
+    o.u = (f.fxr * X) * r + f.cxr;
+    o.v = (f.fyr * yc) * r + f.cyr;
+#else
     o.u = (f.fxr * X) / Z + f.cxr;
     o.v = (f.fyr * yc) / Z + f.cyr;
+#endif
     o.z = Z;
     return o;
 }
