@@ -600,12 +600,13 @@ def extra_measurements(args, r, sc, depth_rgb, color_rgb, sbs, mask, rank, world
     out["product_default_with_finished_infill_mask"] = {
         "fps": 1.0 / (1.0 / out["product_default"]["fps"] + ms[2] * 1e-3 / nf),
         "what": "render + completion, per-frame times added"}
-    # ... and as a two-stream pipeline, which the asynchronous completion allows: batch k's completion (stream B, its own context,
-    # no host wait, 144 levels) beside batch k + 1's render (stream A); two sets of buffers.  The completion waits most of its wave
-    # cycles on dependent launches; the render fills them.
+    # ... and as a two-stream pipeline, which the asynchronous completion allows: batch k's completion (stream B, higher priority, its
+    # own context, no host wait, 144 levels) beside batch k + 1's render (stream A); two sets of buffers.  Measured (r06): NO gain over
+    # the two run one after the other (1.95 k against 2.02 k frames/s) -- the render's chip-filling kernels and the completion's ~260
+    # short dependent launches do not interleave on this part; the figure stays on the line so that a change shows.
     try:
         rq = StereoRerenderer(W, H, device=dev.index, pupillary_distance=65, infill_mask=True)
-        sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=-1)      # (the completion's short dependent launches go first)
         sets = []
         for k in range(2):
             sb, mk = torch.empty_like(sbs[:nf]), torch.empty_like(mask[:nf])
