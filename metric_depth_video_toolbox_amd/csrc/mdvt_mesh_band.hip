@@ -28,6 +28,7 @@
 #include "mdvt_band_common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace mdvt {
 namespace MDVT_GRID {      // one copy per sub-pixel grid (mdvt_internal.h)
@@ -37,6 +38,9 @@ namespace MDVT_GRID {      // one copy per sub-pixel grid (mdvt_internal.h)
 // 745-781); bit 3: the infill-mask seed image (sr:787-803).
 // DBG: the ablation / test hooks of RenderArgs.debug_skip and face culling (mdvt_config.cull) are compiled in: the launcher picks
 // it when a hook is set (tuning build only) or cull != 0; the common case carries none of their scalar state
+// (`a` must stay the kernel's FIRST parameter and a plain-old-data struct: the body re-reads it through the kernarg segment at offset 0)
+static_assert(std::is_trivially_copyable<RenderArgs>::value && std::is_standard_layout<RenderArgs>::value,
+              "k_mesh_band reads RenderArgs through the kernarg segment: it must be passed as raw bytes");
 template <int FLAGS, int TPB, bool DBG>
 __global__ void __launch_bounds__(TPB, TPB == 1024 ? 4 : 4) k_mesh_band(RenderArgs a, int rows_per_band, int nbands)
 {
