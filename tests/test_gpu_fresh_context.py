@@ -133,3 +133,46 @@ def test_bank_resources_crowd(tmp_path):
         assert len(firsts) == procs
         for f in firsts[1:]:
             assert np.array_equal(f["sbs"], firsts[0]["sbs"]) and np.array_equal(f["mask"], firsts[0]["mask"])
+
+
+def test_cached_memory_limit_is_per_gpu_and_configurable():
+    """the idle workspace the process keeps is capped per GPU, the cap is configurable, and a caller that is done
+    can hand everything back.  Contexts of two frame sizes leave blocks of different size classes behind; lowering the limit returns
+    the oldest blocks at once, 0 keeps nothing at all, and renders stay correct throughout (fresh blocks are filled before use)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from metric_depth_video_toolbox_amd import _lib, stereo_rerender as sr, synthetic
+    dev = torch.cuda.current_device()
+    _lib.release_cached_memory(-1)
+    assert _lib.cached_memory(dev) == (0, 0)
+
+    def render_once(W, H):
+        d, c = synthetic.SyntheticScene(W, H, config_id=1, n_fg=5).frame(0)
+        r = sr.StereoRerenderer(W, H, pupillary_distance=65, infill_mask=True)
+        out = r.render(torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda(), r.frame_params(xfov=45.0, convergence_distance=2.5))
+        torch.cuda.synchronize()
+        held = r.ctx.workspace_bytes()
+        sbs = out["sbs"].clone()
+        r.close()
+        return held, sbs
+
+    try:
+        h1, ref1 = render_once(200, 120)
+        h2, ref2 = render_once(320, 180)
+        idle, blocks = _lib.cached_memory(dev)
+        assert idle >= max(h1, h2) and blocks > 0                      # both contexts' blocks wait in the pool (default cap: 4 GiB)
+        _lib.set_cached_memory_limit(h2)                                # room for the second context's blocks only
+        idle_b, _ = _lib.cached_memory(dev)
+        assert idle_b <= h2 < idle
+        _lib.set_cached_memory_limit(0)                                 # keep nothing
+        assert _lib.cached_memory(dev) == (0, 0)
+        h1b, again1 = render_once(200, 120)                             # every block fresh from the driver; nothing retained afterwards
+        assert torch.equal(again1, ref1) and _lib.cached_memory(dev) == (0, 0)
+        _lib.set_cached_memory_limit(4 << 30)
+        _, again2 = render_once(320, 180)
+        assert torch.equal(again2, ref2) and _lib.cached_memory(dev)[0] > 0
+        r = sr.StereoRerenderer(64, 48, pupillary_distance=65)
+        r.close(release_cached_memory=True)
+        assert _lib.cached_memory(dev) == (0, 0)
+    finally:
+        _lib.set_cached_memory_limit(4 << 30)
