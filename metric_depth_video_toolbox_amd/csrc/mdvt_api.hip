@@ -450,6 +450,11 @@ int ensure_workspace(mdvt_ctx* c, int frames, bool need_keys, bool need_ekeys, b
     // (blocks that are replaced go back to the pool, where another context may pick them up at once: whatever was submitted
     //  with them -- to any stream -- has to be through first; hipFree used to wait for that implicitly)
     if (grow && c->ws_bytes) MDVT_HIP(c, hipDeviceSynchronize());
+    // (not growing, yet a group that is not complete holds a buffer: an earlier call failed half-way through allocating it -- its
+    //  asynchronous fill may still be pending, and the block must not reach the pool before that is through)
+    if (!grow && ((need_keys && !c->ws_keys && (c->keys[0] || c->keys[1])) || (need_ekeys && !c->ws_ekeys && (c->ekeys[0] || c->ekeys[1] || c->elist)) ||
+                  (need_edges && !c->ws_edges && (c->tri_invalid || c->unused)) || (need_mesh_ws && !c->ws_mesh && (c->cbuf[0] || c->cbuf[1]))))
+        MDVT_HIP(c, hipDeviceSynchronize());
     if (grow || (need_keys && !c->ws_keys)) {
         for (int e = 0; e < 2; ++e) { if (c->keys[e]) ws_free(c, c->keys[e]); c->keys[e] = nullptr; }
         c->ws_keys = false;
